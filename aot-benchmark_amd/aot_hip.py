@@ -1,0 +1,185 @@
+"""ctypes binding of libaot_hip.so (the C ABI declared in include/aot_hip.h).
+
+Host-side plumbing only: torch supplies device memory and the stream, every op below is one
+asynchronous launch of a hand-written gfx950 kernel.  There is NO CPU path: if the library
+is missing, or a tensor is not on a ROCm device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libaot_hip.so')
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_long
+
+_SIGS = {
+    'aot_conv2d_nhwc_f32': [_P] * 5 + [_I] * 16 + [_P],
+    'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 11 + [_P],
+    'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
+    'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
+    'aot_nhwc_to_nchw_f32': [_P, _P] + [_I] * 4 + [_P],
+    'aot_layernorm_f32': [_P] * 6 + [_I] * 6 + [_F, _P],
+    'aot_groupnorm_stats_f32': [_P] * 3 + [_I] * 4 + [_F, _I, _P],
+    'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
+    'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
+    'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
+    'aot_idbank_f32': [_P] * 4 + [_I] * 10 + [_P],
+    'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
+    'aot_logits_finalize_f32': [_P] * 3 + [_I] * 8 + [_P],
+    'aot_add_f32': [_P] * 3 + [_L, _P],
+}
+
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU = 0, 1, 2, 3
+
+
+class AotHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AotHipError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(there is no CPU fallback for the AOT hot path)' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = sig
+            fn.restype = _I
+        lib.aot_hip_version.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ['aot_hip_version'])
+
+
+def version():
+    return load().aot_hip_version().decode()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise AotHipError('%s failed with code %d' % (name, rc))
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise AotHipError('AOT HIP ops need ROCm device tensors (got %s); there is no CPU fallback' % t.device)
+    return t.data_ptr()
+
+
+def _opt(t):
+    return None if t is None else _dev(t)
+
+
+# ---- thin wrappers: 2-D token-major tensors [M, C] with row stride = t.stride(0) ----------------
+def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
+           stream=None):
+    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(bias), _opt(res), _dev(out), H, W, Cin, OH, OW, Cout, KH, KW,
+                                    stride, pad, dil, x.stride(0), w.stride(0), out.stride(0),
+                                    res.stride(0) if res is not None else 0, act,
+                                    stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
+    return out
+
+
+def linear(x, w, bias, out, res=None, act=ACT_NONE, stream=None):
+    """out[M, N] = act(x[M, K] @ w[K, N] + bias (+ res))."""
+    M, K = x.shape
+    return conv2d(x, w, bias, out, 1, M, K, 1, M, out.shape[1], res=res, act=act, stream=stream)
+
+
+def dwconv2d(x, w, bias, out, H, W, C, OH, OW, K, stride=1, pad=0, dil=1, act=ACT_NONE, stream=None):
+    _chk(load().aot_dwconv2d_nhwc_f32(_dev(x), _dev(w), _opt(bias), _dev(out), H, W, C, OH, OW, K, K, stride, pad, dil,
+                                      act, stream if stream is not None else stream_ptr()), 'aot_dwconv2d_nhwc_f32')
+    return out
+
+
+def maxpool3x3s2(x, out, H, W, C, OH, OW, stream=None):
+    _chk(load().aot_maxpool3x3s2_nhwc_f32(_dev(x), _dev(out), H, W, C, OH, OW,
+                                          stream if stream is not None else stream_ptr()), 'aot_maxpool3x3s2_nhwc_f32')
+    return out
+
+
+def nchw_to_nhwc(x, out, C, H, W, Cpad, stream=None):
+    _chk(load().aot_nchw_to_nhwc_f32(_dev(x), _dev(out), C, H, W, Cpad, stream if stream is not None else stream_ptr()),
+         'aot_nchw_to_nhwc_f32')
+    return out
+
+
+def nhwc_to_nchw(x, out, C, H, W, stream=None):
+    _chk(load().aot_nhwc_to_nchw_f32(_dev(x), _dev(out), C, H, W, x.stride(0),
+                                     stream if stream is not None else stream_ptr()), 'aot_nhwc_to_nchw_f32')
+    return out
+
+
+def layernorm(x, gamma, beta, out, add=None, out2=None, eps=1e-5, stream=None):
+    M, C = x.shape
+    _chk(load().aot_layernorm_f32(_dev(x), _dev(gamma), _dev(beta), _dev(out), _opt(add), _opt(out2), M, C, x.stride(0),
+                                  out.stride(0), add.stride(0) if add is not None else 0,
+                                  out2.stride(0) if out2 is not None else 0, eps,
+                                  stream if stream is not None else stream_ptr()), 'aot_layernorm_f32')
+    return out
+
+
+def groupnorm(x, gamma, beta, out, groups, scratch, stats, act=ACT_NONE, eps=1e-5, nsplit=32, stream=None):
+    M, C = x.shape
+    s = stream if stream is not None else stream_ptr()
+    lib = load()
+    _chk(lib.aot_groupnorm_stats_f32(_dev(x), _dev(scratch), _dev(stats), M, C, groups, x.stride(0), eps, nsplit, s),
+         'aot_groupnorm_stats_f32')
+    _chk(lib.aot_groupnorm_apply_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(out), M, C, groups, x.stride(0),
+                                     out.stride(0), act, s), 'aot_groupnorm_apply_f32')
+    return out
+
+
+def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, stream=None):
+    _chk(load().aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev), H, 32,
+                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div, nsplit,
+                             stream if stream is not None else stream_ptr()), 'aot_attn_f32')
+    return out
+
+
+def local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, H, scale_div, max_dis=7, stream=None):
+    _chk(load().aot_local_attn_f32(_dev(q), _dev(k), _dev(v), _dev(relk_w), _dev(relk_b), _dev(relv_t), _dev(out), h, w, H,
+                                   32, max_dis, q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div,
+                                   stream if stream is not None else stream_ptr()), 'aot_local_attn_f32')
+    return out
+
+
+def idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, stream=None):
+    _chk(load().aot_idbank_f32(_dev(mask), _dev(table), _opt(bias), _dev(out), H, W, OH, OW, K, stride, pad, C, nlabel,
+                               out.stride(0), stream if stream is not None else stream_ptr()), 'aot_idbank_f32')
+    return out
+
+
+def bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=None, stream=None):
+    _chk(load().aot_bilinear_nhwc_f32(_dev(x), _opt(add), _dev(out), IH, IW, OH, OW, C, x.stride(0),
+                                      add.stride(0) if add is not None else 0, out.stride(0), int(align_corners),
+                                      stream if stream is not None else stream_ptr()), 'aot_bilinear_nhwc_f32')
+    return out
+
+
+def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_num, align_corners, stream=None):
+    _chk(load().aot_logits_finalize_f32(_dev(logits), _opt(out4), _opt(out), IH, IW, C, logits.stride(0), OH, OW, obj_num,
+                                        int(align_corners), stream if stream is not None else stream_ptr()),
+         'aot_logits_finalize_f32')
+
+
+def add(a, b, out, stream=None):
+    _chk(load().aot_add_f32(_dev(a), _dev(b), _dev(out), a.numel(), stream if stream is not None else stream_ptr()),
+         'aot_add_f32')
+    return out

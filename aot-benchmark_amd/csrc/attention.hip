@@ -1,0 +1,203 @@
+// Long-term / self attention over the memory bank, flash style, exact fp32 on the matrix cores.
+//
+// One 64-lane wave owns a tile of 32 queries of one head and streams the bank in tiles of 32 keys:
+//
+//   S^T[key, q]  = K_tile (32 x d) . Q^T (d x 32)      16 x v_mfma_f32_32x32x2_f32  (d = 32)
+//   online softmax per query column (the query index is the LANE in the C/D layout, so the running
+//   max m and the rescale factor are lane-local; the 32 keys of a column live in 16 registers of lanes
+//   q and q+32 -> one cross-half exchange per tile for the max, none for the sum)
+//   O^T[dv, q]  += V_tile^T (d x 32) . P^T (32 x 32)    16 x v_mfma_f32_32x32x2_f32
+//
+// Both products keep the QUERY on the B side, so P^T is consumed straight from the registers the
+// first product left it in: the contraction index of the second product is simply enumerated in the
+// order the C/D layout holds the keys (key(s, hi) = (s&3) + 8*(s>>2) + 4*hi) and V rows are fetched in
+// that order.  No LDS, no P shuffles.  K/V are read as full 128-byte head slices of the token-major
+// bank ([T, H*32] rows, coalesced); the bank (<= 48 MB/layer) lives in L2 / Infinity Cache across the
+// 53 query tiles.
+//
+// nsplit > 1: the bank is cut into nsplit contiguous ranges handled by different workgroups (fills the
+// 1024 SIMDs when Nq/32 * H = 424 waves would not), each writing an un-normalised partial (O, m, l);
+// attn_merge_kernel combines them.
+#include "common.h"
+
+struct AttnParams {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* out;
+  float* part;  // [nsplit][Nq][H*32] O partials, then [nsplit][Nq][H][2] (m, l)
+  const int* T_dev;
+  int Nq, T, H, ldq, ldk, ldv, ldo, nsplit;
+  float scale_div;
+};
+
+__global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
+  const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
+  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;  // key tiles per split
+  const int t0 = split * tps * 32;
+  const int t1 = min(T, t0 + tps * 32);
+
+  const int qrow = min(qt * 32 + j, p.Nq - 1);
+  // Q fragment (B operand of S^T = K.Q^T): lane (q=j, hi) holds Q[q][c = hi*16 + s], s = 0..15, scaled
+  float qf[16];
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + h * 32 + hi * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = src[i];
+      qf[4 * i + 0] = t.x / p.scale_div;  // reference divides (attention.py:82), so do we
+      qf[4 * i + 1] = t.y / p.scale_div;
+      qf[4 * i + 2] = t.z / p.scale_div;
+      qf[4 * i + 3] = t.w / p.scale_div;
+    }
+  }
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
+  const float* kbase = p.k + h * 32 + hi * 16;
+  const float* vbase = p.v + h * 32 + j;
+
+  float4 kf[4];
+  float vf[16];
+  auto load_kv = [&](int kt) {
+    const int krow = min(kt + j, T - 1);
+    const float4* ks = reinterpret_cast<const float4*>(kbase + (long)krow * p.ldk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kf[i] = ks[i];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int vrow = min(kt + mfma32_row(s, hi), T - 1);
+      vf[s] = vbase[(long)vrow * p.ldv];
+    }
+  };
+
+  if (t0 < t1) load_kv(t0);
+  for (int kt = t0; kt < t1; kt += 32) {
+    // ---- S^T = K . Q^T ----
+    float ka[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ka[4 * i + 0] = kf[i].x; ka[4 * i + 1] = kf[i].y; ka[4 * i + 2] = kf[i].z; ka[4 * i + 3] = kf[i].w;
+    }
+    float va[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) va[s] = vf[s];
+    if (kt + 32 < t1) load_kv(kt + 32);  // prefetch next tile under this tile's MFMAs
+
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qf[s], sc, 0, 0, 0);
+
+    // ---- online softmax over the 32 keys of this tile (per query = per lane column) ----
+    if (kt + 32 > t1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    float mt = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sc[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mnew = fmaxf(m, mt);
+    const float alpha = expf(m - mnew);  // m = -inf on the first tile -> 0
+    float ps = 0.f;
+    float pf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r] = expf(sc[r] - mnew);
+      ps += pf[r];
+    }
+    l = l * alpha + ps;
+    m = mnew;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+
+    // ---- O^T += V^T . P^T  (contraction index = key, enumerated in C/D-layout order) ----
+#pragma unroll
+    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
+  }
+
+  l += __shfl_xor(l, 32);
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / l;
+    float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
+      float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+      *reinterpret_cast<float4*>(dst + 8 * g) = t;
+    }
+  } else {
+    const int C = p.H * 32;
+    float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 t = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+      *reinterpret_cast<float4*>(dst + 8 * g) = t;
+    }
+    if (hi == 0) {
+      float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
+      ml[0] = m;   // -inf if this split saw no key (t0 >= t1)
+      ml[1] = l;
+    }
+  }
+}
+
+// merge of the nsplit partials: one thread per (query, head, 4 channels)
+__global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
+  const int C = p.H * 32;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.Nq * (C / 4);
+  if (idx >= total) return;
+  const int c4 = (int)(idx % (C / 4));
+  const int qi = (int)(idx / (C / 4));
+  const int h = (c4 * 4) / 32;
+  const float* mlb = p.part + (long)p.nsplit * p.Nq * C;
+  float mmax = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) mmax = fmaxf(mmax, mlb[(((long)s * p.Nq + qi) * p.H + h) * 2]);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float lsum = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float* ml = mlb + (((long)s * p.Nq + qi) * p.H + h) * 2;
+    const float ms = ml[0];
+    if (ms == -INFINITY) continue;
+    const float wgt = expf(ms - mmax);
+    lsum += wgt * ml[1];
+    const float4 t = *reinterpret_cast<const float4*>(p.part + ((long)s * p.Nq + qi) * C + c4 * 4);
+    acc.x += wgt * t.x; acc.y += wgt * t.y; acc.z += wgt * t.z; acc.w += wgt * t.w;
+  }
+  const float inv = 1.f / lsum;
+  *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c4 * 4) =
+      make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
+                            int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv,
+                            int ldo, float scale_div, int nsplit, void* stream) {
+  if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0) return AOT_ERR_BADARG;
+  if (d != 32) return AOT_ERR_UNSUPPORTED;
+  if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)out & 15))
+    return AOT_ERR_BADARG;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 1 && !part) return AOT_ERR_BADARG;
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.part = part; p.T_dev = T_dev;
+  p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.nsplit = nsplit;
+  p.scale_div = scale_div;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_fwd_d32_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, s, p);
+  if (nsplit > 1) {
+    const long total = (long)Nq * (H * 32 / 4);
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+  }
+  AOT_LAUNCH_CHECK();
+}

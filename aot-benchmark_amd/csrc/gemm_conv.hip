@@ -1,0 +1,227 @@
+// Implicit-GEMM convolution / linear layer on the exact-fp32 matrix cores of gfx950.
+//
+//   out[m, n] = act( sum_k A[m, k] * W[k, n] + bias[n] + res[m, n] )
+//
+// A is the im2col view of an NHWC activation map, generated on the fly by the loader (never
+// materialised); W is the [KH*KW*Cin, Cout] weight with FrozenBN folded in by the host.
+// MFMA: v_mfma_f32_32x32x2_f32 -- an exact fp32 fmaf chain at the fp32 vector rate (157 TF peak),
+// so results are bit-comparable with an fp32 reference up to summation order.
+//
+// Tiling: a workgroup owns a BM x BN tile, each 64-lane wave a WM x WN sub-tile built from
+// 32x32 MFMA fragments; K is walked in BK=16 slabs through a 2-stage LDS ring (global -> regs
+// issued before the MFMA block, regs -> LDS after it, one barrier per slab).  LDS images:
+//   As[k][m] (k-major, row stride BM+2: conflict-free ds_write_b32 of the transposed float4 and
+//             conflict-free ds_read_b32 of the A fragment, lane i <-> row i)
+//   Bs[k][n] (row stride BN+4, float4 stores, lane j <-> column j)
+// fp32 MFMA issues once per 64 cycles per SIMD, so one ds_read_b32 per operand is far from the
+// LDS limit (section 3 of the guide: 4 LDS cycles per 4 MFMAs = 256 cycles).
+#include "common.h"
+
+struct ConvParams {
+  const float* in;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* out;
+  int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil;
+  int lda, ldb, ldc, ldr, M, K, act;
+};
+
+#define BK 16
+
+template <int BM, int BN, int WM, int WN, bool IS1X1>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+conv_gemm_kernel(const ConvParams p) {
+  constexpr int NW_N = BN / WN;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_F4 = BM * BK / 4;
+  constexpr int B_F4 = BK * BN / 4;
+  constexpr int A_PER = (A_F4 + NT - 1) / NT;
+  constexpr int B_PER = (B_F4 + NT - 1) / NT;
+  constexpr int LDA_S = BM + 2;
+  constexpr int LDB_S = BN + 4;
+
+  __shared__ float As[2][BK][LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN;
+  const int nbm = (p.M + BM - 1) / BM;
+  // XCD-aware bijective remap: block b runs on XCD b%8; give each XCD a contiguous run of tiles
+  // so tiles that share an A row-panel hit the same private L2.
+  const int nwg = nbm * nbn, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int wm0 = (wave / NW_N) * WM, wn0 = (wave % NW_N) * WN;
+
+  // ---- A loader state (one float4 = 4 consecutive k of one output pixel) ----
+  bool a_ok[A_PER];
+  long a_base[A_PER];
+  int a_iy0[A_PER], a_ix0[A_PER], a_c[A_PER], a_ky[A_PER], a_kx[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int f = tid + i * NT;
+    const int r = f >> 2, kq = f & 3;
+    const int m = m0 + r;
+    a_ok[i] = (f < A_F4) && (m < p.M);
+    const int mm = a_ok[i] ? m : 0;
+    const int oy = mm / p.OW, ox = mm - oy * p.OW;
+    if (IS1X1) {
+      a_base[i] = ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kq * 4;
+    } else {
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      const int k = kq * 4;
+      const int tap = k / p.Cin;
+      a_c[i] = k - tap * p.Cin;
+      a_ky[i] = tap / p.KW;
+      a_kx[i] = tap - a_ky[i] * p.KW;
+    }
+  }
+
+  float4 a_reg[A_PER], b_reg[B_PER];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int f = tid + i * NT;
+      const int k = kt * BK + (f & 3) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (IS1X1) {
+        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const float4*>(p.in + a_base[i] + (long)kt * BK);
+      } else {
+        const int iy = a_iy0[i] + a_ky[i] * p.dil, ix = a_ix0[i] + a_kx[i] * p.dil;
+        if (a_ok[i] && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v = *reinterpret_cast<const float4*>(p.in + ((long)iy * p.W + ix) * p.lda + a_c[i]);
+        // advance (tap, c) by BK channels-of-k
+        a_c[i] += BK;
+        while (a_c[i] >= p.Cin) {
+          a_c[i] -= p.Cin;
+          if (++a_kx[i] == p.KW) { a_kx[i] = 0; ++a_ky[i]; }
+        }
+      }
+      a_reg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int f = tid + i * NT;
+      const int kr = f / (BN / 4), n4 = f - kr * (BN / 4);
+      const int k = kt * BK + kr, n = n0 + n4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < B_F4 && k < p.K && n < p.ldb) v = *reinterpret_cast<const float4*>(p.w + (long)k * p.ldb + n);
+      b_reg[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int f = tid + i * NT;
+      if (f < A_F4) {
+        const int r = f >> 2, kq = f & 3;
+        As[buf][kq * 4 + 0][r] = a_reg[i].x;
+        As[buf][kq * 4 + 1][r] = a_reg[i].y;
+        As[buf][kq * 4 + 2][r] = a_reg[i].z;
+        As[buf][kq * 4 + 3][r] = a_reg[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int f = tid + i * NT;
+      if (f < B_F4) {
+        const int kr = f / (BN / 4), n4 = f - kr * (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[buf][kr][n4 * 4]) = b_reg[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);  // global loads fly under the MFMA block below
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + kh][wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + kh][wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (folded BN) + residual + activation; 32 lanes write 128 contiguous bytes ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + l31;
+      if (n >= p.Cout) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + mfma32_row(r, kh);
+        if (m < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (p.res) v += p.res[(long)m * p.ldr + n];
+          p.out[(long)m * p.ldc + n] = apply_act(v, p.act);
+        }
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
+  const int nb = cdiv(p.M, BM) * cdiv(p.Cout, BN);
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  if (is1x1)
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3(nb), dim3(NT), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3(nb), dim3(NT), 0, s, p);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res,
+                                   float* out, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
+                                   int KW, int stride, int pad, int dil, int lda, int ldb, int ldc,
+                                   int ldr, int act, void* stream) {
+  if (!in || !w || !out) return AOT_ERR_BADARG;
+  if (H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
+  if ((Cin & 3) || (lda & 3) || (ldb & 3) || ldb < Cout || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
+  if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return AOT_ERR_BADARG;
+  if (res && ldr < Cout) return AOT_ERR_BADARG;
+  ConvParams p;
+  p.in = in; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+  p.M = OH * OW; p.K = KH * KW * Cin; p.act = act;
+  const bool is1x1 = (KH == 1 && KW == 1 && pad == 0);
+  hipStream_t s = (hipStream_t)stream;
+  // tile choice: fill 256 CUs x 4 SIMDs; big maps take 128x128 (64x64 per wave), small ones 64x64
+  if (Cout <= 32) return launch_cfg<128, 32, 32, 32>(p, is1x1, s);
+  if (p.M >= 4096 && Cout >= 128) return launch_cfg<128, 128, 64, 64>(p, is1x1, s);
+  if (p.M >= 4096) return launch_cfg<128, 64, 64, 32>(p, is1x1, s);
+  return launch_cfg<64, 64, 32, 32>(p, is1x1, s);
+}

@@ -1,0 +1,471 @@
+// HBM/L2-bound glue kernels of the AOT frame: normalisations, depthwise conv, pooling, resize,
+// layout changes, identity-bank gather, logit finalisation.  All are coalesced float4 streamers over
+// token-major (NHWC) maps; none of them is reshaped into a GEMM.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one 64-lane wave per token row, row kept in registers (C <= 1024), two-pass variance.
+// ---------------------------------------------------------------------------------------------
+template <int NV>  // float4 per lane
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        const float* __restrict__ add, float* __restrict__ y2, int M,
+                                                        int C, int ldx, int ldy, int ldadd, int ldy2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + i * 64;
+    v[i] = (c4 < nv) ? *reinterpret_cast<const float4*>(x + (long)row * ldx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(y + (long)row * ldy + c4 * 4) = o;
+      if (y2) {
+        const float4 a = *reinterpret_cast<const float4*>(add + (long)row * ldadd + c4 * 4);
+        *reinterpret_cast<float4*>(y2 + (long)row * ldy2 + c4 * 4) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+      }
+    }
+  }
+}
+
+extern "C" int aot_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, const float* add,
+                                 float* y2, int M, int C, int ldx, int ldy, int ldadd, int ldy2, float eps,
+                                 void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return AOT_ERR_BADARG;
+  if (y2 && (!add || (ldadd & 3) || (ldy2 & 3))) return AOT_ERR_BADARG;
+  if (C > 1024) return AOT_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(cdiv(M, 4)), block(256);
+  if (C <= 256)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+  else if (C <= 512)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm (batch 1, NHWC): deterministic two-level reduction in fp64, then a streaming apply.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, double* __restrict__ scratch, int M,
+                                                         int C, int G, int ldx, int nsplit) {
+  const int g = blockIdx.y, sp = blockIdx.x;
+  const int cg = C / G, v4 = cg >> 2;  // float4 per row of this group
+  const int rows_per_pass = 256 / v4;
+  const int t = threadIdx.x;
+  const int r_in = t / v4, c4 = t - r_in * v4;
+  const int rows = (M + nsplit - 1) / nsplit;
+  const int r0 = sp * rows, r1 = min(M, r0 + rows);
+  double s = 0.0, sq = 0.0;
+  if (r_in < rows_per_pass) {
+    for (int r = r0 + r_in; r < r1; r += rows_per_pass) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + g * cg + c4 * 4);
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  }
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    sq += __shfl_xor(sq, off);
+  }
+  if ((t & 63) == 0) { red[0][t >> 6] = s; red[1][t >> 6] = sq; }
+  __syncthreads();
+  if (t == 0) {
+    scratch[((long)g * nsplit + sp) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    scratch[((long)g * nsplit + sp) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ scratch, double* __restrict__ stats, int M, int C, int G,
+                                   int nsplit, float eps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  double s = 0.0, sq = 0.0;
+  for (int i = 0; i < nsplit; ++i) {
+    s += scratch[((long)g * nsplit + i) * 2];
+    sq += scratch[((long)g * nsplit + i) * 2 + 1];
+  }
+  const double cnt = (double)M * (C / G);
+  const double mean = s / cnt;
+  double var = sq / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[g * 2] = mean;
+  stats[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+}
+
+__device__ __forceinline__ float gn_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact-erf GELU (F.gelu default)
+  return v;
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int M, int C, int G, int ldx, int ldy,
+                                                       int act) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = C >> 2;
+  if (idx >= (long)M * nv) return;
+  const int c4 = (int)(idx % nv);
+  const long r = idx / nv;
+  const int g = (c4 * 4) / (C / G);
+  const float mean = (float)stats[g * 2], rstd = (float)stats[g * 2 + 1];
+  const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
+  float4 o;
+  o.x = gn_act((v.x - mean) * rstd * ga.x + be.x, act);
+  o.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
+  o.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
+  o.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+  *reinterpret_cast<float4*>(y + r * ldy + c4 * 4) = o;
+}
+
+extern "C" int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, int M, int C, int G, int ldx,
+                                       float eps, int nsplit, void* stream) {
+  if (!x || !scratch || !stats || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) || (ldx & 3) || nsplit < 1)
+    return AOT_ERR_BADARG;
+  if ((C / G) / 4 > 256) return AOT_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, G), dim3(256), 0, s, x, scratch, M, C, G, ldx, nsplit);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, s, scratch, stats, M, C, G, nsplit, eps);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                                       float* y, int M, int C, int G, int ldx, int ldy, int act, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) || (ldx & 3) ||
+      (ldy & 3))
+    return AOT_ERR_BADARG;
+  const long total = (long)M * (C / 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y,
+                     M, C, G, ldx, ldy, act);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise KxK conv, NHWC: thread = (output pixel, 4 channels); taps are coalesced float4 rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                     int C, int OH, int OW, int KH, int KW, int stride, int pad, int dil,
+                                                     int act) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = C >> 2;
+  if (idx >= (long)OH * OW * nv) return;
+  const int c4 = (int)(idx % nv);
+  const int pix = (int)(idx / nv);
+  const int oy = pix / OW, ox = pix - oy * OW;
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ky = 0; ky < KH; ++ky) {
+    const int iy = oy * stride - pad + ky * dil;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int kx = 0; kx < KW; ++kx) {
+      const int ix = ox * stride - pad + kx * dil;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(in + ((long)iy * W + ix) * C + c4 * 4);
+      const float4 k = *reinterpret_cast<const float4*>(w + (long)(ky * KW + kx) * C + c4 * 4);
+      acc.x = fmaf(v.x, k.x, acc.x);
+      acc.y = fmaf(v.y, k.y, acc.y);
+      acc.z = fmaf(v.z, k.z, acc.z);
+      acc.w = fmaf(v.w, k.w, acc.w);
+    }
+  }
+  acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act);
+  acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+  *reinterpret_cast<float4*>(out + (long)pix * C + c4 * 4) = acc;
+}
+
+extern "C" int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int H, int W, int C,
+                                     int OH, int OW, int KH, int KW, int stride, int pad, int dil, int act,
+                                     void* stream) {
+  if (!in || !w || !out || H <= 0 || W <= 0 || C <= 0 || (C & 3) || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+  const long total = (long)OH * OW * (C / 4);
+  hipLaunchKernelGGL(dwconv_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, C,
+                     OH, OW, KH, KW, stride, pad, dil, act);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                      int C, int OH, int OW) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = C >> 2;
+  if (idx >= (long)OH * OW * nv) return;
+  const int c4 = (int)(idx % nv);
+  const int pix = (int)(idx / nv);
+  const int oy = pix / OW, ox = pix - oy * OW;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(in + ((long)iy * W + ix) * C + c4 * 4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  *reinterpret_cast<float4*>(out + (long)pix * C + c4 * 4) = m;
+}
+
+extern "C" int aot_maxpool3x3s2_nhwc_f32(const float* in, float* out, int H, int W, int C, int OH, int OW, void* stream) {
+  if (!in || !out || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AOT_ERR_BADARG;
+  const long total = (long)OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, C, OH, OW);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                           long HW, int Cpad) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  for (int c = 0; c < Cpad; ++c) out[p * Cpad + c] = (c < C) ? in[(long)c * HW + p] : 0.f;
+}
+
+extern "C" int aot_nchw_to_nhwc_f32(const float* in, float* out, int C, int H, int W, int Cpad, void* stream) {
+  if (!in || !out || C <= 0 || Cpad < C) return AOT_ERR_BADARG;
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, Cpad);
+  AOT_LAUNCH_CHECK();
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                           long HW, int ld) {
+  // 64 pixels x 64 channels tile through LDS so both sides are coalesced
+  __shared__ float tile[64][65];
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const long p = p0 + i;
+    const int c = c0 + tx;
+    tile[i][tx] = (p < HW && c < C) ? in[p * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i;
+    const long p = p0 + tx;
+    if (c < C && p < HW) out[(long)c * HW + p] = tile[tx][i];
+  }
+}
+
+extern "C" int aot_nhwc_to_nchw_f32(const float* in, float* out, int C, int H, int W, int ld, void* stream) {
+  if (!in || !out || C <= 0 || ld < C) return AOT_ERR_BADARG;
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 64), cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, in, out, C,
+                     HW, ld);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear resize with torch's fp32 source-index arithmetic (ATen UpSample.h:
+// area_pixel_compute_scale / area_pixel_compute_source_index / guard_index_and_lambda).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_coord(int dst, int in_size, int out_size, float scale, int align, int& i0, int& i1,
+                                               float& w0, float& w1) {
+  if (in_size == out_size) { i0 = i1 = dst; w0 = 1.f; w1 = 0.f; return; }
+  float src;
+  if (align) src = scale * (float)dst;
+  else {
+    src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = min((int)floorf(src), in_size - 1);
+  w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+  w0 = 1.f - w1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+}
+
+static inline float bilinear_scale(int in_size, int out_size, int align) {
+  if (align) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  return (float)in_size / (float)out_size;
+}
+
+__global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ in, const float* __restrict__ add,
+                                                       float* __restrict__ out, int IH, int IW, int OH, int OW, int C,
+                                                       int ldi, int ldadd, int ldo, int align, float sh, float sw) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = C >> 2;
+  if (idx >= (long)OH * OW * nv) return;
+  const int c4 = (int)(idx % nv);
+  const int pix = (int)(idx / nv);
+  const int oy = pix / OW, ox = pix - oy * OW;
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bilinear_coord(oy, IH, OH, sh, align, y0, y1, wy0, wy1);
+  bilinear_coord(ox, IW, OW, sw, align, x0, x1, wx0, wx1);
+  const float4 a = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x0) * ldi + c4 * 4);
+  const float4 b = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x1) * ldi + c4 * 4);
+  const float4 c = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x0) * ldi + c4 * 4);
+  const float4 d = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x1) * ldi + c4 * 4);
+  float4 o;
+  o.x = wy0 * (wx0 * a.x + wx1 * b.x) + wy1 * (wx0 * c.x + wx1 * d.x);
+  o.y = wy0 * (wx0 * a.y + wx1 * b.y) + wy1 * (wx0 * c.y + wx1 * d.y);
+  o.z = wy0 * (wx0 * a.z + wx1 * b.z) + wy1 * (wx0 * c.z + wx1 * d.z);
+  o.w = wy0 * (wx0 * a.w + wx1 * b.w) + wy1 * (wx0 * c.w + wx1 * d.w);
+  if (add) {
+    const float4 e = *reinterpret_cast<const float4*>(add + (long)pix * ldadd + c4 * 4);
+    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+  }
+  *reinterpret_cast<float4*>(out + (long)pix * ldo + c4 * 4) = o;
+}
+
+extern "C" int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int IH, int IW, int OH, int OW, int C,
+                                     int ldi, int ldadd, int ldo, int align_corners, void* stream) {
+  if (!in || !out || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C & 3) || (ldi & 3) || (ldo & 3))
+    return AOT_ERR_BADARG;
+  if (add && (ldadd & 3)) return AOT_ERR_BADARG;
+  const long total = (long)OH * OW * (C / 4);
+  hipLaunchKernelGGL(bilinear_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
+                     OW, C, ldi, ldadd, ldo, align_corners, bilinear_scale(IH, OH, align_corners),
+                     bilinear_scale(IW, OW, align_corners));
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Logit finalisation (aot_engine.py:367-378): mask unused identities to -1e10, planar copy at stride 4,
+// bilinear resize to the output size, written planar [C, OH, OW] (what the caller's softmax/argmax reads).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) logits_planar_kernel(const float* __restrict__ in, float* __restrict__ out4, int HW,
+                                                            int C, int ldi, int obj_num) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)HW * C) return;
+  const int c = (int)(idx / HW);
+  const int p = (int)(idx - (long)c * HW);
+  out4[idx] = (c > obj_num) ? -1e10f : in[(long)p * ldi + c];
+}
+
+__global__ void __launch_bounds__(256) logits_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int IH,
+                                                            int IW, int C, int ldi, int OH, int OW, int obj_num, int align,
+                                                            float sh, float sw) {
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long)OH * OW) return;
+  const int oy = (int)(pix / OW), ox = (int)(pix - (long)oy * OW);
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bilinear_coord(oy, IH, OH, sh, align, y0, y1, wy0, wy1);
+  bilinear_coord(ox, IW, OW, sw, align, x0, x1, wx0, wx1);
+  const float* pa = in + ((long)y0 * IW + x0) * ldi;
+  const float* pb = in + ((long)y0 * IW + x1) * ldi;
+  const float* pc = in + ((long)y1 * IW + x0) * ldi;
+  const float* pd = in + ((long)y1 * IW + x1) * ldi;
+  for (int c = 0; c < C; ++c) {
+    float a, b, cc, d;
+    if (c > obj_num) a = b = cc = d = -1e10f;
+    else { a = pa[c]; b = pb[c]; cc = pc[c]; d = pd[c]; }
+    out[(long)c * OH * OW + pix] = wy0 * (wx0 * a + wx1 * b) + wy1 * (wx0 * cc + wx1 * d);
+  }
+}
+
+extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int IH, int IW, int C, int ldi, int OH,
+                                       int OW, int obj_num, int align_corners, void* stream) {
+  if (!logits || IH <= 0 || IW <= 0 || C <= 0 || ldi < C) return AOT_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (out4) {
+    const long total = (long)IH * IW * C;
+    hipLaunchKernelGGL(logits_planar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, out4, IH * IW, C, ldi, obj_num);
+  }
+  if (out) {
+    if (OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+    hipLaunchKernelGGL(logits_resize_kernel, dim3(cdiv((long)OH * OW, 256)), dim3(256), 0, s, logits, out, IH, IW, C, ldi,
+                       OH, OW, obj_num, align_corners, bilinear_scale(IH, OH, align_corners),
+                       bilinear_scale(IW, OW, align_corners));
+  }
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Identity bank: one workgroup per output token; the KxK label patch is staged in LDS, then every
+// thread (= channel quad) walks the taps, gathering coalesced rows of the [label, ky, kx, C] table.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) idbank_kernel(const float* __restrict__ mask, const float* __restrict__ table,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                    int OW, int K, int stride, int pad, int C, int nlabel, int ldo) {
+  extern __shared__ int labels[];  // K*K entries, -1 = contributes nothing
+  const int tok = blockIdx.x;
+  const int Y = tok / OW, X = tok - Y * OW;
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+    const int ky = i / K, kx = i - ky * K;
+    const int iy = Y * stride - pad + ky, ix = X * stride - pad + kx;
+    int lab = -1;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const float v = mask[(long)iy * W + ix];
+      const int li = (int)v;
+      if (v == (float)li && li >= 0 && li < nlabel) lab = li;
+    }
+    labels[i] = lab;
+  }
+  __syncthreads();
+  const int KK = K * K;
+  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < KK; ++i) {
+      const int lab = labels[i];
+      if (lab < 0) continue;
+      const float4 t = *reinterpret_cast<const float4*>(table + ((long)lab * KK + i) * C + c4 * 4);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + (long)tok * ldo + c4 * 4) = acc;
+  }
+}
+
+extern "C" int aot_idbank_f32(const float* mask, const float* table, const float* bias, float* out, int H, int W, int OH,
+                              int OW, int K, int stride, int pad, int C, int nlabel, int ldo, void* stream) {
+  if (!mask || !table || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || C <= 0 || (C & 3) || (ldo & 3))
+    return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(idbank_kernel, dim3(OH * OW), dim3(64), K * K * sizeof(int), (hipStream_t)stream, mask, table, bias,
+                     out, H, W, OW, K, stride, pad, C, nlabel, ldo);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+extern "C" int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
+  if (!a || !b || !out || n <= 0 || (n & 3)) return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(add_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" const char* aot_hip_version(void) { return "aot_hip 0.1 gfx950"; }

@@ -1,0 +1,130 @@
+"""ResNet-50/101 trunk without layer4, output stride 16 (reference networks/encoders/resnet.py:57-175).
+
+HIP path: NHWC activations; every conv+FrozenBN(+ReLU)(+residual) is ONE launch of the fp32-MFMA
+implicit-GEMM kernel (BN folded into weights/bias at pack time, residual add and ReLU in the epilogue);
+the stem is a 7x7/s2 implicit GEMM on a 4-channel-padded image followed by a 3x3/s2 max pool.
+"""
+import torch
+from torch import nn
+
+import aot_hip
+from networks.layers.normalization import fold_conv_bn
+
+
+def _osz(n, k, s, p, d=1):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, BatchNorm=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, dilation=dilation, padding=dilation,
+                               bias=False)
+        self.bn2 = BatchNorm(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+        self.dilation = dilation
+        self._p = None
+
+    def pack(self):
+        if self._p is None:
+            p = {'c1': fold_conv_bn(self.conv1, self.bn1), 'c2': fold_conv_bn(self.conv2, self.bn2),
+                 'c3': fold_conv_bn(self.conv3, self.bn3)}
+            if self.downsample is not None:
+                p['ds'] = fold_conv_bn(self.downsample[0], self.downsample[1])
+            self._p = p
+        return self._p
+
+    def run(self, x, H, W, ws, stream, out=None, tag=''):
+        """x [H*W, Cin] -> [OH*OW, 4*planes]; reference Bottleneck.forward, resnet.py:34-54."""
+        p = self.pack()
+        dev = x.device
+        cin = x.shape[1]
+        planes = self.conv1.out_channels
+        s, d = self.stride, self.dilation
+        OH, OW = _osz(H, 3, s, d, d), _osz(W, 3, s, d, d)
+        t1 = ws.get('bt1' + tag, (H * W, planes), dev)
+        aot_hip.conv2d(x, *p['c1'], t1, H, W, cin, H, W, planes, act=aot_hip.ACT_RELU, stream=stream)
+        t2 = ws.get('bt2' + tag, (OH * OW, planes), dev)
+        aot_hip.conv2d(t1, *p['c2'], t2, H, W, planes, OH, OW, planes, 3, 3, s, d, d, act=aot_hip.ACT_RELU, stream=stream)
+        if self.downsample is not None:
+            res = ws.get('bds' + tag, (OH * OW, planes * 4), dev)
+            aot_hip.conv2d(x, *p['ds'], res, H, W, cin, OH, OW, planes * 4, 1, 1, s, 0, 1, stream=stream)
+        else:
+            res = x
+        if out is None:
+            out = ws.get('bout' + tag, (OH * OW, planes * 4), dev)
+        aot_hip.conv2d(t2, *p['c3'], out, OH, OW, planes, OH, OW, planes * 4, res=res, act=aot_hip.ACT_RELU, stream=stream)
+        return out, OH, OW
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, output_stride, BatchNorm, freeze_at=0):
+        super().__init__()
+        if output_stride != 16:
+            raise NotImplementedError
+        self.inplanes = 64
+        strides, dilations = [1, 2, 2, 1], [1, 1, 1, 2]
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm(64)
+        self.layer1 = self._make_layer(block, 64, layers[0], strides[0], dilations[0], BatchNorm)
+        self.layer2 = self._make_layer(block, 128, layers[1], strides[1], dilations[1], BatchNorm)
+        self.layer3 = self._make_layer(block, 256, layers[2], strides[2], dilations[2], BatchNorm)
+        self._stem = None
+
+    def _make_layer(self, block, planes, blocks, stride, dilation, BatchNorm):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                BatchNorm(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, max(dilation // 2, 1), downsample, BatchNorm)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, dilation=dilation, BatchNorm=BatchNorm))
+        return nn.Sequential(*layers)
+
+    def run(self, img, ws, stream):
+        """img [1,3,H,W] planar -> [(feat [h*w, C], h, w)] for strides 4, 8, 16 (reference forward, :140-157;
+        the reference returns the stride-16 map twice)."""
+        _, _, H, W = img.shape
+        dev = img.device
+        if self._stem is None:
+            self._stem = fold_conv_bn(self.conv1, self.bn1, pad_cin=4)
+        x4 = ws.get('img_nhwc4', (H * W, 4), dev)
+        aot_hip.nchw_to_nhwc(img, x4, 3, H, W, 4, stream=stream)
+        H1, W1 = _osz(H, 7, 2, 3), _osz(W, 7, 2, 3)
+        s1 = ws.get('stem', (H1 * W1, 64), dev)
+        aot_hip.conv2d(x4, *self._stem, s1, H, W, 4, H1, W1, 64, 7, 7, 2, 3, 1, act=aot_hip.ACT_RELU, stream=stream)
+        H2, W2 = _osz(H1, 3, 2, 1), _osz(W1, 3, 2, 1)
+        x = ws.get('pool', (H2 * W2, 64), dev)
+        aot_hip.maxpool3x3s2(s1, x, H1, W1, 64, H2, W2, stream=stream)
+        feats = []
+        h, w = H2, W2
+        for li, layer in enumerate((self.layer1, self.layer2, self.layer3)):
+            nb = len(layer)
+            for bi, blk in enumerate(layer):
+                last = bi == nb - 1
+                out = None
+                if last:   # stage outputs are decoder shortcuts: keep them in their own buffers
+                    planes4 = blk.conv3.out_channels
+                    ho, wo = _osz(h, 3, blk.stride, blk.dilation, blk.dilation), _osz(w, 3, blk.stride, blk.dilation, blk.dilation)
+                    out = ws.get('stage%d' % li, (ho * wo, planes4), dev)
+                # ping-pong block outputs so a block never overwrites its own input / residual
+                x, h, w = blk.run(x, h, w, ws, stream, out=out, tag='_%d_%d' % (li, bi & 1))
+            feats.append((x, h, w))
+        return feats
+
+
+def ResNet50(output_stride, BatchNorm, freeze_at=0):
+    return ResNet(Bottleneck, [3, 4, 6, 3], output_stride, BatchNorm, freeze_at=freeze_at)
+
+
+def ResNet101(output_stride, BatchNorm, freeze_at=0):
+    return ResNet(Bottleneck, [3, 4, 23, 3], output_stride, BatchNorm, freeze_at=freeze_at)

@@ -1,0 +1,12 @@
+"""Engine factory (reference networks/engines/__init__.py:5-21)."""
+from networks.engines.aot_engine import AOTEngine, AOTInferEngine
+
+
+def build_engine(name, phase='train', **kwargs):
+    if name == 'aotengine':
+        if phase == 'eval':
+            return AOTInferEngine(**kwargs)
+        raise NotImplementedError("phase %r: only the inference engine ('eval') is on the scoped hot path" % phase)
+    if name == 'deaotengine':
+        raise NotImplementedError('DeAOT engine: next row of the scope table (SURVEY.md section 8a, a3/a4/a6)')
+    raise NotImplementedError

@@ -1,0 +1,318 @@
+"""Per-clip inference engines (reference networks/engines/aot_engine.py).
+
+``AOTEngine`` is the state machine of one <=10-object group: it owns the long-term memory bank, the
+short-term memory (previous frame) and the current frame's intermediates, and drives the model's fused
+HIP stages.  ``AOTInferEngine`` is the caller-facing wrapper (tools/demo.py:187-235,
+networks/managers/evaluator.py:265-446 call exactly this surface).
+
+MI355X-first differences from the reference implementation (same results):
+  * the bank is a pre-allocated, geometrically grown [cap, C] buffer per layer that frames are
+    APPENDED to (the reference re-copies the whole bank with torch.cat every `gap` frames,
+    aot_engine.py:291-305); softmax attention is order-invariant;
+  * one_hot_mask + the 17x17 identity conv are one gather kernel on the label map;
+  * no NCHW<->sequence copies: token-major buffers are viewed as [1,C,h,w] / [N,1,C] at the API.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import aot_hip
+from networks.models.aot import as_map, to_tokens
+
+
+class AOTEngine(nn.Module):
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1):
+        super().__init__()
+        self.cfg = aot_model.cfg
+        self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
+        self.AOT = aot_model
+        self.max_obj_num = aot_model.max_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.short_term_mem_skip = short_term_mem_skip
+        self.restart_engine()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('training forward (aot_engine.py:33-108) is outside the scoped inference path')
+
+    # ---- state ---------------------------------------------------------------------------------
+    def restart_engine(self, batch_size=1, enable_id_shuffle=False):
+        if batch_size != 1 or enable_id_shuffle:
+            raise NotImplementedError('inference runs batch 1 without id shuffle (aot_engine.py:445-477)')
+        self.batch_size = 1
+        self.frame_step = 0
+        self.last_mem_step = -1
+        self.obj_nums = None
+        self.pos_emb = None
+        self.enc_size_2d = None
+        self.enc_hw = None
+        self.input_size_2d = None
+        self.bank_k, self.bank_v, self.bank_len = None, None, 0
+        self.short_term_memories_list = []
+        self.short_term_memories = None
+        self._feats = None        # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major
+        self._cat = None          # [N, (L+1)*C]: decoder input; block 0 = projected feature, blocks 1.. = LSTT outs
+        self._curr = None         # per layer (curr_K, curr_V) token-major
+        self.curr_id_embs = None
+        self.pred_id_logits = None
+
+    def update_size(self, input_size, enc_size):
+        self.input_size_2d = tuple(int(x) for x in input_size)
+        self.enc_size_2d = tuple(int(x) for x in enc_size)
+        self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+
+    @property
+    def curr_enc_embs(self):
+        """[4x, 8x, 16x, 16x-projected] maps as [1,C,h,w] views (read by multi-group sharing and by callers)."""
+        if self._feats is None:
+            return None
+        return [as_map(t, h, w) for (t, h, w) in self._feats]
+
+    @property
+    def long_term_memories(self):
+        if self.bank_k is None:
+            return None
+        return [[k[:self.bank_len].unsqueeze(1), v[:self.bank_len].unsqueeze(1)] for k, v in zip(self.bank_k, self.bank_v)]
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _encode(self, img, img_embs):
+        L = self.AOT.LSTT.num_layers
+        emb = self.AOT.encoder_projector.out_channels
+        dev = img.device if img is not None else img_embs[-1].device
+        if img_embs is None:
+            h16 = w16 = None
+            cat = None
+            feats = self.AOT.encode_tokens(img)
+            x0, h, w = feats[3]
+            cat = torch.empty(h * w, (L + 1) * emb, dtype=torch.float32, device=dev)
+            cat[:, :emb].copy_(x0)
+            feats[3] = (cat[:, :emb], h, w)
+        else:   # shared image embedding from another object group (aot_engine.py:606-607,612-616)
+            feats = [(to_tokens(e), e.shape[2], e.shape[3]) for e in img_embs]
+            x0, h, w = feats[3]
+            cat = torch.empty(h * w, (L + 1) * emb, dtype=torch.float32, device=dev)
+            cat[:, :emb].copy_(x0)
+            feats[3] = (cat[:, :emb], h, w)
+        self._feats, self._cat = feats, cat
+        return feats
+
+    def assign_identity(self, mask):
+        """mask [1,1,H,W] label ids -> id embedding [N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
+        if mask.dim() == 4 and mask.shape[1] != 1:
+            raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
+        return self.AOT.id_emb_from_mask(mask, self.enc_size_2d)
+
+    def _append_bank(self, ks, vs):
+        N = ks[0].shape[0]
+        if self.bank_k is None:
+            cap = 8 * N
+            self.bank_k = [torch.empty(cap, k.shape[1], dtype=torch.float32, device=k.device) for k in ks]
+            self.bank_v = [torch.empty(cap, v.shape[1], dtype=torch.float32, device=v.device) for v in vs]
+            self.bank_len = 0
+        if self.bank_len + N > self.bank_k[0].shape[0]:
+            cap = 2 * self.bank_k[0].shape[0]
+            for lst in (self.bank_k, self.bank_v):
+                for i, old in enumerate(lst):
+                    new = torch.empty(cap, old.shape[1], dtype=torch.float32, device=old.device)
+                    new[:self.bank_len].copy_(old[:self.bank_len])
+                    lst[i] = new
+        for i, (k, v) in enumerate(zip(ks, vs)):
+            self.bank_k[i][self.bank_len:self.bank_len + N].copy_(k)
+            self.bank_v[i][self.bank_len:self.bank_len + N].copy_(v)
+        self.bank_len += N
+
+    # ---- reference surface ---------------------------------------------------------------------
+    def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
+        if self.obj_nums is None and obj_nums is None:
+            print('No objects for reference frame!')
+            exit()
+        elif obj_nums is not None:
+            self.obj_nums = obj_nums
+        if frame_step == -1:
+            frame_step = self.frame_step
+        if img is None and img_embs is None:
+            print('No image for reference frame!')
+            exit()
+        if mask is None:
+            print('No mask for reference frame!')
+            exit()
+        feats = self._encode(img, img_embs)
+        if self.input_size_2d is None:
+            self.update_size(img.size()[2:] if img is not None else mask.size()[2:], (feats[3][1], feats[3][2]))
+        if self.pos_emb is None:
+            self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(feats[3][0], feats[3][1], feats[3][2])).contiguous(
+                memory_format=torch.channels_last)).contiguous()
+        id_emb = self.assign_identity(mask)
+        self.curr_id_embs = id_emb
+        stream = aot_hip.stream_ptr()
+        C = feats[3][0].shape[1]
+        outs, mems = self.AOT.LSTT.run(self._cat[:, :C], None, None, id_emb, self.pos_emb, self.enc_size_2d,
+                                       self.AOT.ws, stream, self._cat)
+        self._curr = [(m[0], m[1]) for m in mems]
+        self._append_bank([m[2][0] for m in mems], [m[2][1] for m in mems])
+        self.last_mem_step = self.frame_step
+        st = [(m[3][0], m[3][1]) for m in mems]
+        self.short_term_memories_list = [st]
+        self.short_term_memories = st
+
+    def match_propogate_one_frame(self, img=None, img_embs=None):
+        self.frame_step += 1
+        feats = self._encode(img, img_embs)
+        stream = aot_hip.stream_ptr()
+        C = feats[3][0].shape[1]
+        lm = list(zip(self.bank_k, self.bank_v))
+        outs, mems = self.AOT.LSTT.run(self._cat[:, :C], lm, self.short_term_memories, None, self.pos_emb,
+                                       self.enc_size_2d, self.AOT.ws, stream, self._cat, t_long=self.bank_len)
+        self._curr = [(m[0], m[1]) for m in mems]
+
+    def decode_current_logits(self, output_size=None):
+        stream = aot_hip.stream_ptr()
+        f4, f8, f16, _ = self._feats
+        dec = self.AOT.decoder
+        C = self._feats[3][0].shape[1]
+        x_in = self._cat if dec.decode_intermediate_input else self._cat[:, -C:]
+        logits, h4, w4 = dec.run(x_in, f16, f8, f4, self.AOT.ws, stream)
+        nc = logits.shape[1]
+        dev = logits.device
+        obj_num = int(self.obj_nums[0])
+        out4 = torch.empty(1, nc, h4, w4, dtype=torch.float32, device=dev)
+        out = None
+        if output_size is not None:
+            oh, ow = int(output_size[0]), int(output_size[1])
+            out = torch.empty(1, nc, oh, ow, dtype=torch.float32, device=dev)
+            aot_hip.logits_finalize(logits, out4, out, h4, w4, nc, oh, ow, obj_num, self.align_corners, stream=stream)
+        else:
+            aot_hip.logits_finalize(logits, out4, None, h4, w4, nc, 0, 0, obj_num, self.align_corners, stream=stream)
+        self.pred_id_logits = out4
+        return out if out is not None else out4
+
+    def update_long_term_memory(self, new_long_term_memories):
+        """Reference signature (aot_engine.py:291-305): list over layers of [K, V] ([N,1,C]); appended."""
+        self._append_bank([to_tokens(m[0]) for m in new_long_term_memories],
+                          [to_tokens(m[1]) for m in new_long_term_memories])
+
+    def update_short_term_memory(self, curr_mask, curr_id_emb=None, skip_long_term_update=False):
+        if curr_id_emb is None:
+            curr_id_emb = self.assign_identity(curr_mask)
+        else:
+            curr_id_emb = to_tokens(curr_id_emb)
+        self.curr_id_embs = curr_id_emb
+        stream = aot_hip.stream_ptr()
+        fused = []
+        for i, (ck, cv) in enumerate(self._curr):
+            v = self.AOT.LSTT.layers[i].fuse_kv_2d(cv, curr_id_emb, self.AOT.ws, stream)
+            fused.append((ck, v))
+        self._curr = fused
+        self.short_term_memories_list.append(fused)
+        self.short_term_memories_list = self.short_term_memories_list[-self.short_term_mem_skip:]
+        self.short_term_memories = self.short_term_memories_list[0]
+        if self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            if not skip_long_term_update:
+                self._append_bank([f[0] for f in fused], [f[1] for f in fused])
+            self.last_mem_step = self.frame_step
+
+    def predict_current_mask(self, output_size=None, return_prob=False):
+        if output_size is None:
+            output_size = self.input_size_2d
+        logits = F.interpolate(self.pred_id_logits, size=output_size, mode='bilinear', align_corners=self.align_corners)
+        pred_mask = torch.argmax(logits, dim=1)
+        if not return_prob:
+            return pred_mask
+        return pred_mask, torch.softmax(logits, dim=1)
+
+
+class AOTInferEngine(nn.Module):
+    """Caller-facing engine (reference aot_engine.py:485-635): one AOTEngine per group of max_aot_obj_num
+    objects, created lazily; the image embedding is computed once per frame and shared."""
+
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None):
+        super().__init__()
+        self.cfg = aot_model.cfg
+        self.AOT = aot_model
+        if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
+            self.max_aot_obj_num = aot_model.max_obj_num
+        else:
+            self.max_aot_obj_num = max_aot_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.short_term_mem_skip = short_term_mem_skip
+        self.aot_engines = []
+        self.restart_engine()
+
+    def restart_engine(self):
+        del (self.aot_engines)
+        self.aot_engines = []
+        self.obj_nums = None
+
+    def separate_mask(self, mask, obj_nums):
+        if mask is None:
+            return [None] * len(self.aot_engines)
+        if len(self.aot_engines) == 1:
+            return [mask], [obj_nums]
+        separated_obj_nums = [self.max_aot_obj_num for _ in range(len(self.aot_engines))]
+        if obj_nums % self.max_aot_obj_num > 0:
+            separated_obj_nums[-1] = obj_nums % self.max_aot_obj_num
+        if len(mask.size()) == 3 or mask.size()[0] == 1:
+            separated_masks = []
+            for idx in range(len(self.aot_engines)):
+                start_id = idx * self.max_aot_obj_num + 1
+                end_id = (idx + 1) * self.max_aot_obj_num
+                fg_mask = ((mask >= start_id) & (mask <= end_id)).float()
+                separated_masks.append((fg_mask * mask - start_id + 1) * fg_mask)
+            return separated_masks, separated_obj_nums
+        raise NotImplementedError('probability-map masks (aot_engine.py:536-545) are not on the scoped path')
+
+    def soft_logit_aggregation(self, all_logits):
+        """aot_engine.py:565-582.  Identity for <=10 objects (the scoped configs); the multi-group merge is
+        host-side torch plumbing for now."""
+        if len(all_logits) == 1:
+            return all_logits[0]
+        fg_probs, bg_probs = [], []
+        for logit in all_logits:
+            prob = torch.softmax(logit, dim=1)
+            bg_probs.append(prob[:, 0:1])
+            fg_probs.append(prob[:, 1:1 + self.max_aot_obj_num])
+        bg_prob = torch.prod(torch.cat(bg_probs, dim=1), dim=1, keepdim=True)
+        merged_prob = torch.cat([bg_prob] + fg_probs, dim=1).clamp(1e-5, 1 - 1e-5)
+        return torch.logit(merged_prob)
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
+        if isinstance(obj_nums, list):
+            obj_nums = obj_nums[0]
+        self.obj_nums = obj_nums
+        aot_num = max(np.ceil(obj_nums / self.max_aot_obj_num), 1)
+        while aot_num > len(self.aot_engines):
+            new_engine = AOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
+            new_engine.eval()
+            self.aot_engines.append(new_engine)
+        separated_masks, separated_obj_nums = self.separate_mask(mask, obj_nums)
+        img_embs = None
+        for aot_engine, separated_mask, separated_obj_num in zip(self.aot_engines, separated_masks,
+                                                                 separated_obj_nums):
+            aot_engine.add_reference_frame(img, separated_mask, obj_nums=[separated_obj_num], frame_step=frame_step,
+                                           img_embs=img_embs)
+            if img_embs is None:
+                img_embs = aot_engine.curr_enc_embs
+        self.update_size()
+
+    def match_propogate_one_frame(self, img=None):
+        img_embs = None
+        for aot_engine in self.aot_engines:
+            aot_engine.match_propogate_one_frame(img, img_embs=img_embs)
+            if img_embs is None:
+                img_embs = aot_engine.curr_enc_embs
+
+    def decode_current_logits(self, output_size=None):
+        all_logits = [e.decode_current_logits(output_size) for e in self.aot_engines]
+        return self.soft_logit_aggregation(all_logits)
+
+    def update_memory(self, curr_mask, skip_long_term_update=False):
+        separated_masks, _ = self.separate_mask(curr_mask, self.obj_nums)
+        for aot_engine, separated_mask in zip(self.aot_engines, separated_masks):
+            aot_engine.update_short_term_memory(separated_mask, skip_long_term_update=skip_long_term_update)
+
+    def update_size(self):
+        self.input_size_2d = self.aot_engines[0].input_size_2d
+        self.enc_size_2d = self.aot_engines[0].enc_size_2d
+        self.enc_hw = self.aot_engines[0].enc_hw

@@ -1,0 +1,23 @@
+"""Persistent device scratch buffers.  Buffers are allocated once per (name, shape) and reused every
+frame, so the steady state makes no allocator calls for intermediates and all pointers are stable
+(a prerequisite for hipGraph capture of the frame)."""
+import torch
+
+
+class Workspace:
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name, shape, device, dtype=torch.float32):
+        key = (name, tuple(shape), dtype, str(device))
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = buf
+        return buf
+
+    def clear(self):
+        self._bufs.clear()
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self._bufs.values())

@@ -1,0 +1,210 @@
+"""AOT model (reference networks/models/aot.py:9-115): encoder + 1x1 projector + LSTT + identity bank +
+sine positional embedding + FPN decoder, with the reference's method surface and state_dict layout.
+
+Tensors crossing this API keep the reference's shapes ([1,C,h,w] maps, [N,1,C] sequences) but are views
+of token-major (= channels-last) device buffers; inside, everything is [h*w, C] and every stage is a
+hand-written gfx950 kernel (aot_hip).  There is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+import aot_hip
+from networks.decoders import build_decoder
+from networks.encoders import build_encoder
+from networks.layers.normalization import fold_conv_bn
+from networks.layers.position import PositionEmbeddingSine
+from networks.layers.transformer import LongShortTermTransformer
+from networks.layers.workspace import Workspace
+
+
+def to_tokens(t):
+    """[1,C,h,w] or [N,1,C] (reference shapes) -> token-major [N, C] with row stride ld >= C.
+    Zero-copy when the memory already is channels-last / token-major (every tensor this package hands
+    out is); a foreign NCHW-contiguous tensor is transposed once."""
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        assert n == 1, 'the inference path is batch 1 per object group (aot_engine.py:445-447)'
+        if t.stride(1) == 1 and t.stride(2) == w * t.stride(3) and t.stride(3) % 4 == 0:
+            return torch.as_strided(t, (h * w, c), (t.stride(3), 1), t.storage_offset())
+        return t.permute(0, 2, 3, 1).contiguous().view(h * w, c)
+    if t.dim() == 3:
+        n, b, c = t.shape
+        assert b == 1
+        if t.stride(2) == 1 and t.stride(0) % 4 == 0:
+            return t[:, 0, :]
+        return t.reshape(n, c).contiguous()
+    return t
+
+
+def as_map(tok, h, w):
+    """token-major [h*w, C] (row stride ld) -> [1,C,h,w] view (channels-last strides)."""
+    ld = tok.stride(0)
+    return torch.as_strided(tok, (1, tok.shape[1], h, w), (h * w * ld, 1, w * ld, ld), tok.storage_offset())
+
+
+class AOT(nn.Module):
+    def __init__(self, cfg, encoder='mobilenetv2', decoder='fpn'):
+        super().__init__()
+        self.cfg = cfg
+        self.max_obj_num = cfg.MODEL_MAX_OBJ_NUM
+        self.epsilon = cfg.MODEL_EPSILON
+        emb = cfg.MODEL_ENCODER_EMBEDDING_DIM
+        self.encoder = build_encoder(encoder, frozen_bn=cfg.MODEL_FREEZE_BN, freeze_at=cfg.TRAIN_ENCODER_FREEZE_AT)
+        self.encoder_projector = nn.Conv2d(cfg.MODEL_ENCODER_DIM[-1], emb, kernel_size=1)
+        self.LSTT = LongShortTermTransformer(
+            cfg.MODEL_LSTT_NUM, emb, cfg.MODEL_SELF_HEADS, cfg.MODEL_ATT_HEADS,
+            emb_dropout=cfg.TRAIN_LSTT_EMB_DROPOUT, droppath=cfg.TRAIN_LSTT_DROPPATH,
+            lt_dropout=cfg.TRAIN_LSTT_LT_DROPOUT, st_dropout=cfg.TRAIN_LSTT_ST_DROPOUT,
+            droppath_lst=cfg.TRAIN_LSTT_DROPPATH_LST, droppath_scaling=cfg.TRAIN_LSTT_DROPPATH_SCALING,
+            intermediate_norm=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, return_intermediate=True)
+        decoder_indim = emb * (cfg.MODEL_LSTT_NUM + 1) if cfg.MODEL_DECODER_INTERMEDIATE_LSTT else emb
+        self.decoder = build_decoder(decoder, in_dim=decoder_indim, out_dim=cfg.MODEL_MAX_OBJ_NUM + 1,
+                                     decode_intermediate_input=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, hidden_dim=emb,
+                                     shortcut_dims=cfg.MODEL_ENCODER_DIM, align_corners=cfg.MODEL_ALIGN_CORNERS)
+        if cfg.MODEL_ALIGN_CORNERS:
+            self.patch_wise_id_bank = nn.Conv2d(cfg.MODEL_MAX_OBJ_NUM + 1, emb, kernel_size=17, stride=16, padding=8)
+        else:
+            self.patch_wise_id_bank = nn.Conv2d(cfg.MODEL_MAX_OBJ_NUM + 1, emb, kernel_size=16, stride=16, padding=0)
+        self.pos_generator = PositionEmbeddingSine(emb // 2, normalize=True)
+        self.ws = Workspace()
+        self._packed = None
+
+    # ---- packing: kernel-layout copies of the parameters, built once ---------------------------
+    def pack(self):
+        if self._packed is None:
+            if not next(self.parameters()).is_cuda:
+                raise aot_hip.AotHipError('AOT must be moved to a ROCm device before inference (no CPU fallback)')
+            aot_hip.load()
+            idw = self.patch_wise_id_bank.weight.detach().float()            # [C, L, K, K]
+            self._packed = {
+                'proj': fold_conv_bn(self.encoder_projector),
+                'id_table': idw.permute(1, 2, 3, 0).contiguous(),            # [L, K, K, C]
+                'id_bias': self.patch_wise_id_bank.bias.detach().float().contiguous(),
+            }
+            for layer in self.LSTT.layers:
+                layer.pack()
+            self.decoder.pack()
+        return self._packed
+
+    def invalidate(self):
+        """Drop packed weights (call after changing parameters)."""
+        self._packed = None
+        for m in self.modules():
+            for attr in ('_p', '_stem', '_last'):
+                if hasattr(m, attr):
+                    setattr(m, attr, None)
+            if hasattr(m, '_packed') and m is not self:
+                m._packed = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        self.ws.clear()
+        return r
+
+    # ---- token-major internals -----------------------------------------------------------------
+    def encode_tokens(self, img, stream=None, out_cat=None):
+        """img [1,3,H,W] -> [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major.
+        If out_cat is given the projected feature is written into its first C columns."""
+        p = self.pack()
+        stream = stream if stream is not None else aot_hip.stream_ptr()
+        feats = self.encoder.run(img.float().contiguous(), self.ws, stream)
+        if len(feats) == 4:          # mobilenetv2: 4 stages; stage 3 (96 ch) is the 16x shortcut, stage 4 (1280 ch) feeds the projector
+            f4, f8, f16, top = feats
+        else:                        # resnet: stride-16 map is shortcut and projector input
+            f4, f8, f16 = feats
+            top = f16
+        x, h, w = top
+        emb = self.encoder_projector.out_channels
+        if out_cat is None:
+            out = torch.empty(h * w, emb, dtype=torch.float32, device=img.device)
+        else:
+            out = out_cat[:, :emb]
+        aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, stream=stream)
+        return [f4, f8, f16, (out, h, w)]
+
+    def id_emb_from_mask(self, mask, size_2d, stream=None):
+        """Fused one_hot_mask + patch_wise_id_bank (aot.py:76-79, utils/image.py:69-74): label map [1,1,H,W]
+        (float ids) -> id embedding [h*w, C]; the 18 MB one-hot tensor is never built."""
+        p = self.pack()
+        stream = stream if stream is not None else aot_hip.stream_ptr()
+        H, W = mask.shape[-2:]
+        h, w = size_2d
+        conv = self.patch_wise_id_bank
+        K, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        out = torch.empty(h * w, conv.out_channels, dtype=torch.float32, device=mask.device)
+        aot_hip.idbank(mask.float().contiguous(), p['id_table'], p['id_bias'], out, H, W, h, w, K, s, pd,
+                       conv.out_channels, self.max_obj_num + 1, stream=stream)
+        return out
+
+    # ---- reference method surface (aot.py:72-108) ------------------------------------------------
+    def get_pos_emb(self, x):
+        return self.pos_generator(x)
+
+    def get_id_emb(self, x):
+        """x: one-hot [1, max_obj+1, H, W] (reference signature).  Converted to a label map (all-zero columns ->
+        label -1, contributing nothing) and sent through the fused gather kernel."""
+        lab = x.argmax(1, keepdim=True).float()
+        lab = torch.where(x.sum(1, keepdim=True) > 0, lab, torch.full_like(lab, -1.0))
+        H, W = x.shape[-2:]
+        conv = self.patch_wise_id_bank
+        h = (H + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+        w = (W + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+        return as_map(self.id_emb_from_mask(lab, (h, w)), h, w)
+
+    def encode_image(self, img):
+        f4, f8, f16, top = self.encode_tokens(img)
+        return [as_map(t.clone(), h, w) for (t, h, w) in (f4, f8, f16)] + [as_map(top[0], top[1], top[2])]
+
+    def decode_id_logits(self, lstt_emb, shortcuts):
+        stream = aot_hip.stream_ptr()
+        n, c, h, w = shortcuts[-1].shape
+        toks = [to_tokens(shortcuts[-1])] + [to_tokens(e) for e in lstt_emb]
+        cat = self._as_cat(toks)
+        sc = [(to_tokens(s), s.shape[2], s.shape[3]) for s in shortcuts[:3]]
+        x_in = cat if self.decoder.decode_intermediate_input else toks[-1]
+        logits, h4, w4 = self.decoder.run(x_in, sc[2], sc[1], sc[0], self.ws, stream)
+        out = torch.empty(1, logits.shape[1], h4, w4, dtype=torch.float32, device=logits.device)
+        aot_hip.nhwc_to_nchw(logits, out, logits.shape[1], h4, w4, stream=stream)
+        return out
+
+    def _as_cat(self, toks):
+        """Returns a [N, sum C] buffer holding the column-concatenation of ``toks``; zero-copy if they already
+        are adjacent column blocks of one buffer (which is how LSTT_forward lays them out)."""
+        base = toks[0]
+        ld = base.stride(0)
+        total = sum(t.shape[1] for t in toks)
+        ok = ld >= total
+        off = 0
+        for t in toks:
+            ok = ok and t.stride(0) == ld and t.data_ptr() == base.data_ptr() + 4 * off
+            off += t.shape[1]
+        if ok:
+            return torch.as_strided(base, (base.shape[0], total), (ld, 1), base.storage_offset())
+        return torch.cat(toks, 1)
+
+    def LSTT_forward(self, curr_embs, long_term_memories, short_term_memories, curr_id_emb=None, pos_emb=None,
+                     size_2d=(30, 30)):
+        stream = aot_hip.stream_ptr()
+        x = to_tokens(curr_embs[-1])
+        N, C = x.shape
+        L = self.LSTT.num_layers
+        cat = torch.empty(N, (L + 1) * C, dtype=torch.float32, device=x.device)
+        cat[:, :C].copy_(x)
+        pos = to_tokens(pos_emb) if pos_emb is not None else None
+        idt = to_tokens(curr_id_emb) if curr_id_emb is not None else None
+        lm = [(to_tokens(m[0]), to_tokens(m[1])) for m in long_term_memories] if long_term_memories is not None else None
+        sm = [(to_tokens(m[0]), to_tokens(m[1])) for m in short_term_memories] if short_term_memories is not None else None
+        outs, mems = self.LSTT.run(cat[:, :C], lm, sm, idt, pos, size_2d, self.ws, stream, cat)
+        h, w = size_2d
+        seq = lambda t: t.unsqueeze(1)
+        lstt_embs = [seq(o) for o in outs]
+        curr = [[seq(ck), seq(cv)] for (ck, cv, _, _) in mems]
+        long_ = [[seq(g[0][:g[2]]), seq(g[1][:g[2]])] for (_, _, g, _) in mems]
+        short = [[as_map(l[0], h, w), as_map(l[1], h, w)] for (_, _, _, l) in mems]
+        return lstt_embs, curr, long_, short

@@ -1,0 +1,134 @@
+/*
+ * aot_hip.h -- C ABI of libaot_hip.so, the MI355X (gfx950) kernels behind the
+ * AOT/DeAOT per-frame inference path of yoxu515/aot-benchmark.
+ *
+ * The reference has no FFI of its own (it is pure PyTorch); the entry points below
+ * are one call per fused stage of its hot path and each one names the reference code
+ * it replaces (paths relative to the reference repo).  Conventions:
+ *
+ *   - every pointer is DEVICE memory owned by the caller (16-byte aligned, fp32),
+ *     `stream` is a hipStream_t passed as void*;
+ *   - activations are NHWC / token-major:  [H*W, C] row-major with an explicit row
+ *     stride `ld*` in floats, so slices of wider buffers can be read and written in place;
+ *   - no allocation, no synchronisation, no host callbacks inside: every call is
+ *     asynchronous on `stream` and hipGraph-capturable; no global mutable state;
+ *   - return value: 0 on success, AOT_ERR_* (<0) on a rejected argument, or the positive
+ *     hipError_t of a failed launch.  Nothing throws.
+ */
+#ifndef AOT_HIP_H
+#define AOT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOT_OK 0
+#define AOT_ERR_BADARG (-1)
+#define AOT_ERR_UNSUPPORTED (-2)
+
+#define AOT_ACT_NONE 0
+#define AOT_ACT_RELU 1
+#define AOT_ACT_RELU6 2
+
+/* library identification: "aot_hip <version> gfx950" */
+const char* aot_hip_version(void);
+
+/* Implicit-GEMM convolution / linear layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *   out[m, n] = act( sum_k A[m, k] * w[k, n] + bias[n] + res[m, n] )
+ * with A the on-the-fly im2col of the NHWC input, k = (ky*KW + kx)*Cin + c.
+ * w is [KH*KW*Cin, ldb] row-major (ldb >= Cout, multiple of 4; FrozenBN already folded
+ * in by the host), bias/res may be NULL.  A linear layer is the 1x1 case with H=1, W=M.
+ * Requires Cin % 4 == 0 and lda % 4 == 0.
+ * Replaces: every nn.Conv2d + FrozenBatchNorm2d + ReLU of networks/encoders/resnet.py:34-54,
+ * 140-157 and mobilenetv2.py (1x1 / 3x3), encoder_projector (models/aot.py:19-21,81-84),
+ * the nn.Linear layers of networks/layers/transformer.py:321-359 and attention.py:76-79,119,
+ * and the FPN convs of networks/decoders/fpn.py:34-58. */
+int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res,
+                        float* out, int H, int W, int Cin, int OH, int OW, int Cout,
+                        int KH, int KW, int stride, int pad, int dil,
+                        int lda, int ldb, int ldc, int ldr, int act, void* stream);
+
+/* Depthwise KxK convolution, NHWC, w is [KH*KW, C], optional bias, fused activation.
+ * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)
+ * and the depthwise 3x3 of MobileNetV2 InvertedResidual (mobilenetv2.py:93-98). */
+int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                          int H, int W, int C, int OH, int OW, int KH, int KW,
+                          int stride, int pad, int dil, int act, void* stream);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC (resnet.py:79,144). */
+int aot_maxpool3x3s2_nhwc_f32(const float* in, float* out, int H, int W, int C, int OH, int OW,
+                              void* stream);
+
+/* [C,H,W] planar image -> [H*W, Cpad] interleaved, channels >= C zero filled (input layout
+ * change in front of the stem conv; the reference keeps NCHW throughout). */
+int aot_nchw_to_nhwc_f32(const float* in, float* out, int C, int H, int W, int Cpad, void* stream);
+/* [H*W, C] (row stride ld) -> [C,H,W] planar. */
+int aot_nhwc_to_nchw_f32(const float* in, float* out, int C, int H, int W, int ld, void* stream);
+
+/* LayerNorm over the last dim (eps inside sqrt, biased variance, as torch):
+ *   y = LN(x)*gamma + beta ;  if (add && y2)  y2 = y + add   (positional embedding, transformer.py:322)
+ * Replaces nn.LayerNorm in transformer.py:321,329,355 and LSTT.decoder_norms (:124-135). */
+int aot_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                      const float* add, float* y2, int M, int C, int ldx, int ldy, int ldadd,
+                      int ldy2, float eps, void* stream);
+
+/* GroupNorm over [M, C] (NHWC, batch 1) in two launches: stats (deterministic two-level
+ * fp64 reduction into `stats` = [G][2] doubles mean, rstd) then apply with fused activation
+ * (0 none, 1 relu, 3 exact-erf GELU).  `scratch` must hold G*nsplit*2 doubles.
+ * Replaces nn.GroupNorm in GNActDWConv2d (basic.py:18,31-32) and ConvGN (basic.py:82-85) +
+ * F.relu_ (fpn.py:41-56). */
+int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, int M, int C, int G,
+                            int ldx, float eps, int nsplit, void* stream);
+int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma,
+                            const float* beta, float* y, int M, int C, int G, int ldx, int ldy,
+                            int act, void* stream);
+
+/* Multi-head softmax attention over a key/value bank, flash style (no S materialised):
+ *   out[n, h*d:(h+1)*d] = softmax_t( (q[n,h]/scale_div) . k[t,h] ) @ v[t,h]          (d == 32)
+ * q [Nq, ldq], k/v [T, ldk/ldv], out [Nq, ldo]; H heads of width 32.  `T_dev` (optional) is a
+ * device int overriding T so a captured graph can follow a growing bank.  nsplit > 1 splits the
+ * bank over blocks; `part` must then hold nsplit*Nq*(H*32 + 2*H) floats and a second launch
+ * merges the partial (O, m, l).  Exact fp32: QK^T and PV on v_mfma_f32_32x32x2_f32.
+ * Replaces MultiheadAttention.forward's core, networks/layers/attention.py:82-117 (long-term
+ * attention over the memory bank and self-attention). */
+int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
+                 int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo,
+                 float scale_div, int nsplit, void* stream);
+
+/* Short-term (windowed) attention of AOT, fused: window dot products, relative-position key
+ * bias (grouped 1x1 conv on the UNSCALED q), border masking, softmax over the (2*max_dis+1)^2
+ * window, aggregation of v plus relative_emb_v.  q,k,v,out are token-major [h*w, ld*] with H
+ * heads of width 32.  relk_w [H*W2, 32], relk_b [H*W2], relv_t [H, W2, 32] (transposed
+ * relative_emb_v).  Replaces MultiheadLocalAttentionV2.forward + local2global + pad_and_unfold
+ * (attention.py:308-428) i.e. what spatial_correlation_sampler computes, minus `projection`. */
+int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_w,
+                       const float* relk_b, const float* relv_t, float* out, int h, int w, int H,
+                       int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
+                       void* stream);
+
+/* Identity-bank embedding of a label map: out[(Y,X), c] = bias[c] + sum_{ky,kx} table[label(16Y+ky-pad,
+ * 16X+kx-pad), ky, kx, c] over in-image taps; labels outside [0, nlabel) or non-integer add nothing.
+ * mask is [H,W] float label ids, table [nlabel, K, K, C].  Replaces one_hot_mask (utils/image.py:69-74)
+ * + patch_wise_id_bank conv (models/aot.py:50-63,76-79). */
+int aot_idbank_f32(const float* mask, const float* table, const float* bias, float* out,
+                   int H, int W, int OH, int OW, int K, int stride, int pad, int C, int nlabel,
+                   int ldo, void* stream);
+
+/* Bilinear resize NHWC with torch's fp32 source-index arithmetic; out = resize(in) (+ add).
+ * Replaces F.interpolate(mode='bilinear') in fpn.py:44-55. */
+int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int IH, int IW, int OH,
+                          int OW, int C, int ldi, int ldadd, int ldo, int align_corners, void* stream);
+
+/* Logit finalisation: channels > obj_num of the stride-4 NHWC logits are set to -1e10, the masked
+ * map is written planar to out4 [C,IH,IW] (may be NULL) and bilinearly resized to out [C,OH,OW].
+ * Replaces aot_engine.py:367-378. */
+int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int IH, int IW, int C,
+                            int ldi, int OH, int OW, int obj_num, int align_corners, void* stream);
+
+/* out = a + b over n floats (n % 4 == 0) -- V + id_emb in fuse_key_value_id (transformer.py:364-367). */
+int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOT_HIP_H */
