@@ -28,6 +28,7 @@ _SIGS = {
     'aot_groupnorm_stats_f32': [_P] * 3 + [_I] * 4 + [_F, _I, _P],
     'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
     'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
+    'aot_attn_merge_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
     'aot_idbank_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
@@ -146,10 +147,21 @@ def groupnorm(x, gamma, beta, out, groups, scratch, stats, act=ACT_NONE, eps=1e-
     return out
 
 
+attn_probe = None   # optional callable(phase, nq, t, heads) -> None; bench.py uses it to bracket the MFMA kernel with events
+
+
 def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, stream=None):
-    _chk(load().aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev), H, 32,
-                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div, nsplit,
-                             stream if stream is not None else stream_ptr()), 'aot_attn_f32')
+    s = stream if stream is not None else stream_ptr()
+    lib = load()
+    if attn_probe is not None:
+        attn_probe(0, q.shape[0], T, H)
+    _chk(lib.aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev), H, 32,
+                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div, nsplit, s), 'aot_attn_f32')
+    if attn_probe is not None:
+        attn_probe(1, q.shape[0], T, H)
+    if nsplit > 1:
+        _chk(lib.aot_attn_merge_f32(_dev(part), _dev(out), q.shape[0], H, 32, out.stride(0), nsplit, s),
+             'aot_attn_merge_f32')
     return out
 
 

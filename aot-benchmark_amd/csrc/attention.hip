@@ -180,24 +180,37 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
       make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
-extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
-                            int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv,
-                            int ldo, float scale_div, int nsplit, void* stream) {
+static int fill_params(AttnParams& p, const float* q, const float* k, const float* v, float* out, float* part, int Nq,
+                       int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div,
+                       int nsplit) {
   if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0) return AOT_ERR_BADARG;
   if (d != 32) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)out & 15))
     return AOT_ERR_BADARG;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1) return AOT_ERR_BADARG;
   if (nsplit > 1 && !part) return AOT_ERR_BADARG;
-  AttnParams p;
   p.q = q; p.k = k; p.v = v; p.out = out; p.part = part; p.T_dev = T_dev;
   p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.nsplit = nsplit;
   p.scale_div = scale_div;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_fwd_d32_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, s, p);
-  if (nsplit > 1) {
-    const long total = (long)Nq * (H * 32 / 4);
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
-  }
+  return AOT_OK;
+}
+
+extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int Nq, int T,
+                            const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div,
+                            int nsplit, void* stream) {
+  AttnParams p;
+  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, d, ldq, ldk, ldv, ldo, scale_div, nsplit);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_fwd_d32_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_attn_merge_f32(const float* part, float* out, int Nq, int H, int d, int ldo, int nsplit, void* stream) {
+  if (!part || !out || Nq <= 0 || H <= 0 || nsplit < 2 || (ldo & 3)) return AOT_ERR_BADARG;
+  if (d != 32) return AOT_ERR_UNSUPPORTED;
+  AttnParams p = {};
+  p.part = const_cast<float*>(part); p.out = out; p.Nq = Nq; p.H = H; p.ldo = ldo; p.nsplit = nsplit;
+  const long total = (long)Nq * (H * 32 / 4);
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

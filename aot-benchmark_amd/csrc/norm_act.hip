@@ -302,7 +302,7 @@ __device__ __forceinline__ void bilinear_coord(int dst, int in_size, int out_siz
   float src;
   if (align) src = scale * (float)dst;
   else {
-    src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = fmaf(scale, (float)dst + 0.5f, -0.5f);   // torch (CPU AVX2 and CUDA builds) contracts this into one FMA
     if (src < 0.f) src = 0.f;
   }
   i0 = min((int)floorf(src), in_size - 1);

@@ -87,13 +87,16 @@ int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* ga
  *   out[n, h*d:(h+1)*d] = softmax_t( (q[n,h]/scale_div) . k[t,h] ) @ v[t,h]          (d == 32)
  * q [Nq, ldq], k/v [T, ldk/ldv], out [Nq, ldo]; H heads of width 32.  `T_dev` (optional) is a
  * device int overriding T so a captured graph can follow a growing bank.  nsplit > 1 splits the
- * bank over blocks; `part` must then hold nsplit*Nq*(H*32 + 2*H) floats and a second launch
- * merges the partial (O, m, l).  Exact fp32: QK^T and PV on v_mfma_f32_32x32x2_f32.
+ * bank over workgroups; `part` must then hold nsplit*Nq*(H*32 + 2*H) floats, receives the un-normalised
+ * partial (O, m, l) of every split, and aot_attn_merge_f32 must follow on the same stream to produce
+ * `out`.  Exact fp32: QK^T and PV on v_mfma_f32_32x32x2_f32.
  * Replaces MultiheadAttention.forward's core, networks/layers/attention.py:82-117 (long-term
  * attention over the memory bank and self-attention). */
 int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
                  int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo,
                  float scale_div, int nsplit, void* stream);
+/* Merge of the nsplit partials written by aot_attn_f32(nsplit > 1) into out [Nq, ldo]. */
+int aot_attn_merge_f32(const float* part, float* out, int Nq, int H, int d, int ldo, int nsplit, void* stream);
 
 /* Short-term (windowed) attention of AOT, fused: window dot products, relative-position key
  * bias (grouped 1x1 conv on the UNSCALED q), border masking, softmax over the (2*max_dis+1)^2

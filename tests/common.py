@@ -1,0 +1,82 @@
+"""Shared helpers for the parity tests."""
+import importlib
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+LOGIT_TOL = 1e-3          # BASELINE.json north_star: pre-softmax logits within 1e-3 of the reference
+TIE_GAP = 2e-4            # reference pixels whose top-2 logit gap is below this are argmax near-ties
+
+
+def cases():
+    with open(os.path.join(GOLD, 'cases.json')) as f:
+        return json.load(f)
+
+
+def load_case(name):
+    c = cases()[name]
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    return c, g
+
+
+def model_cfg(name):
+    return importlib.import_module('configs.models.' + name).ModelConfig()
+
+
+def synth_model_state(name):
+    """Keyed synthetic weights for model `name`, built from THIS package's parameter tree (whose keys and
+    shapes are tested against the reference's in test_state_dict_layout)."""
+    from networks.models import build_vos_model
+    from utils.synth import synth_state_dict
+    cfg = model_cfg(name)
+    model = build_vos_model(cfg.MODEL_VOS, cfg)
+    sd = synth_state_dict(model.state_dict())
+    model.load_state_dict(sd)
+    return cfg, model, sd
+
+
+def case_clip(c, device='cpu'):
+    from utils.synth import synth_clip
+    return synth_clip(c['clip'], c['frames'], tuple(c['in_size']), tuple(c['out_size']), c['num_obj'], device=device)
+
+
+def unpack_gapmask(g, t, shape):
+    bits = np.unpackbits(g['gapmask_%d' % t])[:shape[0] * shape[1]]
+    return bits.reshape(shape).astype(bool)
+
+
+def check_masks(pred, g, t, what):
+    """argmax mask ids must equal the reference's except on the reference's own near-tie pixels."""
+    ref = g['masks'][t - 1]
+    pred = np.asarray(pred)
+    bad = pred != ref
+    tie = unpack_gapmask(g, t, ref.shape)
+    hard = int((bad & ~tie).sum())
+    assert hard == 0, '%s frame %d: %d mask pixels differ outside near-ties (total diff %d)' % (what, t, hard, int(bad.sum()))
+    assert int(bad.sum()) <= max(8, int(tie.sum())), '%s frame %d: too many tie flips %d' % (what, t, int(bad.sum()))
+    return int(bad.sum())
+
+
+def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lambda x: x):
+    """demo loop (tools/demo.py:187-235) with the GOLDEN mask fed back into memory at every frame, so frame t is
+    compared on identical history.  Returns {t: (logits4 [no,h,w], mask uint8 [H,W])}."""
+    out = {}
+    engine.restart_engine()
+    with torch.no_grad():
+        engine.add_reference_frame(to_dev(frames[0]), to_dev(mask), objs, frame_step=0)
+        for t in range(1, len(frames)):
+            engine.match_propogate_one_frame(to_dev(frames[t]))
+            logit = engine.decode_current_logits(out_size)
+            lab = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True)
+            l4 = engine.pred_id_logits if hasattr(engine, 'pred_id_logits') else engine.aot_engines[0].pred_id_logits
+            out[t] = (l4[0].detach().float().cpu().numpy() if t in keep else None, lab[0, 0].to(torch.uint8).cpu().numpy())
+            fb = torch.from_numpy(g['masks'][t - 1].astype(np.float32)).view(1, 1, *out_size)
+            fb = F.interpolate(to_dev(fb), size=engine.input_size_2d, mode='nearest')
+            engine.update_memory(fb)
+    return out

@@ -1,0 +1,110 @@
+"""Host-side logic, state_dict layout, C-ABI surface.  No GPU."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from common import GOLD, ROOT, model_cfg
+
+
+def test_state_dict_layout_matches_reference():
+    """Keys, order and shapes of the parameter tree equal the reference's (recorded from /root/reference by
+    make_golden.py), so reference checkpoints load unchanged (utils/checkpoint.py:94-121)."""
+    from networks.models import build_vos_model
+    with open(os.path.join(GOLD, 'state_dict_keys.json')) as f:
+        ref = json.load(f)
+    for name, entries in ref.items():
+        cfg = model_cfg(name)
+        sd = build_vos_model(cfg.MODEL_VOS, cfg).state_dict()
+        assert [k for k, _ in entries] == list(sd.keys()), name
+        for k, shp in entries:
+            assert list(sd[k].shape) == shp, (name, k)
+
+
+def test_load_network_conventions(tmp_path):
+    from networks.models import build_vos_model
+    from utils.checkpoint import load_network
+    cfg = model_cfg('aott')
+    m = build_vos_model(cfg.MODEL_VOS, cfg)
+    sd = {('module.' + k): v + 1 for k, v in m.state_dict().items() if v.is_floating_point()}
+    sd['module.not_a_key'] = torch.zeros(1)
+    p = tmp_path / 'ck.pth'
+    torch.save({'state_dict': sd}, p)
+    m2, removed = load_network(build_vos_model(cfg.MODEL_VOS, cfg), str(p), -1)
+    assert removed == ['module.not_a_key']
+    k = 'encoder_projector.bias'
+    assert torch.equal(m2.state_dict()[k], m.state_dict()[k] + 1)
+
+
+def test_cabi_exports_every_declared_symbol():
+    import aot_hip
+    hdr = open(os.path.join(ROOT, 'include', 'aot_hip.h')).read()
+    declared = set(re.findall(r'\b(aot_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert os.path.exists(aot_hip.LIB_PATH), 'libaot_hip.so not built (run __graft_entry__.build())'
+    lib = ctypes.CDLL(aot_hip.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), 'missing export ' + sym
+    assert set(aot_hip.exported_symbols()) == declared
+    lib.aot_hip_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.aot_hip_version()
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a ROCm device tensor -- never compute on the CPU."""
+    import aot_hip
+    from networks.engines import build_engine
+    from networks.models import build_vos_model
+    cfg = model_cfg('aott')
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0)
+    with pytest.raises(aot_hip.AotHipError):
+        eng.add_reference_frame(torch.zeros(1, 3, 33, 33), torch.zeros(1, 1, 33, 33), [1], frame_step=0)
+    with pytest.raises(aot_hip.AotHipError):
+        aot_hip.add(torch.zeros(4), torch.zeros(4), torch.zeros(4), stream=0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'aot-benchmark_amd')
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                assert not pat.search(open(os.path.join(d, f)).read()), os.path.join(d, f)
+
+
+def test_synth_is_deterministic_and_keyed():
+    from utils.synth import align_size, synth_clip, synth_state_dict
+    ref = {'a.weight': torch.zeros(8, 4, 3, 3), 'a.bias': torch.zeros(8), 'n.weight': torch.zeros(8),
+           'n.bias': torch.zeros(8), 'n.running_var': torch.zeros(8)}
+    s1, s2 = synth_state_dict(ref), synth_state_dict(dict(reversed(list(ref.items()))))
+    for k in ref:
+        assert torch.equal(s1[k], s2[k])
+    assert (s1['n.running_var'] >= 1).all()
+    assert align_size(480, 854, True) == (481, 849)        # video_transforms.py:640-648
+    assert align_size(480, 854, False) == (480, 848)
+    f1, m1, o1, _ = synth_clip(2, 2, (33, 49), (32, 48), 3)
+    f2, m2, _, _ = synth_clip(2, 2, (33, 49), (32, 48), 3)
+    assert torch.equal(f1[1], f2[1]) and torch.equal(m1, m2) and o1 == [3]
+    assert sorted(m1.unique().tolist()) == [0, 1, 2, 3]
+
+
+def test_attn_split_heuristic():
+    from networks.layers.attention import attn_splits
+    assert attn_splits(1674, 8, 1674) >= 2            # 424 waves alone cannot fill 1024 SIMDs
+    assert attn_splits(1674, 8, 64) == 1              # never split a tiny bank
+    assert 1 <= attn_splits(1674, 8, 1674 * 14) <= 16
+
+
+def test_engine_factories_and_errors():
+    from networks.engines import build_engine
+    from networks.models import build_vos_model
+    cfg = model_cfg('r50_aotl')
+    assert cfg.TEST_LONG_TERM_MEM_GAP == 5 and cfg.MODEL_LSTT_NUM == 3
+    with pytest.raises(NotImplementedError):
+        build_vos_model('nope', cfg)
+    with pytest.raises(NotImplementedError):
+        build_engine('aotengine', phase='train', aot_model=None)
