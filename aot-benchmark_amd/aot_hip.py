@@ -20,6 +20,7 @@ _L = ctypes.c_long
 
 _SIGS = {
     'aot_conv2d_nhwc_f32': [_P] * 5 + [_I] * 16 + [_P],
+    'aot_conv2d_nhwc_f32_cfg': [_P] * 5 + [_I] * 17 + [_P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 11 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
@@ -94,6 +95,15 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     stride, pad, dil, x.stride(0), w.stride(0), out.stride(0),
                                     res.stride(0) if res is not None else 0, act,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
+    return out
+
+
+def conv2d_cfg(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
+               cfg=-1, stream=None):
+    _chk(load().aot_conv2d_nhwc_f32_cfg(_dev(x), _dev(w), _opt(bias), _opt(res), _dev(out), H, W, Cin, OH, OW, Cout, KH,
+                                        KW, stride, pad, dil, x.stride(0), w.stride(0), out.stride(0),
+                                        res.stride(0) if res is not None else 0, act, cfg,
+                                        stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32_cfg')
     return out
 
 

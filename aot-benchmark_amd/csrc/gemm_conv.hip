@@ -27,9 +27,7 @@ struct ConvParams {
   int lda, ldb, ldc, ldr, M, K, act;
 };
 
-#define BK 16
-
-template <int BM, int BN, int WM, int WN, bool IS1X1>
+template <int BM, int BN, int WM, int WN, int BK, bool IS1X1>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 conv_gemm_kernel(const ConvParams p) {
   constexpr int NW_N = BN / WN;
@@ -39,7 +37,8 @@ conv_gemm_kernel(const ConvParams p) {
   constexpr int B_F4 = BK * BN / 4;
   constexpr int A_PER = (A_F4 + NT - 1) / NT;
   constexpr int B_PER = (B_F4 + NT - 1) / NT;
-  constexpr int LDA_S = BM + 2;
+  constexpr int KQ = BK / 4;                 // float4 per A row of a slab
+  constexpr int LDA_S = BM + (BK == 16 ? 2 : 1);   // keeps the transposed ds_write_b32 conflict-free
   constexpr int LDB_S = BN + 4;
 
   __shared__ float As[2][BK][LDA_S];
@@ -65,7 +64,7 @@ conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int f = tid + i * NT;
-    const int r = f >> 2, kq = f & 3;
+    const int r = f / KQ, kq = f % KQ;
     const int m = m0 + r;
     a_ok[i] = (f < A_F4) && (m < p.M);
     const int mm = a_ok[i] ? m : 0;
@@ -89,7 +88,7 @@ conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int f = tid + i * NT;
-      const int k = kt * BK + (f & 3) * 4;
+      const int k = kt * BK + (f % KQ) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (IS1X1) {
         if (a_ok[i] && k < p.K) v = *reinterpret_cast<const float4*>(p.in + a_base[i] + (long)kt * BK);
@@ -122,7 +121,7 @@ conv_gemm_kernel(const ConvParams p) {
     for (int i = 0; i < A_PER; ++i) {
       const int f = tid + i * NT;
       if (f < A_F4) {
-        const int r = f >> 2, kq = f & 3;
+        const int r = f / KQ, kq = f % KQ;
         As[buf][kq * 4 + 0][r] = a_reg[i].x;
         As[buf][kq * 4 + 1][r] = a_reg[i].y;
         As[buf][kq * 4 + 2][r] = a_reg[i].z;
@@ -191,21 +190,146 @@ conv_gemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+
+// ---------------------------------------------------------------------------------------------------------
+// Small-M GEMM / conv (the stride-16 maps: M = 1674 at 480p).  A 64x64-tiled launch has only ~100 workgroups
+// for 256 CUs and each walks K serially, so here every WAVE is independent: it owns a 32x32 output tile and
+// a contiguous K range, loads its MFMA operands straight from global/L2 into registers (A: 16 consecutive k of
+// its row as 4 x float4, the contraction index being enumerated as k = slab + 16*half + s for both operands;
+// B: one coalesced 128-byte row segment per k), and never touches a barrier in the main loop.  KS waves of a
+// workgroup split K; their accumulators meet in LDS once, are summed in fixed wave order (deterministic) and
+// each wave finishes 16/KS of the fragment rows with the bias/residual/activation epilogue.
+// Requires Cin % 32 == 0 (a 32-wide k slab never straddles a filter tap).
+// ---------------------------------------------------------------------------------------------------------
+template <int KS, bool IS1X1>
+__global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p) {
+  __shared__ float red[KS > 1 ? KS : 1][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int nbn = (p.Cout + 31) >> 5, nbm = (p.M + 31) >> 5;
+  const int nwg = nbm * nbn, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * 32, n0 = bn * 32;
+
+  const int nslab = p.K >> 5;
+  const int per = (nslab + KS - 1) / KS;
+  const int s0 = wave * per, s1 = min(nslab, s0 + per);
+
+  const int m = m0 + j;
+  const bool row_ok = m < p.M;
+  const int mm = row_ok ? m : 0;
+  const int oy = mm / p.OW, ox = mm - oy * p.OW;
+  long a_base = 0;
+  int iy0 = 0, ix0 = 0, c = 0, ky = 0, kx = 0;
+  if (IS1X1) {
+    a_base = ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kh * 16;
+  } else {
+    iy0 = oy * p.stride - p.pad;
+    ix0 = ox * p.stride - p.pad;
+    const int k = s0 * 32;
+    const int tap = k / p.Cin;
+    c = k - tap * p.Cin;
+    ky = tap / p.KW;
+    kx = tap - ky * p.KW;
+  }
+  const int n = n0 + j;
+  const bool col_ok = n < p.ldb;
+  const float* bcol = p.w + (col_ok ? n : 0);
+
+  float4 an[4];
+  float bn_[16];
+  auto load = [&](int s) {
+    const float* src = nullptr;
+    if (IS1X1) {
+      if (row_ok) src = p.in + a_base + (long)s * 32;
+    } else {
+      const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
+      if (row_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        src = p.in + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
+      c += 32;
+      if (c >= p.Cin) { c = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) an[i] = src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* bp = bcol + ((long)s * 32 + kh * 16) * p.ldb;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) bn_[t] = col_ok ? bp[(long)t * p.ldb] : 0.f;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (s0 < s1) load(s0);
+  for (int s = s0; s < s1; ++s) {
+    float a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[4 * i] = an[i].x; a[4 * i + 1] = an[i].y; a[4 * i + 2] = an[i].z; a[4 * i + 3] = an[i].w; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) b[t] = bn_[t];
+    if (s + 1 < s1) load(s + 1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+  }
+
+  constexpr int RPW = 16 / KS;   // fragment registers finished by each wave
+  float fin[RPW];
+  if (KS > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave * RPW + i;
+      float v = red[0][r][lane];
+#pragma unroll
+      for (int w = 1; w < KS; ++w) v += red[w][r][lane];
+      fin[i] = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) fin[i] = acc[i];
+  }
+  if (n < p.Cout) {
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = (KS > 1 ? wave * RPW : 0) + i;
+      const int mo = m0 + mfma32_row(r, kh);
+      if (mo < p.M) {
+        float v = fin[i] + bv;
+        if (p.res) v += p.res[(long)mo * p.ldr + n];
+        p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
+      }
+    }
+  }
+}
+
+template <int KS>
+static int launch_direct(const ConvParams& p, bool is1x1, hipStream_t s) {
+  const int nb = cdiv(p.M, 32) * cdiv(p.Cout, 32);
+  if (is1x1)
+    hipLaunchKernelGGL((gemm_direct_kernel<KS, true>), dim3(nb), dim3(KS * 64), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_direct_kernel<KS, false>), dim3(nb), dim3(KS * 64), 0, s, p);
+  AOT_LAUNCH_CHECK();
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
   const int nb = cdiv(p.M, BM) * cdiv(p.Cout, BN);
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   if (is1x1)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3(nb), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, true>), dim3(nb), dim3(NT), 0, s, p);
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3(nb), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, false>), dim3(nb), dim3(NT), 0, s, p);
   AOT_LAUNCH_CHECK();
 }
 
-extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res,
-                                   float* out, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
-                                   int KW, int stride, int pad, int dil, int lda, int ldb, int ldc,
-                                   int ldr, int act, void* stream) {
+static int conv_dispatch(const float* in, const float* w, const float* bias, const float* res, float* out, int H, int W,
+                         int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int lda,
+                         int ldb, int ldc, int ldr, int act, int cfg, void* stream) {
   if (!in || !w || !out) return AOT_ERR_BADARG;
   if (H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((Cin & 3) || (lda & 3) || (ldb & 3) || ldb < Cout || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
@@ -219,9 +343,49 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
   p.M = OH * OW; p.K = KH * KW * Cin; p.act = act;
   const bool is1x1 = (KH == 1 && KW == 1 && pad == 0);
   hipStream_t s = (hipStream_t)stream;
-  // tile choice: fill 256 CUs x 4 SIMDs; big maps take 128x128 (64x64 per wave), small ones 64x64
-  if (Cout <= 32) return launch_cfg<128, 32, 32, 32>(p, is1x1, s);
-  if (p.M >= 4096 && Cout >= 128) return launch_cfg<128, 128, 64, 64>(p, is1x1, s);
-  if (p.M >= 4096) return launch_cfg<128, 64, 64, 32>(p, is1x1, s);
-  return launch_cfg<64, 64, 32, 32>(p, is1x1, s);
+  const bool direct_ok = (Cin % 32 == 0) && (p.K % 32 == 0);
+  if (cfg < 0) {
+    // Heuristic (scratch/mb_gemm.py): LDS-tiled 64x64 when the grid alone gives >= 2 workgroups per CU,
+    // otherwise independent 32x32 waves with in-block split-K sized to ~2 waves per SIMD.
+    const long tiles64 = (long)cdiv(p.M, 64) * cdiv(Cout, 64);
+    if (Cout <= 32) cfg = 3;
+    else if (tiles64 >= 512 || !direct_ok) cfg = 4;
+    else {
+      const long tiles32 = (long)cdiv(p.M, 32) * cdiv(Cout, 32);
+      const int nslab = p.K / 32;
+      int ks = 1;
+      while (ks < 8 && tiles32 * ks < 2048 && nslab / (ks * 2) >= 2) ks *= 2;
+      cfg = 10 + ks;
+    }
+  }
+  if (cfg >= 10 && !direct_ok) return AOT_ERR_UNSUPPORTED;
+  switch (cfg) {
+    case 0: return launch_cfg<128, 128, 64, 64, 16>(p, is1x1, s);
+    case 1: return launch_cfg<128, 64, 64, 32, 16>(p, is1x1, s);
+    case 2: return launch_cfg<64, 64, 32, 32, 16>(p, is1x1, s);
+    case 3: return launch_cfg<128, 32, 32, 32, 16>(p, is1x1, s);
+    case 4: return launch_cfg<64, 64, 32, 32, 32>(p, is1x1, s);
+    case 5: return launch_cfg<128, 64, 64, 32, 32>(p, is1x1, s);
+    case 11: return launch_direct<1>(p, is1x1, s);
+    case 12: return launch_direct<2>(p, is1x1, s);
+    case 14: return launch_direct<4>(p, is1x1, s);
+    case 18: return launch_direct<8>(p, is1x1, s);
+    default: return AOT_ERR_BADARG;
+  }
+}
+
+extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out,
+                                   int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                                   int dil, int lda, int ldb, int ldc, int ldr, int act, void* stream) {
+  return conv_dispatch(in, w, bias, res, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, lda, ldb, ldc, ldr, act,
+                       -1, stream);
+}
+
+// Tuning entry: same as aot_conv2d_nhwc_f32 with an explicit tile configuration (cfg < 0 = heuristic).
+extern "C" int aot_conv2d_nhwc_f32_cfg(const float* in, const float* w, const float* bias, const float* res, float* out,
+                                       int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                                       int pad, int dil, int lda, int ldb, int ldc, int ldr, int act, int cfg,
+                                       void* stream) {
+  return conv_dispatch(in, w, bias, res, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, lda, ldb, ldc, ldr, act,
+                       cfg, stream);
 }

@@ -47,6 +47,12 @@ int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, cons
                         float* out, int H, int W, int Cin, int OH, int OW, int Cout,
                         int KH, int KW, int stride, int pad, int dil,
                         int lda, int ldb, int ldc, int ldr, int act, void* stream);
+/* Tuning/benchmark variant: explicit kernel configuration `cfg` (see csrc/gemm_conv.hip; cfg < 0 = the
+ * heuristic the plain entry uses).  Same results for every valid cfg. */
+int aot_conv2d_nhwc_f32_cfg(const float* in, const float* w, const float* bias, const float* res,
+                            float* out, int H, int W, int Cin, int OH, int OW, int Cout,
+                            int KH, int KW, int stride, int pad, int dil,
+                            int lda, int ldb, int ldc, int ldr, int act, int cfg, void* stream);
 
 /* Depthwise KxK convolution, NHWC, w is [KH*KW, C], optional bias, fused activation.
  * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)

@@ -1,0 +1,50 @@
+"""Per-shape microbenchmark of the implicit-GEMM conv for every conv/linear of the R50-AOTL 480p frame.
+usage: python scratch/mb_gemm.py [cfgs e.g. -1,0,1,2]"""
+import sys, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
+import torch, aot_hip
+aot_hip.load()
+cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
+# (name, H, W, Cin, Cout, K, stride, count per frame)
+S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
+     ('l1.c1 64>64', 121, 213, 64, 64, 1, 1, 1), ('l1.c1 256>64', 121, 213, 256, 64, 1, 1, 2),
+     ('l1.c2 3x3 64', 121, 213, 64, 64, 3, 1, 3), ('l1.c3 64>256', 121, 213, 64, 256, 1, 1, 4),
+     ('l2.c1 256>128@4x', 121, 213, 256, 128, 1, 1, 1), ('l2.c2 3x3s2 128', 121, 213, 128, 128, 3, 2, 1),
+     ('l2.c1 512>128', 61, 107, 512, 128, 1, 1, 3), ('l2.c2 3x3 128', 61, 107, 128, 128, 3, 1, 3),
+     ('l2.c3 128>512', 61, 107, 128, 512, 1, 1, 4), ('l2.ds 256>512 s2', 121, 213, 256, 512, 1, 2, 1),
+     ('l3.c1 512>256@8x', 61, 107, 512, 256, 1, 1, 1), ('l3.c2 3x3s2 256', 61, 107, 256, 256, 3, 2, 1),
+     ('l3.c1 1024>256', 31, 54, 1024, 256, 1, 1, 5 + 3), ('l3.c2 3x3 256', 31, 54, 256, 256, 3, 1, 5 + 1),
+     ('l3.c3 256>1024', 31, 54, 256, 1024, 1, 1, 6 + 3), ('l3.ds 512>1024 s2', 61, 107, 512, 1024, 1, 2, 1),
+     ('lstt 256>512', 31, 54, 256, 512, 1, 1, 3), ('lstt 256>256', 31, 54, 256, 256, 1, 1, 12),
+     ('lstt 512>256', 31, 54, 512, 256, 1, 1, 3), ('lstt 1024>256', 31, 54, 1024, 256, 1, 1, 0),
+     ('dec ad8 512>256', 61, 107, 512, 256, 1, 1, 1), ('dec c8 3x3 256>128', 61, 107, 256, 128, 3, 1, 1),
+     ('dec ad4 256>128', 121, 213, 256, 128, 1, 1, 1), ('dec c4 3x3 128', 121, 213, 128, 128, 3, 1, 1),
+     ('dec out 128>11', 121, 213, 128, 11, 1, 1, 1)]
+tot = {c: 0.0 for c in cfgs}; totf = 0.0
+print('%-20s %7s %5s %5s %8s | ' % ('shape', 'M', 'K', 'N', 'GF') + ' | '.join('cfg%2d us    TF' % c for c in cfgs))
+for (name, H, W, Cin, Cout, K, s, cnt) in S:
+    p = K // 2
+    OH, OW = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    M, KK = OH * OW, K * K * Cin
+    x = torch.randn(H * W, Cin, device='cuda'); ldb = (Cout + 3) // 4 * 4
+    w = torch.randn(KK, ldb, device='cuda') / KK ** 0.5; b = torch.randn(Cout, device='cuda')
+    out = torch.empty(M, ldb, device='cuda')
+    gf = 2.0 * M * KK * Cout / 1e9
+    row = []
+    for c in cfgs:
+        if (c == 3 and Cout > 32) or (c >= 10 and Cin % 32): row.append('      -      -'); continue
+        def run():
+            aot_hip.conv2d_cfg(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, cfg=c)
+        for _ in range(3): run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n): run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        tot[c] += us * cnt
+        row.append('%7.1f %6.1f' % (us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 if False else gf * 1e3 / us))
+    totf += gf * cnt
+    print('%-20s %7d %5d %5d %8.3f | ' % (name, M, KK, Cout, gf) + ' | '.join(row) + '   x%d' % cnt)
+print('per-frame total GF %.1f ; ' % totf + ' ; '.join('cfg%d: %.0f us (%.1f TF)' % (c, tot[c], totf * 1e3 / tot[c]) for c in cfgs))
