@@ -175,6 +175,19 @@ def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, st
     return out
 
 
+def pack_local_tables(relk_weight, relk_bias, relv, heads, max_dis=7):
+    """relative_emb_k.weight [H*W2, d(,1,1)], .bias [H*W2], relative_emb_v [H, d, W2] -> the scalar-load
+    layouts of aot_local_attn_f32: ([H,WS,d,16], [H,WS,16], [H,WS,d,16])."""
+    ws = 2 * max_dis + 1
+    d = relv.shape[1]
+    # key table pre-multiplied by sqrt(d): the kernel keeps only q/sqrt(d) in registers
+    wk = (relk_weight.detach().double().reshape(heads, ws, ws, d) * (float(d) ** 0.5)).float().permute(0, 1, 3, 2)  # [H, dy, c, dx]
+    rv = relv.detach().float().reshape(heads, d, ws, ws).permute(0, 2, 1, 3)            # [H, dy, c, dx]
+    bk = relk_bias.detach().float().reshape(heads, ws, ws)
+    pad = lambda t: torch.nn.functional.pad(t, (0, 16 - ws)).contiguous()
+    return pad(wk), pad(bk), pad(rv)
+
+
 def local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, H, scale_div, max_dis=7, stream=None):
     _chk(load().aot_local_attn_f32(_dev(q), _dev(k), _dev(v), _dev(relk_w), _dev(relk_b), _dev(relv_t), _dev(out), h, w, H,
                                    32, max_dis, q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div,

@@ -82,11 +82,8 @@ class MultiheadLocalAttention(nn.Module):
 
     def pack(self):
         if self._packed is None:
-            w2 = self.window_size * self.window_size
-            relk_w = self.relative_emb_k.weight.detach().float().reshape(self.num_head * w2, self.d_att).contiguous()
-            relk_b = self.relative_emb_k.bias.detach().float().contiguous()
-            relv_t = self.relative_emb_v.detach().float().permute(0, 2, 1).contiguous()   # [H, W2, d]
-            self._packed = (relk_w, relk_b, relv_t)
+            self._packed = aot_hip.pack_local_tables(self.relative_emb_k.weight, self.relative_emb_k.bias,
+                                                     self.relative_emb_v, self.num_head, self.max_dis)
         return self._packed
 
     def core(self, q, k, v, out, size_2d, stream):

@@ -107,10 +107,14 @@ int aot_attn_merge_f32(const float* part, float* out, int Nq, int H, int d, int 
 /* Short-term (windowed) attention of AOT, fused: window dot products, relative-position key
  * bias (grouped 1x1 conv on the UNSCALED q), border masking, softmax over the (2*max_dis+1)^2
  * window, aggregation of v plus relative_emb_v.  q,k,v,out are token-major [h*w, ld*] with H
- * heads of width 32.  relk_w [H*W2, 32], relk_b [H*W2], relv_t [H, W2, 32] (transposed
- * relative_emb_v).  Replaces MultiheadLocalAttentionV2.forward + local2global + pad_and_unfold
+ * heads of width 32.  The wave-uniform tables are laid out for 64-byte scalar loads, WS = 2*max_dis+1:
+ *   relk_t [H][WS][32][16]: relk_t[hd][dy][c][dx] = sqrt(d) * relative_emb_k.weight[hd*WS*WS + dy*WS + dx][c]
+ *                           (the kernel holds q/scale_div only; scale_div must equal sqrt(d))
+ *   relk_b [H][WS][16]    : relative_emb_k.bias[hd*WS*WS + dy*WS + dx]
+ *   relv_t [H][WS][32][16]: relative_emb_v[hd][c][dy*WS + dx]           (dx = 15 is padding)
+ * Replaces MultiheadLocalAttentionV2.forward + local2global + pad_and_unfold
  * (attention.py:308-428) i.e. what spatial_correlation_sampler computes, minus `projection`. */
-int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_w,
+int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_t,
                        const float* relk_b, const float* relv_t, float* out, int h, int w, int H,
                        int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
                        void* stream);

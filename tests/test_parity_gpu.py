@@ -281,9 +281,9 @@ def test_local_attention_vs_oracle(hip, h, w):
     to2d = lambda t: t.double().view(h, w, 1, C).permute(2, 3, 0, 1)
     ref = aot_local_attention({kk: vv.double() for kk, vv in sd.items()}, 'st', to2d(q), to2d(k), to2d(v), H)[:, 0].float()
     out = torch.empty(N, C, device='cuda')
-    hip.local_attention(_dev(q), _dev(k), _dev(v), _dev(sd['st.relative_emb_k.weight'].view(H * 225, 32)),
-                        _dev(sd['st.relative_emb_k.bias']), _dev(sd['st.relative_emb_v'].permute(0, 2, 1)), out, h, w, H,
-                        32 ** 0.5)
+    tk, tb, tv = hip.pack_local_tables(sd['st.relative_emb_k.weight'], sd['st.relative_emb_k.bias'],
+                                       sd['st.relative_emb_v'], H)
+    hip.local_attention(_dev(q), _dev(k), _dev(v), _dev(tk), _dev(tb), _dev(tv), out, h, w, H, 32 ** 0.5)
     _close(out, ref, 2e-5, 'local attention')
 
 
