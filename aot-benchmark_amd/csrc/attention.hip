@@ -31,6 +31,22 @@ struct AttnParams {
   float scale_div;
 };
 
+// exp(x) = 2^(x*log2(e)) on the hardware v_exp_f32, with the product carried in two floats so the result is
+// good to ~1.5e-7 relative (the accurate libm expf costs ~20 VALU instructions, 17 of them per key tile were
+// as expensive as the tile's 32 MFMAs).  x <= 0 here; anything below -150 (incl. -inf) gives exactly 0.
+__device__ __forceinline__ float exp_fast(float x) {
+#ifdef EXP_REF
+  return expf(x);
+#endif
+  x = fmaxf(x, -150.f);              // keeps -inf out of the residual (inf - inf); 2^-216 flushes to 0
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);      // exact rounding error of the product
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e * 0.693147182464599609375f, r, e);   // e * 2^r ~ e * (1 + r ln2)
+}
+
 __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
   const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
@@ -55,74 +71,84 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
     }
   }
 
+  // V through a buffer descriptor: the per-lane byte offset is loop invariant, the tile/row part is a wave-uniform
+  // scalar offset (SALU), and rows >= T read as 0 by the hardware bounds check -- no address VALU, no clamping.
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
+  const int ldv4 = p.ldv * 4;
+
   float m = -INFINITY, l = 0.f;
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
 
-  const float* kbase = p.k + h * 32 + hi * 16;
-  const float* vbase = p.v + h * 32 + j;
-
-  float4 kf[4];
-  float vf[16];
-  auto load_kv = [&](int kt) {
-    const int krow = min(kt + j, T - 1);
-    const float4* ks = reinterpret_cast<const float4*>(kbase + (long)krow * p.ldk);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kf[i] = ks[i];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int vrow = min(kt + mfma32_row(s, hi), T - 1);
-      vf[s] = vbase[(long)vrow * p.ldv];
-    }
-  };
-
-  if (t0 < t1) load_kv(t0);
-  for (int kt = t0; kt < t1; kt += 32) {
-    // ---- S^T = K . Q^T ----
-    float ka[16];
+  // (K uses plain 16-byte global loads: the raw_buffer_load_b64/b96/b128 builtins of ROCm 7.2's hipcc lower to a
+  //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable.)
+  const float* kptr = p.k + h * 32 + hi * 16;
+  auto load_k = [&](float (&kf)[16], int kt) {
+    const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ka[4 * i + 0] = kf[i].x; ka[4 * i + 1] = kf[i].y; ka[4 * i + 2] = kf[i].z; ka[4 * i + 3] = kf[i].w;
+      const float4 t = src[i];
+      kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
     }
-    float va[16];
+  };
+  auto load_v = [&](float (&vf)[16], int kt) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) va[s] = vf[s];
-    if (kt + 32 < t1) load_kv(kt + 32);  // prefetch next tile under this tile's MFMAs
+    for (int s = 0; s < 16; ++s)
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+  };
 
+  auto tile = [&](const float (&kf)[16], const float (&vf)[16], int kt) {
+    // ---- S^T = K . Q^T ----
     f32x16 sc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qf[s], sc, 0, 0, 0);
-
+    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
     // ---- online softmax over the 32 keys of this tile (per query = per lane column) ----
     if (kt + 32 > t1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
     }
-    float mt = sc[0];
+    float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sc[r]);
+    for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float mnew = fmaxf(m, mt);
-    const float alpha = expf(m - mnew);  // m = -inf on the first tile -> 0
-    float ps = 0.f;
-    float pf[16];
+    if (__any(mt > m)) {   // wave-uniform: only rescale when some query's running max moved (alpha == 1 otherwise)
+      const float mnew = fmaxf(m, mt);
+      const float alpha = exp_fast(m - mnew);  // m = -inf on the first tile -> 0
+      l *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pf[r] = expf(sc[r] - mnew);
-      ps += pf[r];
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      m = mnew;
     }
-    l = l * alpha + ps;
-    m = mnew;
+    float pf[16];
+    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-
+    for (int r = 0; r < 16; r += 2) {
+      pf[r] = exp_fast(sc[r] - m);
+      pf[r + 1] = exp_fast(sc[r + 1] - m);
+      ps0 += pf[r];
+      ps1 += pf[r + 1];
+    }
+    l += ps0 + ps1;
     // ---- O^T += V^T . P^T  (contraction index = key, enumerated in C/D-layout order) ----
 #pragma unroll
-    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], pf[s], o, 0, 0, 0);
+  };
+
+  // ping-pong register sets: the next tile's loads fly under the current tile's MFMAs, no register copies
+  float ka[16], va[16], kb[16], vb[16];
+  if (t0 < t1) { load_k(ka, t0); load_v(va, t0); }
+  for (int kt = t0; kt < t1; kt += 64) {
+    if (kt + 32 < t1) { load_k(kb, kt + 32); load_v(vb, kt + 32); }
+    tile(ka, va, kt);
+    if (kt + 32 < t1) {
+      if (kt + 64 < t1) { load_k(ka, kt + 64); load_v(va, kt + 64); }
+      tile(kb, vb, kt + 32);
+    }
   }
 
   l += __shfl_xor(l, 32);

@@ -15,11 +15,13 @@ _TARGET_WAVES = 2048          # 256 CUs x 4 SIMDs x 2 waves: one 32-query x 1-he
 
 
 def attn_splits(nq, heads, t):
-    """How many key ranges to cut the bank into so the launch fills the chip (csrc/attention.hip)."""
+    """How many key ranges to cut the bank into (csrc/attention.hip).  Measured on MI355X (scratch/mb_attn.py):
+    the kernel wants several waves per SIMD but >= ~12 key tiles per split; tiny problems split just enough to
+    put a wave on every SIMD."""
     waves = ((nq + 31) // 32) * heads
     tiles = (t + 31) // 32
-    want = (_TARGET_WAVES + waves - 1) // waves
-    return max(1, min(want, tiles // 4 if tiles >= 8 else 1, 16))
+    fill = min((_TARGET_WAVES + waves - 1) // waves, tiles // 4)
+    return max(1, min(16, max(tiles // 12, fill)))
 
 
 class MultiheadAttention(nn.Module):
