@@ -29,15 +29,17 @@ _SIGS = {
     'aot_groupnorm_stats_f32': [_P] * 3 + [_I] * 4 + [_F, _I, _P],
     'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
     'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
-    'aot_attn_merge_f32': [_P, _P] + [_I] * 5 + [_P],
+    'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
+    'aot_gated_attn_f32': [_P] * 6 + [_I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
+    'aot_local_gated_f32': [_P] * 8 + [_I] * 10 + [_F, _P],
     'aot_idbank_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 8 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
 }
 
-ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 
 
 class AotHipError(RuntimeError):
@@ -170,7 +172,23 @@ def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, st
     if attn_probe is not None:
         attn_probe(1, q.shape[0], T, H)
     if nsplit > 1:
-        _chk(lib.aot_attn_merge_f32(_dev(part), _dev(out), q.shape[0], H, 32, out.stride(0), nsplit, s),
+        _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
+             'aot_attn_merge_f32')
+    return out
+
+
+def gated_attention(q, k, v, gate, out, T, scale_div, part=None, nsplit=1, T_dev=None, stream=None):
+    """DeAOT single-head attention with a wide value: q [Nq,128], k [>=T,128], v [>=T,dv], gate/out [Nq,dv]."""
+    s = stream if stream is not None else stream_ptr()
+    lib = load()
+    dv = out.shape[1]
+    _chk(lib.aot_gated_attn_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev),
+                                q.shape[1], dv, q.stride(0), k.stride(0), v.stride(0),
+                                gate.stride(0) if gate is not None else 0, out.stride(0), scale_div, nsplit, s),
+         'aot_gated_attn_f32')
+    if nsplit > 1:
+        _chk(lib.aot_attn_merge_f32(_dev(part), _opt(gate), _dev(out), q.shape[0], dv // 256, dv,
+                                    gate.stride(0) if gate is not None else 0, out.stride(0), nsplit, s),
              'aot_attn_merge_f32')
     return out
 
@@ -192,6 +210,14 @@ def local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, H, scale_div, ma
     _chk(load().aot_local_attn_f32(_dev(q), _dev(k), _dev(v), _dev(relk_w), _dev(relk_b), _dev(relv_t), _dev(out), h, w, H,
                                    32, max_dis, q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div,
                                    stream if stream is not None else stream_ptr()), 'aot_local_attn_f32')
+    return out
+
+
+def local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_dis=7, stream=None):
+    _chk(load().aot_local_gated_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(relk_t), _dev(relk_b), _dev(prob),
+                                    _dev(out), h, w, q.shape[1], out.shape[1], max_dis, q.stride(0), k.stride(0),
+                                    v.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0), scale_div,
+                                    stream if stream is not None else stream_ptr()), 'aot_local_gated_f32')
     return out
 
 

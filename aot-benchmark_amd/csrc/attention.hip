@@ -27,7 +27,9 @@ struct AttnParams {
   float* out;
   float* part;  // [nsplit][Nq][H*32] O partials, then [nsplit][Nq][H][2] (m, l)
   const int* T_dev;
+  const float* gate;  // optional [Nq, ldg]: out *= gate (GatedPropagation, attention.py:707)
   int Nq, T, H, ldq, ldk, ldv, ldo, nsplit;
+  int ldg, C;         // C = output width (H*32 for the multi-head form, dv for the gated form)
   float scale_div;
 };
 
@@ -160,6 +162,10 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
       float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+      if (p.gate) {
+        const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
+        t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+      }
       *reinterpret_cast<float4*>(dst + 8 * g) = t;
     }
   } else {
@@ -178,15 +184,16 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
   }
 }
 
-// merge of the nsplit partials: one thread per (query, head, 4 channels)
+// merge of the nsplit partials: one thread per (query, 4 channels).  Stats (m, l) are stored per `group` of
+// p.C / p.H channels (one per head in the multi-head form, one per V chunk in the gated form).
 __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
-  const int C = p.H * 32;
+  const int C = p.C;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)p.Nq * (C / 4);
   if (idx >= total) return;
   const int c4 = (int)(idx % (C / 4));
   const int qi = (int)(idx / (C / 4));
-  const int h = (c4 * 4) / 32;
+  const int h = (c4 * 4) / (C / p.H);
   const float* mlb = p.part + (long)p.nsplit * p.Nq * C;
   float mmax = -INFINITY;
   for (int s = 0; s < p.nsplit; ++s) mmax = fmaxf(mmax, mlb[(((long)s * p.Nq + qi) * p.H + h) * 2]);
@@ -202,21 +209,171 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
     acc.x += wgt * t.x; acc.y += wgt * t.y; acc.z += wgt * t.z; acc.w += wgt * t.w;
   }
   const float inv = 1.f / lsum;
-  *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c4 * 4) =
-      make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  float4 r = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (p.gate) {
+    const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c4 * 4);
+    r.x *= u.x; r.y *= u.y; r.z *= u.z; r.w *= u.w;
+  }
+  *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c4 * 4) = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gated-propagation form (DeAOT, attention.py:672-707): ONE query/key head of width DQK = 128 and a value of
+// width NCH * 32*NDV (1024 = [V | ID_V]).  A wave owns 32 queries and one chunk of 32*NDV value channels; it
+// recomputes the 32x32 score tile (DQK/2 MFMAs) and spends 16*NDV MFMAs on its chunk, so with NDV = 8 the
+// shared score work is a third of the total.  One wave per SIMD (the accumulators of a 256-wide chunk fill the
+// AGPR file), K double-buffered across key tiles and V across chunks so loads fly under the MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <int DQK, int NDV>
+__global__ void __launch_bounds__(64) attn_fwd_wide_kernel(const AttnParams p) {
+  constexpr int HK = DQK / 2;   // contraction values per lane
+  const int ch = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
+  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int t0 = split * tps * 32;
+  const int t1 = min(T, t0 + tps * 32);
+  const int qrow = min(qt * 32 + j, p.Nq - 1);
+
+  float qf[HK];
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + hi * HK);
+#pragma unroll
+    for (int i = 0; i < HK / 4; ++i) {
+      const float4 t = src[i];
+      qf[4 * i] = t.x / p.scale_div; qf[4 * i + 1] = t.y / p.scale_div;
+      qf[4 * i + 2] = t.z / p.scale_div; qf[4 * i + 3] = t.w / p.scale_div;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  const int vvoff = (4 * hi * p.ldv + ch * 32 * NDV + j) * 4;
+  const int ldv4 = p.ldv * 4;
+  const float* kptr = p.k + hi * HK;
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[NDV];
+#pragma unroll
+  for (int d = 0; d < NDV; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+  auto load_k = [&](float (&kf)[HK], int kt) {
+    const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
+#pragma unroll
+    for (int i = 0; i < HK / 4; ++i) {
+      const float4 t = src[i];
+      kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
+    }
+  };
+  auto load_v = [&](float (&vf)[16], int kt, int d) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+  };
+
+  float va[16], vb[16];
+  auto tile = [&](const float (&kf)[HK], int kt) {
+    load_v(va, kt, 0);
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HK; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
+    if (kt + 32 > t1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    if (__any(mt > m)) {
+      const float mnew = fmaxf(m, mt);
+      const float alpha = exp_fast(m - mnew);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      m = mnew;
+    }
+    float pf[16];
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r] = exp_fast(sc[r] - m);
+      ps += pf[r];
+    }
+    l += ps;
+    static_assert(NDV % 2 == 0, "chunk ping-pong below needs an even NDV");
+#pragma unroll
+    for (int d = 0; d < NDV; d += 2) {
+      load_v(vb, kt, d + 1);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o[d], 0, 0, 0);
+      if (d + 2 < NDV) load_v(va, kt, d + 2);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) o[d + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[s], pf[s], o[d + 1], 0, 0, 0);
+    }
+  };
+
+  float ka[HK], kb[HK];
+  if (t0 < t1) load_k(ka, t0);
+  for (int kt = t0; kt < t1; kt += 64) {
+    if (kt + 32 < t1) load_k(kb, kt + 32);
+    tile(ka, kt);
+    if (kt + 32 < t1) {
+      if (kt + 64 < t1) load_k(ka, kt + 64);
+      tile(kb, kt + 32);
+    }
+  }
+
+  l += __shfl_xor(l, 32);
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  const int cbase = ch * 32 * NDV + 4 * hi;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        const int c = cbase + d * 32 + 8 * g;
+        if (p.gate) {
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c);
+          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+        }
+        *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c) = t;
+      }
+  } else {
+    float* dst = p.part + ((long)split * p.Nq + qi) * p.C;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
+            make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
+    if (hi == 0) {
+      float* ml = p.part + (long)p.nsplit * p.Nq * p.C + (((long)split * p.Nq + qi) * p.H + ch) * 2;
+      ml[0] = m;
+      ml[1] = l;
+    }
+  }
 }
 
 static int fill_params(AttnParams& p, const float* q, const float* k, const float* v, float* out, float* part, int Nq,
-                       int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div,
-                       int nsplit) {
+                       int T, const int* T_dev, int H, int ldq, int ldk, int ldv, int ldo, float scale_div, int nsplit) {
   if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0) return AOT_ERR_BADARG;
-  if (d != 32) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)out & 15))
     return AOT_ERR_BADARG;
   if (nsplit < 1) return AOT_ERR_BADARG;
   if (nsplit > 1 && !part) return AOT_ERR_BADARG;
-  p.q = q; p.k = k; p.v = v; p.out = out; p.part = part; p.T_dev = T_dev;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.part = part; p.T_dev = T_dev; p.gate = nullptr; p.ldg = 0;
   p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.nsplit = nsplit;
+  p.C = H * 32;
   p.scale_div = scale_div;
   return AOT_OK;
 }
@@ -224,19 +381,38 @@ static int fill_params(AttnParams& p, const float* q, const float* k, const floa
 extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int Nq, int T,
                             const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div,
                             int nsplit, void* stream) {
+  if (d != 32) return AOT_ERR_UNSUPPORTED;
   AttnParams p;
-  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, d, ldq, ldk, ldv, ldo, scale_div, nsplit);
+  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_fwd_d32_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 
-extern "C" int aot_attn_merge_f32(const float* part, float* out, int Nq, int H, int d, int ldo, int nsplit, void* stream) {
-  if (!part || !out || Nq <= 0 || H <= 0 || nsplit < 2 || (ldo & 3)) return AOT_ERR_BADARG;
-  if (d != 32) return AOT_ERR_UNSUPPORTED;
+extern "C" int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq, int H, int C, int ldg,
+                                  int ldo, int nsplit, void* stream) {
+  if (!part || !out || Nq <= 0 || H <= 0 || C <= 0 || (C % H) || ((C / H) & 3) || nsplit < 2 || (ldo & 3)) return AOT_ERR_BADARG;
+  if (gate && (ldg & 3)) return AOT_ERR_BADARG;
   AttnParams p = {};
-  p.part = const_cast<float*>(part); p.out = out; p.Nq = Nq; p.H = H; p.ldo = ldo; p.nsplit = nsplit;
-  const long total = (long)Nq * (H * 32 / 4);
+  p.part = const_cast<float*>(part); p.out = out; p.Nq = Nq; p.H = H; p.C = C; p.ldo = ldo; p.nsplit = nsplit;
+  p.gate = gate; p.ldg = ldg;
+  const long total = (long)Nq * (C / 4);
   hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_gated_attn_f32(const float* q, const float* k, const float* v, const float* gate, float* out,
+                                  float* part, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldk,
+                                  int ldv, int ldg, int ldo, float scale_div, int nsplit, void* stream) {
+  if (dqk != 128 || dv <= 0 || (dv % 256)) return AOT_ERR_UNSUPPORTED;
+  const int nch = dv / 256;
+  AttnParams p;
+  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, nch, ldq, ldk, ldv, ldo, scale_div, nsplit);
+  if (rc) return rc;
+  if (gate && (ldg & 3)) return AOT_ERR_BADARG;
+  p.C = dv;
+  p.gate = (nsplit == 1) ? gate : nullptr;   // with splits the gate is applied by aot_attn_merge_f32
+  p.ldg = ldg;
+  hipLaunchKernelGGL((attn_fwd_wide_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

@@ -1,0 +1,223 @@
+// Short-term gated propagation of DeAOT (LocalGatedPropagation.forward, reference attention.py:789-861):
+// one head, q = k of width 128, a value of width C = 1024 ([V | ID_V]) and a gate u:
+//   s_w  = (q/sqrt(128)) . k[p + delta(w)] + relk[w, :] . q + relk_b[w]       over the 15x15 window
+//   a    = softmax_w(s)   (window slots outside the image excluded)
+//   out  = ( sum_w a_w * v[p + delta(w)] ) * u
+// The value is 32x wider than the key, so the work is split in three launches that share the slot-major
+// probability map P [225, N] (1.5 MB at 480p, L2 resident):
+//   lgp_scores_kernel    window scores -> P (raw, -inf outside the image)
+//   lgp_softmax_kernel   in-place softmax over the 225 slots of every query
+//   lgp_aggregate_kernel sum_w P * v over 32-channel chunks of the value, times the gate
+// Staging, LDS layout (token-major rows, 36-float stride, conflict-free ds_read_b128), the split of the window
+// rows over the waves of a workgroup and the DPP row_newbcast broadcast of the wave-uniform relative-position
+// table are those of local_attn.hip.
+#include "common.h"
+
+struct LgpParams {
+  const float* q;       // [N, ldq] (128 wide)
+  const float* k;       // [N, ldk]
+  const float* v;       // [N, ldv] (C wide)
+  const float* gate;    // [N, ldg] or null
+  const float* relk_t;  // [WS][128][16]  sqrt(128) * relative_emb_k.weight[dy*WS+dx][c]
+  const float* relk_b;  // [WS][16]
+  float* prob;          // [WS*WS][N]
+  float* out;           // [N, ldo]
+  int h, w, C, ldq, ldk, ldv, ldg, ldo;
+  float scale_div;
+};
+
+#define LGP_DPPF(acc, N) "v_fmac_f32_dpp " acc ", %[t], %[x] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void lgp_dpp_axpy15(float (&s)[15], float t, float x) {
+  asm("s_nop 1\n\t"
+      LGP_DPPF("%0", 0) LGP_DPPF("%1", 1) LGP_DPPF("%2", 2) LGP_DPPF("%3", 3) LGP_DPPF("%4", 4) LGP_DPPF("%5", 5)
+      LGP_DPPF("%6", 6) LGP_DPPF("%7", 7) LGP_DPPF("%8", 8) LGP_DPPF("%9", 9) LGP_DPPF("%10", 10) LGP_DPPF("%11", 11)
+      LGP_DPPF("%12", 12) LGP_DPPF("%13", 13) LGP_DPPF("%14", 14)
+      : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]),
+        "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14])
+      : [t] "v"(t), [x] "v"(x));
+}
+#undef LGP_DPPF
+
+constexpr int LGP_R = 7, LGP_WS = 15, LGP_NPOS = 64 + 2 * LGP_R, LGP_LD = 36;
+constexpr int LGP_NF4 = LGP_NPOS * 8, LGP_PER = (LGP_NF4 + 63) / 64, LGP_SLAB = (LGP_NPOS + 2) * LGP_LD;
+
+// stage 32 channels [c0, c0+32) of image row ky, key positions x0-R .. x0+63+R, into a wave-private LDS slab
+__device__ __forceinline__ void lgp_stage(const float* base, int ld, int c0, int ky, int x0, int w, int lane, float* slab) {
+  float4 st[LGP_PER];
+#pragma unroll
+  for (int i = 0; i < LGP_PER; ++i) {
+    const int f = lane + i * 64;
+    const int pos = f >> 3, c4 = f & 7;
+    const int kx = x0 - LGP_R + pos;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < LGP_NF4 && kx >= 0 && kx < w) t = *reinterpret_cast<const float4*>(base + ((long)ky * w + kx) * ld + c0 + c4 * 4);
+    st[i] = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < LGP_PER; ++i) {
+    const int f = lane + i * 64;
+    if (f < LGP_NF4) *reinterpret_cast<float4*>(&slab[(f >> 3) * LGP_LD + (f & 7) * 4]) = st[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NWV>
+__global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x0 = blockIdx.x * 64, y = blockIdx.y;
+  const bool active = x0 + lane < p.w;
+  const int x = active ? x0 + lane : p.w - 1;
+  const int n = y * p.w + x;
+  const int N = p.h * p.w;
+  float* slab = lds + wave * LGP_SLAB;
+  for (int dy = wave; dy < LGP_WS; dy += NWV) {
+    const int ky = y + dy - LGP_R;
+    if (ky < 0 || ky >= p.h) {           // whole window row outside the image
+      if (active)
+#pragma unroll
+        for (int dx = 0; dx < LGP_WS; ++dx) p.prob[(long)(dy * LGP_WS + dx) * N + n] = -INFINITY;
+      continue;
+    }
+    float s[LGP_WS];
+#pragma unroll
+    for (int dx = 0; dx < LGP_WS; ++dx) s[dx] = p.relk_b[dy * 16 + dx];
+    for (int c0 = 0; c0 < 128; c0 += 32) {
+      float qs[32], tk[32];
+      {
+        const float4* src = reinterpret_cast<const float4*>(p.q + (long)n * p.ldq + c0);
+        const float* wk = p.relk_t + ((long)dy * 128 + c0) * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 t = src[i];
+          qs[4 * i] = t.x / p.scale_div; qs[4 * i + 1] = t.y / p.scale_div;
+          qs[4 * i + 2] = t.z / p.scale_div; qs[4 * i + 3] = t.w / p.scale_div;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) tk[c] = __builtin_nontemporal_load(wk + c * 16);
+      }
+      lgp_stage(p.k, p.ldk, c0, ky, x0, p.w, lane, slab);
+#pragma unroll
+      for (int dx = 0; dx < LGP_WS; ++dx) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+          const float4 kk = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LGP_LD + c4 * 4]);
+          dot = fmaf(qs[4 * c4], kk.x, dot);
+          dot = fmaf(qs[4 * c4 + 1], kk.y, dot);
+          dot = fmaf(qs[4 * c4 + 2], kk.z, dot);
+          dot = fmaf(qs[4 * c4 + 3], kk.w, dot);
+        }
+        s[dx] += dot;
+      }
+#pragma unroll
+      for (int c = 0; c < 32; ++c) lgp_dpp_axpy15(s, tk[c], qs[c]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // slab reads done before the next chunk overwrites it
+    }
+    if (active)
+#pragma unroll
+      for (int dx = 0; dx < LGP_WS; ++dx) {
+        const int kx = x + dx - LGP_R;
+        p.prob[(long)(dy * LGP_WS + dx) * N + n] = (kx >= 0 && kx < p.w) ? s[dx] : -INFINITY;
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ prob, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  constexpr int W2 = LGP_WS * LGP_WS;
+  float m = -INFINITY;
+  for (int w = 0; w < W2; ++w) m = fmaxf(m, prob[(long)w * N + n]);
+  float l = 0.f;
+  for (int w = 0; w < W2; ++w) {
+    const float e = expf(prob[(long)w * N + n] - m);   // exp(-inf) = 0 for slots outside the image
+    prob[(long)w * N + n] = e;
+    l += e;
+  }
+  const float inv = 1.f / l;
+  for (int w = 0; w < W2; ++w) prob[(long)w * N + n] *= inv;
+}
+
+template <int NWV>
+__global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x0 = blockIdx.x * 64, y = blockIdx.y, c0 = blockIdx.z * 32;
+  const bool active = x0 + lane < p.w;
+  const int x = active ? x0 + lane : p.w - 1;
+  const int n = y * p.w + x;
+  const int N = p.h * p.w;
+  float* slab = lds + wave * LGP_SLAB;
+  float o[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) o[c] = 0.f;
+  for (int dy = wave; dy < LGP_WS; dy += NWV) {
+    const int ky = y + dy - LGP_R;
+    if (ky < 0 || ky >= p.h) continue;
+    float pw[LGP_WS];
+#pragma unroll
+    for (int dx = 0; dx < LGP_WS; ++dx) pw[dx] = p.prob[(long)(dy * LGP_WS + dx) * N + n];
+    lgp_stage(p.v, p.ldv, c0, ky, x0, p.w, lane, slab);
+#pragma unroll
+    for (int dx = 0; dx < LGP_WS; ++dx) {
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 vv = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LGP_LD + c4 * 4]);
+        o[4 * c4] = fmaf(pw[dx], vv.x, o[4 * c4]);
+        o[4 * c4 + 1] = fmaf(pw[dx], vv.y, o[4 * c4 + 1]);
+        o[4 * c4 + 2] = fmaf(pw[dx], vv.z, o[4 * c4 + 2]);
+        o[4 * c4 + 3] = fmaf(pw[dx], vv.w, o[4 * c4 + 3]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // sum the NWV partials in fixed order
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 32; ++c) slab[c * 64 + lane] = o[c];
+  __syncthreads();
+  if (wave == 0 && active) {
+    float t[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) t[c] = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NWV; ++w2)
+#pragma unroll
+      for (int c = 0; c < 32; ++c) t[c] += lds[w2 * LGP_SLAB + c * 64 + lane];
+    float4* dst = reinterpret_cast<float4*>(p.out + (long)n * p.ldo + c0);
+    const float4* g = p.gate ? reinterpret_cast<const float4*>(p.gate + (long)n * p.ldg + c0) : nullptr;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      float4 r = make_float4(t[4 * c4], t[4 * c4 + 1], t[4 * c4 + 2], t[4 * c4 + 3]);
+      if (g) { const float4 u = g[c4]; r.x *= u.x; r.y *= u.y; r.z *= u.z; r.w *= u.w; }
+      dst[c4] = r;
+    }
+  }
+}
+
+extern "C" int aot_local_gated_f32(const float* q, const float* k, const float* v, const float* gate, const float* relk_t,
+                                   const float* relk_b, float* prob, float* out, int h, int w, int dqk, int dv,
+                                   int max_dis, int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div,
+                                   void* stream) {
+  if (!q || !k || !v || !relk_t || !relk_b || !prob || !out || h <= 0 || w <= 0) return AOT_ERR_BADARG;
+  if (dqk != 128 || max_dis != 7 || dv <= 0 || (dv & 31)) return AOT_ERR_UNSUPPORTED;
+  if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (gate && (ldg & 3))) return AOT_ERR_BADARG;
+  LgpParams p;
+  p.q = q; p.k = k; p.v = v; p.gate = gate; p.relk_t = relk_t; p.relk_b = relk_b; p.prob = prob; p.out = out;
+  p.h = h; p.w = w; p.C = dv; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldg = ldg; p.ldo = ldo; p.scale_div = scale_div;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int NWV = 8;
+  hipLaunchKernelGGL((lgp_scores_kernel<NWV>), dim3(cdiv(w, 64), h, 1), dim3(NWV * 64), 0, s, p);
+  hipLaunchKernelGGL(lgp_softmax_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, prob, h * w);
+  hipLaunchKernelGGL((lgp_aggregate_kernel<NWV>), dim3(cdiv(w, 64), h, dv / 32), dim3(NWV * 64), 0, s, p);
+  AOT_LAUNCH_CHECK();
+}

@@ -1,5 +1,5 @@
 """Engine factory (reference networks/engines/__init__.py:5-21)."""
-from networks.engines.aot_engine import AOTEngine, AOTInferEngine
+from networks.engines.aot_engine import AOTEngine, AOTInferEngine, DeAOTEngine, DeAOTInferEngine
 
 
 def build_engine(name, phase='train', **kwargs):
@@ -8,5 +8,7 @@ def build_engine(name, phase='train', **kwargs):
             return AOTInferEngine(**kwargs)
         raise NotImplementedError("phase %r: only the inference engine ('eval') is on the scoped hot path" % phase)
     if name == 'deaotengine':
-        raise NotImplementedError('DeAOT engine: next row of the scope table (SURVEY.md section 8a, a3/a4/a6)')
+        if phase == 'eval':
+            return DeAOTInferEngine(**kwargs)
+        raise NotImplementedError("phase %r: only the inference engine ('eval') is on the scoped hot path" % phase)
     raise NotImplementedError

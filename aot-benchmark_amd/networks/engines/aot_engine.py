@@ -52,8 +52,8 @@ class AOTEngine(nn.Module):
         self.short_term_memories_list = []
         self.short_term_memories = None
         self._feats = None        # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major
-        self._cat = None          # [N, (L+1)*C]: decoder input; block 0 = projected feature, blocks 1.. = LSTT outs
-        self._curr = None         # per layer (curr_K, curr_V) token-major
+        self._dec_in = None       # decoder input: AOT [N, (L+1)*C] (projected feature | LSTT outs), DeAOT [N, 2C]
+        self._curr = None         # per layer current-frame memories (token-major), as returned by LSTT.run
         self.curr_id_embs = None
         self.pred_id_logits = None
 
@@ -77,24 +77,11 @@ class AOTEngine(nn.Module):
 
     # ---- helpers -------------------------------------------------------------------------------
     def _encode(self, img, img_embs):
-        L = self.AOT.LSTT.num_layers
-        emb = self.AOT.encoder_projector.out_channels
-        dev = img.device if img is not None else img_embs[-1].device
         if img_embs is None:
-            h16 = w16 = None
-            cat = None
             feats = self.AOT.encode_tokens(img)
-            x0, h, w = feats[3]
-            cat = torch.empty(h * w, (L + 1) * emb, dtype=torch.float32, device=dev)
-            cat[:, :emb].copy_(x0)
-            feats[3] = (cat[:, :emb], h, w)
         else:   # shared image embedding from another object group (aot_engine.py:606-607,612-616)
             feats = [(to_tokens(e), e.shape[2], e.shape[3]) for e in img_embs]
-            x0, h, w = feats[3]
-            cat = torch.empty(h * w, (L + 1) * emb, dtype=torch.float32, device=dev)
-            cat[:, :emb].copy_(x0)
-            feats[3] = (cat[:, :emb], h, w)
-        self._feats, self._cat = feats, cat
+        self._feats = feats
         return feats
 
     def assign_identity(self, mask):
@@ -146,10 +133,9 @@ class AOTEngine(nn.Module):
         id_emb = self.assign_identity(mask)
         self.curr_id_embs = id_emb
         stream = aot_hip.stream_ptr()
-        C = feats[3][0].shape[1]
-        outs, mems = self.AOT.LSTT.run(self._cat[:, :C], None, None, id_emb, self.pos_emb, self.enc_size_2d,
-                                       self.AOT.ws, stream, self._cat)
-        self._curr = [(m[0], m[1]) for m in mems]
+        self._dec_in, outs, mems = self.AOT.LSTT.run(feats[3][0], None, None, id_emb, self.pos_emb, self.enc_size_2d,
+                                                     self.AOT.ws, stream)
+        self._curr = list(mems)
         self._append_bank([m[2][0] for m in mems], [m[2][1] for m in mems])
         self.last_mem_step = self.frame_step
         st = [(m[3][0], m[3][1]) for m in mems]
@@ -160,19 +146,16 @@ class AOTEngine(nn.Module):
         self.frame_step += 1
         feats = self._encode(img, img_embs)
         stream = aot_hip.stream_ptr()
-        C = feats[3][0].shape[1]
         lm = list(zip(self.bank_k, self.bank_v))
-        outs, mems = self.AOT.LSTT.run(self._cat[:, :C], lm, self.short_term_memories, None, self.pos_emb,
-                                       self.enc_size_2d, self.AOT.ws, stream, self._cat, t_long=self.bank_len)
-        self._curr = [(m[0], m[1]) for m in mems]
+        self._dec_in, outs, mems = self.AOT.LSTT.run(feats[3][0], lm, self.short_term_memories, None, self.pos_emb,
+                                                     self.enc_size_2d, self.AOT.ws, stream, t_long=self.bank_len)
+        self._curr = list(mems)
 
     def decode_current_logits(self, output_size=None):
         stream = aot_hip.stream_ptr()
         f4, f8, f16, _ = self._feats
         dec = self.AOT.decoder
-        C = self._feats[3][0].shape[1]
-        x_in = self._cat if dec.decode_intermediate_input else self._cat[:, -C:]
-        logits, h4, w4 = dec.run(x_in, f16, f8, f4, self.AOT.ws, stream)
+        logits, h4, w4 = dec.run(self._dec_in, f16, f8, f4, self.AOT.ws, stream)
         nc = logits.shape[1]
         dev = logits.device
         obj_num = int(self.obj_nums[0])
@@ -199,11 +182,8 @@ class AOTEngine(nn.Module):
             curr_id_emb = to_tokens(curr_id_emb)
         self.curr_id_embs = curr_id_emb
         stream = aot_hip.stream_ptr()
-        fused = []
-        for i, (ck, cv) in enumerate(self._curr):
-            v = self.AOT.LSTT.layers[i].fuse_kv_2d(cv, curr_id_emb, self.AOT.ws, stream)
-            fused.append((ck, v))
-        self._curr = fused
+        fused = [self.AOT.LSTT.layers[i].update_memory_kv(m, curr_id_emb, self.AOT.ws, stream)
+                 for i, m in enumerate(self._curr)]
         self.short_term_memories_list.append(fused)
         self.short_term_memories_list = self.short_term_memories_list[-self.short_term_mem_skip:]
         self.short_term_memories = self.short_term_memories_list[0]
@@ -222,9 +202,17 @@ class AOTEngine(nn.Module):
         return pred_mask, torch.softmax(logits, dim=1)
 
 
+class DeAOTEngine(AOTEngine):
+    """reference networks/engines/deaot_engine.py:9-56.  The memory layout differences of DeAOT ([K 128 | V 512 | ID_V 512]
+    per token, only ID_V refreshed at update time) live in GatedPropagationModule.update_memory_kv / run; the state
+    machine is the same."""
+
+
 class AOTInferEngine(nn.Module):
     """Caller-facing engine (reference aot_engine.py:485-635): one AOTEngine per group of max_aot_obj_num
     objects, created lazily; the image embedding is computed once per frame and shared."""
+
+    engine_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None):
         super().__init__()
@@ -283,7 +271,7 @@ class AOTInferEngine(nn.Module):
         self.obj_nums = obj_nums
         aot_num = max(np.ceil(obj_nums / self.max_aot_obj_num), 1)
         while aot_num > len(self.aot_engines):
-            new_engine = AOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
+            new_engine = self.engine_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
             new_engine.eval()
             self.aot_engines.append(new_engine)
         separated_masks, separated_obj_nums = self.separate_mask(mask, obj_nums)
@@ -316,3 +304,8 @@ class AOTInferEngine(nn.Module):
         self.input_size_2d = self.aot_engines[0].input_size_2d
         self.enc_size_2d = self.aot_engines[0].enc_size_2d
         self.enc_hw = self.aot_engines[0].enc_hw
+
+
+class DeAOTInferEngine(AOTInferEngine):
+    """reference networks/engines/deaot_engine.py:59-94."""
+    engine_cls = DeAOTEngine

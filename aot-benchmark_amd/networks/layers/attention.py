@@ -9,7 +9,8 @@ import torch
 from torch import nn
 
 import aot_hip
-from networks.layers.normalization import linear_t
+from networks.layers.basic import DWConv2d
+from networks.layers.normalization import fold_dwconv_bn, linear_t
 
 _TARGET_WAVES = 2048          # 256 CUs x 4 SIMDs x 2 waves: one 32-query x 1-head tile = one wave
 
@@ -94,3 +95,106 @@ class MultiheadLocalAttention(nn.Module):
         aot_hip.local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, self.num_head, self.T,
                                 max_dis=self.max_dis, stream=stream)
         return out
+
+
+class GatedPropagation(nn.Module):
+    """Global gated propagation of DeAOT (reference attention.py:589-717): single head, q = k of width d_att,
+    value/gate of width expand_d_vu; out = projection(dw_conv5x5((softmax(qk^T) v) * u)).  With use_linear the
+    inputs are projected first (self-attention form, :648-669)."""
+
+    def __init__(self, d_qk, d_vu, num_head=8, dropout=0., use_linear=True, d_att=None, use_dis=False, qk_chunks=1,
+                 max_mem_len_ratio=-1, top_k=-1, expand_ratio=2.):
+        super().__init__()
+        if num_head != 1:
+            raise NotImplementedError('DeAOT configs use a single head (configs/models/default_deaot.py:14-15)')
+        if use_dis or top_k > 0 or max_mem_len_ratio > 0:
+            raise NotImplementedError('default-off eval knobs (attention.py:597-600) are not built')
+        self.expand_d_vu = int(d_vu * expand_ratio)
+        self.d_vu, self.d_qk, self.num_head = d_vu, d_qk, num_head
+        self.hidden_dim = self.expand_d_vu // num_head
+        self.d_att = d_qk // num_head if d_att is None else d_att
+        self.T = self.d_att ** 0.5
+        self.use_linear = use_linear
+        if use_linear:
+            self.linear_QK = nn.Linear(d_qk, self.d_att * num_head)
+            half = self.hidden_dim * num_head // 2
+            self.linear_V1 = nn.Linear(d_vu // 2, half)
+            self.linear_V2 = nn.Linear(d_vu // 2, half)
+            self.linear_U1 = nn.Linear(d_vu // 2, half)
+            self.linear_U2 = nn.Linear(d_vu // 2, half)
+        self.dw_conv = DWConv2d(self.expand_d_vu)
+        self.projection = nn.Linear(self.expand_d_vu, d_vu)
+        self._p = None
+
+    def pack(self):
+        if self._p is None:
+            p = {'dw': fold_dwconv_bn(self.dw_conv.conv)[0]}
+            p['proj_w'], p['proj_b'] = linear_t(self.projection)
+            if self.use_linear:
+                for n in ('QK', 'V1', 'V2', 'U1', 'U2'):
+                    p[n + '_w'], p[n + '_b'] = linear_t(getattr(self, 'linear_' + n))
+            self._p = p
+        return self._p
+
+    def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None):
+        """(softmax((q/T) k^T) v) * gate : q [Nq,128], k [>=t,128], v [>=t,E], gate/out [Nq,E]."""
+        nq = q.shape[0]
+        ns = attn_splits(nq, out.shape[1] // 256, t)
+        part = None
+        if ns > 1:
+            part = ws.get('gattn_part', (ns * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)
+        aot_hip.gated_attention(q, k, v, gate, out, t, self.T, part=part, nsplit=ns, T_dev=t_dev, stream=stream)
+        return out
+
+    def tail(self, raw, out, size_2d, ws, stream, res=None):
+        """projection(dw_conv(raw)) (+ res): attention.py:709-710."""
+        p = self.pack()
+        h, w = size_2d
+        E = raw.shape[1]
+        tmp = ws.get('gp_dw', (raw.shape[0], E), raw.device)
+        aot_hip.dwconv2d(raw, p['dw'], None, tmp, h, w, E, h, w, 5, 1, 2, 1, stream=stream)
+        aot_hip.linear(tmp, p['proj_w'], p['proj_b'], out, res=res, stream=stream)
+        return out
+
+
+class LocalGatedPropagation(nn.Module):
+    """Short-term gated propagation of DeAOT over the 15x15 window (reference attention.py:720-914, use_linear=False)."""
+
+    def __init__(self, d_qk, d_vu, num_head, dropout=0., max_dis=7, dilation=1, use_linear=False, d_att=None,
+                 use_dis=False, expand_ratio=2.):
+        super().__init__()
+        if num_head != 1 or use_linear or dilation != 1 or use_dis:
+            raise NotImplementedError('DeAOT uses one head, use_linear=False, dilation=1 (transformer.py:550-559)')
+        self.expand_d_vu = int(d_vu * expand_ratio)
+        self.window_size = 2 * max_dis + 1
+        self.max_dis, self.num_head = max_dis, num_head
+        self.hidden_dim = self.expand_d_vu // num_head
+        self.d_att = d_qk // num_head if d_att is None else d_att
+        self.T = self.d_att ** 0.5
+        self.relative_emb_k = nn.Conv2d(self.d_att * num_head, num_head * self.window_size * self.window_size,
+                                        kernel_size=1, groups=num_head)
+        self.dw_conv = DWConv2d(self.expand_d_vu)
+        self.projection = nn.Linear(self.expand_d_vu, d_vu)
+        self._p = None
+
+    def pack(self):
+        if self._p is None:
+            ws_ = self.window_size
+            d = self.d_att
+            wk = (self.relative_emb_k.weight.detach().double().reshape(ws_, ws_, d) * (float(d) ** 0.5)).float()
+            wk = torch.nn.functional.pad(wk.permute(0, 2, 1), (0, 16 - ws_)).contiguous()            # [dy, c, 16]
+            bk = torch.nn.functional.pad(self.relative_emb_k.bias.detach().float().reshape(ws_, ws_), (0, 16 - ws_)).contiguous()
+            p = {'relk_t': wk, 'relk_b': bk, 'dw': fold_dwconv_bn(self.dw_conv.conv)[0]}
+            p['proj_w'], p['proj_b'] = linear_t(self.projection)
+            self._p = p
+        return self._p
+
+    def core(self, q, k, v, gate, out, size_2d, ws, stream):
+        p = self.pack()
+        h, w = size_2d
+        prob = ws.get('lgp_prob', (self.window_size * self.window_size * h * w,), q.device)
+        aot_hip.local_gated(q, k, v, gate, p['relk_t'], p['relk_b'], prob, out, h, w, self.T, max_dis=self.max_dis,
+                            stream=stream)
+        return out
+
+    tail = GatedPropagation.tail

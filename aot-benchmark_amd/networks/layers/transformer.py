@@ -10,8 +10,9 @@ import torch
 from torch import nn
 
 import aot_hip
-from networks.layers.attention import MultiheadAttention, MultiheadLocalAttention
-from networks.layers.basic import GNActDWConv2d
+from networks.layers.attention import (GatedPropagation, LocalGatedPropagation, MultiheadAttention,
+                                       MultiheadLocalAttention)
+from networks.layers.basic import GNActDWConv2d, GroupNorm1D
 from networks.layers.normalization import fold_dwconv_bn, linear_t
 
 
@@ -133,6 +134,11 @@ class LongShortTermTransformerBlock(nn.Module):
         aot_hip.linear(tmp, p['v_w'], p['v_b'], out, stream=stream)
         return out
 
+    def update_memory_kv(self, mem, id_emb, ws, stream):
+        """Engine hook after the frame's mask is known (aot_engine.py:317-327): (curr_K, curr_V) -> memorised (K, V)."""
+        ck, cv = mem[0], mem[1]
+        return ck, self.fuse_kv_2d(cv, id_emb, ws, stream)
+
     def fuse_key_value_id(self, key, value, id_emb):
         """Reference API (transformer.py:364-367): K unchanged, V <- linear_V(V + id_emb); [N,1,C] tensors."""
         n, b, c = value.shape
@@ -165,12 +171,15 @@ class LongShortTermTransformer(nn.Module):
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
-    def run(self, x, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, out_cat, t_long=None):
-        """Runs the stack; layer outputs (after their decoder norm, transformer.py:124-135) are written to
-        column blocks 1.. of ``out_cat`` [N, (L+1)*C] (block 0 = projected encoder feature), which is the
-        decoder's concatenated input (models/aot.py:86-92) -- the concat is never a separate copy."""
-        C = x.shape[1]
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, t_long=None):
+        """Runs the stack on the projected encoder feature x0 [N, C].  Returns (dec_in, outs, mems): dec_in is the
+        decoder's concatenated input [N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0, blocks 1.. = the layer
+        outputs after their decoder norm (transformer.py:124-135), written in place so the concat is never a copy."""
+        N, C = x0.shape
         L = self.num_layers
+        out_cat = torch.empty(N, (L + 1) * C, dtype=torch.float32, device=x0.device)
+        out_cat[:, :C].copy_(x0)
+        x = out_cat[:, :C]
         outs, mems = [], []
         for i, layer in enumerate(self.layers):
             x, ck, cv, glob, loc = layer.run(x, long_mems[i] if long_mems is not None else None,
@@ -190,4 +199,186 @@ class LongShortTermTransformer(nn.Module):
             else:
                 dst.copy_(x)
             outs.append(dst)
-        return outs, mems
+        return out_cat, outs, mems
+
+
+class GatedPropagationModule(nn.Module):
+    """DeAOT block (reference transformer.py:501-670).  The two branches live in ONE token-major state
+    X = [tgt | tgt_id] of width 2*d_model, so both residual updates are GEMM epilogues on a 512-wide buffer."""
+
+    def __init__(self, d_model, self_nhead, att_nhead, dim_feedforward=1024, droppath=0.1, lt_dropout=0.,
+                 st_dropout=0., droppath_lst=False, activation='gelu', local_dilation=1, max_local_dis=7,
+                 layer_idx=0, expand_ratio=2.):
+        super().__init__()
+        expand_d_model = int(d_model * expand_ratio)
+        self.expand_d_model, self.d_model, self.att_nhead = expand_d_model, d_model, att_nhead
+        d_att = d_model // 2 if att_nhead == 1 else d_model // att_nhead
+        self.d_att, self.layer_idx = d_att, layer_idx
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear_QV = nn.Linear(d_model, d_att * att_nhead + expand_d_model)
+        self.linear_U = nn.Linear(d_model, expand_d_model)
+        if layer_idx == 0:
+            self.linear_ID_V = nn.Linear(d_model, expand_d_model)
+        else:
+            self.id_norm1 = nn.LayerNorm(d_model)
+            self.linear_ID_V = nn.Linear(d_model * 2, expand_d_model)
+            self.linear_ID_U = nn.Linear(d_model, expand_d_model)
+        self.long_term_attn = GatedPropagation(d_qk=d_model, d_vu=d_model * 2, num_head=att_nhead, use_linear=False,
+                                               dropout=lt_dropout, d_att=d_att, top_k=-1, expand_ratio=expand_ratio)
+        self.short_term_attn = LocalGatedPropagation(d_qk=d_model, d_vu=d_model * 2, num_head=att_nhead,
+                                                     dilation=local_dilation, use_linear=False, dropout=st_dropout,
+                                                     d_att=d_att, max_dis=max_local_dis, expand_ratio=expand_ratio)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.id_norm2 = nn.LayerNorm(d_model)
+        self.self_attn = GatedPropagation(d_model * 2, d_model * 2, self_nhead, d_att=d_att)
+        self._p = None
+
+    def pack(self):
+        if self._p is None:
+            p = {}
+            wqv, bqv = linear_t(self.linear_QV)                       # [256, 128 + 512]
+            da = self.d_att * self.att_nhead
+            p['q_w'], p['q_b'] = wqv[:, :da], bqv[:da].contiguous()   # column views of one packed matrix (ldb = 640)
+            p['v_w'], p['v_b'] = wqv[:, da:], bqv[da:].contiguous()
+            p['u_w'], p['u_b'] = linear_t(self.linear_U)
+            widv, p['idv_b'] = linear_t(self.linear_ID_V)
+            if self.layer_idx == 0:
+                p['idv_w_id'] = widv
+            else:
+                D = self.d_model
+                p['idv_w_prev'], p['idv_w_id'] = widv[:D].contiguous(), widv[D:].contiguous()
+                p['idu_w'], p['idu_b'] = linear_t(self.linear_ID_U)
+                p['id_norm1'] = _ln_params(self.id_norm1)
+            for n in ('norm1', 'norm2', 'id_norm2'):
+                p[n] = _ln_params(getattr(self, n))
+            for m in (self.long_term_attn, self.short_term_attn, self.self_attn):
+                m.pack()
+            self._p = p
+        return self._p
+
+    def fuse_id_into(self, vcat, prev_idv, id_emb, ws, stream):
+        """ID_V = silu(linear_ID_V([prev_ID_V,] id_emb)) written into vcat[:, E:] (transformer.py:659-665)."""
+        p = self.pack()
+        E = self.expand_d_model
+        dst = vcat[:, E:]
+        if self.layer_idx == 0:
+            aot_hip.linear(id_emb, p['idv_w_id'], p['idv_b'], dst, act=aot_hip.ACT_SILU, stream=stream)
+        else:
+            tmp = ws.get('gpm_idv_tmp', (vcat.shape[0], E), vcat.device)
+            aot_hip.linear(prev_idv, p['idv_w_prev'], p['idv_b'], tmp, stream=stream)
+            aot_hip.linear(id_emb, p['idv_w_id'], None, dst, res=tmp, act=aot_hip.ACT_SILU, stream=stream)
+        return vcat
+
+    def update_memory_kv(self, mem, id_emb, ws, stream):
+        """deaot_engine.py:29-45: only ID_V is refreshed with the new identity embedding; K, V stay."""
+        ck, vcat, xi = mem[0], mem[1], mem[4]
+        return ck, self.fuse_id_into(vcat, xi, id_emb, ws, stream)
+
+    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, t_long=None):
+        """X [N, 2D] = [tgt | tgt_id] (tgt_id = 0 into layer 0).  Returns (X_out, curr_K, curr_Vcat, glob, loc, curr_ID_V)."""
+        p = self.pack()
+        N = X.shape[0]
+        D, E, da = self.d_model, self.expand_d_model, self.d_att
+        dev = X.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        x1 = ws.get('gpm_x1', (N, D), dev)
+        aot_hip.layernorm(X[:, :D], *p['norm1'], x1, stream=stream)
+        qc = new(N, da)                                                     # curr_Q == curr_K (:597)
+        aot_hip.linear(x1, p['q_w'], p['q_b'], qc, stream=stream)
+        vcat = new(N, 2 * E)                                                # [curr_V | ID_V]
+        aot_hip.linear(x1, p['v_w'], p['v_b'], vcat[:, :E], act=aot_hip.ACT_SILU, stream=stream)
+        if self.layer_idx == 0:                                             # U = [silu(U) | 1] (:602-606)
+            key = ('gpm_U0', (N, 2 * E), torch.float32, str(dev))
+            fresh = key not in ws._bufs
+            U = ws.get('gpm_U0', (N, 2 * E), dev)
+            if fresh:
+                U[:, E:].fill_(1.0)
+            aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
+            xi = None
+        else:                                                               # U = silu([U | linear_ID_U(LN(tgt_id))]) (:608-611)
+            xi = new(N, D)
+            aot_hip.layernorm(X[:, D:], *p['id_norm1'], xi, stream=stream)
+            U = ws.get('gpm_U', (N, 2 * E), dev)
+            aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
+            aot_hip.linear(xi, p['idu_w'], p['idu_b'], U[:, E:], act=aot_hip.ACT_SILU, stream=stream)
+        if id_emb is not None:                                              # reference frame (:613-620)
+            self.fuse_id_into(vcat, xi, id_emb, ws, stream)
+            gk, gv, t = qc, vcat, N
+            lk, lv = qc, vcat
+        else:
+            gk, gv = long_mem
+            lk, lv = short_mem
+            t = t_long if t_long is not None else gk.shape[0]
+        raw = ws.get('gpm_raw', (N, 2 * E), dev)
+        self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream)
+        Xm = ws.get('gpm_Xm', (N, 2 * D), dev)
+        self.long_term_attn.tail(raw, Xm, size_2d, ws, stream, res=X)      # X + lt
+        self.short_term_attn.core(qc, lk, lv, U, raw, size_2d, ws, stream)
+        self.short_term_attn.tail(raw, Xm, size_2d, ws, stream, res=Xm)     # + st   (:633-641)
+        # self gated propagation on [LN(tgt) | LN(tgt_id)]  (:643-653)
+        z = ws.get('gpm_z', (N, 2 * D), dev)
+        aot_hip.layernorm(Xm[:, :D], *p['norm2'], z[:, :D], stream=stream)
+        aot_hip.layernorm(Xm[:, D:], *p['id_norm2'], z[:, D:], stream=stream)
+        sp = self.self_attn.pack()
+        qk = ws.get('gpm_sqk', (N, da), dev)
+        aot_hip.linear(z, sp['QK_w'], sp['QK_b'], qk, stream=stream)
+        sv = ws.get('gpm_sv', (N, 2 * E), dev)
+        su = ws.get('gpm_su', (N, 2 * E), dev)
+        aot_hip.linear(z[:, :D], sp['V1_w'], sp['V1_b'], sv[:, :E], act=aot_hip.ACT_SILU, stream=stream)
+        aot_hip.linear(z[:, D:], sp['V2_w'], sp['V2_b'], sv[:, E:], act=aot_hip.ACT_SILU, stream=stream)
+        aot_hip.linear(z[:, :D], sp['U1_w'], sp['U1_b'], su[:, :E], act=aot_hip.ACT_SILU, stream=stream)
+        aot_hip.linear(z[:, D:], sp['U2_w'], sp['U2_b'], su[:, E:], act=aot_hip.ACT_SILU, stream=stream)
+        self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream)
+        Xo = ws.get('gpm_Xo_%d' % self.layer_idx, (N, 2 * D), dev)
+        self.self_attn.tail(raw, Xo, size_2d, ws, stream, res=Xm)
+        return Xo, qc, vcat, (gk, gv, t), (lk, lv), xi
+
+    def fuse_key_value_id(self, key, value, id_emb):
+        """Reference API (transformer.py:659-665): returns (None, ID_V [N,1,E])."""
+        n, b, c = id_emb.shape
+        E = self.expand_d_model
+        vcat = torch.empty(n * b, 2 * E, dtype=torch.float32, device=id_emb.device)
+        prev = value.reshape(n * b, -1).contiguous() if value is not None else None
+        from networks.layers.workspace import Workspace
+        if not hasattr(self, '_own_ws'):
+            self._own_ws = Workspace()
+        self.fuse_id_into(vcat, prev, id_emb.reshape(n * b, c).contiguous(), self._own_ws, aot_hip.stream_ptr())
+        return None, vcat[:, E:].unsqueeze(1)
+
+
+class DualBranchGPM(nn.Module):
+    """DeAOT stack (reference transformer.py:143-255)."""
+
+    def __init__(self, num_layers=2, d_model=256, self_nhead=8, att_nhead=8, dim_feedforward=1024, emb_dropout=0.,
+                 droppath=0.1, lt_dropout=0., st_dropout=0., droppath_lst=False, droppath_scaling=False,
+                 activation='gelu', return_intermediate=False, intermediate_norm=True, final_norm=True):
+        super().__init__()
+        self.intermediate_norm, self.final_norm = intermediate_norm, final_norm
+        self.num_layers, self.return_intermediate = num_layers, return_intermediate
+        self.d_model = d_model
+        self.layers = nn.ModuleList([
+            GatedPropagationModule(d_model, self_nhead, att_nhead, dim_feedforward, droppath, lt_dropout, st_dropout,
+                                   droppath_lst, activation, layer_idx=i) for i in range(num_layers)])
+        num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
+        self.decoder_norms = nn.ModuleList([GroupNorm1D(d_model * 2, 2) for _ in range(num_norms)]) if num_norms > 0 else None
+        if intermediate_norm:
+            raise NotImplementedError('DeAOT decodes the last GPM output only (default_deaot.py:12)')
+
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, t_long=None):
+        """Returns (dec_in [N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last layer, [dec_in], mems)."""
+        N, D = x0.shape
+        dev = x0.device
+        X = ws.get('gpm_X0', (N, 2 * D), dev)
+        X[:, :D].copy_(x0)
+        X[:, D:].zero_()                                                    # tgt_id = 0 (transformer.py:602-603)
+        mems = []
+        for i, layer in enumerate(self.layers):
+            X, ck, cv, glob, loc, xi = layer.run(X, long_mems[i] if long_mems is not None else None,
+                                                 short_mems[i] if short_mems is not None else None,
+                                                 id_emb, pos, size_2d, ws, stream, t_long)
+            mems.append((ck, cv, glob, loc, xi))
+        out = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+        gn = self.decoder_norms[-1].gn
+        aot_hip.groupnorm(X, gn.weight, gn.bias, out, 2, ws.get('gn_scratch', (32 * 64 * 2,), dev, torch.float64),
+                          ws.get('gn_stats', (64,), dev, torch.float64), act=aot_hip.ACT_NONE, nsplit=64, stream=stream)
+        return out, [out], mems

@@ -168,6 +168,8 @@ class AOT(nn.Module):
         cat = self._as_cat(toks)
         sc = [(to_tokens(s), s.shape[2], s.shape[3]) for s in shortcuts[:3]]
         x_in = cat if self.decoder.decode_intermediate_input else toks[-1]
+        if x_in.shape[1] != self.decoder.in_dim:
+            raise aot_hip.AotHipError('decoder expects %d input channels, got %d' % (self.decoder.in_dim, x_in.shape[1]))
         logits, h4, w4 = self.decoder.run(x_in, sc[2], sc[1], sc[0], self.ws, stream)
         out = torch.empty(1, logits.shape[1], h4, w4, dtype=torch.float32, device=logits.device)
         aot_hip.nhwc_to_nchw(logits, out, logits.shape[1], h4, w4, stream=stream)
@@ -188,23 +190,25 @@ class AOT(nn.Module):
             return torch.as_strided(base, (base.shape[0], total), (ld, 1), base.storage_offset())
         return torch.cat(toks, 1)
 
+    def _mems_in(self, mems):
+        """reference-shaped per-layer memories -> token-major (K, V) pairs."""
+        return [(to_tokens(m[0]), to_tokens(m[1])) for m in mems] if mems is not None else None
+
+    def _mems_out(self, mems, size_2d):
+        h, w = size_2d
+        seq = lambda t: t.unsqueeze(1)
+        curr = [[seq(m[0]), seq(m[1])] for m in mems]
+        long_ = [[seq(m[2][0][:m[2][2]]), seq(m[2][1][:m[2][2]])] for m in mems]
+        short = [[as_map(m[3][0], h, w), as_map(m[3][1], h, w)] for m in mems]
+        return curr, long_, short
+
     def LSTT_forward(self, curr_embs, long_term_memories, short_term_memories, curr_id_emb=None, pos_emb=None,
                      size_2d=(30, 30)):
         stream = aot_hip.stream_ptr()
         x = to_tokens(curr_embs[-1])
-        N, C = x.shape
-        L = self.LSTT.num_layers
-        cat = torch.empty(N, (L + 1) * C, dtype=torch.float32, device=x.device)
-        cat[:, :C].copy_(x)
         pos = to_tokens(pos_emb) if pos_emb is not None else None
         idt = to_tokens(curr_id_emb) if curr_id_emb is not None else None
-        lm = [(to_tokens(m[0]), to_tokens(m[1])) for m in long_term_memories] if long_term_memories is not None else None
-        sm = [(to_tokens(m[0]), to_tokens(m[1])) for m in short_term_memories] if short_term_memories is not None else None
-        outs, mems = self.LSTT.run(cat[:, :C], lm, sm, idt, pos, size_2d, self.ws, stream, cat)
-        h, w = size_2d
-        seq = lambda t: t.unsqueeze(1)
-        lstt_embs = [seq(o) for o in outs]
-        curr = [[seq(ck), seq(cv)] for (ck, cv, _, _) in mems]
-        long_ = [[seq(g[0][:g[2]]), seq(g[1][:g[2]])] for (_, _, g, _) in mems]
-        short = [[as_map(l[0], h, w), as_map(l[1], h, w)] for (_, _, _, l) in mems]
-        return lstt_embs, curr, long_, short
+        _, outs, mems = self.LSTT.run(x, self._mems_in(long_term_memories), self._mems_in(short_term_memories), idt, pos,
+                                      size_2d, self.ws, stream)
+        curr, long_, short = self._mems_out(mems, size_2d)
+        return [o.unsqueeze(1) for o in outs], curr, long_, short

@@ -1,0 +1,53 @@
+"""DeAOT model (reference networks/models/deaot.py:8-55): AOT with the LSTT replaced by the dual-branch gated
+propagation stack, a decoder fed by the last GPM output only, and a LayerNorm on the identity embedding."""
+import torch
+import torch.nn as nn
+
+import aot_hip
+from networks.decoders import build_decoder
+from networks.layers.transformer import DualBranchGPM
+from networks.models.aot import AOT, as_map, to_tokens
+
+
+class DeAOT(AOT):
+    def __init__(self, cfg, encoder='mobilenetv2', decoder='fpn'):
+        super().__init__(cfg, encoder, decoder)
+        emb = cfg.MODEL_ENCODER_EMBEDDING_DIM
+        self.LSTT = DualBranchGPM(
+            cfg.MODEL_LSTT_NUM, emb, cfg.MODEL_SELF_HEADS, cfg.MODEL_ATT_HEADS,
+            emb_dropout=cfg.TRAIN_LSTT_EMB_DROPOUT, droppath=cfg.TRAIN_LSTT_DROPPATH,
+            lt_dropout=cfg.TRAIN_LSTT_LT_DROPOUT, st_dropout=cfg.TRAIN_LSTT_ST_DROPOUT,
+            droppath_lst=cfg.TRAIN_LSTT_DROPPATH_LST, droppath_scaling=cfg.TRAIN_LSTT_DROPPATH_SCALING,
+            intermediate_norm=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, return_intermediate=True)
+        decoder_indim = emb * (cfg.MODEL_LSTT_NUM * 2 + 1) if cfg.MODEL_DECODER_INTERMEDIATE_LSTT else emb * 2
+        self.decoder = build_decoder(decoder, in_dim=decoder_indim, out_dim=cfg.MODEL_MAX_OBJ_NUM + 1,
+                                     decode_intermediate_input=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, hidden_dim=emb,
+                                     shortcut_dims=cfg.MODEL_ENCODER_DIM, align_corners=cfg.MODEL_ALIGN_CORNERS)
+        self.id_norm = nn.LayerNorm(emb)
+
+    def id_emb_from_mask(self, mask, size_2d, stream=None):
+        """fused one-hot + id bank (models/aot.py:76-79) followed by LayerNorm over channels (deaot.py:51-55)."""
+        stream = stream if stream is not None else aot_hip.stream_ptr()
+        raw = super().id_emb_from_mask(mask, size_2d, stream)
+        out = torch.empty_like(raw)
+        aot_hip.layernorm(raw, self.id_norm.weight, self.id_norm.bias, out, stream=stream)
+        return out
+
+    # reference-shaped memories: [K, V, None, ID_V] per layer (transformer.py:655-657) <-> token-major (K, [V | ID_V])
+    def _mems_in(self, mems):
+        if mems is None:
+            return None
+        out = []
+        for m in mems:
+            k, v, idv = to_tokens(m[0]), to_tokens(m[1]), to_tokens(m[3])
+            out.append((k, torch.cat([v, idv], 1)))
+        return out
+
+    def _mems_out(self, mems, size_2d):
+        h, w = size_2d
+        E = self.LSTT.layers[0].expand_d_model
+        seq = lambda t: t.unsqueeze(1)
+        curr = [[seq(m[0]), seq(m[1][:, :E]), None, None if m[4] is None else seq(m[4])] for m in mems]
+        long_ = [[seq(m[2][0][:m[2][2]]), seq(m[2][1][:m[2][2], :E]), None, seq(m[2][1][:m[2][2], E:])] for m in mems]
+        short = [[as_map(m[3][0], h, w), as_map(m[3][1][:, :E], h, w), None, as_map(m[3][1][:, E:], h, w)] for m in mems]
+        return curr, long_, short

@@ -29,6 +29,8 @@ extern "C" {
 #define AOT_ACT_NONE 0
 #define AOT_ACT_RELU 1
 #define AOT_ACT_RELU6 2
+#define AOT_ACT_GELU 3 /* GroupNorm apply only */
+#define AOT_ACT_SILU 4 /* conv/linear epilogue only */
 
 /* library identification: "aot_hip <version> gfx950" */
 const char* aot_hip_version(void);
@@ -101,8 +103,18 @@ int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* ga
 int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
                  int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo,
                  float scale_div, int nsplit, void* stream);
-/* Merge of the nsplit partials written by aot_attn_f32(nsplit > 1) into out [Nq, ldo]. */
-int aot_attn_merge_f32(const float* part, float* out, int Nq, int H, int d, int ldo, int nsplit, void* stream);
+/* Merge of the nsplit partials written by aot_attn_f32 / aot_gated_attn_f32 (nsplit > 1) into out [Nq, ldo]:
+ * C output channels in H groups that carry one (m, l) each; optional gate [Nq, ldg] multiplies the result. */
+int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq, int H, int C, int ldg,
+                       int ldo, int nsplit, void* stream);
+
+/* Gated-propagation attention of DeAOT, single head: out = softmax((q/scale_div) k^T) v  (* gate), with
+ * q [Nq, dqk=128], k [T, 128], v [T, dv] (dv a multiple of 256; 1024 = [V | ID_V]), gate/out [Nq, dv].
+ * Same split/merge protocol as aot_attn_f32 with H := dv/256 groups; with nsplit > 1 pass the gate to
+ * aot_attn_merge_f32 instead.  Replaces GatedPropagation.forward's core, attention.py:672-707. */
+int aot_gated_attn_f32(const float* q, const float* k, const float* v, const float* gate, float* out,
+                       float* part, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldk,
+                       int ldv, int ldg, int ldo, float scale_div, int nsplit, void* stream);
 
 /* Short-term (windowed) attention of AOT, fused: window dot products, relative-position key
  * bias (grouped 1x1 conv on the UNSCALED q), border masking, softmax over the (2*max_dis+1)^2
@@ -118,6 +130,15 @@ int aot_local_attn_f32(const float* q, const float* k, const float* v, const flo
                        const float* relk_b, const float* relv_t, float* out, int h, int w, int H,
                        int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
                        void* stream);
+
+/* Short-term gated propagation of DeAOT (single head): window scores on q = k [h*w, 128] with the relative-position
+ * key bias, softmax over the 15x15 window, aggregation of v [h*w, dv] (dv % 32 == 0) and multiplication by the
+ * gate [h*w, dv] (may be NULL).  relk_t [15][128][16] (sqrt(128)-scaled, layout of aot_local_attn_f32 with one
+ * head), relk_b [15][16]; prob is a [225, h*w] scratch map.  Three launches (scores, softmax, aggregate).
+ * Replaces LocalGatedPropagation.forward up to `agg_value * u`, attention.py:789-855. */
+int aot_local_gated_f32(const float* q, const float* k, const float* v, const float* gate, const float* relk_t,
+                        const float* relk_b, float* prob, float* out, int h, int w, int dqk, int dv, int max_dis,
+                        int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div, void* stream);
 
 /* Identity-bank embedding of a label map: out[(Y,X), c] = bias[c] + sum_{ky,kx} table[label(16Y+ky-pad,
  * 16X+kx-pad), ky, kx, c] over in-image taps; labels outside [0, nlabel) or non-integer add nothing.

@@ -436,8 +436,8 @@ class OracleModel:
         sd = self.sd
         if self.deaot:
             def norm(t, j):   # GroupNorm1D(512, 2 groups), basic.py:6-12
-                return F.group_norm(t.permute(1, 2, 0), 2, sd['LSTT.decoder_norms.%d.weight' % j],
-                                    sd['LSTT.decoder_norms.%d.bias' % j], 1e-5).permute(2, 0, 1)
+                return F.group_norm(t.permute(1, 2, 0), 2, sd['LSTT.decoder_norms.%d.gn.weight' % j],
+                                    sd['LSTT.decoder_norms.%d.gn.bias' % j], 1e-5).permute(2, 0, 1)
         else:
             def norm(t, j):
                 return _ln(t, sd, 'LSTT.decoder_norms.%d' % j)

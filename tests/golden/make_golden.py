@@ -32,6 +32,11 @@ CASES = {
     # BASELINE config 2: R50-AOTL, 480p, 10 objects; 7 frames so the long-term bank grows to M=2 (gap 5)
     'c2_r50_aotl': dict(model='r50_aotl', frames=7, in_size=(481, 849), out_size=(480, 854), num_obj=10, clip=0,
                         keep_logits=(1, 5, 6)),
+    # DeAOT (gated propagation): DeAOTT small, and R50-DeAOTL at 480p with bank growth
+    'c3a_deaott': dict(model='deaott', frames=4, in_size=(257, 257), out_size=(256, 256), num_obj=2, clip=1,
+                       keep_logits=(1, 3)),
+    'c3b_r50_deaotl': dict(model='r50_deaotl', frames=7, in_size=(481, 849), out_size=(480, 854), num_obj=10, clip=2,
+                           keep_logits=(1, 6), keep_lstt=False),
     # ragged case: odd sizes, 3 objects, AOTT
     'c1b_aott_ragged': dict(model='aott', frames=4, in_size=(193, 305), out_size=(190, 300), num_obj=3, clip=3,
                             keep_logits=(1, 3)),
@@ -42,7 +47,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     keys = {}
+    only = set(sys.argv[1:])
+    kp = os.path.join(HERE, 'state_dict_keys.json')
+    if only and os.path.exists(kp):
+        keys = json.load(open(kp))
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         net, make_engine, cfg = refdriver.build_reference(c['model'])
         ref_sd = net.state_dict()
         keys[c['model']] = [[k, list(v.shape)] for k, v in ref_sd.items()]
@@ -58,7 +69,8 @@ def main():
             gaps.append([int((gap < 1e-3).sum()), int((gap < 1e-4).sum()), float(gap.min())])
             if t in c['keep_logits']:
                 out['logits4_%d' % t] = r['logits4'][0, :no].numpy()
-                out['lstt_last_%d' % t] = r['lstt'][-1][:, 0].numpy()
+                if c.get('keep_lstt', True):
+                    out['lstt_last_%d' % t] = r['lstt'][-1][:, 0].numpy()
             out['gapmask_%d' % t] = np.packbits((gap < 2e-4).numpy())     # pixels where argmax is a near-tie
         out['gaps'] = np.array(gaps)
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)

@@ -287,6 +287,43 @@ def test_local_attention_vs_oracle(hip, h, w):
     _close(out, ref, 2e-5, 'local attention')
 
 
+@pytest.mark.parametrize('Nq,T,nsplit', [(1674, 1674, 1), (1674, 2 * 1674 + 7, 6), (100, 45, 1), (289, 289, 3)])
+def test_gated_attention_vs_fp64(hip, Nq, T, nsplit):
+    """DeAOT global gated propagation core (attention.py:672-707): one 128-wide head, 1024-wide value, gate."""
+    g = torch.Generator().manual_seed(Nq * 7 + T)
+    q, k = torch.randn(Nq, 128, generator=g), torch.randn(T + 3, 128, generator=g)
+    v, u = torch.randn(T + 3, 1024, generator=g), torch.randn(Nq, 1024, generator=g)
+    k[T:], v[T:] = float('nan'), float('nan')
+    ref = (torch.softmax((q.double() / 128 ** 0.5) @ k[:T].double().t(), -1) @ v[:T].double() * u.double()).float()
+    out = torch.full((Nq, 1024), float('nan'), device='cuda')
+    part = torch.empty(nsplit * Nq * (1024 + 8), device='cuda') if nsplit > 1 else None
+    hip.gated_attention(_dev(q), _dev(k), _dev(v), _dev(u), out, T, 128 ** 0.5, part=part, nsplit=nsplit)
+    _close(out, ref, 3e-5, 'gated attention')
+
+
+@pytest.mark.parametrize('h,w', [(31, 54), (9, 70), (17, 17)])
+def test_local_gated_vs_oracle(hip, h, w):
+    """DeAOT short-term gated propagation up to `agg * u` (attention.py:814-855) vs the oracle's window helpers."""
+    from oracle.aot_oracle import local_window_aggregate, local_window_scores
+    g = torch.Generator().manual_seed(h * 31 + w)
+    N, E = h * w, 1024
+    q, k = torch.randn(N, 128, generator=g) * 1.5, torch.randn(N, 128, generator=g) * 1.5
+    v, u = torch.randn(N, E, generator=g), torch.randn(N, E, generator=g)
+    relw, relb = torch.randn(225, 128, generator=g) * 0.2, torch.randn(225, generator=g) * 0.3
+    to2d = lambda t: t.double().view(h, w, 1, -1).permute(2, 3, 0, 1)
+    q2, k2, v2 = to2d(q), to2d(k), to2d(v)
+    rel = F.conv2d(q2, relw.double().view(225, 128, 1, 1), relb.double()).view(1, 1, 225, h, w)
+    sc, valid = local_window_scores(q2 / 128 ** 0.5, k2, 1)
+    a = torch.softmax((sc + rel).masked_fill(~valid.view(1, 1, 225, h, w), float('-inf')), dim=2)
+    ref = (local_window_aggregate(a, v2, 1).view(E, N).t() * u.double()).float()
+    tk = F.pad((relw.double().view(15, 15, 128) * 128 ** 0.5).float().permute(0, 2, 1), (0, 1)).contiguous()
+    tb = F.pad(relb.view(15, 15), (0, 1)).contiguous()
+    out = torch.empty(N, E, device='cuda')
+    prob = torch.empty(225 * N, device='cuda')
+    hip.local_gated(_dev(q), _dev(k), _dev(v), _dev(u), _dev(tk), _dev(tb), prob, out, h, w, 128 ** 0.5)
+    _close(out, ref, 3e-5, 'local gated')
+
+
 # ------------------------------------------------------------------ end to end -------------------
 def _hip_engine(model_name, **kw):
     from networks.engines import build_engine
@@ -297,7 +334,7 @@ def _hip_engine(model_name, **kw):
     return cfg, model, eng, sd
 
 
-@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl'])
+@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl'])
 def test_end_to_end_vs_reference_golden(hip, case):
     """BASELINE configs 1 and 2 through the engine API on the GPU vs the real reference's outputs
     (teacher-forced with the reference masks so every frame sees identical history)."""
