@@ -33,6 +33,8 @@ _SIGS = {
     'aot_gated_attn_f32': [_P] * 6 + [_I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
     'aot_local_gated_f32': [_P] * 8 + [_I] * 10 + [_F, _P],
+    'aot_swin_window_attn_f32': [_P] * 4 + [_I] * 8 + [_F, _P],
+    'aot_patch_merge_f32': [_P, _P] + [_I] * 4 + [_P],
     'aot_idbank_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 8 + [_P],
@@ -218,6 +220,19 @@ def local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_d
                                     _dev(out), h, w, q.shape[1], out.shape[1], max_dis, q.stride(0), k.stride(0),
                                     v.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0), scale_div,
                                     stream if stream is not None else stream_ptr()), 'aot_local_gated_f32')
+    return out
+
+
+def swin_window_attention(qkv, qkv_bias, table, out, H, W, C, nH, shift, scale, stream=None):
+    _chk(load().aot_swin_window_attn_f32(_dev(qkv), _dev(qkv_bias), _dev(table), _dev(out), H, W, C, nH, 7, shift,
+                                         qkv.stride(0), out.stride(0), scale,
+                                         stream if stream is not None else stream_ptr()), 'aot_swin_window_attn_f32')
+    return out
+
+
+def patch_merge(x, out, H, W, C, stream=None):
+    _chk(load().aot_patch_merge_f32(_dev(x), _dev(out), H, W, C, x.stride(0),
+                                    stream if stream is not None else stream_ptr()), 'aot_patch_merge_f32')
     return out
 
 

@@ -22,6 +22,7 @@ __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == AOT_ACT_RELU) return fmaxf(v, 0.f);
   if (act == AOT_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  if (act == AOT_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // exact-erf GELU (nn.GELU)
   if (act == AOT_ACT_SILU) return v * (1.f / (1.f + expf(-v)));   // x * sigmoid(x), attention.py:585-586
   return v;
 }

@@ -1,7 +1,8 @@
-"""Encoder factory (reference networks/encoders/__init__.py:10-35).  Built: resnet50 / resnet101 and
-mobilenetv2 (BASELINE configs 1, 2, 4); the other backbones of the reference are not on the scoped path."""
+"""Encoder factory (reference networks/encoders/__init__.py:10-35).  Built: resnet50 / resnet101,
+mobilenetv2 and swin_base (BASELINE configs 1-4); the other backbones of the reference are not on the scoped path."""
 from networks.encoders.mobilenetv2 import MobileNetV2
 from networks.encoders.resnet import ResNet50, ResNet101
+from networks.encoders.swin import build_swin_model
 from networks.layers.normalization import FrozenBatchNorm2d
 
 
@@ -14,4 +15,6 @@ def build_encoder(name, frozen_bn=True, freeze_at=-1):
         return ResNet50(16, FrozenBatchNorm2d, freeze_at=freeze_at)
     if name == 'resnet101':
         return ResNet101(16, FrozenBatchNorm2d, freeze_at=freeze_at)
+    if 'swin' in name:
+        return build_swin_model(name, freeze_at=freeze_at)
     raise NotImplementedError('encoder %r is outside the scoped hot path (SURVEY.md section 2, rows 9-10)' % name)

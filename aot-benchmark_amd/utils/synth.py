@@ -25,11 +25,13 @@ def synth_tensor(key, ref, all_keys):
     g = _gen(key)
     leaf = key.rsplit('.', 1)[-1]
     if not ref.is_floating_point():
-        return torch.zeros(shape, dtype=ref.dtype)
+        return ref.detach().clone()          # index buffers (Swin relative_position_index) are structural: keep
     if leaf == 'running_mean':
         return 0.1 * torch.randn(shape, generator=g)
     if leaf == 'running_var':
         return 1.0 + 0.1 * torch.rand(shape, generator=g)
+    if leaf == 'relative_position_bias_table':
+        return 0.5 * torch.randn(shape, generator=g)
     if leaf == 'relative_emb_v':
         return 0.05 * torch.randn(shape, generator=g)
     if leaf == 'mask_token':

@@ -29,7 +29,7 @@ extern "C" {
 #define AOT_ACT_NONE 0
 #define AOT_ACT_RELU 1
 #define AOT_ACT_RELU6 2
-#define AOT_ACT_GELU 3 /* GroupNorm apply only */
+#define AOT_ACT_GELU 3 /* exact-erf GELU */
 #define AOT_ACT_SILU 4 /* conv/linear epilogue only */
 
 /* library identification: "aot_hip <version> gfx950" */
@@ -139,6 +139,16 @@ int aot_local_attn_f32(const float* q, const float* k, const float* v, const flo
 int aot_local_gated_f32(const float* q, const float* k, const float* v, const float* gate, const float* relk_t,
                         const float* relk_b, float* prob, float* out, int h, int w, int dqk, int dv, int max_dis,
                         int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div, void* stream);
+
+/* Swin window attention (W-MSA / SW-MSA, 7x7 windows, heads of width 32), fused with the reference's pad / roll /
+ * window_partition / window_reverse / crop: qkv [H*W, ld] = [q | k | v] (C each) is the output of the qkv Linear on the
+ * LayerNormed tokens, qkv_bias [3C] is its bias (the value padded tokens take), rpb_table [169, nH], out [H*W, ldo]
+ * (pre-projection).  shift = 0 or 3.  Replaces WindowAttention.forward + the index plumbing of
+ * SwinTransformerBlock.forward, networks/encoders/swin/swin_transformer.py:159-199, 262-312. */
+int aot_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* rpb_table, float* out, int H, int W,
+                             int C, int nH, int window, int shift, int ld, int ldo, float scale, void* stream);
+/* PatchMerging gather (swin_transformer.py:338-356): x [H*W, ldx] -> out [ceil(H/2)*ceil(W/2), 4C], zero padded. */
+int aot_patch_merge_f32(const float* x, float* out, int H, int W, int C, int ldx, void* stream);
 
 /* Identity-bank embedding of a label map: out[(Y,X), c] = bias[c] + sum_{ky,kx} table[label(16Y+ky-pad,
  * 16X+kx-pad), ky, kx, c] over in-image taps; labels outside [0, nlabel) or non-integer add nothing.

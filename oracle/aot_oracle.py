@@ -48,6 +48,10 @@ SPECS = {
     'deaotl': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=3, mem_gap=5),
     'r50_deaotl': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, encoder='resnet50',
                        enc_dims=(256, 512, 1024, 1024), lstt_num=3, mem_gap=5),
+    'swinb_aotl': dict(_BASE, encoder='swin_base', enc_dims=(128, 256, 512, 512), lstt_num=3, mem_gap=5,
+                       align_corners=False),
+    'swinb_deaotl': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, encoder='swin_base',
+                         enc_dims=(128, 256, 512, 512), lstt_num=3, mem_gap=5, align_corners=False),
 }
 
 
@@ -153,6 +157,71 @@ def mobilenetv2_features(sd, x, p='encoder'):
         outs[idx] = x
     x = cbr(x, p + '.features.18')
     return [outs[3], outs[6], outs[13], x]
+
+
+def swin_features(sd, x, p='encoder', depths=(2, 2, 18), heads=(4, 8, 16), ws=7):
+    """Swin-B trunk, 3 stages (networks/encoders/swin/swin_transformer.py:684-716, build.py:11-27)."""
+    B, _, H, W = x.shape
+    if W % 4:
+        x = F.pad(x, (0, 4 - W % 4))                                                    # PatchEmbed :474-481
+    if H % 4:
+        x = F.pad(x, (0, 0, 0, 4 - H % 4))
+    x = _conv(x, sd, p + '.patch_embed.proj', 4)
+    h, w = x.shape[2:]
+    x = _ln(x.flatten(2).transpose(1, 2), sd, p + '.patch_embed.norm')                  # [B, hw, C]
+    outs = []
+    for li, (depth, nh) in enumerate(zip(depths, heads)):
+        C = x.shape[-1]
+        hp, wp = -(-h // ws) * ws, -(-w // ws) * ws
+        shift = ws // 2
+        # BasicLayer.forward :392-411: region labels of the shifted map -> additive -100 mask
+        img = torch.zeros(1, hp, wp, 1)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, hp // ws, ws, wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+        amask = mw.unsqueeze(1) - mw.unsqueeze(2)
+        amask = amask.masked_fill(amask != 0, -100.0).masked_fill(amask == 0, 0.0).to(x.dtype)
+        for bi in range(depth):
+            q = '%s.layers.%d.blocks.%d' % (p, li, bi)
+            sh = 0 if bi % 2 == 0 else shift
+            # SwinTransformerBlock.forward :262-318
+            y = _ln(x, sd, q + '.norm1').view(B, h, w, C)
+            y = F.pad(y, (0, 0, 0, wp - w, 0, hp - h))
+            if sh:
+                y = torch.roll(y, shifts=(-sh, -sh), dims=(1, 2))
+            win = y.view(B, hp // ws, ws, wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+            # WindowAttention.forward :159-199
+            nW, Nt, _ = win.shape
+            qkv = _lin(win, sd, q + '.attn.qkv').reshape(nW, Nt, 3, nh, C // nh).permute(2, 0, 3, 1, 4)
+            att = (qkv[0] * (C // nh) ** -0.5) @ qkv[1].transpose(-2, -1)
+            rpb = sd[q + '.attn.relative_position_bias_table'][sd[q + '.attn.relative_position_index'].view(-1)]
+            att = att + rpb.view(Nt, Nt, -1).permute(2, 0, 1).unsqueeze(0)
+            if sh:
+                att = att.view(B, nW // B, nh, Nt, Nt) + amask.unsqueeze(1).unsqueeze(0)
+                att = att.view(-1, nh, Nt, Nt)
+            att = torch.softmax(att, -1)
+            o = (att @ qkv[2]).transpose(1, 2).reshape(nW, Nt, C)
+            o = _lin(o, sd, q + '.attn.proj')
+            o = o.view(B, hp // ws, wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hp, wp, C)
+            if sh:
+                o = torch.roll(o, shifts=(sh, sh), dims=(1, 2))
+            x = x + o[:, :h, :w, :].reshape(B, h * w, C)
+            x = x + _lin(F.gelu(_lin(_ln(x, sd, q + '.norm2'), sd, q + '.mlp.fc1')), sd, q + '.mlp.fc2')   # Mlp :56-62
+        xo = _ln(x, sd, '%s.norm%d' % (p, li))
+        outs.append(xo.view(B, h, w, C).permute(0, 3, 1, 2).contiguous())
+        if li < len(depths) - 1:                                                         # PatchMerging :338-359
+            q = '%s.layers.%d.downsample' % (p, li)
+            y = x.view(B, h, w, C)
+            if h % 2 or w % 2:
+                y = F.pad(y, (0, 0, 0, w % 2, 0, h % 2))
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+            h, w = (h + 1) // 2, (w + 1) // 2
+            x = F.linear(_ln(y.view(B, h * w, 4 * C), sd, q + '.norm'), sd[q + '.reduction.weight'])
+    outs.append(outs[-1])
+    return outs
 
 
 # --------------------------------------------------------------------------
@@ -293,7 +362,7 @@ class OracleModel:
     # aot.py:81-84
     def encode_image(self, img):
         img = img.to(self.dtype)
-        f = resnet50_features if self.spec['encoder'] == 'resnet50' else mobilenetv2_features
+        f = {'resnet50': resnet50_features, 'swin_base': swin_features}.get(self.spec['encoder'], mobilenetv2_features)
         xs = f(self.sd, img)
         xs[-1] = _conv(xs[-1], self.sd, 'encoder_projector')
         return xs

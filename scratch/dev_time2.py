@@ -8,7 +8,8 @@ from utils.synth import synth_state_dict, synth_clip
 name = sys.argv[1]; T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = importlib.import_module('configs.models.' + name).ModelConfig()
 model = build_vos_model(cfg.MODEL_VOS, cfg); model.load_state_dict(synth_state_dict(model.state_dict())); model = model.cuda().eval()
-frames, mask, objs, out_size = synth_clip(0, T, in_size=(481, 849), out_size=(480, 854), num_obj=10, device='cuda')
+insz = (480, 848) if 'swin' in name else (481, 849)
+frames, mask, objs, out_size = synth_clip(0, T, in_size=insz, out_size=(480, 854), num_obj=10, device='cuda')
 eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP)
 for rep in range(2):
     eng.restart_engine()

@@ -37,6 +37,10 @@ CASES = {
                        keep_logits=(1, 3)),
     'c3b_r50_deaotl': dict(model='r50_deaotl', frames=7, in_size=(481, 849), out_size=(480, 854), num_obj=10, clip=2,
                            keep_logits=(1, 6), keep_lstt=False),
+    # BASELINE config 3 family: SwinB-DeAOTL (align_corners=False, 16x16 id bank, padded + shifted 7x7 windows at
+    # every stage: 48x64 -> 49x70, 24x32 -> 28x35, 12x16 -> 14x21), bank grows to M=2
+    'c3c_swinb_deaotl': dict(model='swinb_deaotl', frames=7, in_size=(192, 256), out_size=(190, 250), num_obj=3, clip=4,
+                             keep_logits=(1, 6), keep_lstt=False),
     # ragged case: odd sizes, 3 objects, AOTT
     'c1b_aott_ragged': dict(model='aott', frames=4, in_size=(193, 305), out_size=(190, 300), num_obj=3, clip=3,
                             keep_logits=(1, 3)),

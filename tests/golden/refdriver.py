@@ -22,11 +22,20 @@ def _enter():
     for name in list(sys.modules):
         if name.split('.')[0] in ('networks', 'configs', 'utils', 'dataloaders'):
             del sys.modules[name]
+    # our package dir holds REGULAR packages with the same names; the reference's are namespace packages (no
+    # __init__.py), which lose against a regular package anywhere on sys.path -- so take ours off the path
+    global _saved
+    _saved = [p for p in sys.path if p.rstrip('/').endswith('aot-benchmark_amd')]
+    sys.path[:] = [p for p in sys.path if p not in _saved]
     sys.path.insert(0, REF)
+
+
+_saved = []
 
 
 def _leave():
     sys.path.remove(REF)
+    sys.path[:0] = _saved
     for name in list(sys.modules):
         if name.split('.')[0] in ('networks', 'configs', 'utils', 'dataloaders'):
             del sys.modules[name]

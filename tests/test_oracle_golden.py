@@ -8,7 +8,7 @@ from common import LOGIT_TOL, case_clip, check_masks, load_case, run_teacher_for
 from oracle.aot_oracle import OracleEngine, OracleModel
 
 
-@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl'])
+@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl'])
 def test_oracle_matches_reference_golden(case):
     c, g = load_case(case)
     _, _, sd = synth_model_state(c['model'])

@@ -334,7 +334,7 @@ def _hip_engine(model_name, **kw):
     return cfg, model, eng, sd
 
 
-@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl'])
+@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl'])
 def test_end_to_end_vs_reference_golden(hip, case):
     """BASELINE configs 1 and 2 through the engine API on the GPU vs the real reference's outputs
     (teacher-forced with the reference masks so every frame sees identical history)."""
@@ -351,6 +351,21 @@ def test_end_to_end_vs_reference_golden(hip, case):
             assert err < 2e-4 < LOGIT_TOL, 'frame %d logits4 err %g' % (t, err)
             assert (l4[no:] == -1e10).all()
     print('%s: %d tie flips over %d frames' % (case, flips, len(res)))
+
+
+def test_swin_encoder_full_size_vs_oracle(hip):
+    """BASELINE config 3 encoder at its real size (480x848 -> 120x212 / 60x106 / 30x53 tokens, windows padded to
+    126x217 / 63x112 / 35x56): all three stage outputs + the projected feature vs the oracle."""
+    from oracle.aot_oracle import OracleModel
+    cfg, model, sd = synth_model_state('swinb_deaotl')
+    model = model.cuda().eval()
+    x = torch.randn(1, 3, 480, 848, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = OracleModel('swinb_deaotl', sd).encode_image(x)
+        got = model.encode_image(x.cuda())
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        _close(a, b, 2e-4, 'swin stage')
 
 
 def test_free_running_bank_growth_vs_oracle(hip):
