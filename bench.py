@@ -123,8 +123,13 @@ def attention_roofline(engine, clip, device):
     ms = sum(a.elapsed_time(b) for a, b, _ in recs)
     flop = sum(f for _, _, f in recs)
     n = len(recs)
+    traffic = None     # HBM/fabric bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
+    tp = os.path.join(ROOT, 'profiles', 'r01_attn_traffic.json')
+    if os.path.exists(tp):
+        with open(tp) as f:
+            traffic = round(json.load(f)['traffic_bytes_per_launch'])
     return {'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2), 'peak': FP32_MFMA_PEAK_TF,
-            'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), 'traffic': None,
+            'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), 'traffic': traffic,
             'kernel': 'attn_fwd_d32_kernel', 'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
             'gflop_per_launch': round(flop / n / 1e9, 3)}
 
