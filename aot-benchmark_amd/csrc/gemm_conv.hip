@@ -316,6 +316,150 @@ static int launch_direct(const ConvParams& p, bool is1x1, hipStream_t s) {
   AOT_LAUNCH_CHECK();
 }
 
+
+// Second generation of the wave-independent kernel: a wave owns a 64x32 output tile (two 32x32 fragments that
+// share the B operand -> two independent MFMA chains and half the B loads per MFMA), the register sets of
+// consecutive k slabs ping-pong (no copies), and B rows come through a buffer descriptor whose row offset is a
+// wave-uniform scalar (no address VALU; columns past ldb read 0 by the hardware bounds check).
+template <int KS, bool IS1X1>
+__global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams p) {
+  __shared__ float red[KS > 1 ? KS : 1][32][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, kh = lane >> 5;
+  const int nbn = (p.Cout + 31) >> 5, nbm = (p.M + 63) >> 6;
+  const int nwg = nbm * nbn, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * 64, n0 = bn * 32;
+  const int nslab = p.K >> 5;
+  const int per = (nslab + KS - 1) / KS;
+  const int s0 = wave * per, s1 = min(nslab, s0 + per);
+
+  bool row_ok[2];
+  const float* a1x1[2];
+  int iy0[2], ix0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + i * 32 + j;
+    row_ok[i] = m < p.M;
+    const int mm = row_ok[i] ? m : 0;
+    const int oy = mm / p.OW, ox = mm - oy * p.OW;
+    a1x1[i] = p.in + ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kh * 16 + (long)s0 * 32;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+  }
+  int c = 0, ky = 0, kx = 0;   // filter tap / channel of the NEXT slab to load (wave-uniform)
+  if (!IS1X1) {
+    const int k = s0 * 32;
+    const int tap = k / p.Cin;
+    c = k - tap * p.Cin;
+    ky = tap / p.KW;
+    kx = tap - ky * p.KW;
+  }
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.K * p.ldb * 4, 0x00020000);
+  const int n = n0 + j;
+  const int bvoff = (n < p.ldb) ? (kh * 16 * p.ldb + n) * 4 : 0x7ffffff0;   // out-of-range columns read 0
+  const int ldb4 = p.ldb * 4;
+
+  auto load = [&](float4 (&a)[2][4], float (&b)[16], int s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* src = nullptr;
+      if (IS1X1) {
+        if (row_ok[i]) src = a1x1[i];
+        a1x1[i] += 32;
+      } else {
+        const int iy = iy0[i] + ky * p.dil, ix = ix0[i] + kx * p.dil;
+        if (row_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          src = p.in + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) a[i][v] = src ? reinterpret_cast<const float4*>(src)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!IS1X1) {
+      c += 32;
+      if (c >= p.Cin) { c = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+    }
+    const int so = s * 32 * ldb4;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      b[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, bvoff, so + t * ldb4, 0));
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  auto mma = [&](const float4 (&a)[2][4], const float (&b)[16]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][v].x, b[4 * v], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][v].x, b[4 * v], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][v].y, b[4 * v + 1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][v].y, b[4 * v + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][v].z, b[4 * v + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][v].z, b[4 * v + 2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][v].w, b[4 * v + 3], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][v].w, b[4 * v + 3], acc1, 0, 0, 0);
+    }
+  };
+  float4 aA[2][4], aB[2][4];
+  float bA[16], bB[16];
+  if (s0 < s1) load(aA, bA, s0);
+  for (int s = s0; s < s1; s += 2) {
+    if (s + 1 < s1) load(aB, bB, s + 1);
+    mma(aA, bA);
+    if (s + 1 < s1) {
+      if (s + 2 < s1) load(aA, bA, s + 2);
+      mma(aB, bB);
+    }
+  }
+
+  // ---- in-block split-K reduction (fixed wave order) + epilogue: wave w finishes 32/KS of the 32 fragment rows ----
+  constexpr int RPW = 32 / KS;
+  float fin[RPW];
+  if (KS > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave][r][lane] = acc0[r]; red[wave][16 + r][lane] = acc1[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave * RPW + i;
+      float v = red[0][r][lane];
+#pragma unroll
+      for (int w = 1; w < KS; ++w) v += red[w][r][lane];
+      fin[i] = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { fin[i] = acc0[i]; fin[16 + i] = acc1[i]; }
+  }
+  if (n < p.Cout) {
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = (KS > 1 ? wave * RPW : 0) + i;      // 0..15 -> fragment 0, 16..31 -> fragment 1
+      const int mo = m0 + (r >> 4) * 32 + mfma32_row(r & 15, kh);
+      if (mo < p.M) {
+        float v = fin[i] + bv;
+        if (p.res) v += p.res[(long)mo * p.ldr + n];
+        p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
+      }
+    }
+  }
+}
+
+template <int KS>
+static int launch_direct2(const ConvParams& p, bool is1x1, hipStream_t s) {
+  const int nb = cdiv(p.M, 64) * cdiv(p.Cout, 32);
+  if (is1x1)
+    hipLaunchKernelGGL((gemm_direct2_kernel<KS, true>), dim3(nb), dim3(KS * 64), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_direct2_kernel<KS, false>), dim3(nb), dim3(KS * 64), 0, s, p);
+  AOT_LAUNCH_CHECK();
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
   const int nb = cdiv(p.M, BM) * cdiv(p.Cout, BN);
@@ -370,6 +514,10 @@ static int conv_dispatch(const float* in, const float* w, const float* bias, con
     case 12: return launch_direct<2>(p, is1x1, s);
     case 14: return launch_direct<4>(p, is1x1, s);
     case 18: return launch_direct<8>(p, is1x1, s);
+    case 21: return launch_direct2<1>(p, is1x1, s);
+    case 22: return launch_direct2<2>(p, is1x1, s);
+    case 24: return launch_direct2<4>(p, is1x1, s);
+    case 28: return launch_direct2<8>(p, is1x1, s);
     default: return AOT_ERR_BADARG;
   }
 }

@@ -288,10 +288,9 @@ class GatedPropagationModule(nn.Module):
         vcat = new(N, 2 * E)                                                # [curr_V | ID_V]
         aot_hip.linear(x1, p['v_w'], p['v_b'], vcat[:, :E], act=aot_hip.ACT_SILU, stream=stream)
         if self.layer_idx == 0:                                             # U = [silu(U) | 1] (:602-606)
-            key = ('gpm_U0', (N, 2 * E), torch.float32, str(dev))
-            fresh = key not in ws._bufs
+            nbuf = len(ws._bufs)
             U = ws.get('gpm_U0', (N, 2 * E), dev)
-            if fresh:
+            if len(ws._bufs) != nbuf:          # freshly allocated: set the constant half once
                 U[:, E:].fill_(1.0)
             aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
             xi = None

@@ -1,6 +1,7 @@
-"""Persistent device scratch buffers.  Buffers are allocated once per (name, shape) and reused every
+"""Persistent device scratch buffers.  Buffers are allocated once per (stream, name, shape) and reused every
 frame, so the steady state makes no allocator calls for intermediates and all pointers are stable
-(a prerequisite for hipGraph capture of the frame)."""
+(a prerequisite for hipGraph capture of the frame).  Keying on the current HIP stream gives every
+concurrently running clip (one stream each, see bench.py --streams) its own scratch set."""
 import torch
 
 
@@ -9,7 +10,7 @@ class Workspace:
         self._bufs = {}
 
     def get(self, name, shape, device, dtype=torch.float32):
-        key = (name, tuple(shape), dtype, str(device))
+        key = (name, tuple(shape), dtype, str(device), torch.cuda.current_stream(device).cuda_stream)
         buf = self._bufs.get(key)
         if buf is None:
             buf = torch.empty(shape, dtype=dtype, device=device)

@@ -8,7 +8,11 @@ A step = one propagated frame of the R50-AOTL engine at 481x849 input / 480x854 
 match_propogate_one_frame -> decode_current_logits -> softmax/argmax/nearest-resize -> update_memory,
 the exact call sequence of the reference's evaluator (networks/managers/evaluator.py:325-446,
 tools/demo.py:219-235).  Clips are 70 frames (the long-term bank grows from 1 to 14 frames, gap 5); frames
-are resident in HBM before the timed region.  Clips shard over ranks with no data-path collective
+are resident in HBM before the timed region.  Per-video inference is embarrassingly parallel, so each GPU
+runs --streams S clips concurrently, one HIP stream and one engine (memory bank, scratch) each, sharing the
+weights: most kernels of one 480p frame cannot fill 256 CUs on their own.  `value` is the whole-job
+throughput; `config.single_stream_fps` is the same job with S = 1 (one clip at a time, the reference's
+evaluation mode).  Clips shard over ranks with no data-path collective
 ("weak" scaling: every rank runs K frames); RCCL is used only for the barrier, the max-over-ranks time and
 one all_gather of a small stats vector (replaces the reference's mp.Queue, evaluator.py:507-531).
 
@@ -163,8 +167,9 @@ def cpu_baseline(sd, budget_s=20.0, max_frames=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=CLIP_FRAMES - 1)
+    ap.add_argument('--steps', type=int, default=3 * (CLIP_FRAMES - 1), help='propagated frames timed per GPU (default: one full 70-frame clip per stream)')
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--streams', type=int, default=3, help='clips processed concurrently per GPU (one HIP stream each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -182,31 +187,45 @@ def main():
 
     from utils.synth import synth_clip
     cfg, model, engine, sd = build_model(device)
-    nclips_rank = max(1, -(-args.steps // (CLIP_FRAMES - 1)))
+    S = max(1, args.streams)
+    nclips_stream = max(1, -(-args.steps // (S * (CLIP_FRAMES - 1))))
+    nclips_rank = S * nclips_stream
     my_ids = shard_clips(nclips_rank * world, rank, world)
     clips = []
     for cid in my_ids:
         frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
         clips.append((frames, mask, objs))
+    from networks.engines import build_engine
+    engines = [engine] + [build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
+                                       long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device) for _ in range(S)]
 
-    with torch.no_grad():
-        # warmup: W frames of a scratch clip (allocations, workspace, code objects)
-        warm = ClipRunner(engine, clips[:1])
-        for _ in range(args.warmup):
-            warm.step()
-        runner = ClipRunner(engine, clips)
+    def timed(runners, steps):
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            runner.step()
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % len(runners)]):
+                runners[i % len(runners)].step()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
-        elapsed = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        # warmup: W frames spread over the streams (allocations, per-stream workspaces, code objects)
+        warm = [ClipRunner(engines[i], clips[i:i + 1]) for i in range(S)]
+        for i in range(max(args.warmup, S)):
+            with torch.cuda.stream(streams[i % S]):
+                warm[i % S].step()
+        runners = [ClipRunner(engines[i], clips[i::S]) for i in range(S)]
+        elapsed = timed(runners, args.steps)
+        single = None
+        if S > 1 and rank == 0 and world == 1:      # the same job one clip at a time, for reference
+            single = args.steps / timed([ClipRunner(engines[0], clips[:1])], args.steps)
 
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if world > 1:
@@ -217,7 +236,8 @@ def main():
 
         roof = None
         if rank == 0 and not args.no_roofline:
-            roof = attention_roofline(engine, clips[0], device)
+            with torch.cuda.stream(streams[0]):
+                roof = attention_roofline(engines[0], clips[0], device)
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -234,7 +254,9 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
                                    '70 frames/clip, long-term gap 5 (configs[1])',
-                       'frames_per_clip': CLIP_FRAMES, 'clips_per_gpu': nclips_rank, 'parallelism': 'clip-sharded dp%d' % world,
+                       'frames_per_clip': CLIP_FRAMES, 'clips_per_gpu': nclips_rank, 'streams_per_gpu': S,
+                       'single_stream_fps': None if single is None else round(single, 2),
+                       'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (world, S),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
                        'timed_region': 'wall clock incl. reference-frame setup of each clip'},
             'roofline': roof, 'cpu_baseline': base,

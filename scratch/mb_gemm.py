@@ -32,11 +32,16 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
     out = torch.empty(M, ldb, device='cuda')
     gf = 2.0 * M * KK * Cout / 1e9
     row = []
+    ref_out = None
     for c in cfgs:
         if (c == 3 and Cout > 32) or (c >= 10 and Cin % 32): row.append('      -      -'); continue
         def run():
             aot_hip.conv2d_cfg(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, cfg=c)
         for _ in range(3): run()
+        if ref_out is None: ref_out = out[:, :Cout].clone()
+        else:
+            err = (out[:, :Cout] - ref_out).abs().max().item()
+            if not err < 1e-3: print('   !! cfg', c, name, 'differs from first cfg by', err)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 20
         e0.record()

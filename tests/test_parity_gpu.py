@@ -391,6 +391,43 @@ def test_free_running_bank_growth_vs_oracle(hip):
     assert e0.bank_len == 15 * e0.enc_hw and e0.bank_k[0].shape[0] >= e0.bank_len
 
 
+def test_concurrent_clips_on_two_streams(hip):
+    """bench.py runs several clips per GPU, one HIP stream + engine each, sharing weights: interleaved execution
+    must give bit-identical logits to running each clip alone (scratch is per stream, banks per engine)."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state('aott')
+    model = model.cuda().eval()
+    mk = lambda: build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=2)
+    clips = [synth_clip(k, 6, (97, 129), (96, 128), 2, device='cuda') for k in (7, 8)]
+
+    def frame(e, img, osz):
+        e.match_propogate_one_frame(img)
+        lg = e.decode_current_logits(osz)
+        e.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=e.input_size_2d, mode='nearest'))
+        return lg
+    with torch.no_grad():
+        alone = []
+        for fr, m, ob, osz in clips:
+            e = mk()
+            e.add_reference_frame(fr[0], m, ob, frame_step=0)
+            alone.append([frame(e, fr[t], osz).clone() for t in range(1, 6)])
+        torch.cuda.synchronize()
+        engs, sts = [mk(), mk()], [torch.cuda.Stream(), torch.cuda.Stream()]
+        for e, st, (fr, m, ob, osz) in zip(engs, sts, clips):
+            with torch.cuda.stream(st):
+                e.add_reference_frame(fr[0], m, ob, frame_step=0)
+        both = [[], []]
+        for t in range(1, 6):
+            for i, (e, st, (fr, m, ob, osz)) in enumerate(zip(engs, sts, clips)):
+                with torch.cuda.stream(st):
+                    both[i].append(frame(e, fr[t], osz))
+        torch.cuda.synchronize()
+    for i in range(2):
+        for a, b in zip(alone[i], both[i]):
+            assert torch.equal(a, b)
+
+
 def test_reference_api_surface(hip):
     """the reference's model-level methods keep working on reference-shaped tensors (aot.py:72-108)."""
     from oracle.aot_oracle import OracleModel, one_hot_mask
