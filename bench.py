@@ -138,6 +138,33 @@ def attention_roofline(engine, clip, device):
             'gflop_per_launch': round(flop / n / 1e9, 3)}
 
 
+def jf_vs_reference(device):
+    """J&F of this engine's FREE-RUNNING masks against the real reference's masks on the committed golden clip of
+    BASELINE config 2 (tests/golden/c2_r50_aotl.npz: R50-AOTL, 481x849, 10 objects, 6 propagated frames)."""
+    import numpy as np
+    from utils.metric import jf_per_object
+    from utils.synth import synth_clip
+    gp = os.path.join(ROOT, 'tests', 'golden', 'c2_r50_aotl.npz')
+    if not os.path.exists(gp):
+        return None
+    gold = np.load(gp)['masks']
+    cfg, model, engine, _ = build_model(device)
+    frames, mask, objs, _ = synth_clip(0, gold.shape[0] + 1, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
+    engine.restart_engine()
+    engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
+    js, fs, diff = [], [], 0
+    for t in range(1, len(frames)):
+        label = one_frame(engine, frames[t])[0, 0].long().cpu()
+        ref = torch.from_numpy(gold[t - 1].astype('int64'))
+        j, f = jf_per_object(label, ref, NUM_OBJ)
+        js.append(j)
+        fs.append(f)
+        diff += int((label != ref).sum())
+    J, Fm = sum(js) / len(js), sum(fs) / len(fs)
+    return {'J': round(J, 6), 'F': round(Fm, 6), 'J&F': round((J + Fm) / 2, 6), 'frames': len(js),
+            'pixels_differing': diff, 'of_pixels': int(gold.size), 'clip': 'tests/golden/c2_r50_aotl.npz (free-running)'}
+
+
 def cpu_baseline(sd, budget_s=20.0, max_frames=12):
     """Oracle (CPU port of the reference algorithm) on the first frames of clip 0, same FPS definition."""
     from oracle.aot_oracle import OracleEngine, OracleModel
@@ -239,7 +266,10 @@ def main():
             with torch.cuda.stream(streams[0]):
                 roof = attention_roofline(engines[0], clips[0], device)
 
-    base = None
+    base = jf = None
+    if rank == 0:
+        with torch.no_grad():
+            jf = jf_vs_reference(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(sd)
     if world > 1:
@@ -258,7 +288,8 @@ def main():
                        'single_stream_fps': None if single is None else round(single, 2),
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (world, S),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
-                       'timed_region': 'wall clock incl. reference-frame setup of each clip'},
+                       'timed_region': 'wall clock incl. reference-frame setup of each clip',
+                       'jf_vs_reference': jf},
             'roofline': roof, 'cpu_baseline': base,
         }
         print(json.dumps(line), flush=True)

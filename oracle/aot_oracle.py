@@ -564,9 +564,9 @@ class OracleEngine:
         oh = one_hot_mask(mask, self.AOT.max_obj_num)
         return self.AOT.get_id_emb(oh).view(1, -1, self.enc_hw).permute(2, 0, 1)
 
-    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):   # :188-251
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1, img_embs=None):   # :188-251
         self.obj_nums = obj_nums if isinstance(obj_nums, (list, tuple)) else [obj_nums]
-        embs = self.AOT.encode_image(img)
+        embs = self.AOT.encode_image(img) if img_embs is None else img_embs
         if self.input_size_2d is None:
             self.input_size_2d = tuple(img.shape[2:])
             self.enc_size_2d = tuple(embs[-1].shape[2:])
@@ -592,9 +592,9 @@ class OracleEngine:
             upd.append([None if (a is None or b is None) else torch.cat([b, a], 0) for a, b in zip(nm, om)])
         self.long_term_memories = upd
 
-    def match_propogate_one_frame(self, img):                      # :340-354
+    def match_propogate_one_frame(self, img, img_embs=None):       # :340-354
         self.frame_step += 1
-        self.curr_enc_embs = self.AOT.encode_image(img)
+        self.curr_enc_embs = self.AOT.encode_image(img) if img_embs is None else img_embs
         self.curr_lstt_output = self.AOT.LSTT_forward(self.curr_enc_embs, self.long_term_memories,
                                                       self.short_term_memories, None, self.pos_emb,
                                                       self.enc_size_2d)
@@ -632,6 +632,72 @@ class OracleEngine:
             if not skip_long_term_update:
                 self._update_long(curr)
             self.last_mem_step = self.frame_step
+
+
+class OracleInferEngine:
+    """AOTInferEngine (aot_engine.py:485-635): one OracleEngine per group of max_obj objects, image embedding
+    computed once per frame and shared, logits merged by soft aggregation."""
+
+    def __init__(self, model, long_term_mem_gap=None, max_aot_obj_num=None):
+        self.AOT = model
+        self.gap = long_term_mem_gap
+        self.max_aot_obj_num = model.max_obj_num if max_aot_obj_num is None else min(max_aot_obj_num, model.max_obj_num)
+        self.restart_engine()
+
+    def restart_engine(self):
+        self.aot_engines = []
+        self.obj_nums = None
+
+    def separate_mask(self, mask, obj_nums):                       # :515-545 (label-map branch)
+        n = len(self.aot_engines)
+        if n == 1:
+            return [mask], [obj_nums]
+        nums = [self.max_aot_obj_num] * n
+        if obj_nums % self.max_aot_obj_num > 0:
+            nums[-1] = obj_nums % self.max_aot_obj_num
+        outs = []
+        for i in range(n):
+            lo, hi = i * self.max_aot_obj_num + 1, (i + 1) * self.max_aot_obj_num
+            fg = ((mask >= lo) & (mask <= hi)).to(mask.dtype)
+            outs.append((fg * mask - lo + 1) * fg)
+        return outs, nums
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):   # :584-609
+        if isinstance(obj_nums, (list, tuple)):
+            obj_nums = obj_nums[0]
+        self.obj_nums = obj_nums
+        n = max(-(-obj_nums // self.max_aot_obj_num), 1)
+        while n > len(self.aot_engines):
+            self.aot_engines.append(OracleEngine(self.AOT, self.gap))
+        masks, nums = self.separate_mask(mask, obj_nums)
+        embs = None
+        for e, m, k in zip(self.aot_engines, masks, nums):
+            e.add_reference_frame(img, m, [k], frame_step, img_embs=embs)
+            embs = e.curr_enc_embs
+        self.input_size_2d = self.aot_engines[0].input_size_2d
+
+    def match_propogate_one_frame(self, img):                      # :611-616
+        embs = None
+        for e in self.aot_engines:
+            e.match_propogate_one_frame(img, img_embs=embs)
+            embs = e.curr_enc_embs
+
+    def decode_current_logits(self, output_size=None):             # :618-623 + soft_logit_aggregation :565-582
+        logits = [e.decode_current_logits(output_size) for e in self.aot_engines]
+        if len(logits) == 1:
+            return logits[0]
+        fg, bg = [], []
+        for lg in logits:
+            pr = torch.softmax(lg, dim=1)
+            bg.append(pr[:, 0:1])
+            fg.append(pr[:, 1:1 + self.max_aot_obj_num])
+        bgp = torch.prod(torch.cat(bg, 1), dim=1, keepdim=True)
+        return torch.logit(torch.cat([bgp] + fg, 1).clamp(1e-5, 1 - 1e-5))
+
+    def update_memory(self, mask, skip_long_term_update=False):    # :625-630
+        masks, _ = self.separate_mask(mask, self.obj_nums)
+        for e, m in zip(self.aot_engines, masks):
+            e.update_memory(m, skip_long_term_update)
 
 
 def run_clip(engine, frames, first_mask, obj_nums, output_size, teacher_masks=None, keep=('logits4',)):

@@ -108,3 +108,17 @@ def test_engine_factories_and_errors():
         build_vos_model('nope', cfg)
     with pytest.raises(NotImplementedError):
         build_engine('aotengine', phase='train', aot_model=None)
+
+
+def test_jf_metric():
+    from utils.metric import jf_per_object
+    a = torch.zeros(60, 80, dtype=torch.long)
+    a[10:30, 10:40] = 1
+    a[35:55, 50:70] = 2
+    assert jf_per_object(a, a, 2) == (1.0, 1.0)
+    b = a.clone()
+    b[10:30, 10:40] = 0
+    b[10:30, 25:55] = 1                       # object 1 shifted by 15 px: IoU = 15/45, boundary mostly outside tolerance
+    j, f = jf_per_object(b, a, 2)
+    assert abs(j - (15 / 45 + 1.0) / 2) < 1e-6 and 0.5 < f < 1.0
+    assert jf_per_object(torch.zeros_like(a), a, 2)[0] == 0.0

@@ -391,6 +391,30 @@ def test_free_running_bank_growth_vs_oracle(hip):
     assert e0.bank_len == 15 * e0.enc_hw and e0.bank_k[0].shape[0] >= e0.bank_len
 
 
+def test_more_than_ten_objects_vs_oracle(hip):
+    """AOTInferEngine with 13 objects = two 10-object groups (aot_engine.py:515-630): mask separation, image embedding
+    shared between the groups, soft logit aggregation -- HIP engine vs the oracle's restatement, teacher-forced."""
+    from oracle.aot_oracle import OracleInferEngine, OracleModel
+    from utils.synth import synth_clip
+    cfg, model, eng, sd = _hip_engine('aott', gap=2)
+    ora = OracleInferEngine(OracleModel('aott', sd), long_term_mem_gap=2)
+    frames, mask, objs, out_size = synth_clip(9, 5, (129, 161), (128, 160), 13)
+    assert mask.max().item() == 13
+    with torch.no_grad():
+        eng.add_reference_frame(frames[0].cuda(), mask.cuda(), objs, frame_step=0)
+        ora.add_reference_frame(frames[0], mask, objs)
+        assert len(eng.aot_engines) == 2
+        for t in range(1, 5):
+            eng.match_propogate_one_frame(frames[t].cuda())
+            ora.match_propogate_one_frame(frames[t])
+            lg, lo = eng.decode_current_logits(out_size), ora.decode_current_logits(out_size)
+            assert lg.shape == lo.shape == (1, 21, 128, 160)       # bg + 10 slots per group (aot_engine.py:577-579)
+            _close(lg, lo, 1e-3, 'aggregated logits frame %d' % t)
+            fb = F.interpolate(torch.argmax(lo, 1, keepdim=True).float(), size=ora.input_size_2d, mode='nearest')
+            eng.update_memory(fb.cuda())
+            ora.update_memory(fb)
+
+
 def test_concurrent_clips_on_two_streams(hip):
     """bench.py runs several clips per GPU, one HIP stream + engine each, sharing weights: interleaved execution
     must give bit-identical logits to running each clip alone (scratch is per stream, banks per engine)."""
