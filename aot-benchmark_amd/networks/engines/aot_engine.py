@@ -48,7 +48,11 @@ class AOTEngine(nn.Module):
         self.enc_size_2d = None
         self.enc_hw = None
         self.input_size_2d = None
-        self.bank_k, self.bank_v, self.bank_len = None, None, 0
+        # the bank buffers survive a restart (same clip geometry re-uses them: no allocator traffic, which would
+        # serialise concurrently running clips); only the fill level is reset
+        if not hasattr(self, 'bank_k'):
+            self.bank_k, self.bank_v = None, None
+        self.bank_len = 0
         self.short_term_memories_list = []
         self.short_term_memories = None
         self._feats = None        # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major
@@ -71,7 +75,7 @@ class AOTEngine(nn.Module):
 
     @property
     def long_term_memories(self):
-        if self.bank_k is None:
+        if self.bank_k is None or self.bank_len == 0:
             return None
         return [[k[:self.bank_len].unsqueeze(1), v[:self.bank_len].unsqueeze(1)] for k, v in zip(self.bank_k, self.bank_v)]
 
@@ -92,13 +96,16 @@ class AOTEngine(nn.Module):
 
     def _append_bank(self, ks, vs):
         N = ks[0].shape[0]
-        if self.bank_k is None:
-            cap = 8 * N
+        fits = (self.bank_k is not None and len(self.bank_k) == len(ks) and
+                all(b.shape[1] == k.shape[1] and b.device == k.device for b, k in zip(self.bank_k, ks)) and
+                all(b.shape[1] == v.shape[1] for b, v in zip(self.bank_v, vs)))
+        if not fits:
+            cap = 16 * N          # 16 memorised frames up front (a 70-frame clip at gap 5 needs 14); doubles beyond
             self.bank_k = [torch.empty(cap, k.shape[1], dtype=torch.float32, device=k.device) for k in ks]
             self.bank_v = [torch.empty(cap, v.shape[1], dtype=torch.float32, device=v.device) for v in vs]
             self.bank_len = 0
         if self.bank_len + N > self.bank_k[0].shape[0]:
-            cap = 2 * self.bank_k[0].shape[0]
+            cap = max(2 * self.bank_k[0].shape[0], self.bank_len + N)
             for lst in (self.bank_k, self.bank_v):
                 for i, old in enumerate(lst):
                     new = torch.empty(cap, old.shape[1], dtype=torch.float32, device=old.device)
