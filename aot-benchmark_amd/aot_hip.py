@@ -35,7 +35,7 @@ _SIGS = {
     'aot_local_gated_f32': [_P] * 8 + [_I] * 10 + [_F, _P],
     'aot_swin_window_attn_f32': [_P] * 4 + [_I] * 8 + [_F, _P],
     'aot_patch_merge_f32': [_P, _P] + [_I] * 4 + [_P],
-    'aot_idbank_f32': [_P] * 4 + [_I] * 10 + [_P],
+    'aot_idbank_f32': [_P] * 5 + [_I] * 10 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 8 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
@@ -236,8 +236,8 @@ def patch_merge(x, out, H, W, C, stream=None):
     return out
 
 
-def idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, stream=None):
-    _chk(load().aot_idbank_f32(_dev(mask), _dev(table), _opt(bias), _dev(out), H, W, OH, OW, K, stride, pad, C, nlabel,
+def idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, sumtab=None, stream=None):
+    _chk(load().aot_idbank_f32(_dev(mask), _dev(table), _opt(sumtab), _opt(bias), _dev(out), H, W, OH, OW, K, stride, pad, C, nlabel,
                                out.stride(0), stream if stream is not None else stream_ptr()), 'aot_idbank_f32')
     return out
 

@@ -183,7 +183,12 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ i
                                                      const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                      int C, int OH, int OW, int KH, int KW, int stride, int pad, int dil,
                                                      int act) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware block order: block b runs on XCD b%8; give each XCD a contiguous range of pixels so the KxK
+  // neighbourhoods it re-reads stay in its own L2 (PMC: 62 MB fetched for a 7 MB map with the plain order)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, sub = bid >> 3;
+  const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + sub;
+  const long idx = (long)blk * blockDim.x + threadIdx.x;
   const int nv = C >> 2;
   if (idx >= (long)OH * OW * nv) return;
   const int c4 = (int)(idx % nv);
@@ -413,13 +418,17 @@ extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* 
 // Identity bank: one workgroup per output token; the KxK label patch is staged in LDS, then every
 // thread (= channel quad) walks the taps, gathering coalesced rows of the [label, ky, kx, C] table.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) idbank_kernel(const float* __restrict__ mask, const float* __restrict__ table,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int H, int W,
-                                                    int OW, int K, int stride, int pad, int C, int nlabel, int ldo) {
-  extern __shared__ int labels[];  // K*K entries, -1 = contributes nothing
+__global__ void __launch_bounds__(256) idbank_kernel(const float* __restrict__ mask, const float* __restrict__ table,
+                                                     const float* __restrict__ sumtab, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int H, int W, int OW, int K, int stride,
+                                                     int pad, int C, int nlabel, int ldo) {
+  extern __shared__ int labels[];  // K*K entries (-1 = contributes nothing), then 3 x 64 float4 partial sums
   const int tok = blockIdx.x;
   const int Y = tok / OW, X = tok - Y * OW;
-  for (int i = threadIdx.x; i < K * K; i += blockDim.x) {
+  const int KK = K * K;
+  bool same = true;
+  int first = -2;
+  for (int i = threadIdx.x; i < KK; i += blockDim.x) {
     const int ky = i / K, kx = i - ky * K;
     const int iy = Y * stride - pad + ky, ix = X * stride - pad + kx;
     int lab = -1;
@@ -429,27 +438,56 @@ __global__ void __launch_bounds__(64) idbank_kernel(const float* __restrict__ ma
       if (v == (float)li && li >= 0 && li < nlabel) lab = li;
     }
     labels[i] = lab;
+    if (first == -2) first = lab;
+    same = same && (lab == first);
   }
-  __syncthreads();
-  const int KK = K * K;
-  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
-    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = 0; i < KK; ++i) {
-      const int lab = labels[i];
-      if (lab < 0) continue;
-      const float4 t = *reinterpret_cast<const float4*>(table + ((long)lab * KK + i) * C + c4 * 4);
-      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+  const int l0raw = __syncthreads_and(same ? 1 : 0);   // barrier + "every thread saw one label"
+  const int l0 = labels[0];
+  // every thread's subset is uniform; the window is uniform iff all subsets agree with labels[0]
+  const bool uniform = sumtab != nullptr && l0 >= 0 && __syncthreads_and((first == -2 || first == l0) ? 1 : 0) && l0raw;
+  // Fast path: the whole window carries ONE valid label (interiors of objects / background, i.e. most tokens of a
+  // real mask): the K*K-tap sum is the precomputed per-label table sum.  Otherwise the 4 waves split the taps.
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float4* psum = reinterpret_cast<float4*>(labels + ((KK + 3) & ~3));
+  for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uniform) {
+      if (part == 0) acc = *reinterpret_cast<const float4*>(sumtab + (long)l0 * C + c4 * 4);
+    } else {
+      for (int i = part; i < KK; i += 4) {
+        const int lab = labels[i];
+        if (lab < 0) continue;
+        const float4 t = *reinterpret_cast<const float4*>(table + ((long)lab * KK + i) * C + c4 * 4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      if (part > 0) psum[(part - 1) * 64 + lane] = acc;
+      __syncthreads();
+      if (part == 0)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 t = psum[q * 64 + lane];
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+      __syncthreads();
     }
-    *reinterpret_cast<float4*>(out + (long)tok * ldo + c4 * 4) = acc;
+    if (part == 0) {
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+      }
+      *reinterpret_cast<float4*>(out + (long)tok * ldo + c4 * 4) = acc;
+    }
   }
 }
 
-extern "C" int aot_idbank_f32(const float* mask, const float* table, const float* bias, float* out, int H, int W, int OH,
-                              int OW, int K, int stride, int pad, int C, int nlabel, int ldo, void* stream) {
+extern "C" int aot_idbank_f32(const float* mask, const float* table, const float* sumtab, const float* bias, float* out,
+                              int H, int W, int OH, int OW, int K, int stride, int pad, int C, int nlabel, int ldo,
+                              void* stream) {
   if (!mask || !table || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || C <= 0 || (C & 3) || (ldo & 3))
     return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(idbank_kernel, dim3(OH * OW), dim3(64), K * K * sizeof(int), (hipStream_t)stream, mask, table, bias,
-                     out, H, W, OW, K, stride, pad, C, nlabel, ldo);
+  hipLaunchKernelGGL(idbank_kernel, dim3(OH * OW), dim3(256), ((K * K + 3) & ~3) * sizeof(int) + 3 * 64 * sizeof(float4),
+                     (hipStream_t)stream, mask, table, sumtab,
+                     bias, out, H, W, OW, K, stride, pad, C, nlabel, ldo);
   AOT_LAUNCH_CHECK();
 }
 

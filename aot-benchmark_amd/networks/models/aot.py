@@ -79,6 +79,7 @@ class AOT(nn.Module):
             self._packed = {
                 'proj': fold_conv_bn(self.encoder_projector),
                 'id_table': idw.permute(1, 2, 3, 0).contiguous(),            # [L, K, K, C]
+                'id_sumtab': idw.double().sum((2, 3)).t().float().contiguous(),  # [L, C]: all-taps sum per label
                 'id_bias': self.patch_wise_id_bank.bias.detach().float().contiguous(),
             }
             for layer in self.LSTT.layers:
@@ -139,7 +140,7 @@ class AOT(nn.Module):
         K, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         out = torch.empty(h * w, conv.out_channels, dtype=torch.float32, device=mask.device)
         aot_hip.idbank(mask.float().contiguous(), p['id_table'], p['id_bias'], out, H, W, h, w, K, s, pd,
-                       conv.out_channels, self.max_obj_num + 1, stream=stream)
+                       conv.out_channels, self.max_obj_num + 1, sumtab=p['id_sumtab'], stream=stream)
         return out
 
     # ---- reference method surface (aot.py:72-108) ------------------------------------------------

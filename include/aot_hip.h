@@ -152,9 +152,10 @@ int aot_patch_merge_f32(const float* x, float* out, int H, int W, int C, int ldx
 
 /* Identity-bank embedding of a label map: out[(Y,X), c] = bias[c] + sum_{ky,kx} table[label(16Y+ky-pad,
  * 16X+kx-pad), ky, kx, c] over in-image taps; labels outside [0, nlabel) or non-integer add nothing.
- * mask is [H,W] float label ids, table [nlabel, K, K, C].  Replaces one_hot_mask (utils/image.py:69-74)
+ * mask is [H,W] float label ids, table [nlabel, K, K, C]; sumtab [nlabel, C] (optional) = sum of table over the
+ * K*K taps, used when a token's whole window carries one label.  Replaces one_hot_mask (utils/image.py:69-74)
  * + patch_wise_id_bank conv (models/aot.py:50-63,76-79). */
-int aot_idbank_f32(const float* mask, const float* table, const float* bias, float* out,
+int aot_idbank_f32(const float* mask, const float* table, const float* sumtab, const float* bias, float* out,
                    int H, int W, int OH, int OW, int K, int stride, int pad, int C, int nlabel,
                    int ldo, void* stream);
 

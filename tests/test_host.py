@@ -122,3 +122,21 @@ def test_jf_metric():
     j, f = jf_per_object(b, a, 2)
     assert abs(j - (15 / 45 + 1.0) / 2) < 1e-6 and 0.5 < f < 1.0
     assert jf_per_object(torch.zeros_like(a), a, 2)[0] == 0.0
+
+
+def test_cabi_rejects_bad_arguments_without_a_gpu():
+    """Every entry point validates its arguments before any HIP call: AOT_ERR_BADARG (-1) / AOT_ERR_UNSUPPORTED (-2),
+    never an exception or a launch (include/aot_hip.h conventions)."""
+    import aot_hip
+    lib = aot_hip.load()
+    P = ctypes.c_void_p
+    assert lib.aot_add_f32(None, None, None, 16, None) == -1
+    assert lib.aot_add_f32(P(16), P(16), P(16), 7, None) == -1                      # n % 4 != 0
+    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 255, 256, 256, 0, 0, 1e-5, None) == -1
+    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 2048, 2048, 2048, 0, 0, 1e-5, None) == -2
+    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 64, 256, 256, 256, 256, 5.65, 1, None) == -2
+    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # splits need `part`
+    assert lib.aot_local_attn_f32(P(16), P(16), P(16), P(16), P(16), P(16), P(16), 4, 4, 8, 32, 5, 256, 256, 256, 256, 5.65, None) == -2
+    assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, P(16), 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 8, 0, 0, None) == -1  # Cin % 4
+    assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
+    assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2

@@ -172,6 +172,7 @@ def test_idbank_matches_onehot_conv(hip, K, pad, H, W):
     """fused gather == one_hot_mask + Conv2d(11->256, k, s16, p) (utils/image.py:69-74, models/aot.py:50-63)."""
     g = torch.Generator().manual_seed(19)
     mask = torch.randint(0, 11, (1, 1, H, W), generator=g).float()
+    mask[0, 0, H // 3:, :] = 4.0        # large uniform region -> exercises the per-label sum fast path
     mask[0, 0, :5, :7] = 13.0           # id above max_obj -> all-zero one-hot column
     mask[0, 0, 9, 9] = 2.5              # non-integer -> matches no id
     wt = torch.randn(256, 11, K, K, generator=g) / K
@@ -180,7 +181,8 @@ def test_idbank_matches_onehot_conv(hip, K, pad, H, W):
     ref = F.conv2d(onehot.double(), wt.double(), b.double(), 16, pad)[0].float()
     oh, ow = ref.shape[1:]
     out = torch.empty(oh * ow, 256, device='cuda')
-    hip.idbank(_dev(mask), _dev(wt.permute(1, 2, 3, 0)), _dev(b), out, H, W, oh, ow, K, 16, pad, 256, 11)
+    hip.idbank(_dev(mask), _dev(wt.permute(1, 2, 3, 0)), _dev(b), out, H, W, oh, ow, K, 16, pad, 256, 11,
+               sumtab=_dev(wt.double().sum((2, 3)).t().float()))
     _close(out.view(oh, ow, 256).permute(2, 0, 1), ref, 2e-5, 'idbank')
 
 
