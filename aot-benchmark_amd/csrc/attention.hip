@@ -49,7 +49,8 @@ __device__ __forceinline__ float exp_fast(float x) {
   return fmaf(e * 0.693147182464599609375f, r, e);   // e * 2^r ~ e * (1 + r ln2)
 }
 
-__global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
+template <int NQ>   // query tiles (of 32) per wave: 2 shares every K/V fetch between two score tiles
+__global__ void __launch_bounds__(64, NQ == 2 ? 2 : 1) attn_fwd_d32_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
   const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -58,18 +59,19 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
   const int t0 = split * tps * 32;
   const int t1 = min(T, t0 + tps * 32);
 
-  const int qrow = min(qt * 32 + j, p.Nq - 1);
-  // Q fragment (B operand of S^T = K.Q^T): lane (q=j, hi) holds Q[q][c = hi*16 + s], s = 0..15, scaled
-  float qf[16];
-  {
+  // Q fragments (B operand of S^T = K.Q^T): lane (q=j, hi) holds Q[q][c = hi*16 + s], s = 0..15, scaled
+  float qf[NQ][16];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a) {
+    const int qrow = min((qt * NQ + a) * 32 + j, p.Nq - 1);
     const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + h * 32 + hi * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 t = src[i];
-      qf[4 * i + 0] = t.x / p.scale_div;  // reference divides (attention.py:82), so do we
-      qf[4 * i + 1] = t.y / p.scale_div;
-      qf[4 * i + 2] = t.z / p.scale_div;
-      qf[4 * i + 3] = t.w / p.scale_div;
+      qf[a][4 * i + 0] = t.x / p.scale_div;  // reference divides (attention.py:82), so do we
+      qf[a][4 * i + 1] = t.y / p.scale_div;
+      qf[a][4 * i + 2] = t.z / p.scale_div;
+      qf[a][4 * i + 3] = t.w / p.scale_div;
     }
   }
 
@@ -79,10 +81,15 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
   const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
   const int ldv4 = p.ldv * 4;
 
-  float m = -INFINITY, l = 0.f;
-  f32x16 o;
+  float m[NQ], l[NQ];
+  f32x16 o[NQ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int a = 0; a < NQ; ++a) {
+    m[a] = -INFINITY;
+    l[a] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
+  }
 
   // (K uses plain 16-byte global loads: the raw_buffer_load_b64/b96/b128 builtins of ROCm 7.2's hipcc lower to a
   //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable.)
@@ -102,43 +109,61 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
   };
 
   auto tile = [&](const float (&kf)[16], const float (&vf)[16], int kt) {
-    // ---- S^T = K . Q^T ----
-    f32x16 sc;
+    // ---- S^T = K . Q^T : NQ independent accumulation chains interleaved ----
+    f32x16 sc[NQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    for (int a = 0; a < NQ; ++a)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) sc[a][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) sc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[a][s], sc[a], 0, 0, 0);
     // ---- online softmax over the 32 keys of this tile (per query = per lane column) ----
-    if (kt + 32 > t1) {
+    float pf[NQ][16];
+    bool moved = false;
+    float mt[NQ];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    for (int a = 0; a < NQ; ++a) {
+      if (kt + 32 > t1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt + mfma32_row(r, hi) >= t1) sc[a][r] = -INFINITY;
+      }
+      float x = fmaxf(fmaxf(sc[a][0], sc[a][1]), fmaxf(sc[a][2], sc[a][3]));
+#pragma unroll
+      for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[a][r], sc[a][r + 1]), fmaxf(sc[a][r + 2], sc[a][r + 3])));
+      mt[a] = fmaxf(x, __shfl_xor(x, 32));
+      moved = moved || (mt[a] > m[a]);
     }
-    float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    if (__any(moved)) {   // wave-uniform: only rescale when some query's running max moved (alpha == 1 otherwise)
 #pragma unroll
-    for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
-    if (__any(mt > m)) {   // wave-uniform: only rescale when some query's running max moved (alpha == 1 otherwise)
-      const float mnew = fmaxf(m, mt);
-      const float alpha = exp_fast(m - mnew);  // m = -inf on the first tile -> 0
-      l *= alpha;
+      for (int a = 0; a < NQ; ++a) {
+        const float mnew = fmaxf(m[a], mt[a]);
+        const float alpha = exp_fast(m[a] - mnew);  // m = -inf on the first tile -> 0
+        l[a] *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= alpha;
-      m = mnew;
+        for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
+        m[a] = mnew;
+      }
     }
-    float pf[16];
-    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      pf[r] = exp_fast(sc[r] - m);
-      pf[r + 1] = exp_fast(sc[r + 1] - m);
-      ps0 += pf[r];
-      ps1 += pf[r + 1];
+    for (int a = 0; a < NQ; ++a) {
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        pf[a][r] = exp_fast(sc[a][r] - m[a]);
+        pf[a][r + 1] = exp_fast(sc[a][r + 1] - m[a]);
+        ps0 += pf[a][r];
+        ps1 += pf[a][r + 1];
+      }
+      l[a] += ps0 + ps1;
     }
-    l += ps0 + ps1;
     // ---- O^T += V^T . P^T  (contraction index = key, enumerated in C/D-layout order) ----
 #pragma unroll
-    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], pf[s], o, 0, 0, 0);
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], pf[a][s], o[a], 0, 0, 0);
   };
 
   // ping-pong register sets: the next tile's loads fly under the current tile's MFMAs, no register copies
@@ -153,33 +178,34 @@ __global__ void __launch_bounds__(64) attn_fwd_d32_kernel(const AttnParams p) {
     }
   }
 
-  l += __shfl_xor(l, 32);
-  const int qi = qt * 32 + j;
-  if (qi >= p.Nq) return;
-  if (p.nsplit == 1) {
-    const float inv = 1.f / l;
-    float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
-      float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-      if (p.gate) {
-        const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
-        t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+  for (int a = 0; a < NQ; ++a) {
+    const float lt = l[a] + __shfl_xor(l[a], 32);
+    const int qi = (qt * NQ + a) * 32 + j;
+    if (qi >= p.Nq) continue;
+    if (p.nsplit == 1) {
+      const float inv = 1.f / lt;
+      float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
+        float4 t = make_float4(o[a][4 * g] * inv, o[a][4 * g + 1] * inv, o[a][4 * g + 2] * inv, o[a][4 * g + 3] * inv);
+        if (p.gate) {
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
+          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+        }
+        *reinterpret_cast<float4*>(dst + 8 * g) = t;
       }
-      *reinterpret_cast<float4*>(dst + 8 * g) = t;
-    }
-  } else {
-    const int C = p.H * 32;
-    float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
+    } else {
+      const int C = p.H * 32;
+      float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 t = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
-      *reinterpret_cast<float4*>(dst + 8 * g) = t;
-    }
-    if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
-      ml[0] = m;   // -inf if this split saw no key (t0 >= t1)
-      ml[1] = l;
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[a][4 * g], o[a][4 * g + 1], o[a][4 * g + 2], o[a][4 * g + 3]);
+      if (hi == 0) {
+        float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
+        ml[0] = m[a];   // -inf if this split saw no key (t0 >= t1)
+        ml[1] = lt;
+      }
     }
   }
 }
@@ -385,7 +411,16 @@ extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, floa
   AttnParams p;
   const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_d32_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
+  // Two query tiles per wave (NQ = 2) share every K/V fetch, but on MI355X the register cost (197 VGPR -> 2 waves
+  // per SIMD instead of 3) loses more than the halved fetch gains: 85 vs 94 TFLOP/s at M = 14 (scratch/mb_attn.py).
+  // Kept as a tuning option; off by default.
+#ifndef AOT_ATTN_NQ2_MIN
+#define AOT_ATTN_NQ2_MIN (1 << 30)
+#endif
+  if (Nq >= AOT_ATTN_NQ2_MIN)
+    hipLaunchKernelGGL(attn_fwd_d32_kernel<2>, dim3(H, nsplit, cdiv(Nq, 64)), dim3(64), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_d32_kernel<1>, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 
