@@ -50,7 +50,12 @@ __device__ __forceinline__ float exp_fast(float x) {
 }
 
 template <int NQ>   // query tiles (of 32) per wave: 2 shares every K/V fetch between two score tiles
-__global__ void __launch_bounds__(64, NQ == 2 ? 2 : 1) attn_fwd_d32_kernel(const AttnParams p) {
+#ifdef AOT_ATTN_PREFETCH
+#define AOT_ATTN_MINW (NQ == 2 ? 2 : 1)
+#else
+#define AOT_ATTN_MINW (NQ == 2 ? 3 : 4)
+#endif
+__global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
   const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -166,6 +171,16 @@ __global__ void __launch_bounds__(64, NQ == 2 ? 2 : 1) attn_fwd_d32_kernel(const
       for (int a = 0; a < NQ; ++a) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], pf[a][s], o[a], 0, 0, 0);
   };
 
+#ifndef AOT_ATTN_PREFETCH
+  // No register double buffering: 82 VGPRs -> 5 waves per SIMD, and the other waves' MFMAs hide this wave's
+  // K/V latency.  Measured 3-5% faster than the ping-pong variant below (162 registers, 3 waves) at every bank size.
+  float ka[16], va[16];
+  for (int kt = t0; kt < t1; kt += 32) {
+    load_k(ka, kt);
+    load_v(va, kt);
+    tile(ka, va, kt);
+  }
+#else
   // ping-pong register sets: the next tile's loads fly under the current tile's MFMAs, no register copies
   float ka[16], va[16], kb[16], vb[16];
   if (t0 < t1) { load_k(ka, t0); load_v(va, t0); }
@@ -177,6 +192,7 @@ __global__ void __launch_bounds__(64, NQ == 2 ? 2 : 1) attn_fwd_d32_kernel(const
       tile(kb, vb, kt + 32);
     }
   }
+#endif
 
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
