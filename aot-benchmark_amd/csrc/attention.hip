@@ -33,27 +33,27 @@ struct AttnParams {
   float scale_div;
 };
 
-// exp(x) = 2^(x*log2(e)) on the hardware v_exp_f32, with the product carried in two floats so the result is
-// good to ~1.5e-7 relative (the accurate libm expf costs ~20 VALU instructions, 17 of them per key tile were
-// as expensive as the tile's 32 MFMAs).  x <= 0 here; anything below -150 (incl. -inf) gives exactly 0.
-__device__ __forceinline__ float exp_fast(float x) {
-#ifdef EXP_REF
-  return expf(x);
+// Softmax in the log2 domain.  With L = log2(e) and a running reference mL = fl(max_score * L), every weight is
+//   p = 2^(fl(s * L - mL))          one v_fma_f32 + one v_exp_f32 per score
+// The value of mL only has to be the SAME number wherever it is used (weights, row sums, rescale factors 2^(mL_old -
+// mL_new), and the split merge, which receives mL itself), so its own rounding cancels in the normalisation; what is
+// left is the rounding of the fused multiply-add, a relative error of |t| * 2^-24 * ln2 on a weight of size 2^t, i.e.
+// <= 3e-8 absolute on any weight -- the level of one fp32 rounding of the largest weight.  (The accurate libm expf
+// costs ~20 VALU instructions per score; 16 scores per lane and tile made that as expensive as the tile's 32 MFMAs.)
+// Masked scores (-inf) and the initial mL = -inf give 2^-inf = 0 exactly; no clamps needed.
+#define AOT_LOG2E 1.44269502162933349609375f
+__device__ __forceinline__ float exp2_w(float s, float mL) {
+#ifdef ABL_NOEXP
+  return fmaf(s, 1e-3f, 1.f);
 #endif
-  x = fmaxf(x, -150.f);              // keeps -inf out of the residual (inf - inf); 2^-216 flushes to 0
-  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
-  const float t = x * L2E_HI;
-  float r = fmaf(x, L2E_HI, -t);      // exact rounding error of the product
-  r = fmaf(x, L2E_LO, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e * 0.693147182464599609375f, r, e);   // e * 2^r ~ e * (1 + r ln2)
+  return __builtin_amdgcn_exp2f(fmaf(s, AOT_LOG2E, -mL));
 }
 
 template <int NQ>   // query tiles (of 32) per wave: 2 shares every K/V fetch between two score tiles
 #ifdef AOT_ATTN_PREFETCH
 #define AOT_ATTN_MINW (NQ == 2 ? 2 : 1)
 #else
-#define AOT_ATTN_MINW (NQ == 2 ? 3 : 4)
+#define AOT_ATTN_MINW (NQ == 2 ? 3 : 5)
 #endif
 __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
@@ -63,6 +63,9 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
   const int tps = (ntile + p.nsplit - 1) / p.nsplit;  // key tiles per split
   const int t0 = split * tps * 32;
   const int t1 = min(T, t0 + tps * 32);
+#ifdef ATTN_CLK
+  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
+#endif
 
   // Q fragments (B operand of S^T = K.Q^T): lane (q=j, hi) holds Q[q][c = hi*16 + s], s = 0..15, scaled
   float qf[NQ][16];
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
   const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
   const int ldv4 = p.ldv * 4;
 
-  float m[NQ], l[NQ];
+  float m[NQ], l[NQ];   // m: running max score times log2(e)
   f32x16 o[NQ];
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
       vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
   };
 
-  auto tile = [&](const float (&kf)[16], const float (&vf)[16], int kt) {
+  auto tile = [&](float (&kf)[16], const float (&vf)[16], int kt, bool rot) {
     // ---- S^T = K . Q^T : NQ independent accumulation chains interleaved ----
     f32x16 sc[NQ];
 #pragma unroll
@@ -124,8 +127,20 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
     for (int s = 0; s < 16; ++s)
 #pragma unroll
       for (int a = 0; a < NQ; ++a) sc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[a][s], sc[a], 0, 0, 0);
+    // K registers are free now: the next tile's K flies under this tile's softmax and PV MFMAs
+    if (rot) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(kf, kt + 32);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- online softmax over the 32 keys of this tile (per query = per lane column) ----
     float pf[NQ][16];
+#ifdef ABL_NOSOFTMAX
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pf[a][r] = sc[a][r];
+#else
     bool moved = false;
     float mt[NQ];
 #pragma unroll
@@ -138,14 +153,14 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
       float x = fmaxf(fmaxf(sc[a][0], sc[a][1]), fmaxf(sc[a][2], sc[a][3]));
 #pragma unroll
       for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[a][r], sc[a][r + 1]), fmaxf(sc[a][r + 2], sc[a][r + 3])));
-      mt[a] = fmaxf(x, __shfl_xor(x, 32));
+      mt[a] = fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E;
       moved = moved || (mt[a] > m[a]);
     }
     if (__any(moved)) {   // wave-uniform: only rescale when some query's running max moved (alpha == 1 otherwise)
 #pragma unroll
       for (int a = 0; a < NQ; ++a) {
         const float mnew = fmaxf(m[a], mt[a]);
-        const float alpha = exp_fast(m[a] - mnew);  // m = -inf on the first tile -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m[a] - mnew);  // m = -inf on the first tile -> 0
         l[a] *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
@@ -157,13 +172,14 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
       float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        pf[a][r] = exp_fast(sc[a][r] - m[a]);
-        pf[a][r + 1] = exp_fast(sc[a][r + 1] - m[a]);
+        pf[a][r] = exp2_w(sc[a][r], m[a]);
+        pf[a][r + 1] = exp2_w(sc[a][r + 1], m[a]);
         ps0 += pf[a][r];
         ps1 += pf[a][r + 1];
       }
       l[a] += ps0 + ps1;
     }
+#endif
     // ---- O^T += V^T . P^T  (contraction index = key, enumerated in C/D-layout order) ----
 #pragma unroll
     for (int s = 0; s < 16; ++s)
@@ -175,10 +191,10 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
   // No register double buffering: 82 VGPRs -> 5 waves per SIMD, and the other waves' MFMAs hide this wave's
   // K/V latency.  Measured 3-5% faster than the ping-pong variant below (162 registers, 3 waves) at every bank size.
   float ka[16], va[16];
+  if (t0 < t1) load_k(ka, t0);
   for (int kt = t0; kt < t1; kt += 32) {
-    load_k(ka, kt);
-    load_v(va, kt);
-    tile(ka, va, kt);
+    load_v(va, kt);                 // lands under the 16 QK MFMAs
+    tile(ka, va, kt, true);         // (the K fetch past the range end is clamped to row T-1 and never used)
   }
 #else
   // ping-pong register sets: the next tile's loads fly under the current tile's MFMAs, no register copies
@@ -186,14 +202,21 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
   if (t0 < t1) { load_k(ka, t0); load_v(va, t0); }
   for (int kt = t0; kt < t1; kt += 64) {
     if (kt + 32 < t1) { load_k(kb, kt + 32); load_v(vb, kt + 32); }
-    tile(ka, va, kt);
+    tile(ka, va, kt, false);
     if (kt + 32 < t1) {
       if (kt + 64 < t1) { load_k(ka, kt + 64); load_v(va, kt + 64); }
-      tile(kb, vb, kt + 32);
+      tile(kb, vb, kt + 32, false);
     }
   }
 #endif
 
+#ifdef ATTN_CLK
+  if (lane == 0) {   // scratch experiment: sum of shader-clock and 100 MHz ticks per wave at the tail of a 32-split part buffer
+    unsigned long long* cb = reinterpret_cast<unsigned long long*>(p.part + 32L * p.Nq * (p.C + 2 * p.H) - 4);
+    atomicAdd(cb, clock64() - clk_c0);
+    atomicAdd(cb + 1, wall_clock64() - clk_w0);
+  }
+#endif
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
     const float lt = l[a] + __shfl_xor(l[a], 32);
@@ -219,7 +242,7 @@ __global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const A
         *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[a][4 * g], o[a][4 * g + 1], o[a][4 * g + 2], o[a][4 * g + 3]);
       if (hi == 0) {
         float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
-        ml[0] = m[a];   // -inf if this split saw no key (t0 >= t1)
+        ml[0] = m[a];   // log2 domain; -inf if this split saw no key (t0 >= t1)
         ml[1] = lt;
       }
     }
@@ -245,7 +268,7 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
     const float* ml = mlb + (((long)s * p.Nq + qi) * p.H + h) * 2;
     const float ms = ml[0];
     if (ms == -INFINITY) continue;
-    const float wgt = expf(ms - mmax);
+    const float wgt = __builtin_amdgcn_exp2f(ms - mmax);   // stats are kept in the log2 domain
     lsum += wgt * ml[1];
     const float4 t = *reinterpret_cast<const float4*>(p.part + ((long)s * p.Nq + qi) * C + c4 * 4);
     acc.x += wgt * t.x; acc.y += wgt * t.y; acc.z += wgt * t.z; acc.w += wgt * t.w;
@@ -293,7 +316,7 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_kernel(const AttnParams p) {
   const int ldv4 = p.ldv * 4;
   const float* kptr = p.k + hi * HK;
 
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;   // m: running max score times log2(e)
   f32x16 o[NDV];
 #pragma unroll
   for (int d = 0; d < NDV; ++d)
@@ -330,10 +353,10 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_kernel(const AttnParams p) {
     float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
 #pragma unroll
     for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt = fmaxf(mt, __shfl_xor(mt, 32)) * AOT_LOG2E;
     if (__any(mt > m)) {
       const float mnew = fmaxf(m, mt);
-      const float alpha = exp_fast(m - mnew);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
       l *= alpha;
 #pragma unroll
       for (int d = 0; d < NDV; ++d)
@@ -345,7 +368,7 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_kernel(const AttnParams p) {
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pf[r] = exp_fast(sc[r] - m);
+      pf[r] = exp2_w(sc[r], m);
       ps += pf[r];
     }
     l += ps;

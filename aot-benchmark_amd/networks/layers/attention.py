@@ -12,17 +12,30 @@ import aot_hip
 from networks.layers.basic import DWConv2d
 from networks.layers.normalization import fold_dwconv_bn, linear_t
 
-_TARGET_WAVES = 2048          # 256 CUs x 4 SIMDs x 2 waves: one 32-query x 1-head tile = one wave
+_SIMDS = 1024                 # 256 CUs x 4 SIMDs; one 32-query x 1-head (or 1-chunk) tile = one wave
+_OCC_EFF = (0.8, 0.9, 0.97, 0.99, 1.0)   # measured MFMA-pipe fill at 1..5 resident waves per SIMD
 
 
-def attn_splits(nq, heads, t):
-    """How many key ranges to cut the bank into (csrc/attention.hip).  Measured on MI355X (scratch/mb_attn.py):
-    the kernel wants several waves per SIMD but >= ~12 key tiles per split; tiny problems split just enough to
-    put a wave on every SIMD."""
-    waves = ((nq + 31) // 32) * heads
+def attn_splits(nq, units, t, occ=5, c0=3.0):
+    """How many key ranges to cut the bank into (csrc/attention.hip).
+
+    The kernel is bound by the MFMA pipe of each SIMD, so its run time is the MAKESPAN over SIMDs: (waves per SIMD,
+    rounded up) x (key tiles per wave + a fixed per-wave cost c0, in key-tile units).  Measured on MI355X
+    (scratch/mb_attn_sweep.py, N=1674, 8 heads): the time follows this model within a few % for every bank size; the
+    minima are the split counts that land just under a whole number of waves per SIMD -- 7 (371 of 384 slots per XCD)
+    and 12 (636 of 640) -- and 16 splits (6.6 -> 7 waves per SIMD for 46 tiles each) is 20% slower than 12.
+    ``units`` = heads (multi-head form) or value chunks (gated form); ``occ`` = resident waves per SIMD of the kernel
+    (5 for the d=32 kernel; 1 for the wide gated kernel, where extra waves just queue)."""
+    waves1 = ((nq + 31) // 32) * units
     tiles = (t + 31) // 32
-    fill = min((_TARGET_WAVES + waves - 1) // waves, tiles // 4)
-    return max(1, min(16, max(tiles // 12, fill)))
+    best, best_cost = 1, None
+    for ns in range(1, max(1, min(16, tiles // 4)) + 1):
+        k = -(-waves1 * ns // _SIMDS)
+        eff = _OCC_EFF[min(k, occ, 5) - 1] if occ > 1 else 1.0
+        cost = k * (-(-tiles // ns) + c0) / eff + (0.15 * ns if ns > 1 else 0.0)   # + merge pass over ns partials
+        if best_cost is None or cost < best_cost * 0.999:
+            best, best_cost = ns, cost
+    return best
 
 
 class MultiheadAttention(nn.Module):
@@ -139,7 +152,7 @@ class GatedPropagation(nn.Module):
     def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None):
         """(softmax((q/T) k^T) v) * gate : q [Nq,128], k [>=t,128], v [>=t,E], gate/out [Nq,E]."""
         nq = q.shape[0]
-        ns = attn_splits(nq, out.shape[1] // 256, t)
+        ns = attn_splits(nq, out.shape[1] // 256, t, occ=1, c0=1.0)
         part = None
         if ns > 1:
             part = ws.get('gattn_part', (ns * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)

@@ -12,6 +12,7 @@ splits = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 and sys.a
 for M in (1, 2, 4, 8, 14):
     T = M * N
     k, v = torch.randn(T, C, generator=g).cuda(), torch.randn(T, C, generator=g).cuda()
+    if os.environ.get('DATA') == 'zeros': q.zero_(); k.zero_(); v.zero_()
     out = torch.empty(N, C, device='cuda')
     part = torch.empty(32 * N * (C + 2 * H), device='cuda')
     row = []
@@ -24,5 +25,7 @@ for M in (1, 2, 4, 8, 14):
         for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
+        if os.environ.get('CLK'):
+            part[-4:].zero_(); run(); torch.cuda.synchronize(); cb = part[-4:].view(torch.int64).tolist(); print('   clk ratio %.2f -> %.0f MHz' % (cb[0] / max(cb[1], 1), cb[0] / max(cb[1], 1) * 100))
         row.append('ns=%2d %7.1f us %5.1f TF' % (n, us, 4.0 * N * T * C / us / 1e6))
     print('M=%2d T=%6d %.2f GF | ' % (M, T, 4.0 * N * T * C / 1e9) + ' | '.join(row))

@@ -4,6 +4,8 @@ import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
+if len(sys.argv) > 2: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])
+ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 else None
 aot_hip.load()
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
 # (name, H, W, Cin, Cout, K, stride, count per frame)
@@ -24,6 +26,7 @@ S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
 tot = {c: 0.0 for c in cfgs}; totf = 0.0
 print('%-20s %7s %5s %5s %8s | ' % ('shape', 'M', 'K', 'N', 'GF') + ' | '.join('cfg%2d us    TF' % c for c in cfgs))
 for (name, H, W, Cin, Cout, K, s, cnt) in S:
+    if ONLY and not any(o in name for o in ONLY): continue
     p = K // 2
     OH, OW = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
     M, KK = OH * OW, K * K * Cin
