@@ -16,7 +16,7 @@ _SIMDS = 1024                 # 256 CUs x 4 SIMDs; one 32-query x 1-head (or 1-c
 _OCC_EFF = (0.8, 0.9, 0.97, 0.99, 1.0)   # measured MFMA-pipe fill at 1..5 resident waves per SIMD
 
 
-def attn_splits(nq, units, t, occ=5, c0=3.0):
+def attn_splits(nq, units, t, occ=4, c0=3.0):
     """How many key ranges to cut the bank into (csrc/attention.hip).
 
     The kernel is bound by the MFMA pipe of each SIMD, so its run time is the MAKESPAN over SIMDs: (waves per SIMD,
@@ -25,7 +25,7 @@ def attn_splits(nq, units, t, occ=5, c0=3.0):
     minima are the split counts that land just under a whole number of waves per SIMD -- 7 (371 of 384 slots per XCD)
     and 12 (636 of 640) -- and 16 splits (6.6 -> 7 waves per SIMD for 46 tiles each) is 20% slower than 12.
     ``units`` = heads (multi-head form) or value chunks (gated form); ``occ`` = resident waves per SIMD of the kernel
-    (5 for the d=32 kernel; 1 for the wide gated kernel, where extra waves just queue)."""
+    (4 for the d=32 kernel; 1 for the wide gated kernel, where extra waves just queue)."""
     waves1 = ((nq + 31) // 32) * units
     tiles = (t + 31) // 32
     best, best_cost = 1, None
