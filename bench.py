@@ -17,7 +17,7 @@ evaluation mode).  Clips shard over ranks with no data-path collective
 one all_gather of a small stats vector (replaces the reference's mp.Queue, evaluator.py:507-531).
 
 The JSON line also carries
-  roofline     -- the long-term attention kernel (attn_fwd_d32_kernel) timed live with HIP events on its
+  roofline     -- the long-term attention kernel (attn_fwd_d32_pipe_kernel) timed live with HIP events on its
                   stream: achieved = 4*N*T*C FLOP per launch / mean launch time, against the 157.3 TFLOP/s fp32
                   MFMA peak;
   cpu_baseline -- the CPU oracle (oracle/aot_oracle.py, a port of the reference's algorithm; the reference
@@ -134,7 +134,7 @@ def attention_roofline(engine, clip, device):
             traffic = round(json.load(f)['traffic_bytes_per_launch'])
     return {'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2), 'peak': FP32_MFMA_PEAK_TF,
             'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), 'traffic': traffic,
-            'kernel': 'attn_fwd_d32_kernel', 'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+            'kernel': 'attn_fwd_d32_pipe_kernel', 'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
             'gflop_per_launch': round(flop / n / 1e9, 3)}
 
 
