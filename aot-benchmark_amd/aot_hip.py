@@ -30,6 +30,7 @@ _SIGS = {
     'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
     'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
+    'aot_attn_topk_f32': [_P] * 5 + [_I] * 8 + [_F, _I, _P],
     'aot_gated_attn_f32': [_P] * 6 + [_I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
     'aot_local_gated_f32': [_P] * 8 + [_I] * 10 + [_F, _P],
@@ -176,6 +177,14 @@ def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, st
     if nsplit > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
              'aot_attn_merge_f32')
+    return out
+
+
+def attention_topk(q, k, v, out, T, H, scale_div, top_k, scores, stream=None):
+    """Top-k sparse attention (MultiheadAttention top_k > 0): scores is scratch of H*Nq*((T+3)&~3) floats."""
+    _chk(load().aot_attn_topk_f32(_dev(q), _dev(k), _dev(v), _dev(out), _dev(scores), q.shape[0], T, H, 32, q.stride(0),
+                                  k.stride(0), v.stride(0), out.stride(0), scale_div, top_k,
+                                  stream if stream is not None else stream_ptr()), 'aot_attn_topk_f32')
     return out
 
 

@@ -3,6 +3,7 @@ from networks.engines.aot_engine import AOTEngine, AOTInferEngine, DeAOTEngine, 
 
 
 def build_engine(name, phase='train', **kwargs):
+    # (kwargs may also carry long_term_mem_max, this repo's bounded-bank extension; default None = reference behaviour)
     if name == 'aotengine':
         if phase == 'eval':
             return AOTInferEngine(**kwargs)

@@ -22,8 +22,13 @@ from networks.models.aot import as_map, to_tokens
 
 
 class AOTEngine(nn.Module):
-    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1):
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None):
         super().__init__()
+        # long_term_mem_max (repo extension; the reference bank grows without bound): at most that many
+        # memorised frames -- the first one (the reference frame) is kept, the others form a ring of the most recent
+        if long_term_mem_max is not None and long_term_mem_max < 2:
+            raise ValueError('long_term_mem_max must be >= 2 (the reference frame + at least one recent frame)')
+        self.long_term_mem_max = long_term_mem_max
         self.cfg = aot_model.cfg
         self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
         self.AOT = aot_model
@@ -53,6 +58,7 @@ class AOTEngine(nn.Module):
         if not hasattr(self, 'bank_k'):
             self.bank_k, self.bank_v = None, None
         self.bank_len = 0
+        self.bank_frames = 0      # frames ever memorised (ring position of a bounded bank)
         self.short_term_memories_list = []
         self.short_term_memories = None
         self._feats = None        # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major
@@ -104,6 +110,15 @@ class AOTEngine(nn.Module):
             self.bank_k = [torch.empty(cap, k.shape[1], dtype=torch.float32, device=k.device) for k in ks]
             self.bank_v = [torch.empty(cap, v.shape[1], dtype=torch.float32, device=v.device) for v in vs]
             self.bank_len = 0
+            self.bank_frames = 0
+        if self.long_term_mem_max is not None and self.bank_frames >= self.long_term_mem_max:
+            # bounded bank: overwrite the oldest non-first frame (attention is order-invariant, so a ring is enough)
+            slot = 1 + (self.bank_frames - 1) % (self.long_term_mem_max - 1)
+            for i, (k, v) in enumerate(zip(ks, vs)):
+                self.bank_k[i][slot * N:(slot + 1) * N].copy_(k)
+                self.bank_v[i][slot * N:(slot + 1) * N].copy_(v)
+            self.bank_frames += 1
+            return
         if self.bank_len + N > self.bank_k[0].shape[0]:
             cap = max(2 * self.bank_k[0].shape[0], self.bank_len + N)
             for lst in (self.bank_k, self.bank_v):
@@ -115,6 +130,7 @@ class AOTEngine(nn.Module):
             self.bank_k[i][self.bank_len:self.bank_len + N].copy_(k)
             self.bank_v[i][self.bank_len:self.bank_len + N].copy_(v)
         self.bank_len += N
+        self.bank_frames += 1
 
     # ---- reference surface ---------------------------------------------------------------------
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
@@ -221,8 +237,10 @@ class AOTInferEngine(nn.Module):
 
     engine_cls = AOTEngine
 
-    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None):
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
+                 long_term_mem_max=None):
         super().__init__()
+        self.long_term_mem_max = long_term_mem_max       # bounded bank per object group (repo extension)
         self.cfg = aot_model.cfg
         self.AOT = aot_model
         if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
@@ -278,7 +296,8 @@ class AOTInferEngine(nn.Module):
         self.obj_nums = obj_nums
         aot_num = max(np.ceil(obj_nums / self.max_aot_obj_num), 1)
         while aot_num > len(self.aot_engines):
-            new_engine = self.engine_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
+            new_engine = self.engine_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
+                                         self.long_term_mem_max)
             new_engine.eval()
             self.aot_engines.append(new_engine)
         separated_masks, separated_obj_nums = self.separate_mask(mask, obj_nums)

@@ -5,6 +5,8 @@ kernels through ``aot_hip``.  All activations are token-major 2-D tensors ``[N, 
 exceed C: kernels take an explicit leading dimension, so column slices of wider buffers are used in
 place of the reference's permute/contiguous copies).
 """
+import math
+
 import torch
 from torch import nn
 
@@ -52,9 +54,10 @@ class MultiheadAttention(nn.Module):
         self.d_att = self.hidden_dim if d_att is None else d_att
         self.T = self.d_att ** 0.5
         self.use_linear = use_linear
-        if use_dis or top_k > 0 or max_mem_len_ratio > 0:
-            raise NotImplementedError('use_dis / top_k / max_mem_len_ratio are default-off eval knobs '
-                                      '(reference attention.py:37-47); not built yet')
+        if use_dis:
+            raise NotImplementedError('use_dis is a default-off knob no reference config enables (attention.py:99-100)')
+        self.max_mem_len_ratio = float(max_mem_len_ratio)     # eval-time Q rescale for long banks, attention.py:84-89
+        self.top_k = int(top_k)                               # eval-time sparse softmax, attention.py:102-105
         if use_linear:
             self.linear_Q = nn.Linear(d_model, d_model)
             self.linear_K = nn.Linear(d_model, d_model)
@@ -64,11 +67,20 @@ class MultiheadAttention(nn.Module):
     def core(self, q, k, v, out, t, ws, stream, t_dev=None):
         """q [Nq, C], k/v [>=t, C] token-major -> out [Nq, C] (pre-projection)."""
         nq = q.shape[0]
+        scale_div = self.T
+        if self.max_mem_len_ratio > 0:
+            ratio = float(t) / nq
+            if ratio > self.max_mem_len_ratio:      # Q *= log(ratio)/log(max ratio), folded into the divisor
+                scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
+        if 0 < self.top_k < t:
+            scores = ws.get('attn_scores', (self.num_head * nq * ((t + 3) // 4 * 4),), q.device)
+            aot_hip.attention_topk(q, k, v, out, t, self.num_head, scale_div, self.top_k, scores, stream=stream)
+            return out
         ns = attn_splits(nq, self.num_head, t)
         part = None
         if ns > 1:
             part = ws.get('attn_part', (ns * nq * (self.d_model + 2 * self.num_head),), q.device)
-        aot_hip.attention(q, k, v, out, t, self.num_head, self.T, part=part, nsplit=ns, T_dev=t_dev, stream=stream)
+        aot_hip.attention(q, k, v, out, t, self.num_head, scale_div, part=part, nsplit=ns, T_dev=t_dev, stream=stream)
         return out
 
 

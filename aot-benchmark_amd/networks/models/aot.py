@@ -57,6 +57,11 @@ class AOT(nn.Module):
             lt_dropout=cfg.TRAIN_LSTT_LT_DROPOUT, st_dropout=cfg.TRAIN_LSTT_ST_DROPOUT,
             droppath_lst=cfg.TRAIN_LSTT_DROPPATH_LST, droppath_scaling=cfg.TRAIN_LSTT_DROPPATH_SCALING,
             intermediate_norm=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, return_intermediate=True)
+        # Long-video knobs of the reference's MultiheadAttention (attention.py:37-38,84-89,102-105).  The reference only
+        # exposes them as constructor arguments that no caller sets; here two optional config keys reach them.
+        for layer in self.LSTT.layers:
+            layer.long_term_attn.top_k = int(getattr(cfg, 'MODEL_LT_TOP_K', -1))
+            layer.long_term_attn.max_mem_len_ratio = float(getattr(cfg, 'MODEL_LT_MAX_MEM_LEN_RATIO', -1))
         decoder_indim = emb * (cfg.MODEL_LSTT_NUM + 1) if cfg.MODEL_DECODER_INTERMEDIATE_LSTT else emb
         self.decoder = build_decoder(decoder, in_dim=decoder_indim, out_dim=cfg.MODEL_MAX_OBJ_NUM + 1,
                                      decode_intermediate_input=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, hidden_dim=emb,

@@ -108,6 +108,14 @@ int aot_attn_f32(const float* q, const float* k, const float* v, float* out, flo
 int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq, int H, int C, int ldg,
                        int ldo, int nsplit, void* stream);
 
+/* Top-k sparse form of aot_attn_f32 (MultiheadAttention with top_k > 0, networks/layers/attention.py:102-105, a
+ * default-off long-video knob): per query row and head only the top_k largest scores enter the softmax and the
+ * value sum.  `scores` is caller-owned scratch of H*Nq*((T+3)&~3) floats (the materialised score matrix).
+ * 0 < top_k < T required (top_k >= T is the dense softmax: call aot_attn_f32).  Among scores EQUAL to the k-th
+ * largest the choice is arbitrary, as in torch.topk. */
+int aot_attn_topk_f32(const float* q, const float* k, const float* v, float* out, float* scores, int Nq, int T,
+                      int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div, int top_k, void* stream);
+
 /* Gated-propagation attention of DeAOT, single head: out = softmax((q/scale_div) k^T) v  (* gate), with
  * q [Nq, dqk=128], k [T, 128], v [T, dv] (dv a multiple of 256; 1024 = [V | ID_V]), gate/out [Nq, dv].
  * Same split/merge protocol as aot_attn_f32 with H := dv/256 groups; with nsplit > 1 pass the gate to

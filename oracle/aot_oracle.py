@@ -227,16 +227,27 @@ def swin_features(sd, x, p='encoder', depths=(2, 2, 18), heads=(4, 8, 16), ws=7)
 # --------------------------------------------------------------------------
 # attention cores
 # --------------------------------------------------------------------------
-def mha_core(Q, K, V, H):
+def mha_core(Q, K, V, H, max_mem_len_ratio=-1., top_k=-1):
     """MultiheadAttention.forward, networks/layers/attention.py:82-117, after the
-    optional input linears and before ``projection``.  Q [Tq,B,C], K,V [Tk,B,C]."""
+    optional input linears and before ``projection``.  Q [Tq,B,C], K,V [Tk,B,C].
+    Eval-time knobs: max_mem_len_ratio (:84-89) rescales Q for banks longer than
+    ratio x the query length; top_k (:102-105) keeps the k largest scores per row."""
     Tq, B, C = Q.shape
     d = C // H
     Q = Q / (d ** 0.5)                                            # :82
+    if max_mem_len_ratio > 0:                                     # :84-89
+        mem_len_ratio = float(K.shape[0]) / Tq
+        if mem_len_ratio > max_mem_len_ratio:
+            Q = Q * (math.log(mem_len_ratio) / math.log(max_mem_len_ratio))
     q = Q.view(Tq, B, H, d).permute(1, 2, 0, 3)
     k = K.view(-1, B, H, d).permute(1, 2, 3, 0)
     v = V.view(-1, B, H, V.shape[-1] // H).permute(1, 2, 0, 3)
-    a = torch.softmax(q @ k, dim=-1)                              # :97,107
+    qk = q @ k                                                    # :97
+    if 0 < top_k < qk.shape[-1]:                                  # :102-105
+        top, idx = torch.topk(qk, k=top_k, dim=-1)
+        a = torch.zeros_like(qk).scatter_(-1, idx, torch.softmax(top, dim=-1))
+    else:
+        a = torch.softmax(qk, dim=-1)                             # :107
     return (a @ v).permute(2, 0, 1, 3).reshape(Tq, B, -1)         # :113-117
 
 
@@ -414,7 +425,7 @@ class OracleModel:
         else:
             gK, gV = long_mem
             lK, lV = short_mem
-        lt_core = mha_core(cQ, gK, gV, H)
+        lt_core = mha_core(cQ, gK, gV, H, self.spec.get('lt_max_mem_len_ratio', -1.), self.spec.get('lt_top_k', -1))
         lt = _lin(lt_core, sd, p + '.long_term_attn.projection')
         st = aot_local_attention(sd, p + '.short_term_attn', lQ, lK, lV, H)
         self._t('L%d.curr_Q' % i, cQ)
@@ -542,10 +553,11 @@ class OracleModel:
 # networks/engines/deaot_engine.py:20-56
 # --------------------------------------------------------------------------
 class OracleEngine:
-    def __init__(self, model, long_term_mem_gap=None, short_term_mem_skip=1):
+    def __init__(self, model, long_term_mem_gap=None, short_term_mem_skip=1, long_term_mem_max=None):
         self.AOT = model
         self.long_term_mem_gap = model.spec['mem_gap'] if long_term_mem_gap is None else long_term_mem_gap
         self.short_term_mem_skip = short_term_mem_skip
+        self.long_term_mem_max = long_term_mem_max     # repo extension: bounded bank, see _update_long
         self.restart_engine()
 
     def restart_engine(self):                                      # aot_engine.py:445-477
@@ -590,6 +602,12 @@ class OracleEngine:
         upd = []
         for nm, om in zip(new, self.long_term_memories):
             upd.append([None if (a is None or b is None) else torch.cat([b, a], 0) for a, b in zip(nm, om)])
+        if self.long_term_mem_max is not None:
+            # bounded bank (not in the reference, which grows without limit): keep the first memorised frame and the
+            # most recent long_term_mem_max - 1 others, i.e. drop the oldest non-first frame
+            N = self.enc_hw
+            upd = [[None if t is None else (t if t.shape[0] <= self.long_term_mem_max * N else
+                                            torch.cat([t[:N], t[2 * N:]], 0)) for t in layer] for layer in upd]
         self.long_term_memories = upd
 
     def match_propogate_one_frame(self, img, img_embs=None):       # :340-354

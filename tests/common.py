@@ -29,12 +29,14 @@ def model_cfg(name):
     return importlib.import_module('configs.models.' + name).ModelConfig()
 
 
-def synth_model_state(name):
+def synth_model_state(name, cfg_overrides=None):
     """Keyed synthetic weights for model `name`, built from THIS package's parameter tree (whose keys and
     shapes are tested against the reference's in test_state_dict_layout)."""
     from networks.models import build_vos_model
     from utils.synth import synth_state_dict
     cfg = model_cfg(name)
+    for k, v in (cfg_overrides or {}).items():
+        setattr(cfg, k, v)
     model = build_vos_model(cfg.MODEL_VOS, cfg)
     sd = synth_state_dict(model.state_dict())
     model.load_state_dict(sd)
@@ -80,3 +82,17 @@ def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lam
             fb = F.interpolate(to_dev(fb), size=engine.input_size_2d, mode='nearest')
             engine.update_memory(fb)
     return out
+
+
+def mha_knob_inputs():
+    """Inputs of tests/golden/mha_knobs.npz (make_golden.make_mha_knobs): same seeded CPU generator."""
+    g = torch.Generator().manual_seed(4242)
+    Tq, Tk, C, H = 96, 1000, 256, 8
+    Q = torch.randn(Tq, 1, C, generator=g) * 2.0
+    K = torch.randn(Tk, 1, C, generator=g)
+    V = torch.randn(Tk, 1, C, generator=g)
+    return Q, K, V, H
+
+
+MHA_KNOB_CASES = {'topk50': dict(top_k=50), 'topk1': dict(top_k=1), 'ratio4': dict(max_mem_len_ratio=4.),
+                  'ratio4_topk200': dict(max_mem_len_ratio=4., top_k=200), 'dense': dict()}

@@ -47,7 +47,38 @@ CASES = {
 }
 
 
+def make_mha_knobs():
+    """Module-level golden for the default-off long-video knobs of the reference's MultiheadAttention
+    (attention.py:84-89 max_mem_len_ratio, :102-105 top_k): the REAL reference module, use_linear=False, projection set
+    to the identity so the output is the attention core."""
+    refdriver._enter()
+    try:
+        from networks.layers.attention import MultiheadAttention
+        g = torch.Generator().manual_seed(4242)
+        Tq, Tk, C, H = 96, 1000, 256, 8
+        Q = torch.randn(Tq, 1, C, generator=g) * 2.0
+        K = torch.randn(Tk, 1, C, generator=g)
+        V = torch.randn(Tk, 1, C, generator=g)
+        # inputs are regenerated from the seed by the tests (tests/common.py: mha_knob_inputs); only a checksum is stored
+        out = {'input_sums': np.array([Q.double().sum().item(), K.double().sum().item(), V.double().sum().item()])}
+        for name, kw in (('topk50', dict(top_k=50)), ('topk1', dict(top_k=1)), ('ratio4', dict(max_mem_len_ratio=4)),
+                         ('ratio4_topk200', dict(max_mem_len_ratio=4, top_k=200)), ('dense', dict())):
+            m = MultiheadAttention(C, H, use_linear=False, **kw).eval()
+            with torch.no_grad():
+                m.projection.weight.copy_(torch.eye(C))
+                m.projection.bias.zero_()
+                out[name] = m(Q, K, V)[0].numpy()
+        np.savez_compressed(os.path.join(HERE, 'mha_knobs.npz'), **out)
+        print('mha_knobs', {k: v.shape for k, v in out.items()}, flush=True)
+    finally:
+        refdriver._leave()
+
+
 def main():
+    if not sys.argv[1:] or 'mha_knobs' in sys.argv[1:]:
+        make_mha_knobs()
+        if sys.argv[1:] == ['mha_knobs']:
+            return
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     keys = {}

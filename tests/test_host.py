@@ -137,6 +137,8 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 64, 256, 256, 256, 256, 5.65, 1, None) == -2
     assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # splits need `part`
     assert lib.aot_local_attn_f32(P(16), P(16), P(16), P(16), P(16), P(16), P(16), 4, 4, 8, 32, 5, 256, 256, 256, 256, 5.65, None) == -2
+    assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), P(16), 8, 8, 8, 32, 256, 256, 256, 256, 5.65, 8, None) == -1  # top_k >= T
+    assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), None, 8, 64, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # no scratch
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, P(16), 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 8, 0, 0, None) == -1  # Cin % 4
     assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
     assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2

@@ -4,8 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from common import LOGIT_TOL, case_clip, check_masks, load_case, run_teacher_forced, synth_model_state
-from oracle.aot_oracle import OracleEngine, OracleModel
+from common import (GOLD, LOGIT_TOL, MHA_KNOB_CASES, case_clip, check_masks, load_case, mha_knob_inputs, run_teacher_forced,
+                    synth_model_state)
+from oracle.aot_oracle import OracleEngine, OracleModel, mha_core
 
 
 @pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c2_r50_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl'])
@@ -40,3 +41,44 @@ def test_oracle_fp64_agrees_with_fp32():
             eng.decode_current_logits(out_size)
         outs.append(eng.pred_id_logits[0, :2].double())
     assert (outs[0] - outs[1]).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize('case', sorted(MHA_KNOB_CASES))
+def test_oracle_attention_knobs_match_reference_module(case):
+    """top_k / max_mem_len_ratio (attention.py:84-89,102-105): the oracle's mha_core against the REAL reference
+    MultiheadAttention run with those constructor knobs (tests/golden/mha_knobs.npz)."""
+    import os
+    g = np.load(os.path.join(GOLD, 'mha_knobs.npz'))
+    Q, K, V, H = mha_knob_inputs()
+    sums = np.array([Q.double().sum().item(), K.double().sum().item(), V.double().sum().item()])
+    assert np.allclose(sums, g['input_sums'], rtol=0, atol=1e-9), 'seeded inputs differ from the ones the golden was made with'
+    out = mha_core(Q, K, V, H, **MHA_KNOB_CASES[case]).numpy()
+    assert np.abs(out - g[case]).max() < 2e-6
+
+
+def test_oracle_bounded_bank_keeps_first_and_most_recent():
+    """long_term_mem_max (repo extension): the bank never exceeds the bound, always holds the reference frame's rows
+    first, and an unbounded engine agrees with it until the bound is reached."""
+    from utils.synth import synth_clip
+    _, _, sd = synth_model_state('aott')
+    frames, mask, objs, out_size = synth_clip(6, 6, (65, 81), (64, 80), 2)
+    a = OracleEngine(OracleModel('aott', sd), long_term_mem_gap=1, long_term_mem_max=3)
+    b = OracleEngine(OracleModel('aott', sd), long_term_mem_gap=1)
+    with torch.no_grad():
+        for e in (a, b):
+            e.add_reference_frame(frames[0], mask, objs)
+        first = a.long_term_memories[0][0].clone()
+        for t in range(1, 6):
+            outs = []
+            for e in (a, b):
+                e.match_propogate_one_frame(frames[t])
+                outs.append(e.decode_current_logits(out_size))
+                e.update_memory(mask)
+            n = a.enc_hw
+            assert a.long_term_memories[0][0].shape[0] == min(t + 1, 3) * n
+            assert torch.equal(a.long_term_memories[0][0][:n], first)
+            if t <= 3:      # frames 1..3 still see identical banks (bank of frame t is built from frames < t)
+                assert torch.equal(outs[0], outs[1])
+            else:
+                assert not torch.equal(outs[0], outs[1])
+            assert torch.equal(a.long_term_memories[0][0][-n:], b.long_term_memories[0][0][-n:])

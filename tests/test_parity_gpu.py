@@ -329,10 +329,11 @@ def test_local_gated_vs_oracle(hip, h, w):
 # ------------------------------------------------------------------ end to end -------------------
 def _hip_engine(model_name, **kw):
     from networks.engines import build_engine
-    cfg, model, sd = synth_model_state(model_name)
+    cfg, model, sd = synth_model_state(model_name, cfg_overrides=kw.get('cfg_overrides'))
     model = model.cuda().eval()
+    extra = {k: kw[k] for k in ('short_term_mem_skip', 'long_term_mem_max') if k in kw}
     eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0,
-                       long_term_mem_gap=kw.get('gap', cfg.TEST_LONG_TERM_MEM_GAP))
+                       long_term_mem_gap=kw.get('gap', cfg.TEST_LONG_TERM_MEM_GAP), **extra)
     return cfg, model, eng, sd
 
 
@@ -391,6 +392,81 @@ def test_free_running_bank_growth_vs_oracle(hip):
             ora.update_memory(fb)
     e0 = eng.aot_engines[0]
     assert e0.bank_len == 15 * e0.enc_hw and e0.bank_k[0].shape[0] >= e0.bank_len
+
+
+@pytest.mark.parametrize('case', ['topk50', 'topk1', 'ratio4', 'ratio4_topk200', 'dense'])
+def test_attention_knobs_vs_reference_module(hip, case):
+    """top_k sparse softmax / max_mem_len_ratio Q rescale (attention.py:84-89,102-105) through the layer's core
+    against the REAL reference module's outputs (tests/golden/mha_knobs.npz)."""
+    import os
+    from common import GOLD, MHA_KNOB_CASES, mha_knob_inputs
+    from networks.layers.attention import MultiheadAttention
+    from networks.layers.workspace import Workspace
+    g = np.load(os.path.join(GOLD, 'mha_knobs.npz'))
+    Q, K, V, H = mha_knob_inputs()
+    m = MultiheadAttention(256, H, use_linear=False, **MHA_KNOB_CASES[case])
+    q, k, v = Q[:, 0].cuda().contiguous(), K[:, 0].cuda().contiguous(), V[:, 0].cuda().contiguous()
+    out = torch.empty(q.shape[0], 256, device='cuda')
+    m.core(q, k, v, out, k.shape[0], Workspace(), hip.stream_ptr())
+    _close(out, torch.from_numpy(g[case][:, 0]), 5e-6, case)
+
+
+@pytest.mark.parametrize('Nq,T,top_k', [(300, 5000, 128), (1674, 3 * 1674, 512), (33, 257, 256), (64, 64, 3)])
+def test_attention_topk_vs_oracle(hip, Nq, T, top_k):
+    """aot_attn_topk_f32 at larger / ragged shapes, through strided views, against the oracle's mha_core."""
+    from oracle.aot_oracle import mha_core
+    g = torch.Generator().manual_seed(Nq + T)
+    H, C = 8, 256
+    qb, kb, vb = torch.randn(Nq, C + 64, generator=g), torch.randn(T + 5, C, generator=g), torch.randn(T + 5, 2 * C, generator=g)
+    q, k, v = qb[:, 32:32 + C], kb, vb[:, C:]
+    ref = mha_core(q.unsqueeze(1).contiguous(), k[:T].unsqueeze(1).contiguous(), v[:T].unsqueeze(1).contiguous(), H, top_k=top_k)[:, 0]
+    qd, kd, vd = qb.cuda()[:, 32:32 + C], kb.cuda(), vb.cuda()[:, C:]
+    out = torch.full((Nq, C + 8), 7.0, device='cuda')
+    scores = torch.empty(H * Nq * ((T + 3) // 4 * 4), device='cuda')
+    hip.attention_topk(qd, kd, vd, out[:, :C], T, H, 32 ** 0.5, top_k, scores)
+    # Which key is the k-th largest is decided by fp32 rounding when the k-th and (k+1)-th scores nearly tie (the two
+    # implementations sum in different orders), and swapping them changes the output by ~ their weight.  Compare the
+    # (query, head) pairs whose reference gap at the cut is clear; the near-ties must still be close to the dense-ish
+    # answer (error bounded by the weight of one boundary key).
+    sc = torch.einsum('qhd,thd->hqt', (q / 32 ** 0.5).reshape(Nq, H, 32).double(), k[:T].reshape(T, H, 32).double())
+    top = torch.topk(sc, min(top_k + 1, T), dim=-1)[0]
+    clear = ((top[..., top_k - 1] - top[..., top_k]) > 1e-4).t()                 # [Nq, H]
+    err = (out[:, :C].cpu() - ref).abs().reshape(Nq, H, 32).amax(-1)
+    assert clear.float().mean().item() > 0.5
+    assert err[clear].max().item() < 5e-6, 'top-k clear rows err %g' % err[clear].max().item()
+    wmax = torch.softmax(top[..., :top_k], -1)[..., -1].t().float()              # weight of the boundary key
+    assert (err[~clear] <= 8.0 * wmax[~clear] + 5e-6).all()
+    assert (out[:, C:] == 7.0).all()
+
+
+@pytest.mark.parametrize('top_k,tol', [(-1, 2e-4), (40, 5e-2)])
+def test_long_video_knobs_engine_vs_oracle(hip, top_k, tol):
+    """SURVEY 8f3 through the engine API, HIP vs oracle, frame by frame on the oracle's masks (AOTT, gap 1):
+    short_term_mem_skip=2, skip_long_term_update on some frames, a bounded bank (long_term_mem_max=3) and
+    max_mem_len_ratio on the long-term attention at the usual 2e-4; with top_k on top the bar is loose, because which key
+    sits at the cut is decided by fp32 rounding (see test_attention_topk_vs_oracle) -- that run checks the plumbing."""
+    from oracle.aot_oracle import SPECS, OracleEngine, OracleModel
+    from utils.synth import synth_clip
+    cfg, model, eng, sd = _hip_engine('aott', gap=1, short_term_mem_skip=2, long_term_mem_max=3,
+                                      cfg_overrides=dict(MODEL_LT_TOP_K=top_k, MODEL_LT_MAX_MEM_LEN_RATIO=1.5))
+    spec = dict(SPECS['aott'], lt_top_k=top_k, lt_max_mem_len_ratio=1.5)
+    ora = OracleEngine(OracleModel(spec, sd), long_term_mem_gap=1, short_term_mem_skip=2, long_term_mem_max=3)
+    frames, mask, objs, out_size = synth_clip(11, 9, (97, 129), (96, 128), 3)
+    with torch.no_grad():
+        eng.add_reference_frame(frames[0].cuda(), mask.cuda(), objs, frame_step=0)
+        ora.add_reference_frame(frames[0], mask, objs)
+        for t in range(1, 9):
+            eng.match_propogate_one_frame(frames[t].cuda())
+            ora.match_propogate_one_frame(frames[t])
+            lg, lo = eng.decode_current_logits(out_size), ora.decode_current_logits(out_size)
+            _close(lg[:, :4], lo[:, :4], tol, 'frame %d logits' % t)
+            assert (torch.argmax(lg, 1).cpu() == torch.argmax(lo, 1)).float().mean().item() > 0.995
+            fb = F.interpolate(torch.argmax(lo, 1, keepdim=True).float(), size=ora.input_size_2d, mode='nearest')
+            skip = (t % 3 == 0)
+            eng.update_memory(fb.cuda(), skip_long_term_update=skip)
+            ora.update_memory(fb, skip_long_term_update=skip)
+    e0 = eng.aot_engines[0]
+    assert e0.bank_len == 3 * e0.enc_hw
 
 
 def test_more_than_ten_objects_vs_oracle(hip):
