@@ -128,7 +128,7 @@ def attention_roofline(engine, clip, device):
     flop = sum(f for _, _, f in recs)
     n = len(recs)
     traffic = None     # HBM/fabric bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-    tp = os.path.join(ROOT, 'profiles', 'r01_attn_traffic.json')
+    tp = os.path.join(ROOT, 'profiles', 'r01c_attn_traffic.json')
     if os.path.exists(tp):
         with open(tp) as f:
             traffic = round(json.load(f)['traffic_bytes_per_launch'])
