@@ -30,6 +30,9 @@ _SIGS = {
     'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
     'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
+    'aot_preprocess_f32': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
+    'aot_fuse_probs_f32': [_P] * 5 + [_I] * 5 + [_P],
+    'aot_label_resize_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_attn_topk_f32': [_P] * 5 + [_I] * 8 + [_F, _I, _P],
     'aot_gated_attn_f32': [_P] * 6 + [_I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
@@ -267,4 +270,46 @@ def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_num, align_corners
 def add(a, b, out, stream=None):
     _chk(load().aot_add_f32(_dev(a), _dev(b), _dev(out), a.numel(), stream if stream is not None else stream_ptr()),
          'aot_add_f32')
+    return out
+
+
+_MEAN3 = (ctypes.c_double * 3)(0.485, 0.456, 0.406)
+_STD3 = (ctypes.c_double * 3)(0.229, 0.224, 0.225)
+
+
+def preprocess(img, out_h, out_w, flip=False, out=None, stream=None):
+    """img [H, W, 3] uint8 or float32 (values 0..255) on the device -> normalised engine input [1, 3, out_h, out_w]
+    (MultiRestrictSize's cubic resize + flip and MultiToTensor, video_transforms.py:655-711)."""
+    if img.dim() != 3 or img.shape[2] != 3 or img.stride(2) != 1 or img.stride(1) != 3:
+        raise AotHipError('preprocess expects an interleaved [H, W, 3] image')
+    if img.dtype not in (torch.uint8, torch.float32):
+        raise AotHipError('preprocess expects uint8 or float32')
+    if out is None:
+        out = torch.empty(1, 3, out_h, out_w, dtype=torch.float32, device=img.device)
+    _chk(load().aot_preprocess_f32(_dev(img), int(img.dtype == torch.uint8), img.shape[0], img.shape[1], img.stride(0),
+                                   _dev(out), out_h, out_w, int(bool(flip)), _MEAN3, _STD3,
+                                   stream if stream is not None else stream_ptr()), 'aot_preprocess_f32')
+    return out
+
+
+def fuse_probs(logits, flips, new_label=None, want_aug_labels=True, want_prob=False, stream=None):
+    """logits [A, nc, H, W] (one row per augmentation, decoded at the original size), flips: list of A bools.
+    Returns (fused_label [1,1,H,W], aug_labels [A,1,H,W] | None, fused_prob [1,nc,H,W] | None) -- evaluator.py:325-372."""
+    A, nc, H, W = logits.shape
+    dev = logits.device
+    fused = torch.empty(1, 1, H, W, dtype=torch.float32, device=dev)
+    augl = torch.empty(A, 1, H, W, dtype=torch.float32, device=dev) if want_aug_labels else None
+    prob = torch.empty(1, nc, H, W, dtype=torch.float32, device=dev) if want_prob else None
+    mask = sum(1 << i for i, f in enumerate(flips) if f)
+    _chk(load().aot_fuse_probs_f32(_dev(logits.contiguous()), _opt(new_label), _dev(fused), _opt(augl), _opt(prob), A, nc, H, W,
+                                   mask, stream if stream is not None else stream_ptr()), 'aot_fuse_probs_f32')
+    return fused, augl, prob
+
+
+def label_resize(label, out_h, out_w, flip=False, stream=None):
+    """label [..., H, W] float -> [1, 1, out_h, out_w]: flip_tensor(label, 3) then F.interpolate(mode='nearest')."""
+    H, W = label.shape[-2:]
+    out = torch.empty(1, 1, out_h, out_w, dtype=torch.float32, device=label.device)
+    _chk(load().aot_label_resize_f32(_dev(label.contiguous()), _dev(out), H, W, out_h, out_w, int(bool(flip)),
+                                     stream if stream is not None else stream_ptr()), 'aot_label_resize_f32')
     return out

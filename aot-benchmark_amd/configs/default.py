@@ -15,8 +15,8 @@ class DefaultEngineConfig():
         self.TEST_CKPT_PATH = None
         self.TEST_FLIP = False
         self.TEST_MULTISCALE = [1]
-        self.TEST_MIN_SIZE = None
-        self.TEST_MAX_SIZE = 800 * 1.3
+        self.TEST_MAX_SHORT_EDGE = None
+        self.TEST_MAX_LONG_EDGE = 800 * 1.3
         self.DIST_BACKEND = 'nccl'  # RCCL on ROCm
 
 

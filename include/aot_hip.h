@@ -181,6 +181,28 @@ int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int IH
 /* out = a + b over n floats (n % 4 == 0) -- V + id_emb in fuse_key_value_id (transformer.py:364-367). */
 int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream);
 
+/* ---- evaluator-side steps: what the reference does on either side of the engine per frame ---- */
+
+/* Frame preparation: cubic resize of an interleaved H x W x 3 image (uint8 or float32 in [0,255], row stride ld_src
+ * elements) to OH x OW with OpenCV's INTER_CUBIC arithmetic (a = -0.75, half-pixel centres, replicated border; a plain copy
+ * when the size is unchanged), optional horizontal flip of the RESULT, then ((v / 255) - mean[c]) / std[c] with the
+ * reference's float32/float64 rounding sequence; dst is the engine input [3, OH, OW] planar.
+ * Replaces MultiRestrictSize's cv2.resize + flip and MultiToTensor, dataloaders/video_transforms.py:655-680,703-711. */
+int aot_preprocess_f32(const void* src, int src_is_u8, int H, int W, int ld_src, float* dst, int OH, int OW,
+                       int flip, const double* mean3, const double* std3, void* stream);
+
+/* Test-time-augmentation fusion: logits [A][nc][OH*OW] (one engine per augmentation, all decoded at the original
+ * size); bit a of flipmask = augmentation a is horizontally flipped.  Per augmentation: un-flip, softmax over the nc
+ * channels, argmax -> aug_labels[a] (optional); mean of the probabilities over A -> fused_prob (optional) -> argmax ->
+ * fused_label.  new_label (optional): pixels where it is non-zero override every label map (new objects).
+ * Replaces networks/managers/evaluator.py:325-372 (flip_tensor, softmax, mean, argmax, keep-merge). */
+int aot_fuse_probs_f32(const float* logits, const float* new_label, float* fused_label, float* aug_labels,
+                       float* fused_prob, int A, int nc, int OH, int OW, int flipmask, void* stream);
+
+/* Label feedback: optional horizontal flip, then F.interpolate(mode="nearest") of a [H, W] float label map to the engine's
+ * input size [OH, OW] (torch's legacy nearest index rule).  Replaces evaluator.py:375-386,399-408. */
+int aot_label_resize_f32(const float* src, float* dst, int H, int W, int OH, int OW, int flip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

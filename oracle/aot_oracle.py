@@ -27,6 +27,8 @@ through this module.
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -743,3 +745,155 @@ def run_clip(engine, frames, first_mask, obj_nums, output_size, teacher_masks=No
             engine.update_memory(fb)
             out.append(rec)
     return out
+
+
+# --------------------------------------------------------------------------
+# evaluator-side steps: dataloaders/video_transforms.py:594-715,
+# networks/managers/evaluator.py:265-446
+# --------------------------------------------------------------------------
+def restrict_size(h, w, max_short_edge=None, max_long_edge=800, scale=1.0, align_corners=True, max_stride=16):
+    """MultiRestrictSize's size arithmetic, video_transforms.py:612-653 (pinned on the reference class by
+    tests/golden/transforms.json)."""
+    sc = 1.
+    if max_short_edge is not None:
+        short_edge = w if h > w else h
+        if short_edge > max_short_edge:
+            sc *= float(max_short_edge) / short_edge
+    new_h, new_w = sc * h, sc * w
+    sc = 1.
+    if max_long_edge is not None:
+        long_edge = new_h if new_h > new_w else new_w
+        if long_edge > max_long_edge:
+            sc *= float(max_long_edge) / long_edge
+    new_h, new_w = sc * new_h, sc * new_w
+    new_h, new_w = int(new_h * scale), int(new_w * scale)
+    if align_corners:
+        if (new_h - 1) % max_stride != 0:
+            new_h = int(np.around((new_h - 1) / max_stride) * max_stride + 1)
+        if (new_w - 1) % max_stride != 0:
+            new_w = int(np.around((new_w - 1) / max_stride) * max_stride + 1)
+    else:
+        if new_h % max_stride != 0:
+            new_h = int(np.around(new_h / max_stride) * max_stride)
+        if new_w % max_stride != 0:
+            new_w = int(np.around(new_w / max_stride) * max_stride)
+    return new_h, new_w
+
+
+def cv2_cubic_resize(img, oh, ow):
+    """cv2.resize(img, (ow, oh), interpolation=cv2.INTER_CUBIC) for a float32 H x W x C image, restated from OpenCV's
+    published algorithm (modules/imgproc/src/resize.cpp: fx = (dx + 0.5) * scale - 0.5, sx = floor(fx), interpolateCubic
+    with A = -0.75, taps clamped to the border, horizontal pass then vertical pass, float32 arithmetic).
+    PARITY UNPINNED for this one function: OpenCV (the reference's dependency, unpinned in its requirements) is not
+    installed here; tests cross-check it against torch's independent bicubic (same formula)."""
+    img = np.asarray(img, dtype=np.float32)
+    H, W = img.shape[:2]
+    if (oh, ow) == (H, W):
+        return img.copy()
+
+    def taps(n_out, n_in):
+        scale = float(n_in) / n_out
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        x = (f - i0).astype(np.float32)
+        A = np.float32(-0.75)
+        c = np.empty((n_out, 4), np.float32)
+        c[:, 0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A
+        c[:, 1] = ((A + 2) * x - (A + 3)) * x * x + 1
+        c[:, 2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1
+        c[:, 3] = np.float32(1) - c[:, 0] - c[:, 1] - c[:, 2]
+        idx = np.clip(i0[:, None] + np.arange(-1, 3)[None], 0, n_in - 1)
+        return idx, c
+
+    ix, cx = taps(ow, W)
+    iy, cy = taps(oh, H)
+    rows = np.zeros((H, ow) + img.shape[2:], np.float32)
+    for t in range(4):
+        rows += img[:, ix[:, t]] * cx[:, t].reshape((1, ow) + (1,) * (img.ndim - 2))
+    out = np.zeros((oh, ow) + img.shape[2:], np.float32)
+    for t in range(4):
+        out += rows[iy[:, t]] * cy[:, t].reshape((oh, 1) + (1,) * (img.ndim - 2))
+    return out
+
+
+def to_tensor_normalise(img):
+    """MultiToTensor on one float32 H x W x 3 image, video_transforms.py:703-711 (numpy arithmetic kept literally)."""
+    tmp = np.asarray(img, dtype=np.float32)
+    tmp = tmp / 255.
+    tmp -= (0.485, 0.456, 0.406)
+    tmp /= (0.229, 0.224, 0.225)
+    return torch.from_numpy(np.ascontiguousarray(tmp.transpose((2, 0, 1))))
+
+
+def flip_tensor(t, dim):                                           # utils/image.py:108-112
+    return t.index_select(dim, torch.arange(t.size(dim) - 1, -1, -1))
+
+
+def sequence_eval(model, frames, labels, obj_nums, flip=False, multiscale=(1,), max_short_edge=None,
+                  max_long_edge=800 * 1.3, long_term_mem_gap=None, short_term_mem_skip=1):
+    """The per-sequence loop of Evaluator.evaluating, networks/managers/evaluator.py:265-446, on in-memory frames
+    (float32 H x W x 3 arrays, 0..255): test-time augmentations from MultiRestrictSize, one engine per augmentation,
+    probability fusion, new-object merge, label feedback.  Returns [(fused label [H,W], fused prob [nc,H,W])] for frames 1.. ."""
+    H, W = frames[0].shape[:2]
+    ac = model.spec['align_corners']
+    augs = []
+    for sc in multiscale:                                          # video_transforms.py:609-682
+        nh, nw = restrict_size(H, W, max_short_edge, max_long_edge, sc, ac)
+        augs.append((nh, nw, False))
+        if flip:
+            augs.append((nh, nw, True))
+    engines = [OracleInferEngine(model, long_term_mem_gap) for _ in augs]
+    out = []
+
+    def prep(img, nh, nw, fl):
+        r = cv2_cubic_resize(img, nh, nw)
+        if fl:
+            r = r[:, ::-1].copy()
+        return to_tensor_normalise(r).unsqueeze(0)
+
+    with torch.no_grad():
+        for t, img in enumerate(frames):
+            ins = [prep(img, *a) for a in augs]
+            label = labels.get(t)
+            if label is not None:
+                label = torch.as_tensor(np.asarray(label)).float().view(1, 1, H, W)
+            if t == 0:
+                for e, x, (nh, nw, fl) in zip(engines, ins, augs):
+                    lab = flip_tensor(label, 3) if fl else label
+                    lab = F.interpolate(lab, size=x.shape[2:], mode='nearest')          # evaluator.py:309-312
+                    e.add_reference_frame(x, lab, int(obj_nums[0]))
+                    _set_skip(e, short_term_mem_skip)
+                continue
+            all_preds = []
+            for e, x, (nh, nw, fl) in zip(engines, ins, augs):
+                e.match_propogate_one_frame(x)
+                lg = e.decode_current_logits((H, W))
+                if fl:
+                    lg = flip_tensor(lg, 3)                                              # :329-330
+                all_preds.append(torch.softmax(lg, dim=1))                              # :332
+            all_labels = [torch.argmax(p, dim=1, keepdim=True).float() for p in all_preds]   # :340-347
+            prob = torch.mean(torch.cat(all_preds, 0), dim=0, keepdim=True)             # :349-352
+            pred = torch.argmax(prob, dim=1, keepdim=True).float()
+            if label is not None:                                                       # :362-392
+                keep = (label == 0).float()
+                all_labels = [l * keep + label * (1 - keep) for l in all_labels]
+                pred = pred * keep + label * (1 - keep)
+                new_nums = int(pred.max().item())
+                for e, x, l, (nh, nw, fl) in zip(engines, ins, all_labels, augs):
+                    cl = flip_tensor(l, 3) if fl else l
+                    cl = F.interpolate(cl, size=x.shape[2:], mode='nearest')
+                    e.add_reference_frame(x, cl, new_nums, frame_step=t)
+                    _set_skip(e, short_term_mem_skip)
+                    e.decode_current_logits((H, W))
+                    e.update_memory(cl)
+            else:                                                                       # :394-408
+                for e, x, l, (nh, nw, fl) in zip(engines, ins, all_labels, augs):
+                    cl = flip_tensor(l, 3) if fl else l
+                    e.update_memory(F.interpolate(cl, size=x.shape[2:], mode='nearest'))
+            out.append((pred[0, 0], prob[0]))
+    return out
+
+
+def _set_skip(infer_engine, skip):
+    for e in infer_engine.aot_engines:
+        e.short_term_mem_skip = skip

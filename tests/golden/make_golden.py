@@ -74,7 +74,70 @@ def make_mha_knobs():
         refdriver._leave()
 
 
+def make_transforms():
+    """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
+    cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
+    cv2.resize only records the size it was asked for), so what is pinned is MultiRestrictSize's size arithmetic, its
+    sample order (scale-major, flipped copy after each scale) and MultiToTensor's normalisation -- not the cubic filter."""
+    import types
+    asked = []
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return _Any(name)
+
+        def __call__(self, *a, **k):
+            return None
+    cv2 = _Any('cv2')
+    cv2.INTER_CUBIC, cv2.INTER_NEAREST, cv2.INTER_LINEAR = 2, 0, 1
+    cv2.setNumThreads = lambda n: None
+
+    def _resize(img, dsize=None, interpolation=None, **k):
+        asked.append((int(dsize[1]), int(dsize[0])))
+        return np.zeros((dsize[1], dsize[0]) + img.shape[2:], img.dtype)
+    cv2.resize = _resize
+    stubs = {'cv2': cv2, 'torchvision': _Any('torchvision'), 'torchvision.transforms': _Any('torchvision.transforms'),
+             'torchvision.transforms.functional': _Any('torchvision.transforms.functional')}
+    refdriver._enter()
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        import dataloaders.video_transforms as tr
+        sizes = []
+        for (h, w) in [(480, 854), (480, 848), (720, 1280), (1080, 1920), (360, 640), (257, 257), (100, 300), (854, 480), (481, 849)]:
+            for ac in (True, False):
+                for kw in (dict(), dict(max_long_edge=800 * 1.3), dict(max_short_edge=480, max_long_edge=800 * 1.3),
+                           dict(multi_scale=[1.3, 0.75, 1.0], max_long_edge=800 * 1.3, flip=True)):
+                    t = tr.MultiRestrictSize(align_corners=ac, **kw)
+                    sample = {'current_img': np.zeros((h, w, 3), np.float32), 'current_label': np.zeros((h, w), np.uint8),
+                              'meta': {'flip': False}}
+                    outs = t(sample)
+                    sizes.append({'h': h, 'w': w, 'align_corners': ac, 'kw': kw,
+                                  'out': [[int(o['current_img'].shape[0]), int(o['current_img'].shape[1]),
+                                           bool(o['meta'].get('flip', False))] for o in outs]})
+        g = np.random.RandomState(7)
+        img = (g.rand(11, 13, 3) * 255).astype(np.float32)
+        tt = tr.MultiToTensor()([{'current_img': img.copy(), 'meta': {}}])[0]['current_img']
+        with open(os.path.join(HERE, 'transforms.json'), 'w') as f:
+            json.dump({'sizes': sizes, 'to_tensor_in': img.tolist(), 'to_tensor_out': tt.numpy().tolist(),
+                       'to_tensor_dtype': str(tt.dtype)}, f)
+        print('transforms: %d size cases, to_tensor %s %s' % (len(sizes), tuple(tt.shape), tt.dtype), flush=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        refdriver._leave()
+
+
 def main():
+    if not sys.argv[1:] or 'transforms' in sys.argv[1:]:
+        make_transforms()
+        if sys.argv[1:] == ['transforms']:
+            return
     if not sys.argv[1:] or 'mha_knobs' in sys.argv[1:]:
         make_mha_knobs()
         if sys.argv[1:] == ['mha_knobs']:

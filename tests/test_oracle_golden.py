@@ -82,3 +82,47 @@ def test_oracle_bounded_bank_keeps_first_and_most_recent():
             else:
                 assert not torch.equal(outs[0], outs[1])
             assert torch.equal(a.long_term_memories[0][0][-n:], b.long_term_memories[0][0][-n:])
+
+
+def test_transforms_match_reference_classes():
+    """MultiRestrictSize's size rule and sample order, MultiToTensor's normalisation (video_transforms.py:594-715):
+    oracle restatement AND the product's host helper against the real reference classes (tests/golden/transforms.json)."""
+    import json
+    import os
+    from oracle.aot_oracle import restrict_size as o_rs, to_tensor_normalise
+    from utils.image import restrict_size as p_rs
+    g = json.load(open(os.path.join(GOLD, 'transforms.json')))
+    assert len(g['sizes']) >= 70
+    for c in g['sizes']:
+        kw = c['kw']
+        scales = kw.get('multi_scale', [1.3])            # the class default (video_transforms.py:598)
+        want = []
+        for sc in scales:
+            for rs in (o_rs, p_rs):
+                hw = rs(c['h'], c['w'], kw.get('max_short_edge'), kw.get('max_long_edge', 800), sc, c['align_corners'])
+                assert list(hw) == c['out'][len(want)][:2], (c, sc, hw)
+            want.append([hw[0], hw[1], False])
+            if kw.get('flip'):
+                want.append([hw[0], hw[1], True])
+        assert want == c['out']
+    out = to_tensor_normalise(np.array(g['to_tensor_in'], np.float32))
+    assert str(out.dtype) == g['to_tensor_dtype']
+    assert np.array_equal(out.numpy(), np.array(g['to_tensor_out'], np.float32))     # bit-exact
+
+
+def test_cubic_resize_restatement_vs_torch_bicubic():
+    """cv2 is absent (parity unpinned for the cubic filter): the restated OpenCV algorithm is cross-checked against torch's
+    independent bicubic, which implements the same a = -0.75 kernel and half-pixel mapping but computes the source
+    coordinate in float32 (so noise images differ by ~gradient x 1e-4; smooth ones agree to float rounding)."""
+    import torch.nn.functional as F
+    from oracle.aot_oracle import cv2_cubic_resize
+    rs = np.random.RandomState(0)
+    yy, xx = np.meshgrid(np.arange(120, dtype=np.float32), np.arange(213, dtype=np.float32), indexing='ij')
+    smooth = np.stack([128 + 100 * np.sin(yy / 17) * np.cos(xx / 23), 0.5 * yy + 0.3 * xx, 255 - 0.7 * xx], -1).astype(np.float32)
+    for img, tol in ((smooth, 2e-3), ((rs.rand(120, 213, 3) * 255).astype(np.float32), 5e-2)):
+        for (oh, ow) in ((121, 209), (65, 97), (240, 431)):
+            a = cv2_cubic_resize(img, oh, ow)
+            b = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode='bicubic',
+                              align_corners=False)[0].permute(1, 2, 0).numpy()
+            assert np.abs(a - b).max() < tol
+    assert np.array_equal(cv2_cubic_resize(smooth, 120, 213), smooth)

@@ -469,6 +469,94 @@ def test_long_video_knobs_engine_vs_oracle(hip, top_k, tol):
     assert e0.bank_len == 3 * e0.enc_hw
 
 
+@pytest.mark.parametrize('H,W,OH,OW,flip,u8', [(480, 854, 481, 849, False, False), (480, 854, 625, 1105, True, False),
+                                                (97, 131, 97, 131, True, True), (360, 640, 273, 481, False, True)])
+def test_preprocess_vs_oracle(hip, H, W, OH, OW, flip, u8):
+    """aot_preprocess_f32 (cubic resize + flip + normalise) vs the oracle's restatement of cv2.resize / MultiToTensor.
+    The normalisation is bit-exact; the cubic filter agrees to float rounding (same tap order, no FMA contraction)."""
+    from oracle.aot_oracle import cv2_cubic_resize, to_tensor_normalise
+    rs = np.random.RandomState(H + OW)
+    img = rs.rand(H, W, 3) * 255
+    img = img.astype(np.uint8) if u8 else img.astype(np.float32)
+    r = cv2_cubic_resize(img.astype(np.float32), OH, OW)
+    if flip:
+        r = r[:, ::-1].copy()
+    ref = to_tensor_normalise(r)
+    out = hip.preprocess(torch.from_numpy(img).cuda(), OH, OW, flip)
+    assert out.shape == (1, 3, OH, OW)
+    if (H, W) == (OH, OW):
+        assert torch.equal(out[0].cpu(), ref)
+    else:
+        _close(out[0], ref, 2e-5, 'preprocess')
+
+
+@pytest.mark.parametrize('A,nc,H,W,newobj', [(1, 11, 480, 854, False), (4, 11, 97, 131, True), (6, 21, 60, 70, False)])
+def test_fuse_probs_and_label_resize_vs_torch(hip, A, nc, H, W, newobj):
+    """aot_fuse_probs_f32 / aot_label_resize_f32 vs the torch ops the reference's evaluator uses (evaluator.py:325-408)."""
+    g = torch.Generator().manual_seed(A * 100 + nc)
+    logits = torch.randn(A, nc, H, W, generator=g) * 3
+    flips = [bool(a % 2) for a in range(A)]
+    new = None
+    if newobj:
+        new = torch.zeros(1, 1, H, W)
+        new[..., 10:30, 20:50] = 12.0
+    preds = [torch.softmax(l.flip(-1) if f else l, 0) for l, f in zip(logits, flips)]
+    augl = [torch.argmax(p, 0).float() for p in preds]
+    prob = torch.stack(preds).mean(0)
+    fused = torch.argmax(prob, 0).float()
+    if new is not None:
+        keep = (new[0, 0] == 0).float()
+        augl = [l * keep + new[0, 0] * (1 - keep) for l in augl]
+        fused = fused * keep + new[0, 0] * (1 - keep)
+    f_d, a_d, p_d = hip.fuse_probs(logits.cuda(), flips, new_label=new.cuda() if new is not None else None, want_prob=True)
+    _close(p_d[0], prob, 2e-6, 'fused prob')
+    top2 = torch.topk(prob, 2, 0)[0]
+    sure = (top2[0] - top2[1]) > 1e-5
+    assert (f_d[0, 0].cpu() == fused)[sure | (new[0, 0] != 0 if new is not None else False)].all()
+    assert (f_d[0, 0].cpu() == fused).float().mean() > 0.9999
+    for a in range(A):
+        t2 = torch.topk(preds[a], 2, 0)[0]
+        ok = (t2[0] - t2[1]) > 1e-5
+        assert (a_d[a, 0].cpu() == augl[a])[ok].all()
+    for (oh, ow, fl) in ((H + 1, W - 5, False), (2 * H + 1, W // 2, True), (H, W, True)):
+        ref = F.interpolate((fused.flip(-1) if fl else fused)[None, None], size=(oh, ow), mode='nearest')
+        assert torch.equal(hip.label_resize(f_d, oh, ow, fl).cpu(), ref if not fl else F.interpolate(f_d.cpu().flip(-1), size=(oh, ow), mode='nearest'))
+
+
+@pytest.mark.parametrize('flip,ms', [(False, (1,)), (True, (1.3, 1.0))])
+def test_sequence_evaluator_vs_oracle(hip, flip, ms):
+    """The evaluator loop end to end on the device vs the oracle's restatement of evaluator.py:265-446:
+    multi-scale + flip test-time augmentation, probability fusion, a new object injected at frame 2, label feedback."""
+    from networks.managers.evaluator import SequenceEvaluator
+    from oracle.aot_oracle import OracleModel, sequence_eval
+    cfg, model, sd = synth_model_state('aott', cfg_overrides=dict(TEST_FLIP=flip, TEST_MULTISCALE=list(ms),
+                                                                  TEST_MAX_SHORT_EDGE=None, TEST_MAX_LONG_EDGE=800 * 1.3,
+                                                                  TEST_LONG_TERM_MEM_GAP=2))
+    model = model.cuda().eval()
+    rs = np.random.RandomState(3)
+    H, W = 96, 150
+    base = rs.rand(H + 8, W + 8, 3).astype(np.float32)
+    k = np.ones(5, np.float32) / 5
+    for ax in (0, 1):       # smooth the noise so the cubic resize is well conditioned
+        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), ax, base)
+    base = (base - base.min()) / (base.max() - base.min()) * 255
+    frames = [np.ascontiguousarray(base[t:t + H, 2 * t:2 * t + W]).astype(np.float32) for t in range(4)]
+    lab0 = np.zeros((H, W), np.float32); lab0[20:60, 30:80] = 1; lab0[50:90, 90:140] = 2
+    lab2 = np.zeros((H, W), np.float32); lab2[5:25, 100:140] = 3
+    labels, nums = {0: lab0, 2: lab2}, {0: 2, 2: 3}
+    ref = sequence_eval(OracleModel('aott', sd), frames, labels, nums, flip=flip, multiscale=ms, long_term_mem_gap=2)
+    ev = SequenceEvaluator(cfg, model)
+    got = ev.run([torch.from_numpy(f).cuda() for f in frames], {t: torch.from_numpy(l).cuda() for t, l in labels.items()}, nums)
+    assert len(got) == len(ref) == 3 and len(ev.engines) == len(ms) * (2 if flip else 1)
+    for t, (g_, (rl, rp)) in enumerate(zip(got, ref), start=1):
+        top2 = torch.topk(rp, 2, 0)[0]
+        sure = (top2[0] - top2[1]) > 1e-3
+        agree = (g_.cpu() == rl)
+        assert agree[sure].all(), 'frame %d: %d sure pixels differ' % (t, int((~agree[sure]).sum()))
+        assert agree.float().mean() > 0.999
+    assert (got[1].cpu()[5:25, 100:140] == 3).all()
+
+
 def test_more_than_ten_objects_vs_oracle(hip):
     """AOTInferEngine with 13 objects = two 10-object groups (aot_engine.py:515-630): mask separation, image embedding
     shared between the groups, soft logit aggregation -- HIP engine vs the oracle's restatement, teacher-forced."""
