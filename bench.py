@@ -74,11 +74,13 @@ def build_model(device):
 
 def one_frame(engine, img):
     """The per-frame body of the evaluator loop; the predicted mask feeds the memory update on device."""
+    import aot_hip
     engine.match_propogate_one_frame(img)
     logit = engine.decode_current_logits(OUT_SIZE)
-    prob = torch.softmax(logit, dim=1)
-    label = torch.argmax(prob, dim=1, keepdim=True).float()
-    engine.update_memory(F.interpolate(label, size=engine.input_size_2d, mode='nearest'))
+    # softmax -> mean over the (single) augmentation -> argmax, then the nearest-resized label feedback
+    # (evaluator.py:332-352,394-408) as the two device kernels of csrc/prepost.hip
+    label, aug_labels, _ = aot_hip.fuse_probs(logit, [False])
+    engine.update_memory(aot_hip.label_resize(aug_labels[0], engine.input_size_2d[0], engine.input_size_2d[1]))
     return label
 
 
