@@ -731,6 +731,170 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
   }
 }
 
+// Cooperative form of the gated-propagation kernel for dv = 4 x 256: the four waves of a workgroup own the four value
+// chunks of the SAME 32 queries and share the score tile instead of recomputing it -- wave w contracts channels
+// [32w, 32w+32) of q.k (DQK/8 MFMAs instead of DQK/2), the four partial tiles meet in LDS (summed in wave order by every
+// wave, so all four hold bit-identical scores) and each wave runs the softmax and its own 16*NDV value MFMAs.  144 instead
+// of 192 MFMAs per key tile and wave, q/k fragments of 16 registers instead of 64.  One barrier per key tile; the score
+// partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
+template <int NDV>
+__global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParams p) {
+  const int split = blockIdx.x, qt = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int ch = wave;
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int t0 = split * tps * 32;
+  const int t1 = min(T, t0 + tps * 32);
+  const int qrow = min(qt * 32 + j, p.Nq - 1);
+  __shared__ float part[2][4][16][64];     // [buffer][wave][score register][lane]: 32 KB, conflict-free b32 accesses
+
+  float qf[16];
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + wave * 32 + hi * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = src[i];
+      qf[4 * i] = t.x / p.scale_div; qf[4 * i + 1] = t.y / p.scale_div;
+      qf[4 * i + 2] = t.z / p.scale_div; qf[4 * i + 3] = t.w / p.scale_div;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  const int vvoff = (4 * hi * p.ldv + ch * 32 * NDV + j) * 4;
+  const int ldv4 = p.ldv * 4;
+  const float* kptr = p.k + wave * 32 + hi * 16;
+
+  float m = -INFINITY, l = 0.f;   // m in the log2 domain
+  f32x16 o[NDV];
+#pragma unroll
+  for (int d = 0; d < NDV; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+  auto load_k = [&](float (&kf)[16], int kt) {
+    const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = src[i];
+      kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
+    }
+  };
+  auto load_v = [&](float (&vf)[16], int kt, int d) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+  };
+  auto qk_part = [&](const float (&kf)[16], int buf) {     // this wave's 32-channel share of the score tile -> LDS
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[buf][wave][r][lane] = sc[r];
+  };
+
+  float ka[16], vb[3][16];
+  if (t0 < t1) {
+    load_k(ka, t0);
+    qk_part(ka, 0);
+    load_k(ka, t0 + 32);
+  }
+  __syncthreads();
+  int it = 0;
+  auto step = [&](int kt, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
+    const int buf = it & 1;
+    load_v(vb[0], kt, 0);
+    load_v(vb[1], kt, 1);
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)     // fixed wave order: every wave of the workgroup gets the same bits
+      sc[r] = ((part[buf][0][r][lane] + part[buf][1][r][lane]) + part[buf][2][r][lane]) + part[buf][3][r][lane];
+    qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of the softmax below
+    if (TAIL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    const bool moved = mnew > m;
+    m = mnew;
+    l *= alpha;
+    float pf[16];
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      pf[r] = exp2_w(sc[r], m);
+      pf[r + 1] = exp2_w(sc[r + 1], m);
+      ps0 += pf[r];
+      ps1 += pf[r + 1];
+    }
+    l += ps0 + ps1;
+    load_k(ka, kt + 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+    }
+    if (__any(moved)) {
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+#pragma unroll
+    for (int d = 0; d < NDV; ++d) {
+      if (d + 2 < NDV) load_v(vb[(d + 2) % 3], kt, d + 2);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[d % 3][s], pf[s], o[d], 0, 0, 0);
+    }
+    ++it;
+    __syncthreads();     // next tile's partials visible; this tile's buffer free for the tile after next
+  };
+  int kt = t0;
+  for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
+  if (kt < t1) step(kt, std::true_type{});
+
+  l += __shfl_xor(l, 32);
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  const int cbase = ch * 32 * NDV + 4 * hi;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        const int c = cbase + d * 32 + 8 * g;
+        if (p.gate) {
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c);
+          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+        }
+        *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c) = t;
+      }
+  } else {
+    float* dst = p.part + ((long)split * p.Nq + qi) * p.C;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
+            make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
+    if (hi == 0) {
+      float* ml = p.part + (long)p.nsplit * p.Nq * p.C + (((long)split * p.Nq + qi) * p.H + ch) * 2;
+      ml[0] = m;
+      ml[1] = l;
+    }
+  }
+}
+
 static int fill_params(AttnParams& p, const float* q, const float* k, const float* v, float* out, float* part, int Nq,
                        int T, const int* T_dev, int H, int ldq, int ldk, int ldv, int ldo, float scale_div, int nsplit) {
   if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0) return AOT_ERR_BADARG;
@@ -795,6 +959,12 @@ extern "C" int aot_gated_attn_f32(const float* q, const float* k, const float* v
   p.C = dv;
   p.gate = (nsplit == 1) ? gate : nullptr;   // with splits the gate is applied by aot_attn_merge_f32
   p.ldg = ldg;
+#ifndef AOT_GATTN_NOCOOP
+  if (nch == 4) {   // dv = 1024 (every DeAOT config): the four chunk waves share one score tile
+    hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(nsplit, cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+    AOT_LAUNCH_CHECK();
+  }
+#endif
 #ifdef AOT_GATTN_NOPIPE
   hipLaunchKernelGGL((attn_fwd_wide_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
 #else
