@@ -47,6 +47,8 @@ SPECS = {
     'aotl': dict(_BASE, lstt_num=3, mem_gap=5),
     'r50_aotl': dict(_BASE, encoder='resnet50', enc_dims=(256, 512, 1024, 1024), lstt_num=3, mem_gap=5),
     'deaott': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False),
+    'deaots': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=2),
+    'deaotb': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=3),
     'deaotl': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=3, mem_gap=5),
     'r50_deaotl': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, encoder='resnet50',
                        enc_dims=(256, 512, 1024, 1024), lstt_num=3, mem_gap=5),

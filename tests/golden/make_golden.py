@@ -41,6 +41,14 @@ CASES = {
     # every stage: 48x64 -> 49x70, 24x32 -> 28x35, 12x16 -> 14x21), bank grows to M=2
     'c3c_swinb_deaotl': dict(model='swinb_deaotl', frames=7, in_size=(192, 256), out_size=(190, 250), num_obj=3, clip=4,
                              keep_logits=(1, 6), keep_lstt=False),
+    # remaining model families: AOT on Swin-B (align_corners=False with the AOT block: 16x16 id bank, half-pixel
+    # bilinear, LSTT intermediate outputs), AOT-B (MobileNetV2, 3 LSTT layers, no bank growth), DeAOT-S (2 GPM layers)
+    'c2b_swinb_aotl': dict(model='swinb_aotl', frames=7, in_size=(160, 224), out_size=(158, 220), num_obj=4, clip=5,
+                           keep_logits=(1, 6), keep_lstt=False),
+    'c1c_aotb': dict(model='aotb', frames=4, in_size=(129, 193), out_size=(128, 190), num_obj=5, clip=6,
+                     keep_logits=(1, 3)),
+    'c3d_deaots': dict(model='deaots', frames=4, in_size=(145, 177), out_size=(144, 176), num_obj=3, clip=7,
+                       keep_logits=(1, 3), keep_lstt=False),
     # ragged case: odd sizes, 3 objects, AOTT
     'c1b_aott_ragged': dict(model='aott', frames=4, in_size=(193, 305), out_size=(190, 300), num_obj=3, clip=3,
                             keep_logits=(1, 3)),
