@@ -15,9 +15,6 @@
 // bank ([T, H*32] rows, coalesced); the bank (<= 48 MB/layer) lives in L2 / Infinity Cache across the
 // 53 query tiles.
 //
-// Two kernels implement this: attn_fwd_d32_pipe_kernel (default; the next tile's score MFMAs are interleaved with
-// the current tile's softmax in one instruction stream) and the plain attn_fwd_d32_kernel<NQ> (tuning variants).
-//
 // nsplit > 1: the bank is cut into nsplit contiguous ranges handled by different workgroups (fills the
 // 1024 SIMDs when Nq/32 * H = 424 waves would not), each writing an un-normalised partial (O, m, l);
 // attn_merge_kernel combines them.
@@ -47,217 +44,16 @@ struct AttnParams {
 // Masked scores (-inf) and the initial mL = -inf give 2^-inf = 0 exactly; no clamps needed.
 #define AOT_LOG2E 1.44269502162933349609375f
 __device__ __forceinline__ float exp2_w(float s, float mL) {
-#ifdef ABL_NOEXP
-  return fmaf(s, 1e-3f, 1.f);
-#endif
   return __builtin_amdgcn_exp2f(fmaf(s, AOT_LOG2E, -mL));
 }
 
-template <int NQ>   // query tiles (of 32) per wave: 2 shares every K/V fetch between two score tiles
-#ifdef AOT_ATTN_PREFETCH
-#define AOT_ATTN_MINW (NQ == 2 ? 2 : 1)
-#else
-#define AOT_ATTN_MINW (NQ == 2 ? 3 : 5)
-#endif
-__global__ void __launch_bounds__(64, AOT_ATTN_MINW) attn_fwd_d32_kernel(const AttnParams p) {
-  const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
-  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
-  const int T = p.T_dev ? *p.T_dev : p.T;
-  const int ntile = (T + 31) >> 5;
-  const int tps = (ntile + p.nsplit - 1) / p.nsplit;  // key tiles per split
-  const int t0 = split * tps * 32;
-  const int t1 = min(T, t0 + tps * 32);
-#ifdef ATTN_CLK
-  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
-#endif
-
-  // Q fragments (B operand of S^T = K.Q^T): lane (q=j, hi) holds Q[q][c = hi*16 + s], s = 0..15, scaled
-  float qf[NQ][16];
-#pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    const int qrow = min((qt * NQ + a) * 32 + j, p.Nq - 1);
-    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + h * 32 + hi * 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t = src[i];
-      qf[a][4 * i + 0] = t.x / p.scale_div;  // reference divides (attention.py:82), so do we
-      qf[a][4 * i + 1] = t.y / p.scale_div;
-      qf[a][4 * i + 2] = t.z / p.scale_div;
-      qf[a][4 * i + 3] = t.w / p.scale_div;
-    }
-  }
-
-  // V through a buffer descriptor: the per-lane byte offset is loop invariant, the tile/row part is a wave-uniform
-  // scalar offset (SALU), and rows >= T read as 0 by the hardware bounds check -- no address VALU, no clamping.
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
-  const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
-  const int ldv4 = p.ldv * 4;
-
-  float m[NQ], l[NQ];   // m: running max score times log2(e)
-  f32x16 o[NQ];
-#pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    m[a] = -INFINITY;
-    l[a] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
-  }
-
-  // (K uses plain 16-byte global loads: the raw_buffer_load_b64/b96/b128 builtins of ROCm 7.2's hipcc lower to a
-  //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable.)
-  const float* kptr = p.k + h * 32 + hi * 16;
-  auto load_k = [&](float (&kf)[16], int kt) {
-    const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t = src[i];
-      kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-    }
-  };
-  auto load_v = [&](float (&vf)[16], int kt) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
-  };
-
-  auto tile = [&](float (&kf)[16], const float (&vf)[16], int kt, bool rot) {
-    // ---- S^T = K . Q^T : NQ independent accumulation chains interleaved ----
-    f32x16 sc[NQ];
-#pragma unroll
-    for (int a = 0; a < NQ; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[a][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int a = 0; a < NQ; ++a) sc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[a][s], sc[a], 0, 0, 0);
-    // K registers are free now: the next tile's K flies under this tile's softmax and PV MFMAs
-    if (rot) {
-      __builtin_amdgcn_sched_barrier(0);
-      load_k(kf, kt + 32);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- online softmax over the 32 keys of this tile (per query = per lane column) ----
-    float pf[NQ][16];
-#ifdef ABL_NOSOFTMAX
-#pragma unroll
-    for (int a = 0; a < NQ; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pf[a][r] = sc[a][r];
-#else
-    bool moved = false;
-    float mt[NQ];
-#pragma unroll
-    for (int a = 0; a < NQ; ++a) {
-      if (kt + 32 > t1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt + mfma32_row(r, hi) >= t1) sc[a][r] = -INFINITY;
-      }
-      float x = fmaxf(fmaxf(sc[a][0], sc[a][1]), fmaxf(sc[a][2], sc[a][3]));
-#pragma unroll
-      for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[a][r], sc[a][r + 1]), fmaxf(sc[a][r + 2], sc[a][r + 3])));
-      mt[a] = fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E;
-      moved = moved || (mt[a] > m[a]);
-    }
-    if (__any(moved)) {   // wave-uniform: only rescale when some query's running max moved (alpha == 1 otherwise)
-#pragma unroll
-      for (int a = 0; a < NQ; ++a) {
-        const float mnew = fmaxf(m[a], mt[a]);
-        const float alpha = __builtin_amdgcn_exp2f(m[a] - mnew);  // m = -inf on the first tile -> 0
-        l[a] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
-        m[a] = mnew;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < NQ; ++a) {
-      float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        pf[a][r] = exp2_w(sc[a][r], m[a]);
-        pf[a][r + 1] = exp2_w(sc[a][r + 1], m[a]);
-        ps0 += pf[a][r];
-        ps1 += pf[a][r + 1];
-      }
-      l[a] += ps0 + ps1;
-    }
-#endif
-    // ---- O^T += V^T . P^T  (contraction index = key, enumerated in C/D-layout order) ----
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int a = 0; a < NQ; ++a) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], pf[a][s], o[a], 0, 0, 0);
-  };
-
-#ifndef AOT_ATTN_PREFETCH
-  // No register double buffering: 82 VGPRs -> 5 waves per SIMD, and the other waves' MFMAs hide this wave's
-  // K/V latency.  Measured 3-5% faster than the ping-pong variant below (162 registers, 3 waves) at every bank size.
-  float ka[16], va[16];
-  if (t0 < t1) load_k(ka, t0);
-  for (int kt = t0; kt < t1; kt += 32) {
-    load_v(va, kt);                 // lands under the 16 QK MFMAs
-    tile(ka, va, kt, true);         // (the K fetch past the range end is clamped to row T-1 and never used)
-  }
-#else
-  // ping-pong register sets: the next tile's loads fly under the current tile's MFMAs, no register copies
-  float ka[16], va[16], kb[16], vb[16];
-  if (t0 < t1) { load_k(ka, t0); load_v(va, t0); }
-  for (int kt = t0; kt < t1; kt += 64) {
-    if (kt + 32 < t1) { load_k(kb, kt + 32); load_v(vb, kt + 32); }
-    tile(ka, va, kt, false);
-    if (kt + 32 < t1) {
-      if (kt + 64 < t1) { load_k(ka, kt + 64); load_v(va, kt + 64); }
-      tile(kb, vb, kt + 32, false);
-    }
-  }
-#endif
-
-#ifdef ATTN_CLK
-  if (lane == 0) {   // scratch experiment: sum of shader-clock and 100 MHz ticks per wave at the tail of a 32-split part buffer
-    unsigned long long* cb = reinterpret_cast<unsigned long long*>(p.part + 32L * p.Nq * (p.C + 2 * p.H) - 4);
-    atomicAdd(cb, clock64() - clk_c0);
-    atomicAdd(cb + 1, wall_clock64() - clk_w0);
-  }
-#endif
-#pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    const float lt = l[a] + __shfl_xor(l[a], 32);
-    const int qi = (qt * NQ + a) * 32 + j;
-    if (qi >= p.Nq) continue;
-    if (p.nsplit == 1) {
-      const float inv = 1.f / lt;
-      float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
-        float4 t = make_float4(o[a][4 * g] * inv, o[a][4 * g + 1] * inv, o[a][4 * g + 2] * inv, o[a][4 * g + 3] * inv);
-        if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
-          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
-        }
-        *reinterpret_cast<float4*>(dst + 8 * g) = t;
-      }
-    } else {
-      const int C = p.H * 32;
-      float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[a][4 * g], o[a][4 * g + 1], o[a][4 * g + 2], o[a][4 * g + 3]);
-      if (hi == 0) {
-        float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
-        ml[0] = m[a];   // log2 domain; -inf if this split saw no key (t0 >= t1)
-        ml[1] = lt;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Software-pipelined form of attn_fwd_d32_kernel<1>: the score MFMAs of key tile i+1 are issued in the same
-// instruction stream as the softmax VALU work of tile i (they are independent), so a wave keeps the matrix pipe
-// fed while it exponentiates, instead of relying on other waves being in a different phase.  Costs one more
-// 16-register score tile (4 waves per SIMD) and one wasted score tile at the end of each wave's key range.
+// Software pipelining: the score MFMAs of key tile i+1 are issued in the same instruction stream as the softmax VALU
+// work of tile i (they are independent), so a wave keeps the matrix pipe fed while it exponentiates, instead of relying
+// on other waves being in a different phase (+10-12 % over the plain tile-by-tile order at every bank size).  Costs one
+// more 16-register score tile (110 VGPRs, 4 waves per SIMD) and one wasted score tile at the end of a wave's key range.
+// Variants measured and dropped: register double-buffering of K/V (162 VGPRs, 3 waves: -4 %), two
+// query tiles per wave (halves the K/V fetch, 197 VGPRs: -10 %).
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64, 4) attn_fwd_d32_pipe_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
@@ -433,152 +229,11 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Gated-propagation form (DeAOT, attention.py:672-707): ONE query/key head of width DQK = 128 and a value of
-// width NCH * 32*NDV (1024 = [V | ID_V]).  A wave owns 32 queries and one chunk of 32*NDV value channels; it
-// recomputes the 32x32 score tile (DQK/2 MFMAs) and spends 16*NDV MFMAs on its chunk, so with NDV = 8 the
-// shared score work is a third of the total.  One wave per SIMD (the accumulators of a 256-wide chunk fill the
-// AGPR file), K double-buffered across key tiles and V across chunks so loads fly under the MFMAs.
+// width NCH * 32*NDV (1024 = [V | ID_V]).  A wave owns 32 queries and one chunk of 32*NDV value channels (NDV = 8:
+// 128 accumulator registers, one wave per SIMD).
 // ---------------------------------------------------------------------------------------------------------
-template <int DQK, int NDV>
-__global__ void __launch_bounds__(64) attn_fwd_wide_kernel(const AttnParams p) {
-  constexpr int HK = DQK / 2;   // contraction values per lane
-  const int ch = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
-  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
-  const int T = p.T_dev ? *p.T_dev : p.T;
-  const int ntile = (T + 31) >> 5;
-  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = split * tps * 32;
-  const int t1 = min(T, t0 + tps * 32);
-  const int qrow = min(qt * 32 + j, p.Nq - 1);
-
-  float qf[HK];
-  {
-    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + hi * HK);
-#pragma unroll
-    for (int i = 0; i < HK / 4; ++i) {
-      const float4 t = src[i];
-      qf[4 * i] = t.x / p.scale_div; qf[4 * i + 1] = t.y / p.scale_div;
-      qf[4 * i + 2] = t.z / p.scale_div; qf[4 * i + 3] = t.w / p.scale_div;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
-  const int vvoff = (4 * hi * p.ldv + ch * 32 * NDV + j) * 4;
-  const int ldv4 = p.ldv * 4;
-  const float* kptr = p.k + hi * HK;
-
-  float m = -INFINITY, l = 0.f;   // m: running max score times log2(e)
-  f32x16 o[NDV];
-#pragma unroll
-  for (int d = 0; d < NDV; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-
-  auto load_k = [&](float (&kf)[HK], int kt) {
-    const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
-#pragma unroll
-    for (int i = 0; i < HK / 4; ++i) {
-      const float4 t = src[i];
-      kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-    }
-  };
-  auto load_v = [&](float (&vf)[16], int kt, int d) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
-  };
-
-  float va[16], vb[16];
-  auto tile = [&](const float (&kf)[HK], int kt) {
-    load_v(va, kt, 0);
-    f32x16 sc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < HK; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
-    if (kt + 32 > t1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
-    }
-    float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-    mt = fmaxf(mt, __shfl_xor(mt, 32)) * AOT_LOG2E;
-    if (__any(mt > m)) {
-      const float mnew = fmaxf(m, mt);
-      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-      l *= alpha;
-#pragma unroll
-      for (int d = 0; d < NDV; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-      m = mnew;
-    }
-    float pf[16];
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pf[r] = exp2_w(sc[r], m);
-      ps += pf[r];
-    }
-    l += ps;
-    static_assert(NDV % 2 == 0, "chunk ping-pong below needs an even NDV");
-#pragma unroll
-    for (int d = 0; d < NDV; d += 2) {
-      load_v(vb, kt, d + 1);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o[d], 0, 0, 0);
-      if (d + 2 < NDV) load_v(va, kt, d + 2);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) o[d + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[s], pf[s], o[d + 1], 0, 0, 0);
-    }
-  };
-
-  float ka[HK], kb[HK];
-  if (t0 < t1) load_k(ka, t0);
-  for (int kt = t0; kt < t1; kt += 64) {
-    if (kt + 32 < t1) load_k(kb, kt + 32);
-    tile(ka, kt);
-    if (kt + 32 < t1) {
-      if (kt + 64 < t1) load_k(ka, kt + 64);
-      tile(kb, kt + 32);
-    }
-  }
-
-  l += __shfl_xor(l, 32);
-  const int qi = qt * 32 + j;
-  if (qi >= p.Nq) return;
-  const int cbase = ch * 32 * NDV + 4 * hi;
-  if (p.nsplit == 1) {
-    const float inv = 1.f / l;
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        const int c = cbase + d * 32 + 8 * g;
-        if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c);
-          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
-        }
-        *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c) = t;
-      }
-  } else {
-    float* dst = p.part + ((long)split * p.Nq + qi) * p.C;
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
-            make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
-    if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * p.Nq * p.C + (((long)split * p.Nq + qi) * p.H + ch) * 2;
-      ml[0] = m;
-      ml[1] = l;
-    }
-  }
-}
-
-// Software-pipelined form of attn_fwd_wide_kernel (same idea as attn_fwd_d32_pipe_kernel): the DQK/2 score MFMAs of
+// General form (any number of chunks; used when dv != 1024): every wave recomputes the score tile of its queries
+// (DQK/2 MFMAs, a third of its work at NDV = 8).  Software-pipelined like attn_fwd_d32_pipe_kernel: the score MFMAs of
 // key tile i+1 share an instruction stream with the softmax of tile i, K needs a single register set (its next load is
 // issued as soon as the score MFMAs have consumed it and lands under the 16*NDV value MFMAs), and the value chunks are
 // fetched TWO chunks ahead through three rotating register sets (one wave per SIMD: nothing else hides that latency).
@@ -916,22 +571,7 @@ extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, floa
   AttnParams p;
   const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
-  // Two query tiles per wave (NQ = 2) share every K/V fetch, but on MI355X the register cost (197 VGPR -> 2 waves
-  // per SIMD instead of 3) loses more than the halved fetch gains: 85 vs 94 TFLOP/s at M = 14 (scratch/mb_attn.py).
-  // Kept as a tuning option; off by default.
-#ifndef AOT_ATTN_NQ2_MIN
-#define AOT_ATTN_NQ2_MIN (1 << 30)
-#endif
-  // Default: the software-pipelined kernel (10-12% faster than the plain one at every bank size, scratch/mb_attn.py).
-#ifndef AOT_ATTN_NOPIPE
-  if (true)
-    hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
-  else
-#endif
-  if (Nq >= AOT_ATTN_NQ2_MIN)
-    hipLaunchKernelGGL(attn_fwd_d32_kernel<2>, dim3(H, nsplit, cdiv(Nq, 64)), dim3(64), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(attn_fwd_d32_kernel<1>, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 
@@ -959,16 +599,9 @@ extern "C" int aot_gated_attn_f32(const float* q, const float* k, const float* v
   p.C = dv;
   p.gate = (nsplit == 1) ? gate : nullptr;   // with splits the gate is applied by aot_attn_merge_f32
   p.ldg = ldg;
-#ifndef AOT_GATTN_NOCOOP
-  if (nch == 4) {   // dv = 1024 (every DeAOT config): the four chunk waves share one score tile
+  if (nch == 4)     // dv = 1024 (every DeAOT config): the four chunk waves share one score tile
     hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(nsplit, cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
-    AOT_LAUNCH_CHECK();
-  }
-#endif
-#ifdef AOT_GATTN_NOPIPE
-  hipLaunchKernelGGL((attn_fwd_wide_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
-#else
-  hipLaunchKernelGGL((attn_fwd_wide_pipe_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
-#endif
+  else
+    hipLaunchKernelGGL((attn_fwd_wide_pipe_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

@@ -152,38 +152,22 @@ conv_gemm_kernel(const ConvParams p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-#ifdef ABL_NOGLOBAL
-    if (kt + 1 < nk && p.act == 77) load_tiles(kt + 1);
-#else
     if (kt + 1 < nk) load_tiles(kt + 1);  // global loads fly under the MFMA block below
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
 #pragma unroll
-#ifdef ABL_NOLDSR
-      for (int i = 0; i < TM; ++i) a[i] = a_reg[0].x + kk;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = b_reg[0].y;
-#else
       for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + kh][wm0 + i * 32 + l31];
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + kh][wn0 + j * 32 + l31];
-#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-#ifdef ABL_NOLDSW
-    if (kt + 1 < nk && p.act == 77) store_tiles(buf ^ 1);
-#else
     if (kt + 1 < nk) store_tiles(buf ^ 1);
-#endif
-#ifndef ABL_NOSYNC
     __syncthreads();
-#endif
   }
 
   // ---- epilogue: bias (folded BN) + residual + activation; 32 lanes write 128 contiguous bytes ----
