@@ -78,7 +78,8 @@ def version():
 
 
 def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream on the current device."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _chk(rc, name):
