@@ -52,10 +52,12 @@ __device__ __forceinline__ float exp2_w(float s, float mL) {
 // work of tile i (they are independent), so a wave keeps the matrix pipe fed while it exponentiates, instead of relying
 // on other waves being in a different phase (+10-12 % over the plain tile-by-tile order at every bank size).  Costs one
 // more 16-register score tile (110 VGPRs, 4 waves per SIMD) and one wasted score tile at the end of a wave's key range.
-// Variants measured and dropped: register double-buffering of K/V (162 VGPRs, 3 waves: -4 %), two
-// query tiles per wave (halves the K/V fetch, 197 VGPRs: -10 %).
+// Variants measured and dropped: register double-buffering of K/V (162 VGPRs, 3 waves: -4 %); two
+// query tiles per wave (NQ = 2, -DAOT_ATTN_NQ=2: halves the K/V fetch per MFMA but needs 168-182 VGPRs, 2-3 waves: 379 vs
+// 370 us at M = 14, 123 vs 121 us at M = 4).
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64, 4) attn_fwd_d32_pipe_kernel(const AttnParams p) {
+template <int NQ>   // query tiles (of 32) per wave; NQ = 2 shares every K/V fetch between two score tiles (tuning variant)
+__global__ void __launch_bounds__(64, NQ == 1 ? 4 : 3) attn_fwd_d32_pipe_kernel(const AttnParams p) {
   const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
   const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -64,28 +66,38 @@ __global__ void __launch_bounds__(64, 4) attn_fwd_d32_pipe_kernel(const AttnPara
   const int t0 = split * tps * 32;
   const int t1 = min(T, t0 + tps * 32);
 
-  float qf[16];
-  {
-    const int qrow = min(qt * 32 + j, p.Nq - 1);
+  float qf[NQ][16];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a) {
+    const int qrow = min((qt * NQ + a) * 32 + j, p.Nq - 1);
     const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + h * 32 + hi * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 t = src[i];
-      qf[4 * i + 0] = t.x / p.scale_div;
-      qf[4 * i + 1] = t.y / p.scale_div;
-      qf[4 * i + 2] = t.z / p.scale_div;
-      qf[4 * i + 3] = t.w / p.scale_div;
+      qf[a][4 * i + 0] = t.x / p.scale_div;    // the reference divides (attention.py:82), so do we
+      qf[a][4 * i + 1] = t.y / p.scale_div;
+      qf[a][4 * i + 2] = t.z / p.scale_div;
+      qf[a][4 * i + 3] = t.w / p.scale_div;
     }
   }
+  // V through a buffer descriptor: the per-lane byte offset is loop invariant, the tile/row part is a wave-uniform
+  // scalar offset (SALU), and rows >= T read as 0 by the hardware bounds check -- no address VALU, no clamping.
+  // (K uses plain 16-byte global loads: the raw_buffer_load_b64/b96/b128 builtins of ROCm 7.2's hipcc lower to a
+  //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable.)
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
-  const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;
+  const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
   const int ldv4 = p.ldv * 4;
   const float* kptr = p.k + h * 32 + hi * 16;
 
-  float m = -INFINITY, l = 0.f;   // m in the log2 domain
-  f32x16 o;
+  float m[NQ], l[NQ];   // m: running max score times log2(e)
+  f32x16 o[NQ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int a = 0; a < NQ; ++a) {
+    m[a] = -INFINITY;
+    l[a] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
+  }
 
   auto load_k = [&](float (&kf)[16], int kt) {
     const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
@@ -100,21 +112,23 @@ __global__ void __launch_bounds__(64, 4) attn_fwd_d32_pipe_kernel(const AttnPara
     for (int s = 0; s < 16; ++s)
       vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
   };
-  auto qk = [&](const float (&kf)[16]) {
-    f32x16 sc;
+  auto qk = [&](const float (&kf)[16], f32x16 (&sc)[NQ]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    for (int a = 0; a < NQ; ++a)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
-    return sc;
+      for (int r = 0; r < 16; ++r) sc[a][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) sc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[a][s], sc[a], 0, 0, 0);
   };
 
   float ka[16], va[16];
-  f32x16 sc;
+  f32x16 sc[NQ];
   if (t0 < t1) {
     load_k(ka, t0);
     load_v(va, t0);
-    sc = qk(ka);
+    qk(ka, sc);
     load_k(ka, t0 + 32);
   }
   // One straight-line step (no branches, so the scheduler can interleave the next tile's score MFMAs with this tile's
@@ -122,74 +136,82 @@ __global__ void __launch_bounds__(64, 4) attn_fwd_d32_pipe_kernel(const AttnPara
   auto step = [&](int kt, auto tail) {
     constexpr bool TAIL = decltype(tail)::value;
     // scores of the NEXT tile (past the range end: clamped rows, result unused) -- independent of everything below
-    f32x16 scn = qk(ka);
-    if (TAIL) {
+    f32x16 scn[NQ];
+    qk(ka, scn);
+    float pf[NQ][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    for (int a = 0; a < NQ; ++a) {
+      if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt + mfma32_row(r, hi) >= t1) sc[a][r] = -INFINITY;
+      }
+      float x = fmaxf(fmaxf(sc[a][0], sc[a][1]), fmaxf(sc[a][2], sc[a][3]));
+#pragma unroll
+      for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[a][r], sc[a][r + 1]), fmaxf(sc[a][r + 2], sc[a][r + 3])));
+      const float mnew = fmaxf(m[a], fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+      const float alpha = __builtin_amdgcn_exp2f(m[a] - mnew);   // 1 when the max did not move; 0 on the first tile
+      m[a] = mnew;
+      l[a] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        pf[a][r] = exp2_w(sc[a][r], m[a]);
+        pf[a][r + 1] = exp2_w(sc[a][r + 1], m[a]);
+        ps0 += pf[a][r];
+        ps1 += pf[a][r + 1];
+      }
+      l[a] += ps0 + ps1;
     }
-    float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // 1 when the max did not move; 0 on the first tile
-    m = mnew;
-    l *= alpha;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-    float pf[16];
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      pf[r] = exp2_w(sc[r], m);
-      pf[r + 1] = exp2_w(sc[r + 1], m);
-      ps0 += pf[r];
-      ps1 += pf[r + 1];
-    }
-    l += ps0 + ps1;
     load_k(ka, kt + 64);     // K registers were consumed by qk() above
 #pragma unroll
-    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < NQ; ++a) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[a][s], o[a], 0, 0, 0);
     load_v(va, kt + 32);     // rows >= T read as 0
-    sc = scn;
-#ifndef AOT_ATTN_PIPE_NOGROUPS
-    // issue order: 16 x (1 score MFMA, 5 softmax VALU), then the rest as the scheduler likes
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) sc[a] = scn[a];
+    // issue order: 16 x (NQ score MFMAs, 5*NQ softmax VALU), then the rest as the scheduler likes
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5 * NQ, 0);
     }
-#endif
   };
   int kt = t0;
   for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
   if (kt < t1) step(kt, std::true_type{});
 
-  const float lt = l + __shfl_xor(l, 32);
-  const int qi = qt * 32 + j;
-  if (qi >= p.Nq) return;
-  if (p.nsplit == 1) {
-    const float inv = 1.f / lt;
-    float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-      if (p.gate) {
-        const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
-        t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+  for (int a = 0; a < NQ; ++a) {
+    const float lt = l[a] + __shfl_xor(l[a], 32);
+    const int qi = (qt * NQ + a) * 32 + j;
+    if (qi >= p.Nq) continue;
+    if (p.nsplit == 1) {
+      const float inv = 1.f / lt;
+      float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
+        float4 t = make_float4(o[a][4 * g] * inv, o[a][4 * g + 1] * inv, o[a][4 * g + 2] * inv, o[a][4 * g + 3] * inv);
+        if (p.gate) {
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
+          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+        }
+        *reinterpret_cast<float4*>(dst + 8 * g) = t;
       }
-      *reinterpret_cast<float4*>(dst + 8 * g) = t;
-    }
-  } else {
-    const int C = p.H * 32;
-    float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
+    } else {
+      const int C = p.H * 32;
+      float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
-    if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
-      ml[0] = m;
-      ml[1] = lt;
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[a][4 * g], o[a][4 * g + 1], o[a][4 * g + 2], o[a][4 * g + 3]);
+      if (hi == 0) {
+        float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
+        ml[0] = m[a];   // log2 domain; -inf if this split saw no key (t0 >= t1)
+        ml[1] = lt;
+      }
     }
   }
 }
@@ -571,7 +593,11 @@ extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, floa
   AttnParams p;
   const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
+#ifndef AOT_ATTN_NQ
+#define AOT_ATTN_NQ 1      // 2: measured 2 % slower, see the kernel's header
+#endif
+  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel<AOT_ATTN_NQ>, dim3(H, nsplit, cdiv(Nq, 32 * AOT_ATTN_NQ)), dim3(64), 0,
+                     (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 
