@@ -46,6 +46,7 @@ SPECS = {
     'aotb': dict(_BASE, lstt_num=3),
     'aotl': dict(_BASE, lstt_num=3, mem_gap=5),
     'r50_aotl': dict(_BASE, encoder='resnet50', enc_dims=(256, 512, 1024, 1024), lstt_num=3, mem_gap=5),
+    'r101_aotl': dict(_BASE, encoder='resnet101', enc_dims=(256, 512, 1024, 1024), lstt_num=3, mem_gap=5),
     'deaott': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False),
     'deaots': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=2),
     'deaotb': dict(_BASE, vos='deaot', heads=1, intermediate_lstt=False, lstt_num=3),
@@ -100,12 +101,12 @@ def one_hot_mask(mask, cls_num):
 # --------------------------------------------------------------------------
 # encoders
 # --------------------------------------------------------------------------
-def resnet50_features(sd, x, p='encoder'):
-    """networks/encoders/resnet.py:140-157 (ResNet-50 without layer4, stride 16)."""
+def resnet50_features(sd, x, p='encoder', blocks=(3, 4, 6)):
+    """networks/encoders/resnet.py:140-157 (ResNet-50 [3,4,6] / ResNet-101 [3,4,23], :171-189, without layer4, stride 16)."""
     x = F.relu(_fbn(_conv(x, sd, p + '.conv1', 2, 3), sd, p + '.bn1'))
     x = F.max_pool2d(x, 3, 2, 1)
     xs = []
-    for li, (nblk, stride) in enumerate(((3, 1), (4, 2), (6, 2)), start=1):
+    for li, (nblk, stride) in enumerate(((blocks[0], 1), (blocks[1], 2), (blocks[2], 2)), start=1):
         for b in range(nblk):
             q = '%s.layer%d.%d' % (p, li, b)
             s = stride if b == 0 else 1
@@ -377,7 +378,8 @@ class OracleModel:
     # aot.py:81-84
     def encode_image(self, img):
         img = img.to(self.dtype)
-        f = {'resnet50': resnet50_features, 'swin_base': swin_features}.get(self.spec['encoder'], mobilenetv2_features)
+        f = {'resnet50': resnet50_features, 'swin_base': swin_features,
+             'resnet101': lambda sd, x: resnet50_features(sd, x, blocks=(3, 4, 23))}.get(self.spec['encoder'], mobilenetv2_features)
         xs = f(self.sd, img)
         xs[-1] = _conv(xs[-1], self.sd, 'encoder_projector')
         return xs

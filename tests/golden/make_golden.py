@@ -45,6 +45,8 @@ CASES = {
     # bilinear, LSTT intermediate outputs), AOT-B (MobileNetV2, 3 LSTT layers, no bank growth), DeAOT-S (2 GPM layers)
     'c2b_swinb_aotl': dict(model='swinb_aotl', frames=7, in_size=(160, 224), out_size=(158, 220), num_obj=4, clip=5,
                            keep_logits=(1, 6), keep_lstt=False),
+    'c2c_r101_aotl': dict(model='r101_aotl', frames=7, in_size=(113, 145), out_size=(112, 144), num_obj=3, clip=8,
+                          keep_logits=(1, 6), keep_lstt=False),
     'c1c_aotb': dict(model='aotb', frames=4, in_size=(129, 193), out_size=(128, 190), num_obj=5, clip=6,
                      keep_logits=(1, 3)),
     'c3d_deaots': dict(model='deaots', frames=4, in_size=(145, 177), out_size=(144, 176), num_obj=3, clip=7,

@@ -9,7 +9,7 @@ from common import (GOLD, LOGIT_TOL, MHA_KNOB_CASES, case_clip, check_masks, loa
 from oracle.aot_oracle import OracleEngine, OracleModel, mha_core
 
 
-@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
+@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c2c_r101_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
 def test_oracle_matches_reference_golden(case):
     c, g = load_case(case)
     _, _, sd = synth_model_state(c['model'])

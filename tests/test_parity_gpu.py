@@ -337,7 +337,7 @@ def _hip_engine(model_name, **kw):
     return cfg, model, eng, sd
 
 
-@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
+@pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c2c_r101_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
 def test_end_to_end_vs_reference_golden(hip, case):
     """BASELINE configs 1 and 2 through the engine API on the GPU vs the real reference's outputs
     (teacher-forced with the reference masks so every frame sees identical history)."""
