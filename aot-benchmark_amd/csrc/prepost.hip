@@ -94,7 +94,8 @@ struct FuseParams {
   int A, nc, OH, OW, flipmask;
 };
 
-#define AOT_FUSE_MAXC 32
+// MAXC = register-array bound on the channel count (1 + 10 objects per group; datasets/Demo: 44 objects -> 51 channels)
+template <int AOT_FUSE_MAXC>
 __global__ void __launch_bounds__(256) fuse_probs_kernel(const FuseParams p) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= p.OW) return;
@@ -140,11 +141,14 @@ __global__ void __launch_bounds__(256) fuse_probs_kernel(const FuseParams p) {
 
 extern "C" int aot_fuse_probs_f32(const float* logits, const float* new_label, float* fused_label, float* aug_labels,
                                   float* fused_prob, int A, int nc, int OH, int OW, int flipmask, void* stream) {
-  if (!logits || !fused_label || A <= 0 || A > 30 || nc <= 0 || nc > AOT_FUSE_MAXC || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+  if (!logits || !fused_label || A <= 0 || A > 30 || nc <= 0 || nc > 64 || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
   FuseParams p;
   p.logits = logits; p.new_label = new_label; p.fused_label = fused_label; p.aug_labels = aug_labels;
   p.fused_prob = fused_prob; p.A = A; p.nc = nc; p.OH = OH; p.OW = OW; p.flipmask = flipmask;
-  hipLaunchKernelGGL(fuse_probs_kernel, dim3(cdiv(OW, 256), OH), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid(cdiv(OW, 256), OH);
+  if (nc <= 16) hipLaunchKernelGGL(fuse_probs_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (nc <= 32) hipLaunchKernelGGL(fuse_probs_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(fuse_probs_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 

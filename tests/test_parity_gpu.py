@@ -490,7 +490,7 @@ def test_preprocess_vs_oracle(hip, H, W, OH, OW, flip, u8):
         _close(out[0], ref, 2e-5, 'preprocess')
 
 
-@pytest.mark.parametrize('A,nc,H,W,newobj', [(1, 11, 480, 854, False), (4, 11, 97, 131, True), (6, 21, 60, 70, False)])
+@pytest.mark.parametrize('A,nc,H,W,newobj', [(1, 11, 480, 854, False), (4, 11, 97, 131, True), (6, 21, 60, 70, False), (2, 51, 33, 47, True)])
 def test_fuse_probs_and_label_resize_vs_torch(hip, A, nc, H, W, newobj):
     """aot_fuse_probs_f32 / aot_label_resize_f32 vs the torch ops the reference's evaluator uses (evaluator.py:325-408)."""
     g = torch.Generator().manual_seed(A * 100 + nc)
