@@ -12,31 +12,24 @@ def one_hot_mask(mask, cls_num):
     return (mask == ids).float()
 
 
+def _snap(n, stride, plus_one):
+    """n -> nearest k*stride (+1): numpy's round-half-to-even on the quotient, as the reference uses np.around."""
+    off = 1 if plus_one else 0
+    if (n - off) % stride == 0:
+        return n
+    return int(np.around((n - off) / stride) * stride + off)
+
+
 def restrict_size(h, w, max_short_edge=None, max_long_edge=800, scale=1.0, align_corners=True, max_stride=16):
-    """Network input size of an h x w frame: MultiRestrictSize's arithmetic, dataloaders/video_transforms.py:612-653
-    (short/long edge caps, the multi-scale factor, then rounding to k*stride(+1 with align_corners))."""
-    sc = 1.
-    if max_short_edge is not None:
-        short_edge = w if h > w else h
-        if short_edge > max_short_edge:
-            sc *= float(max_short_edge) / short_edge
-    new_h, new_w = sc * h, sc * w
-    sc = 1.
-    if max_long_edge is not None:
-        long_edge = new_h if new_h > new_w else new_w
-        if long_edge > max_long_edge:
-            sc *= float(max_long_edge) / long_edge
-    new_h, new_w = sc * new_h, sc * new_w
-    new_h = int(new_h * scale)
-    new_w = int(new_w * scale)
-    if align_corners:
-        if (new_h - 1) % max_stride != 0:
-            new_h = int(np.around((new_h - 1) / max_stride) * max_stride + 1)
-        if (new_w - 1) % max_stride != 0:
-            new_w = int(np.around((new_w - 1) / max_stride) * max_stride + 1)
-    else:
-        if new_h % max_stride != 0:
-            new_h = int(np.around(new_h / max_stride) * max_stride)
-        if new_w % max_stride != 0:
-            new_w = int(np.around(new_w / max_stride) * max_stride)
-    return new_h, new_w
+    """Network input size of an h x w frame (the rule of MultiRestrictSize, dataloaders/video_transforms.py:612-653):
+    cap the short edge, then the long edge (both by uniform float scaling), apply the multi-scale factor with truncation,
+    then snap each side to k*stride (+1 when the model aligns corners).  Pinned on the reference class by
+    tests/golden/transforms.json."""
+    fh, fw = float(h), float(w)
+    if max_short_edge is not None and min(h, w) > max_short_edge:
+        r = float(max_short_edge) / min(h, w)
+        fh, fw = r * fh, r * fw
+    if max_long_edge is not None and max(fh, fw) > max_long_edge:
+        r = float(max_long_edge) / max(fh, fw)
+        fh, fw = r * fh, r * fw
+    return (_snap(int(fh * scale), max_stride, align_corners), _snap(int(fw * scale), max_stride, align_corners))
