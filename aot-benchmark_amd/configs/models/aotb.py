@@ -1,9 +1,3 @@
-"""AOTB preset (reference configs/models/aotb.py)."""
-from .default import DefaultModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'AOTB'
-        self.MODEL_LSTT_NUM = 3
+ModelConfig = preset('aotb')

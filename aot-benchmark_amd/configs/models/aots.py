@@ -1,9 +1,3 @@
-"""AOTS preset (reference configs/models/aots.py)."""
-from .default import DefaultModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'AOTS'
-        self.MODEL_LSTT_NUM = 2
+ModelConfig = preset('aots')

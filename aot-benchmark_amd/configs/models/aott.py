@@ -1,8 +1,3 @@
-"""AOTT preset (reference configs/models/aott.py)."""
-from .default import DefaultModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'AOTT'
+ModelConfig = preset('aott')

@@ -1,9 +1,3 @@
-"""DeAOTB preset (reference configs/models/deaotb.py)."""
-from .default import DefaultDeAOTModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultDeAOTModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'DeAOTB'
-        self.MODEL_LSTT_NUM = 3
+ModelConfig = preset('deaotb')

@@ -1,9 +1,3 @@
-"""DeAOTS preset (reference configs/models/deaots.py)."""
-from .default import DefaultDeAOTModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultDeAOTModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'DeAOTS'
-        self.MODEL_LSTT_NUM = 2
+ModelConfig = preset('deaots')

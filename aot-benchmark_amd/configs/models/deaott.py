@@ -1,8 +1,3 @@
-"""DeAOTT preset (reference configs/models/deaott.py)."""
-from .default import DefaultDeAOTModelConfig
+from .default import preset
 
-
-class ModelConfig(DefaultDeAOTModelConfig):
-    def __init__(self):
-        super().__init__()
-        self.MODEL_NAME = 'DeAOTT'
+ModelConfig = preset('deaott')

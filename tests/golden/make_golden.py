@@ -143,7 +143,27 @@ def make_transforms():
         refdriver._leave()
 
 
+def make_configs():
+    """Every attribute of every model preset of the reference (configs/models/*.py) -> tests/golden/model_configs.json."""
+    import importlib
+    out = {}
+    refdriver._enter()
+    try:
+        for name in ('aott', 'aots', 'aotb', 'aotl', 'r50_aotl', 'r101_aotl', 'swinb_aotl', 'deaott', 'deaots', 'deaotb',
+                     'deaotl', 'r50_deaotl', 'swinb_deaotl'):
+            out[name] = dict(importlib.import_module('configs.models.' + name).ModelConfig().__dict__)
+    finally:
+        refdriver._leave()
+    with open(os.path.join(HERE, 'model_configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('model_configs:', len(out), 'presets', flush=True)
+
+
 def main():
+    if not sys.argv[1:] or 'configs' in sys.argv[1:]:
+        make_configs()
+        if sys.argv[1:] == ['configs']:
+            return
     if not sys.argv[1:] or 'transforms' in sys.argv[1:]:
         make_transforms()
         if sys.argv[1:] == ['transforms']:

@@ -24,6 +24,20 @@ def test_state_dict_layout_matches_reference():
             assert list(sd[k].shape) == shp, (name, k)
 
 
+def test_model_presets_equal_reference_configs():
+    """configs.models.<name>.ModelConfig() carries exactly the reference's attributes and values for all 13 presets
+    (tests/golden/model_configs.json, dumped from /root/reference/configs/models by make_golden.py)."""
+    with open(os.path.join(GOLD, 'model_configs.json')) as f:
+        ref = json.load(f)
+    assert len(ref) == 13
+    for name, attrs in ref.items():
+        mine = model_cfg(name).__dict__
+        for k, v in attrs.items():
+            assert k in mine, (name, k)
+            if k != 'MODEL_ENCODER_PRETRAIN':       # a checkpoint path, not used on the inference path
+                assert mine[k] == v, (name, k, mine[k], v)
+
+
 def test_load_network_conventions(tmp_path):
     from networks.models import build_vos_model
     from utils.checkpoint import load_network
