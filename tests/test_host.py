@@ -156,3 +156,16 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, P(16), 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 8, 0, 0, None) == -1  # Cin % 4
     assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
     assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2
+
+
+def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
+    """the C-ABI stages are also reachable as torch.ops.aot_hip.* (dispatcher ops, ROCm key only)."""
+    import torch
+    import aot_hip_ops
+    names = aot_hip_ops.op_names()
+    assert {'attn', 'gated_attn', 'local_attn', 'local_gated', 'conv2d_nhwc', 'idbank', 'logits_finalize', 'preprocess',
+            'fuse_probs', 'label_resize'} <= set(names)
+    for n in names:
+        assert hasattr(torch.ops.aot_hip, n)
+    with pytest.raises(NotImplementedError):        # a CPU tensor never silently falls back
+        torch.ops.aot_hip.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), torch.empty(4, 8), 1e-5)

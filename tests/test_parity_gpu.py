@@ -557,6 +557,40 @@ def test_sequence_evaluator_vs_oracle(hip, flip, ms):
     assert (got[1].cpu()[5:25, 100:140] == 3).all()
 
 
+def test_torch_ops_match_direct_calls(hip):
+    """torch.ops.aot_hip.* (aot_hip_ops.py) run the same kernels as the direct ctypes wrappers: bit-identical outputs."""
+    import aot_hip_ops  # noqa: F401
+    g = torch.Generator().manual_seed(5)
+    N, C, H = 300, 256, 8
+    q, k, v = (torch.randn(n, C, generator=g).cuda() for n in (N, 1000, 1000))
+    a, b = torch.empty(N, C, device='cuda'), torch.empty(N, C, device='cuda')
+    part = torch.empty(4 * N * (C + 2 * H), device='cuda')
+    hip.attention(q, k, v, a, 1000, H, 32 ** 0.5, part=part, nsplit=4)
+    torch.ops.aot_hip.attn(q, k, v, b, 1000, H, 32 ** 0.5, part, 4)
+    assert torch.equal(a, b)
+    x, w, bias = torch.randn(N, 64, generator=g).cuda(), torch.randn(64, 128, generator=g).cuda(), torch.randn(128, generator=g).cuda()
+    o1, o2 = torch.empty(N, 128, device='cuda'), torch.empty(N, 128, device='cuda')
+    hip.linear(x, w, bias, o1, act=hip.ACT_RELU)
+    torch.ops.aot_hip.conv2d_nhwc(x, w, bias, None, o2, 1, N, 64, 1, N, 128, 1, 1, 1, 0, 1, hip.ACT_RELU)
+    assert torch.equal(o1, o2)
+    ga, be = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    l1, l2 = torch.empty(N, C, device='cuda'), torch.empty(N, C, device='cuda')
+    hip.layernorm(q, ga, be, l1)
+    torch.ops.aot_hip.layernorm(q, ga, be, l2, 1e-5)
+    assert torch.equal(l1, l2)
+    lg = torch.randn(2, 11, 40, 50, generator=g).cuda()
+    f1, a1, _ = hip.fuse_probs(lg, [False, True])
+    f2, a2 = torch.ops.aot_hip.fuse_probs(lg, [0, 1], None)
+    assert torch.equal(f1, f2) and torch.equal(a1, a2)
+    assert torch.equal(hip.label_resize(f1, 33, 65, True), torch.ops.aot_hip.label_resize(f1, 33, 65, True))
+    img = (torch.rand(60, 80, 3, generator=g) * 255).cuda()
+    p2 = torch.empty(1, 3, 49, 65, device='cuda')
+    torch.ops.aot_hip.preprocess(img, p2, False)
+    assert torch.equal(hip.preprocess(img, 49, 65), p2)
+    with pytest.raises(NotImplementedError):
+        torch.ops.aot_hip.layernorm(q.cpu(), ga.cpu(), be.cpu(), l2.cpu(), 1e-5)
+
+
 def test_more_than_ten_objects_vs_oracle(hip):
     """AOTInferEngine with 13 objects = two 10-object groups (aot_engine.py:515-630): mask separation, image embedding
     shared between the groups, soft logit aggregation -- HIP engine vs the oracle's restatement, teacher-forced."""
