@@ -23,7 +23,13 @@ Parity pin: the reference ships no tests or golden vectors for this path
 itself* run in the build container: ``tests/golden/make_golden.py`` imports
 /root/reference, drives the demo loop (tools/demo.py:187-235) and stores the
 results under ``tests/golden/``; ``tests/test_oracle_golden.py`` replays them
-through this module.
+through this module (nine clips over all model families, the reference's
+MultiheadAttention with its top_k / max_mem_len_ratio knobs, its MultiRestrictSize
+/ MultiToTensor transform classes, all 13 model presets).
+
+One function is PARITY UNPINNED: ``cv2_cubic_resize`` restates OpenCV's INTER_CUBIC
+(the reference's un-vendored, unpinned dependency ``opencv-python``, absent here)
+from its published algorithm and is only cross-checked against torch's bicubic.
 """
 import math
 
