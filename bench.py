@@ -84,23 +84,58 @@ def one_frame(engine, img):
     return label
 
 
-class ClipRunner:
-    """Walks clips frame by frame; a new clip (restart + reference frame) starts whenever one is exhausted."""
+class StreamClip:
+    """One clip on one HIP stream with its own engine.  `t` is the next frame to propagate (1 .. CLIP_FRAMES-1)."""
 
-    def __init__(self, engine, clips):
-        self.engine, self.clips = engine, clips
-        self.ci, self.t = -1, CLIP_FRAMES
+    def __init__(self, engine, stream, clip):
+        self.engine, self.stream, self.clip = engine, stream, clip
+        self.t = None
 
-    def step(self):
-        if self.t >= CLIP_FRAMES:
-            self.ci = (self.ci + 1) % len(self.clips)
-            frames, mask, objs = self.clips[self.ci]
-            self.frames = frames
+    def restart(self):
+        """restart_engine + add_reference_frame: per-clip set-up, never inside the timed region (the reference's
+        FPS excludes the first frame, evaluator.py:325-330,444-446)."""
+        frames, mask, objs = self.clip
+        with torch.cuda.stream(self.stream):
             self.engine.restart_engine()
             self.engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
-            self.t = 1
-        one_frame(self.engine, self.frames[self.t])
+        self.t = 1
+
+    def step(self):
+        with torch.cuda.stream(self.stream):
+            one_frame(self.engine, self.clip[0][self.t])
         self.t += 1
+
+    def advance_to(self, t):
+        while self.t < t:
+            self.step()
+
+
+def plan_windows(steps, streams, frames=CLIP_FRAMES - 1):
+    """Which frames of a clip the `steps` timed frames are.  Returns a list of passes; a pass is a list of rounds; a round
+    holds one (first_frame, count) window per stream.  Every pass uses a fresh clip per stream; within a pass the
+    windows are spread evenly over frames 1..`frames` so that the timed frames sample the clip's bank-size
+    distribution (M = 1 + (t-1)//gap) whatever `steps` is: a full pass is the whole clip on every stream, a short run
+    is a few windows centred on equally spaced quantiles of the clip."""
+    passes, left = [], steps
+    while left > 0:
+        kp = min(left, streams * frames)
+        left -= kp
+        rounds = 1 if kp >= streams * frames else max(1, round(3 / streams))
+        nw = rounds * streams
+        base, extra = divmod(kp, nw)
+        wins = []
+        for j in range(nw):
+            n = base + (1 if j < extra else 0)
+            centre = 1 + (j + 0.5) / nw * frames
+            first = max(1, min(int(round(centre - n / 2.0)), frames + 1 - n))
+            wins.append((first, n))
+        passes.append([[wins[r * streams + i] for i in range(streams)] for r in range(rounds)])
+    return passes
+
+
+def bank_frames_at(t, gap):
+    """Frames in the long-term bank while frame t is matched (reference frame at step 0, one more every `gap` steps)."""
+    return 1 + (t - 1) // gap
 
 
 def attention_roofline(engine, clip, device):
@@ -193,7 +228,49 @@ def cpu_baseline(sd, budget_s=20.0, max_frames=12):
                       % (done, 1 + done // 5, threads)}
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec this file under torch.distributed.run, one rank per GPU
+    (what tools/eval.py:100-106 does with mp.spawn).  Fails loudly when fewer than N devices are visible."""
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d ROCm device(s) visible' % (args.gpus, have))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+class _DryClip:
+    """--dry-run stand-in for StreamClip (CPU launcher test, tests/test_sharding_gloo.py): same stepping protocol, no
+    device work.  A dry run prints value = null."""
+
+    def __init__(self):
+        self.t = None
+
+    def restart(self):
+        self.t = 1
+
+    def step(self):
+        self.t += 1
+
+    def advance_to(self, t):
+        self.t = max(self.t, t)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3 * (CLIP_FRAMES - 1), help='propagated frames timed per GPU (default: one full 70-frame clip per stream)')
@@ -201,86 +278,139 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='clips processed concurrently per GPU (one HIP stream each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (default); gloo only with --dry-run')
+    ap.add_argument('--dry-run', action='store_true', help='launcher / sharding / gather plumbing only, no device work (CPU tests)')
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1:
+        raise SystemExit('bench.py: --gpus and --steps must be >= 1')
+    if args.backend == 'gloo' and not args.dry_run:
+        raise SystemExit('bench.py: the gloo backend is only for --dry-run (the hot path has no CPU fallback)')
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(spawn_ranks(args, argv))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ['WORLD_SIZE'])
+        rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if world != args.gpus:      # never emit a scaling number for a world the caller did not ask for
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the AOT hot path has no CPU fallback')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device('cpu') if dry else torch.device('cuda', local_rank)
+    if not dry:
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+        if dry:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+    joined = dist.get_world_size() if world > 1 else 1
 
-    from utils.synth import synth_clip
-    cfg, model, engine, sd = build_model(device)
+    def sync():
+        if not dry:
+            torch.cuda.synchronize(device)
+
+    def fence(collective=True):
+        sync()
+        if world > 1 and collective:
+            dist.barrier()
+        sync()
+
     S = max(1, args.streams)
-    nclips_stream = max(1, -(-args.steps // (S * (CLIP_FRAMES - 1))))
-    nclips_rank = S * nclips_stream
-    my_ids = shard_clips(nclips_rank * world, rank, world)
-    clips = []
-    for cid in my_ids:
-        frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
-        clips.append((frames, mask, objs))
-    from networks.engines import build_engine
-    engines = [engine] + [build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
-                                       long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP) for _ in range(S - 1)]
-    streams = [torch.cuda.Stream(device) for _ in range(S)]
+    passes = plan_windows(args.steps, S)
+    nclips_rank = S * len(passes)
+    my_ids = shard_clips(nclips_rank * world, rank, world)          # clip i -> rank i mod world
+    gap = 5
+    sd = None
+    if dry:
+        lanes = [_DryClip() for _ in range(S)]
+        set_clip = lambda lane, j: None
+    else:
+        from networks.engines import build_engine
+        from utils.synth import synth_clip
+        cfg, model, engine, sd = build_model(device)
+        gap = cfg.TEST_LONG_TERM_MEM_GAP
+        if hasattr(model, 'prepare'):
+            model.prepare()        # pack the weights once, before the clips fan out over streams
+        clips = []
+        for cid in my_ids:
+            frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
+            clips.append((frames, mask, objs))
+        engines = [engine] + [build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
+                                           long_term_mem_gap=gap) for _ in range(S - 1)]
+        streams = [torch.cuda.Stream(device) for _ in range(S)]
+        lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
 
-    def timed(runners, steps):
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            with torch.cuda.stream(streams[i % len(runners)]):
-                runners[i % len(runners)].step()
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        return time.perf_counter() - t0
+        def set_clip(lane, j):
+            lane.clip = clips[j]
+
+    def run_plan(lanes, passes, clip_of, collective=True):
+        """Runs the window plan; returns (timed seconds, timed frames, sum of bank sizes over the timed frames).  Only
+        the windows are timed: restart + reference frame and the fast-forward between windows are set-up."""
+        spent, done, msum = 0.0, 0, 0
+        for pi, rounds in enumerate(passes):
+            for i, lane in enumerate(lanes):
+                set_clip(lane, clip_of(pi, i))
+                lane.restart()
+            for wins in rounds:
+                for lane, (first, n) in zip(lanes, wins):
+                    lane.advance_to(first)
+                fence(collective)
+                t0 = time.perf_counter()
+                for k in range(max(n for _, n in wins)):
+                    for lane, (first, n) in zip(lanes, wins):
+                        if k < n:
+                            msum += bank_frames_at(lane.t, gap)
+                            lane.step()
+                            done += 1
+                fence(collective)
+                spent += time.perf_counter() - t0
+        return spent, done, msum
 
     with torch.no_grad():
-        # priming (setup, untimed): one full clip per stream so the caching allocator, the per-stream scratch and the
+        # priming (set-up, untimed): one full clip per stream so the caching allocator, the per-stream scratch and the
         # memory banks have reached their steady-state size -- a growing allocator calls hipMalloc, which
-        # synchronises the device and serialises the concurrently running clips (395 vs 445 fps on first/second pass)
-        prime = [ClipRunner(engines[i], clips[i:i + 1]) for i in range(S)]
-        for i in range(S * (CLIP_FRAMES - 1)):
-            with torch.cuda.stream(streams[i % S]):
-                prime[i % S].step()
-        # warmup: W frames spread over the streams
-        warm = [ClipRunner(engines[i], clips[i:i + 1]) for i in range(S)]
-        for i in range(max(args.warmup, S)):
-            with torch.cuda.stream(streams[i % S]):
-                warm[i % S].step()
-        runners = [ClipRunner(engines[i], clips[i::S]) for i in range(S)]
-        elapsed = timed(runners, args.steps)
+        # synchronises the device and serialises the concurrently running clips
+        for i, lane in enumerate(lanes):
+            lane.restart()
+        for t in range(1, CLIP_FRAMES):
+            for lane in lanes:
+                lane.step()
+        # warmup: W frames spread over the streams (fresh clip state; the plan below restarts every lane anyway)
+        for lane in lanes:
+            lane.restart()
+        for i in range(max(args.warmup, 0)):
+            lanes[i % S].step()
+        elapsed, frames_done, msum = run_plan(lanes, passes, lambda pi, i: pi * S + i)
+        assert frames_done == args.steps
         single = None
-        if S > 1 and rank == 0 and world == 1:      # the same job one clip at a time, for reference
-            single = args.steps / timed([ClipRunner(engines[0], clips[:1])], args.steps)
+        if S > 1 and rank == 0 and not dry:      # the same job one clip at a time (the reference's evaluation mode)
+            e1, f1, m1 = run_plan(lanes[:1], plan_windows(args.steps, 1), lambda pi, i: 0, collective=False)
+            single = {'fps': round(f1 / e1, 2), 'timed_M_mean': round(m1 / f1, 2)}
 
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmax = float(tmax.item())
-        stats = gather_stats(torch.tensor([elapsed, float(args.steps), torch.cuda.max_memory_allocated(device) / 2**30],
-                                          dtype=torch.float64, device=device), world)
+        peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
+        stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
+                                          device=device), world)
 
         roof = None
-        if rank == 0 and not args.no_roofline:
+        if rank == 0 and not args.no_roofline and not dry:
             with torch.cuda.stream(streams[0]):
                 roof = attention_roofline(engines[0], clips[0], device)
 
     base = jf = None
-    if rank == 0:
+    if rank == 0 and not dry:
         with torch.no_grad():
             jf = jf_vs_reference(device)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(sd)
+        if not args.no_cpu_baseline:
+            base = cpu_baseline(sd)          # rank 0 only, after the timed region; the other ranks wait at the barrier
     if world > 1:
         dist.barrier()
 
@@ -288,17 +418,23 @@ def main():
         total_frames = float(stats[:, 1].sum())
         line = {
             'metric': 'frames/sec, 480p 10-object synthetic clips; J&F vs reference',
-            'value': round(total_frames / tmax, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'value': None if dry else round(total_frames / tmax, 2), 'unit': 'frames/s', 'n_gpus': joined,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'dry-run (no device work)' if dry else 'synthetic',
             'config': {'workload': 'R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
                                    '70 frames/clip, long-term gap 5 (configs[1])',
                        'frames_per_clip': CLIP_FRAMES, 'clips_per_gpu': nclips_rank, 'streams_per_gpu': S,
-                       'single_stream_fps': None if single is None else round(single, 2),
-                       'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (world, S),
+                       'timed_M_mean': round(float(stats[:, 3].sum()) / total_frames, 2),
+                       'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
+                       'single_stream': single,
+                       'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
-                       'timed_region': 'wall clock incl. reference-frame setup of each clip; steady state (one untimed '
-                                       'priming clip per stream before the warmup steps)',
+                       'timed_region': 'wall clock (barrier + device sync on both sides) over the propagated frames '
+                                       'only: windows of consecutive frames spread over the 70-frame clip so that the '
+                                       'bank size M is sampled like a whole clip (timed_M_mean; a whole clip is 7.41); '
+                                       'restart + reference frame and the fast-forward between windows are untimed '
+                                       'set-up, as in the reference FPS (evaluator.py:325-330,444-446)',
                        'jf_vs_reference': jf},
             'roofline': roof, 'cpu_baseline': base,
         }

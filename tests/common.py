@@ -43,9 +43,23 @@ def synth_model_state(name, cfg_overrides=None):
     return cfg, model, sd
 
 
-def case_clip(c, device='cpu'):
+def case_clip(c, device='cpu', g=None):
+    """Synthetic clip of a golden case; cases made from a real label map (datasets/Demo) carry it as `first_mask`."""
     from utils.synth import synth_clip
-    return synth_clip(c['clip'], c['frames'], tuple(c['in_size']), tuple(c['out_size']), c['num_obj'], device=device)
+    frames, mask, objs, out_size = synth_clip(c['clip'], c['frames'], tuple(c['in_size']), tuple(c['out_size']),
+                                              c['num_obj'], device=device)
+    if g is not None and 'first_mask' in g:
+        mask = torch.from_numpy(g['first_mask'].astype(np.float32))[None, None].to(device)
+    return frames, mask, objs, out_size
+
+
+def lstt_last_of(engine):
+    """Last LSTT/GPM layer output after its decoder norm, [N, C] (AOT) / [N, 2C] (DeAOT) -- what the reference keeps
+    in curr_lstt_output[0][-1] (aot_engine.py:340-354); first object group."""
+    e0 = engine.aot_engines[0] if hasattr(engine, 'aot_engines') else engine
+    if hasattr(e0, 'curr_lstt_output'):                       # oracle / reference layout [N, 1, C]
+        return e0.curr_lstt_output[0][-1][:, 0]
+    return e0.lstt_last()
 
 
 def unpack_gapmask(g, t, shape):
@@ -65,9 +79,10 @@ def check_masks(pred, g, t, what):
     return int(bad.sum())
 
 
-def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lambda x: x):
+def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lambda x: x, extra=None, sub=None):
     """demo loop (tools/demo.py:187-235) with the GOLDEN mask fed back into memory at every frame, so frame t is
-    compared on identical history.  Returns {t: (logits4 [no,h,w], mask uint8 [H,W])}."""
+    compared on identical history.  Returns {t: (logits4 [no,h,w], mask uint8 [H,W])}.  `extra` (dict) receives, for the
+    kept frames, 'lstt_last_<t>' and -- with `sub` -- the merged output-size logits subsampled by `sub`."""
     out = {}
     engine.restart_engine()
     with torch.no_grad():
@@ -78,6 +93,10 @@ def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lam
             lab = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True)
             l4 = engine.pred_id_logits if hasattr(engine, 'pred_id_logits') else engine.aot_engines[0].pred_id_logits
             out[t] = (l4[0].detach().float().cpu().numpy() if t in keep else None, lab[0, 0].to(torch.uint8).cpu().numpy())
+            if extra is not None and t in keep:
+                extra['lstt_last_%d' % t] = lstt_last_of(engine).detach().float().cpu().numpy()
+                if sub:
+                    extra['merged_%d' % t] = logit[0, :, ::sub, ::sub].detach().float().cpu().numpy()
             fb = torch.from_numpy(g['masks'][t - 1].astype(np.float32)).view(1, 1, *out_size)
             fb = F.interpolate(to_dev(fb), size=engine.input_size_2d, mode='nearest')
             engine.update_memory(fb)

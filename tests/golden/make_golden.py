@@ -51,6 +51,24 @@ CASES = {
                      keep_logits=(1, 3)),
     'c3d_deaots': dict(model='deaots', frames=4, in_size=(145, 177), out_size=(144, 176), num_obj=3, clip=7,
                        keep_logits=(1, 3), keep_lstt=False),
+    # ---- round 2 -------------------------------------------------------------------------------------------
+    # BASELINE config 2 over a full 70-frame clip (same clip 0 as c2_r50_aotl: its first 7 frames are identical), the
+    # long-term bank grows to M = 14: every mask, logits + last LSTT output early / mid / end of the clip
+    'c2_r50_aotl_70': dict(model='r50_aotl', frames=70, in_size=(481, 849), out_size=(480, 854), num_obj=10, clip=0,
+                           keep_logits=(1, 35, 69)),
+    # BASELINE config 3 at its full size: SwinB-DeAOTL, 480x848 input (align_corners=False -> multiples of 16),
+    # 10 objects, 8 frames (bank M -> 2)
+    'c3_swinb_deaotl_480': dict(model='swinb_deaotl', frames=8, in_size=(480, 848), out_size=(480, 854), num_obj=10,
+                                clip=10, keep_logits=(1, 7)),
+    # more than 10 objects (AOTInferEngine's object groups, aot_engine.py:485-635): 13 synthetic rectangles = 2 groups,
+    # and the 44-object first-frame mask of datasets/Demo/masks/1001_3iEIq5HBY1s = 5 groups (nearest-resized; the
+    # mask itself is stored in the fixture).  `sub` = stride of the stored merged output-size logits.
+    'c4_aott_13obj': dict(model='aott', frames=5, in_size=(129, 161), out_size=(128, 160), num_obj=13, clip=9,
+                          keep_logits=(1, 4), gap=2, sub=2),
+    'c4_r50_aotl_44obj': dict(model='r50_aotl', frames=7, in_size=(241, 433), out_size=(240, 428), num_obj=44, clip=11,
+                              keep_logits=(1, 6), sub=4, demo_mask='1001_3iEIq5HBY1s/00002058.png'),
+    'c4_deaott_44obj': dict(model='deaott', frames=4, in_size=(193, 337), out_size=(192, 336), num_obj=43, clip=12,
+                            keep_logits=(1, 3), gap=2, sub=4, demo_mask='1007_YCTBBdbKSSg/00000693.png'),
     # ragged case: odd sizes, 3 objects, AOTT
     'c1b_aott_ragged': dict(model='aott', frames=4, in_size=(193, 305), out_size=(190, 300), num_obj=3, clip=3,
                             keep_logits=(1, 3)),
@@ -182,23 +200,33 @@ def main():
     for name, c in CASES.items():
         if only and name not in only:
             continue
-        net, make_engine, cfg = refdriver.build_reference(c['model'])
+        net, make_engine, cfg = refdriver.build_reference(c['model'], gap=c.get('gap'))
         ref_sd = net.state_dict()
         keys[c['model']] = [[k, list(v.shape)] for k, v in ref_sd.items()]
         net.load_state_dict(synth_state_dict(ref_sd))
         frames, mask, objs, out_size = synth_clip(c['clip'], c['frames'], c['in_size'], c['out_size'], c['num_obj'])
-        recs = refdriver.run_reference_clip(make_engine(), frames, mask, objs, out_size)
-        no = c['num_obj'] + 1
-        out = {'masks': np.stack([r['mask'].numpy() for r in recs])}
+        out = {}
+        if c.get('demo_mask'):
+            # real first-frame label map (PIL palette PNG), nearest-resized like the evaluator's label path
+            from PIL import Image
+            lab = torch.from_numpy(np.array(Image.open(os.path.join(refdriver.REF, 'datasets', 'Demo', 'masks',
+                                                                    c['demo_mask'])))).float()
+            mask = F.interpolate(lab[None, None], size=c['in_size'], mode='nearest')
+            out['first_mask'] = mask[0, 0].to(torch.uint8).numpy()
+            assert int(lab.max()) == c['num_obj']
+        recs = refdriver.run_reference_clip(make_engine(), frames, mask, objs, out_size, keep=set(c['keep_logits']))
+        no = min(c['num_obj'], 10) + 1
+        out['masks'] = np.stack([r['mask'].numpy() for r in recs])
         gaps = []
         for t, r in enumerate(recs, start=1):
-            top2 = torch.topk(r['logits'][0, :no], 2, dim=0)[0]
-            gap = (top2[0] - top2[1])
+            gap = r['gap']
             gaps.append([int((gap < 1e-3).sum()), int((gap < 1e-4).sum()), float(gap.min())])
             if t in c['keep_logits']:
-                out['logits4_%d' % t] = r['logits4'][0, :no].numpy()
+                out['logits4_%d' % t] = r['logits4'][0, :no].numpy()      # first object group, stride 4
                 if c.get('keep_lstt', True):
                     out['lstt_last_%d' % t] = r['lstt'][-1][:, 0].numpy()
+                if c.get('sub'):                                          # merged logits of all groups, subsampled
+                    out['merged_%d' % t] = r['logits'][0, :, ::c['sub'], ::c['sub']].numpy()
             out['gapmask_%d' % t] = np.packbits((gap < 2e-4).numpy())     # pixels where argmax is a near-tie
         out['gaps'] = np.array(gaps)
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)

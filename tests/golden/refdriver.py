@@ -41,7 +41,7 @@ def _leave():
             del sys.modules[name]
 
 
-def build_reference(model_name):
+def build_reference(model_name, gap=None):
     """Returns (net, engine_factory, cfg) built from the reference's own code."""
     _enter()
     try:
@@ -64,13 +64,13 @@ def build_reference(model_name):
 
         def make_engine():
             return build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=net, gpu_id=-1,
-                                long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP)
+                                long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP if gap is None else gap)
         return net, make_engine, cfg
     finally:
         _leave()
 
 
-def run_reference_clip(engine, frames, first_mask, obj_nums, output_size, teacher_masks=None):
+def run_reference_clip(engine, frames, first_mask, obj_nums, output_size, teacher_masks=None, keep=None):
     """tools/demo.py:187-235 on tensors; returns per-frame dicts (mask, logits4, and
     per-layer LSTT outputs of the first engine)."""
     out = []
@@ -83,9 +83,12 @@ def run_reference_clip(engine, frames, first_mask, obj_nums, output_size, teache
             prob = torch.softmax(logit, dim=1)
             label = torch.argmax(prob, dim=1, keepdim=True).float()
             e0 = engine.aot_engines[0]
-            rec = {'mask': label[0, 0].to(torch.uint8), 'logits4': e0.pred_id_logits.clone(),
-                   'logits': logit.clone(),
-                   'lstt': [x.clone() for x in e0.curr_lstt_output[0]]}
+            rec = {'mask': label[0, 0].to(torch.uint8)}
+            top2 = torch.topk(logit[0], 2, dim=0)[0]
+            rec['gap'] = (top2[0] - top2[1]).clone()
+            if keep is None or t in keep:          # heavy tensors only for the frames the caller stores
+                rec.update({'logits4': e0.pred_id_logits.clone(), 'logits': logit.clone(),
+                            'lstt': [x.clone() for x in e0.curr_lstt_output[0]]})
             fb = label if teacher_masks is None else teacher_masks[t - 1].view(1, 1, *output_size).float()
             fb = F.interpolate(fb, size=engine.input_size_2d, mode='nearest')
             engine.update_memory(fb)

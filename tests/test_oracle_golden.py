@@ -6,7 +6,7 @@ import torch
 
 from common import (GOLD, LOGIT_TOL, MHA_KNOB_CASES, case_clip, check_masks, load_case, mha_knob_inputs, run_teacher_forced,
                     synth_model_state)
-from oracle.aot_oracle import OracleEngine, OracleModel, mha_core
+from oracle.aot_oracle import OracleEngine, OracleInferEngine, OracleModel, mha_core
 
 
 @pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c2c_r101_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
@@ -24,6 +24,51 @@ def test_oracle_matches_reference_golden(case):
             err = np.abs(l4[:no] - g['logits4_%d' % t]).max()
             assert err < 1e-4, 'frame %d logits4 err %g' % (t, err)        # far inside the 1e-3 bar
             assert err < LOGIT_TOL
+
+
+@pytest.mark.parametrize('case', ['c2_r50_aotl_70', 'c3_swinb_deaotl_480'])
+def test_oracle_matches_reference_full_size(case):
+    """BASELINE configs 2 and 3 at their full size against the REAL reference: the 70-frame R50-AOTL clip (bank M 1 -> 14;
+    every mask, logits and last-layer LSTT output at frames 1 / 35 / 69) and SwinB-DeAOTL at 480x848 with 10 objects."""
+    c, g = load_case(case)
+    _, _, sd = synth_model_state(c['model'])
+    frames, mask, objs, out_size = case_clip(c, g=g)
+    eng = OracleEngine(OracleModel(c['model'], sd))
+    extra = {}
+    res = run_teacher_forced(eng, frames, mask, objs, out_size, g, set(c['keep_logits']), extra=extra)
+    assert len(res) == c['frames'] - 1
+    no = c['num_obj'] + 1
+    for t, (l4, m) in res.items():
+        check_masks(m, g, t, 'oracle')
+        if l4 is not None:
+            assert np.abs(l4[:no] - g['logits4_%d' % t]).max() < 1e-4
+            ref = g['lstt_last_%d' % t]
+            assert np.abs(extra['lstt_last_%d' % t] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('case', ['c4_aott_13obj', 'c4_r50_aotl_44obj', 'c4_deaott_44obj'])
+def test_oracle_multi_group_matches_reference(case):
+    """More than 10 objects (aot_engine.py:485-635): OracleInferEngine against the REAL reference's AOTInferEngine -- 13
+    synthetic objects (2 groups) and the 44 / 43-object first-frame masks of datasets/Demo (5 groups): merged
+    output-size logits (subsampled), the first group's stride-4 logits and every mask."""
+    c, g = load_case(case)
+    _, _, sd = synth_model_state(c['model'])
+    frames, mask, objs, out_size = case_clip(c, g=g)
+    assert int(mask.max()) == c['num_obj'] > 10
+    eng = OracleInferEngine(OracleModel(c['model'], sd), long_term_mem_gap=c.get('gap'))
+    extra = {}
+    res = run_teacher_forced(eng, frames, mask, objs, out_size, g, set(c['keep_logits']), extra=extra, sub=c['sub'])
+    assert len(eng.aot_engines) == -(-c['num_obj'] // 10)
+    for t, (l4, m) in res.items():
+        check_masks(m, g, t, 'oracle')
+        if l4 is not None:
+            assert np.abs(l4[:11] - g['logits4_%d' % t]).max() < 1e-4
+            ref = g['merged_%d' % t]
+            got = extra['merged_%d' % t]
+            assert got.shape == ref.shape == (1 + 10 * len(eng.aot_engines),) + ref.shape[1:]
+            # logit() of a clamped probability: the slope is 1/p(1-p) <= 1e5 at the clamp, so compare probabilities too
+            assert np.abs(got - ref).max() < 2e-3
+            assert np.abs(1 / (1 + np.exp(-got)) - 1 / (1 + np.exp(-ref))).max() < 1e-5
 
 
 def test_oracle_fp64_agrees_with_fp32():

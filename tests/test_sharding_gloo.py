@@ -47,3 +47,57 @@ def test_two_rank_sharding_and_gather():
     assert abs(len(c0) - len(c1)) <= 1
     assert s0 == s1 and len(s0) == 2                                        # every rank sees both stat rows
     assert s0[0][2] == 1.0 and s0[1][2] == 2.0
+
+
+def test_bench_entry_point_spawns_two_gloo_ranks():
+    """`python bench.py --gpus 2` as the driver invokes it (no launcher, WORLD_SIZE unset): bench.py re-execs itself
+    under torch.distributed.run with one rank per device and prints ONE line whose n_gpus is the number of ranks that
+    joined the process group.  --dry-run/--backend gloo replace the device work, everything else is the real path
+    (argument handling, window plan, clip sharding, barrier-bracketed timing, max-over-ranks, stats all_gather)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+                        '--dry-run', '--backend', 'gloo'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 20 and line['warmup'] == 5
+    assert line['value'] is None and 'dry-run' in line['data']          # a dry run never reports a throughput
+    assert line['config']['parallelism'].startswith('clip-sharded dp2')
+    assert 6.5 <= line['config']['timed_M_mean'] <= 8.3                   # a whole 70-frame clip is 7.41
+
+
+def test_bench_refuses_a_world_it_was_not_asked_for():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--dry-run', '--backend', 'gloo'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
+
+
+def test_window_plan_samples_the_bank_size_distribution():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = sum(bench.bank_frames_at(t, 5) for t in range(1, 70)) / 69.0
+    assert abs(full - 7.406) < 1e-3
+    for steps, streams in ((20, 3), (20, 1), (207, 3), (500, 3), (69, 1), (40, 2)):
+        frames, msum = 0, 0
+        for rounds in bench.plan_windows(steps, streams):
+            last = [0] * streams
+            for wins in rounds:
+                assert len(wins) == streams
+                for i, (first, n) in enumerate(wins):
+                    assert first >= max(1, last[i]) and first + n <= 70       # forward in time, inside the clip
+                    last[i] = first + n
+                    frames += n
+                    msum += sum(bench.bank_frames_at(t, 5) for t in range(first, first + n))
+        assert frames == steps
+        assert abs(msum / frames - full) < 0.6, (steps, streams, msum / frames)
