@@ -79,6 +79,14 @@ class AOTEngine(nn.Module):
             return None
         return [as_map(t, h, w) for (t, h, w) in self._feats]
 
+    def lstt_last(self):
+        """Last LSTT / GPM layer output after its decoder norm, token-major [N, C] (AOT) / [N, 2C] (DeAOT): what the
+        reference keeps as curr_lstt_output[0][-1] (aot_engine.py:340-354)."""
+        C = self.AOT.encoder_projector.out_channels
+        if self._dec_in.shape[1] == 2 * C and not self.AOT.decoder.decode_intermediate_input:
+            return self._dec_in
+        return self._dec_in[:, -C:]
+
     @property
     def long_term_memories(self):
         if self.bank_k is None or self.bank_len == 0:
