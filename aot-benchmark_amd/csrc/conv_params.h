@@ -1,0 +1,20 @@
+// Parameters shared by the implicit-GEMM convolution kernels (gemm_conv.hip: register-staged general kernel,
+// gemm_lds.hip: LDS-direct tile kernel).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+  const float* in;    // NHWC activations of B images: [B*H*W, lda]
+  const float* w;     // [K, ldb]   (k-major; general kernel)
+  const float* wt;    // [Cout, ldwt] (k-contiguous rows; LDS-direct kernel) or nullptr
+  const float* bias;  // [Cout] or nullptr
+  const float* res;   // residual [res_rows, ldr] or nullptr; row = m % res_rows (a map shared by several lanes)
+  float* out;         // [B*OH*OW, ldc]
+  int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil;
+  int lda, ldb, ldwt, ldc, ldr, res_rows, M, K, act;
+};
+
+// LDS-direct kernel (gemm_lds.hip).  variant: 0 = 128x64 tile, 1 = 64x64 tile.  ksplit > 1 cuts K into ksplit slices
+// whose fp32 partial tiles go to `scratch` ([ksplit][M][Cout] floats) and are summed in slice order by a second launch.
+int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s);
+bool gemm_lds_eligible(const ConvParams& p);

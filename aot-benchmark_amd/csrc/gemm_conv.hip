@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution / linear layer on the exact-fp32 matrix cores of gfx950.
+// Implicit-GEMM convolution / linear layer on the exact-fp32 matrix cores of gfx950: the register-staged LDS kernel, the
+// wave-independent small-M kernels and the dispatcher (the LDS-direct tile kernel lives in gemm_lds.hip).
 //
 //   out[m, n] = act( sum_k A[m, k] * W[k, n] + bias[n] + res[m, n] )
 //
@@ -15,17 +16,7 @@
 //   Bs[k][n] (row stride BN+4, float4 stores, lane j <-> column j)
 // fp32 MFMA issues once per 64 cycles per SIMD, so one ds_read_b32 per operand is far from the
 // LDS limit (section 3 of the guide: 4 LDS cycles per 4 MFMAs = 256 cycles).
-#include "common.h"
-
-struct ConvParams {
-  const float* in;
-  const float* w;
-  const float* bias;
-  const float* res;
-  float* out;
-  int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil;
-  int lda, ldb, ldc, ldr, M, K, act;
-};
+#include "conv_params.h"
 
 template <int BM, int BN, int WM, int WN, int BK, bool IS1X1>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
@@ -59,7 +50,7 @@ conv_gemm_kernel(const ConvParams p) {
 
   // ---- A loader state (one float4 = 4 consecutive k of one output pixel) ----
   bool a_ok[A_PER];
-  long a_base[A_PER];
+  long a_base[A_PER], a_img[A_PER];
   int a_iy0[A_PER], a_ix0[A_PER], a_c[A_PER], a_ky[A_PER], a_kx[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
@@ -68,9 +59,12 @@ conv_gemm_kernel(const ConvParams p) {
     const int m = m0 + r;
     a_ok[i] = (f < A_F4) && (m < p.M);
     const int mm = a_ok[i] ? m : 0;
-    const int oy = mm / p.OW, ox = mm - oy * p.OW;
+    const int hw_out = p.OH * p.OW;
+    const int bi = mm / hw_out, pix = mm - bi * hw_out;     // image of the batch, output pixel
+    const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    a_img[i] = (long)bi * p.H * p.W * p.lda;
     if (IS1X1) {
-      a_base[i] = ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kq * 4;
+      a_base[i] = a_img[i] + ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kq * 4;
     } else {
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
@@ -95,7 +89,7 @@ conv_gemm_kernel(const ConvParams p) {
       } else {
         const int iy = a_iy0[i] + a_ky[i] * p.dil, ix = a_ix0[i] + a_kx[i] * p.dil;
         if (a_ok[i] && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          v = *reinterpret_cast<const float4*>(p.in + ((long)iy * p.W + ix) * p.lda + a_c[i]);
+          v = *reinterpret_cast<const float4*>(p.in + a_img[i] + ((long)iy * p.W + ix) * p.lda + a_c[i]);
         // advance (tap, c) by BK channels-of-k
         a_c[i] += BK;
         while (a_c[i] >= p.Cin) {
@@ -183,7 +177,7 @@ conv_gemm_kernel(const ConvParams p) {
         const int m = m0 + wm0 + i * 32 + mfma32_row(r, kh);
         if (m < p.M) {
           float v = acc[i][j][r] + bv;
-          if (p.res) v += p.res[(long)m * p.ldr + n];
+          if (p.res) v += p.res[(long)(p.res_rows ? m % p.res_rows : m) * p.ldr + n];
           p.out[(long)m * p.ldc + n] = apply_act(v, p.act);
         }
       }
@@ -220,7 +214,10 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
   const int m = m0 + j;
   const bool row_ok = m < p.M;
   const int mm = row_ok ? m : 0;
-  const int oy = mm / p.OW, ox = mm - oy * p.OW;
+  const int hw_out = p.OH * p.OW;
+  const int bi = mm / hw_out, pix = mm - bi * hw_out;       // image of the batch, output pixel
+  const int oy = pix / p.OW, ox = pix - oy * p.OW;
+  const float* img = p.in + (long)bi * p.H * p.W * p.lda;
   long a_base = 0;
   int iy0 = 0, ix0 = 0, c = 0, ky = 0, kx = 0;
   if (IS1X1) {
@@ -243,11 +240,11 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
   auto load = [&](int s) {
     const float* src = nullptr;
     if (IS1X1) {
-      if (row_ok) src = p.in + a_base + (long)s * 32;
+      if (row_ok) src = img + a_base + (long)s * 32;
     } else {
       const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
       if (row_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        src = p.in + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
+        src = img + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
       c += 32;
       if (c >= p.Cin) { c = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
     }
@@ -299,7 +296,7 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
       const int mo = m0 + mfma32_row(r, kh);
       if (mo < p.M) {
         float v = fin[i] + bv;
-        if (p.res) v += p.res[(long)mo * p.ldr + n];
+        if (p.res) v += p.res[(long)(p.res_rows ? mo % p.res_rows : mo) * p.ldr + n];
         p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
       }
     }
@@ -339,14 +336,18 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
 
   bool row_ok[2];
   const float* a1x1[2];
+  const float* img2[2];
   int iy0[2], ix0[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + i * 32 + j;
     row_ok[i] = m < p.M;
     const int mm = row_ok[i] ? m : 0;
-    const int oy = mm / p.OW, ox = mm - oy * p.OW;
-    a1x1[i] = p.in + ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kh * 16 + (long)s0 * 32;
+    const int hw_out = p.OH * p.OW;
+    const int bi = mm / hw_out, pix = mm - bi * hw_out;
+    const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    img2[i] = p.in + (long)bi * p.H * p.W * p.lda;
+    a1x1[i] = img2[i] + ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kh * 16 + (long)s0 * 32;
     iy0[i] = oy * p.stride - p.pad;
     ix0[i] = ox * p.stride - p.pad;
   }
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
       } else {
         const int iy = iy0[i] + ky * p.dil, ix = ix0[i] + kx * p.dil;
         if (row_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          src = p.in + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
+          src = img2[i] + ((long)iy * p.W + ix) * p.lda + c + kh * 16;
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) a[i][v] = src ? reinterpret_cast<const float4*>(src)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
       const int mo = m0 + (r >> 4) * 32 + mfma32_row(r & 15, kh);
       if (mo < p.M) {
         float v = fin[i] + bv;
-        if (p.res) v += p.res[(long)mo * p.ldr + n];
+        if (p.res) v += p.res[(long)(p.res_rows ? mo % p.res_rows : mo) * p.ldr + n];
         p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
       }
     }
@@ -471,38 +472,59 @@ static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
   AOT_LAUNCH_CHECK();
 }
 
-static int conv_dispatch(const float* in, const float* w, const float* bias, const float* res, float* out, int H, int W,
-                         int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int lda,
-                         int ldb, int ldc, int ldr, int act, int cfg, void* stream) {
+// Kernel choice (cfg < 0): a table read off the sweep of tools/dev/gemm_check.hip on MI355X (profiles/r02_gemm_sweep.txt;
+// every kernel family on every conv / linear shape of the R50-AOTL frame, one clip and three lanes stacked):
+//   * register-staged 64x64x32 LDS kernel (cfg 4): >= 512 tiles of 64x64, and everything the other kernels cannot take
+//     (stem, MobileNet channel counts); 128x32 tiles for Cout <= 32;
+//   * LDS-direct 64x64 tile kernel (gemm_lds.hip, cfg 117): KxK convs with >= 192 tiles (the filter tap is wave-uniform per
+//     k-step there: 10-40 % faster than the per-lane tap arithmetic of the register-staged loader), and the mid-sized 1x1
+//     shapes with K = 512 or Cout >= 1024 (192 <= tiles < 512);
+//   * wave-independent kernels with in-block split-K (cfg 1x: 32x32 waves, cfg 2x: 64x32 waves): the stride-16 maps
+//     (M = 1674 per lane), where neither LDS-tiled kernel -- with or without split-K slabs -- beats them.
+static int auto_cfg(const ConvParams& p, long scratch_floats) {
+  (void)scratch_floats;
+  const bool direct_ok = (p.Cin % 32 == 0) && (p.K % 32 == 0);
+  const bool lds_ok = gemm_lds_eligible(p);
+  const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const bool kxk = p.KH * p.KW > 1;
+  if (p.Cout <= 32) return 3;
+  if (kxk && lds_ok && tiles64 >= 192 && !(tiles64 < 400 && p.K >= 2048 && p.Cout >= 256)) return 116 + 1;
+  if (tiles64 >= 512 || !direct_ok) return 4;
+  if (!kxk && lds_ok && tiles64 >= 192 && p.K <= 512 && (p.K == 512 || p.Cout >= 1024)) return 116 + 1;
+  if (kxk && tiles64 < 192 && p.K >= 1024) return 24;
+  const long tiles32 = (long)cdiv(p.M, 32) * cdiv(p.Cout, 32);
+  const int nslab = p.K / 32;
+  int ks = 1;
+  while (ks < 8 && tiles32 * ks < 2048 && nslab / (ks * 2) >= 2) ks *= 2;
+  return 10 + ks;
+}
+
+extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const float* bias, const float* res,
+                                   float* out, float* scratch, long scratch_floats, int B, int H, int W, int Cin, int OH,
+                                   int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int lda, int ldb,
+                                   int ldwt, int ldc, int ldr, int res_rows, int act, int cfg, void* stream) {
   if (!in || !w || !out) return AOT_ERR_BADARG;
-  if (H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((Cin & 3) || (lda & 3) || (ldb & 3) || ldb < Cout || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return AOT_ERR_BADARG;
-  if (res && ldr < Cout) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   ConvParams p;
-  p.in = in; p.w = w; p.bias = bias; p.res = res; p.out = out;
-  p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.in = in; p.w = w; p.wt = wt; p.bias = bias; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
-  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
-  p.M = OH * OW; p.K = KH * KW * Cin; p.act = act;
+  p.lda = lda; p.ldb = ldb; p.ldwt = ldwt; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
+  if (wt && ldwt < p.K) return AOT_ERR_BADARG;
   const bool is1x1 = (KH == 1 && KW == 1 && pad == 0);
   hipStream_t s = (hipStream_t)stream;
-  const bool direct_ok = (Cin % 32 == 0) && (p.K % 32 == 0);
-  if (cfg < 0) {
-    // Heuristic (scratch/mb_gemm.py): LDS-tiled 64x64 when the grid alone gives >= 2 workgroups per CU,
-    // otherwise independent 32x32 waves with in-block split-K sized to ~2 waves per SIMD.
-    const long tiles64 = (long)cdiv(p.M, 64) * cdiv(Cout, 64);
-    if (Cout <= 32) cfg = 3;
-    else if (tiles64 >= 512 || !direct_ok) cfg = 4;
-    else {
-      const long tiles32 = (long)cdiv(p.M, 32) * cdiv(Cout, 32);
-      const int nslab = p.K / 32;
-      int ks = 1;
-      while (ks < 8 && tiles32 * ks < 2048 && nslab / (ks * 2) >= 2) ks *= 2;
-      cfg = 10 + ks;
-    }
+  if (!scratch) scratch_floats = 0;
+  if (cfg < 0) cfg = auto_cfg(p, scratch_floats);
+  if (cfg >= 100) {      // LDS-direct kernel: variant (cfg - 100) / 16, split-K factor (cfg - 100) % 16
+    const int variant = (cfg - 100) / 16, ks = (cfg - 100) % 16;
+    if (ks > 1 && (long)ks * p.M * p.Cout > scratch_floats) return AOT_ERR_BADARG;
+    return launch_gemm_lds(p, variant, ks, scratch, s);
   }
-  if (cfg >= 10 && !direct_ok) return AOT_ERR_UNSUPPORTED;
   switch (cfg) {
     case 0: return launch_cfg<128, 128, 64, 64, 16>(p, is1x1, s);
     case 1: return launch_cfg<128, 64, 64, 32, 16>(p, is1x1, s);
@@ -510,30 +532,18 @@ static int conv_dispatch(const float* in, const float* w, const float* bias, con
     case 3: return launch_cfg<128, 32, 32, 32, 16>(p, is1x1, s);
     case 4: return launch_cfg<64, 64, 32, 32, 32>(p, is1x1, s);
     case 5: return launch_cfg<128, 64, 64, 32, 32>(p, is1x1, s);
-    case 11: return launch_direct<1>(p, is1x1, s);
-    case 12: return launch_direct<2>(p, is1x1, s);
-    case 14: return launch_direct<4>(p, is1x1, s);
-    case 18: return launch_direct<8>(p, is1x1, s);
-    case 21: return launch_direct2<1>(p, is1x1, s);
-    case 22: return launch_direct2<2>(p, is1x1, s);
-    case 24: return launch_direct2<4>(p, is1x1, s);
-    case 28: return launch_direct2<8>(p, is1x1, s);
+    case 11: case 12: case 14: case 18: case 21: case 22: case 24: case 28:
+      if ((Cin % 32) || (p.K % 32)) return AOT_ERR_UNSUPPORTED;
+      switch (cfg) {
+        case 11: return launch_direct<1>(p, is1x1, s);
+        case 12: return launch_direct<2>(p, is1x1, s);
+        case 14: return launch_direct<4>(p, is1x1, s);
+        case 18: return launch_direct<8>(p, is1x1, s);
+        case 21: return launch_direct2<1>(p, is1x1, s);
+        case 22: return launch_direct2<2>(p, is1x1, s);
+        case 24: return launch_direct2<4>(p, is1x1, s);
+        default: return launch_direct2<8>(p, is1x1, s);
+      }
     default: return AOT_ERR_BADARG;
   }
-}
-
-extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out,
-                                   int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
-                                   int dil, int lda, int ldb, int ldc, int ldr, int act, void* stream) {
-  return conv_dispatch(in, w, bias, res, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, lda, ldb, ldc, ldr, act,
-                       -1, stream);
-}
-
-// Tuning entry: same as aot_conv2d_nhwc_f32 with an explicit tile configuration (cfg < 0 = heuristic).
-extern "C" int aot_conv2d_nhwc_f32_cfg(const float* in, const float* w, const float* bias, const float* res, float* out,
-                                       int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
-                                       int pad, int dil, int lda, int ldb, int ldc, int ldr, int act, int cfg,
-                                       void* stream) {
-  return conv_dispatch(in, w, bias, res, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, lda, ldb, ldc, ldr, act,
-                       cfg, stream);
 }

@@ -36,25 +36,25 @@ extern "C" {
 const char* aot_hip_version(void);
 
 /* Implicit-GEMM convolution / linear layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
- *   out[m, n] = act( sum_k A[m, k] * w[k, n] + bias[n] + res[m, n] )
- * with A the on-the-fly im2col of the NHWC input, k = (ky*KW + kx)*Cin + c.
- * w is [KH*KW*Cin, ldb] row-major (ldb >= Cout, multiple of 4; FrozenBN already folded
- * in by the host), bias/res may be NULL.  A linear layer is the 1x1 case with H=1, W=M.
- * Requires Cin % 4 == 0 and lda % 4 == 0.
+ *   out[m, n] = act( sum_k A[m, k] * w[k, n] + bias[n] + res[m % res_rows, n] )
+ * with A the on-the-fly im2col of B NHWC images ([B*H*W, lda]), m = (b, oy, ox), k = (ky*KW + kx)*Cin + c.
+ * w is [KH*KW*Cin, ldb] row-major (ldb >= Cout, multiple of 4; FrozenBN already folded in by the host);
+ * wt (optional) is the same weight with k-contiguous rows, [Cout, ldwt] (ldwt >= KH*KW*Cin): when it is given and
+ * Cin % 32 == 0 the LDS-direct tile kernel (csrc/gemm_lds.hip) runs, otherwise the register-staged one
+ * (csrc/gemm_conv.hip).  bias / res may be NULL; res_rows = 0 means one residual row per output row, otherwise the
+ * residual is a [res_rows, ldr] map shared by the images (row m % res_rows).  A linear layer is the 1x1 case with
+ * B = 1, H = 1, W = M.  `scratch` (optional, scratch_floats floats) enables split-K for shapes with too few tiles
+ * (partials summed in slice order: deterministic).  cfg < 0 = heuristic kernel choice; cfg >= 0 forces a kernel
+ * configuration (tuning / tests; same results up to summation order).  Requires Cin % 4 == 0 and lda % 4 == 0.
  * Replaces: every nn.Conv2d + FrozenBatchNorm2d + ReLU of networks/encoders/resnet.py:34-54,
  * 140-157 and mobilenetv2.py (1x1 / 3x3), encoder_projector (models/aot.py:19-21,81-84),
  * the nn.Linear layers of networks/layers/transformer.py:321-359 and attention.py:76-79,119,
  * and the FPN convs of networks/decoders/fpn.py:34-58. */
-int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res,
-                        float* out, int H, int W, int Cin, int OH, int OW, int Cout,
-                        int KH, int KW, int stride, int pad, int dil,
-                        int lda, int ldb, int ldc, int ldr, int act, void* stream);
-/* Tuning/benchmark variant: explicit kernel configuration `cfg` (see csrc/gemm_conv.hip; cfg < 0 = the
- * heuristic the plain entry uses).  Same results for every valid cfg. */
-int aot_conv2d_nhwc_f32_cfg(const float* in, const float* w, const float* bias, const float* res,
-                            float* out, int H, int W, int Cin, int OH, int OW, int Cout,
-                            int KH, int KW, int stride, int pad, int dil,
-                            int lda, int ldb, int ldc, int ldr, int act, int cfg, void* stream);
+int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const float* bias, const float* res,
+                        float* out, float* scratch, long scratch_floats, int B, int H, int W, int Cin,
+                        int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                        int lda, int ldb, int ldwt, int ldc, int ldr, int res_rows, int act, int cfg,
+                        void* stream);
 
 /* Depthwise KxK convolution, NHWC, w is [KH*KW, C], optional bias, fused activation.
  * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)
