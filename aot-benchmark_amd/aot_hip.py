@@ -19,29 +19,29 @@ _F = ctypes.c_float
 _L = ctypes.c_long
 
 _SIGS = {
-    'aot_conv2d_nhwc_f32': [_P] * 5 + [_I] * 16 + [_P],
-    'aot_conv2d_nhwc_f32_cfg': [_P] * 5 + [_I] * 17 + [_P],
-    'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 11 + [_P],
+    'aot_conv2d_nhwc_f32': [_P] * 7 + [_L] + [_I] * 20 + [_P],
+    'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
     'aot_nhwc_to_nchw_f32': [_P, _P] + [_I] * 4 + [_P],
-    'aot_layernorm_f32': [_P] * 6 + [_I] * 6 + [_F, _P],
-    'aot_groupnorm_stats_f32': [_P] * 3 + [_I] * 4 + [_F, _I, _P],
-    'aot_groupnorm_apply_f32': [_P] * 5 + [_I] * 6 + [_P],
-    'aot_attn_f32': [_P] * 5 + [_I, _I, _P] + [_I] * 6 + [_F, _I, _P],
+    'aot_layernorm_f32': [_P] * 6 + [_I] * 7 + [_F, _P],
+    'aot_groupnorm_stats_f32': [_P] * 4 + [_I] * 5 + [_F, _I, _P],
+    'aot_groupnorm_apply_f32': [_P] * 6 + [_I] * 9 + [_P],
+    'aot_gn_act_dwconv5_f32': [_P] * 6 + [_I] * 8 + [_P],
+    'aot_attn_f32': [_P] * 5 + [_I, _L, _I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
     'aot_preprocess_f32': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     'aot_fuse_probs_f32': [_P] * 5 + [_I] * 5 + [_P],
     'aot_label_resize_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_attn_topk_f32': [_P] * 5 + [_I] * 8 + [_F, _I, _P],
-    'aot_gated_attn_f32': [_P] * 6 + [_I, _I, _P] + [_I] * 7 + [_F, _I, _P],
-    'aot_local_attn_f32': [_P] * 7 + [_I] * 9 + [_F, _P],
-    'aot_local_gated_f32': [_P] * 8 + [_I] * 10 + [_F, _P],
+    'aot_gated_attn_f32': [_P] * 6 + [_I, _L, _I, _I, _P] + [_I] * 7 + [_F, _I, _P],
+    'aot_local_attn_f32': [_P] * 7 + [_I, _L] + [_I] * 9 + [_F, _P],
+    'aot_local_gated_f32': [_P] * 8 + [_I, _L] + [_I] * 10 + [_F, _P],
     'aot_swin_window_attn_f32': [_P] * 4 + [_I] * 8 + [_F, _P],
     'aot_patch_merge_f32': [_P, _P] + [_I] * 4 + [_P],
-    'aot_idbank_f32': [_P] * 5 + [_I] * 10 + [_P],
-    'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 9 + [_P],
-    'aot_logits_finalize_f32': [_P] * 3 + [_I] * 8 + [_P],
+    'aot_idbank_f32': [_P] * 5 + [_I] * 13 + [_P, _P] + [_I] * 3 + [_P],
+    'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
+    'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
 }
 
@@ -82,9 +82,16 @@ def stream_ptr():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
+_DEBUG_SYNC = bool(os.environ.get('AOT_HIP_DEBUG_SYNC'))     # development aid: wait for every launch and name the one that faults
+
+
 def _chk(rc, name):
     if rc != 0:
         raise AotHipError('%s failed with code %d' % (name, rc))
+    if _DEBUG_SYNC:
+        import sys
+        print('[aot_hip] %s' % name, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
 
 
 def _dev(t):
@@ -98,32 +105,46 @@ def _opt(t):
 
 
 # ---- thin wrappers: 2-D token-major tensors [M, C] with row stride = t.stride(0) ----------------
+def attach_wt(w, cin=None):
+    """Gives a packed GEMM weight w [K, ld] its k-contiguous twin [Cout_ld, K] (attribute `_aot_wt`), which lets
+    aot_conv2d_nhwc_f32 pick the LDS-direct tile kernel (csrc/gemm_lds.hip) when the shape allows it."""
+    if w.shape[0] % 32 == 0 and (cin is None or cin % 32 == 0):
+        w._aot_wt = w.t().contiguous()
+    return w
+
+
 def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
-           stream=None):
-    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(bias), _opt(res), _dev(out), H, W, Cin, OH, OW, Cout, KH, KW,
-                                    stride, pad, dil, x.stride(0), w.stride(0), out.stride(0),
-                                    res.stride(0) if res is not None else 0, act,
+           B=1, res_rows=0, cfg=-1, stream=None):
+    """B NHWC images [B*H*W, lda] -> [B*OH*OW, ldc]; res_rows > 0: the residual is one [res_rows, ldr] map shared by the
+    images (row m % res_rows)."""
+    wt = getattr(w, '_aot_wt', None)
+    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), None, 0, B, H, W, Cin, OH,
+                                    OW, Cout, KH, KW, stride, pad, dil, x.stride(0), w.stride(0),
+                                    wt.stride(0) if wt is not None else 0, out.stride(0),
+                                    res.stride(0) if res is not None else 0, res_rows, act, cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 
 
 def conv2d_cfg(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
-               cfg=-1, stream=None):
-    _chk(load().aot_conv2d_nhwc_f32_cfg(_dev(x), _dev(w), _opt(bias), _opt(res), _dev(out), H, W, Cin, OH, OW, Cout, KH,
-                                        KW, stride, pad, dil, x.stride(0), w.stride(0), out.stride(0),
-                                        res.stride(0) if res is not None else 0, act, cfg,
-                                        stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32_cfg')
+               cfg=-1, wt=None, scratch=None, B=1, res_rows=0, stream=None):
+    """Tuning / test form: explicit kernel configuration, explicit k-contiguous weight and split-K scratch."""
+    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), _opt(scratch),
+                                    scratch.numel() if scratch is not None else 0, B, H, W, Cin, OH, OW, Cout, KH, KW,
+                                    stride, pad, dil, x.stride(0), w.stride(0), wt.stride(0) if wt is not None else 0,
+                                    out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, cfg,
+                                    stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 
 
-def linear(x, w, bias, out, res=None, act=ACT_NONE, stream=None):
+def linear(x, w, bias, out, res=None, act=ACT_NONE, res_rows=0, stream=None):
     """out[M, N] = act(x[M, K] @ w[K, N] + bias (+ res))."""
     M, K = x.shape
-    return conv2d(x, w, bias, out, 1, M, K, 1, M, out.shape[1], res=res, act=act, stream=stream)
+    return conv2d(x, w, bias, out, 1, M, K, 1, M, out.shape[1], res=res, act=act, res_rows=res_rows, stream=stream)
 
 
-def dwconv2d(x, w, bias, out, H, W, C, OH, OW, K, stride=1, pad=0, dil=1, act=ACT_NONE, stream=None):
-    _chk(load().aot_dwconv2d_nhwc_f32(_dev(x), _dev(w), _opt(bias), _dev(out), H, W, C, OH, OW, K, K, stride, pad, dil,
+def dwconv2d(x, w, bias, out, H, W, C, OH, OW, K, stride=1, pad=0, dil=1, act=ACT_NONE, B=1, stream=None):
+    _chk(load().aot_dwconv2d_nhwc_f32(_dev(x), _dev(w), _opt(bias), _dev(out), B, H, W, C, OH, OW, K, K, stride, pad, dil,
                                       act, stream if stream is not None else stream_ptr()), 'aot_dwconv2d_nhwc_f32')
     return out
 
@@ -146,38 +167,63 @@ def nhwc_to_nchw(x, out, C, H, W, stream=None):
     return out
 
 
-def layernorm(x, gamma, beta, out, add=None, out2=None, eps=1e-5, stream=None):
+def layernorm(x, gamma, beta, out, add=None, out2=None, eps=1e-5, add_rows=0, stream=None):
     M, C = x.shape
     _chk(load().aot_layernorm_f32(_dev(x), _dev(gamma), _dev(beta), _dev(out), _opt(add), _opt(out2), M, C, x.stride(0),
                                   out.stride(0), add.stride(0) if add is not None else 0,
-                                  out2.stride(0) if out2 is not None else 0, eps,
+                                  out2.stride(0) if out2 is not None else 0, add_rows, eps,
                                   stream if stream is not None else stream_ptr()), 'aot_layernorm_f32')
     return out
 
 
-def groupnorm(x, gamma, beta, out, groups, scratch, stats, act=ACT_NONE, eps=1e-5, nsplit=32, stream=None):
-    M, C = x.shape
-    s = stream if stream is not None else stream_ptr()
-    lib = load()
-    _chk(lib.aot_groupnorm_stats_f32(_dev(x), _dev(scratch), _dev(stats), M, C, groups, x.stride(0), eps, nsplit, s),
+def gn_buffers(ws, device, B, groups, nsplit):
+    """(scratch, stats, ticket) for aot_groupnorm_stats_f32 out of a Workspace; the ticket words start at zero and the
+    kernel leaves them zero."""
+    scratch = ws.get('gn_scratch', (B * groups * nsplit * 2,), device, torch.float64)
+    stats = ws.get('gn_stats', (B * groups * 2,), device, torch.float64)
+    ticket = ws.get_zeroed('gn_ticket', (B * groups,), device, torch.int32)
+    return scratch, stats, ticket
+
+
+def groupnorm_stats(x, groups, bufs, B=1, eps=1e-5, nsplit=32, stream=None):
+    """x [B*M, C] -> stats [B][G][2] (mean, rstd), one launch."""
+    scratch, stats, ticket = bufs
+    M = x.shape[0] // B
+    _chk(load().aot_groupnorm_stats_f32(_dev(x), _dev(scratch), _dev(stats), _dev(ticket), B, M, x.shape[1], groups,
+                                        x.stride(0), eps, nsplit, stream if stream is not None else stream_ptr()),
          'aot_groupnorm_stats_f32')
-    _chk(lib.aot_groupnorm_apply_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(out), M, C, groups, x.stride(0),
-                                     out.stride(0), act, s), 'aot_groupnorm_apply_f32')
+    return stats
+
+
+def groupnorm(x, gamma, beta, out, groups, bufs, act=ACT_NONE, eps=1e-5, nsplit=32, B=1, add=None, add_rows=0,
+              stream=None):
+    """out = act(GroupNorm(x)) (+ add[row % add_rows]); x [B*M, C], statistics per (lane, group).  Two launches."""
+    s = stream if stream is not None else stream_ptr()
+    stats = groupnorm_stats(x, groups, bufs, B=B, eps=eps, nsplit=nsplit, stream=s)
+    M = x.shape[0] // B
+    _chk(load().aot_groupnorm_apply_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(out), _opt(add), B, M,
+                                        x.shape[1], groups, x.stride(0), out.stride(0),
+                                        add.stride(0) if add is not None else 0, add_rows, act, s),
+         'aot_groupnorm_apply_f32')
     return out
 
 
-attn_probe = None   # optional callable(phase, nq, t, heads) -> None; bench.py uses it to bracket the MFMA kernel with events
+def gn_act_dwconv5(x, gamma, beta, w, out, groups, bufs, h, wd, act=ACT_GELU, eps=1e-5, nsplit=32, B=1, stream=None):
+    """GNActDWConv2d (basic.py:15-35) in two launches: statistics, then GroupNorm-apply + activation + 5x5 depthwise conv."""
+    s = stream if stream is not None else stream_ptr()
+    stats = groupnorm_stats(x, groups, bufs, B=B, eps=eps, nsplit=nsplit, stream=s)
+    _chk(load().aot_gn_act_dwconv5_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(w), _dev(out), B, h, wd, x.shape[1],
+                                       groups, x.stride(0), out.stride(0), act, s), 'aot_gn_act_dwconv5_f32')
+    return out
 
 
-def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, stream=None):
+def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, B=1, kv_brows=0, stream=None):
+    """q/out [B*Nq, .]; lane b attends to rows [b*kv_brows, b*kv_brows + T) of k/v."""
     s = stream if stream is not None else stream_ptr()
     lib = load()
-    if attn_probe is not None:
-        attn_probe(0, q.shape[0], T, H)
-    _chk(lib.aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev), H, 32,
+    nq = q.shape[0] // B
+    _chk(lib.aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), B, kv_brows, nq, T, _opt(T_dev), H, 32,
                           q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div, nsplit, s), 'aot_attn_f32')
-    if attn_probe is not None:
-        attn_probe(1, q.shape[0], T, H)
     if nsplit > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
              'aot_attn_merge_f32')
@@ -192,13 +238,14 @@ def attention_topk(q, k, v, out, T, H, scale_div, top_k, scores, stream=None):
     return out
 
 
-def gated_attention(q, k, v, gate, out, T, scale_div, part=None, nsplit=1, T_dev=None, stream=None):
-    """DeAOT single-head attention with a wide value: q [Nq,128], k [>=T,128], v [>=T,dv], gate/out [Nq,dv]."""
+def gated_attention(q, k, v, gate, out, T, scale_div, part=None, nsplit=1, T_dev=None, B=1, kv_brows=0, stream=None):
+    """DeAOT single-head attention with a wide value: q [B*Nq,128], k [.,128], v [.,dv], gate/out [B*Nq,dv]."""
     s = stream if stream is not None else stream_ptr()
     lib = load()
     dv = out.shape[1]
-    _chk(lib.aot_gated_attn_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(out), _opt(part), q.shape[0], T, _opt(T_dev),
-                                q.shape[1], dv, q.stride(0), k.stride(0), v.stride(0),
+    nq = q.shape[0] // B
+    _chk(lib.aot_gated_attn_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(out), _opt(part), B, kv_brows, nq, T,
+                                _opt(T_dev), q.shape[1], dv, q.stride(0), k.stride(0), v.stride(0),
                                 gate.stride(0) if gate is not None else 0, out.stride(0), scale_div, nsplit, s),
          'aot_gated_attn_f32')
     if nsplit > 1:
@@ -221,18 +268,20 @@ def pack_local_tables(relk_weight, relk_bias, relv, heads, max_dis=7):
     return pad(wk), pad(bk), pad(rv)
 
 
-def local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, H, scale_div, max_dis=7, stream=None):
-    _chk(load().aot_local_attn_f32(_dev(q), _dev(k), _dev(v), _dev(relk_w), _dev(relk_b), _dev(relv_t), _dev(out), h, w, H,
-                                   32, max_dis, q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div,
+def local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, H, scale_div, max_dis=7, B=1, kv_brows=0, stream=None):
+    _chk(load().aot_local_attn_f32(_dev(q), _dev(k), _dev(v), _dev(relk_w), _dev(relk_b), _dev(relv_t), _dev(out), B,
+                                   kv_brows if kv_brows else h * w, h, w, H, 32, max_dis, q.stride(0), k.stride(0),
+                                   v.stride(0), out.stride(0), scale_div,
                                    stream if stream is not None else stream_ptr()), 'aot_local_attn_f32')
     return out
 
 
-def local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_dis=7, stream=None):
+def local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_dis=7, B=1, kv_brows=0, stream=None):
     _chk(load().aot_local_gated_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(relk_t), _dev(relk_b), _dev(prob),
-                                    _dev(out), h, w, q.shape[1], out.shape[1], max_dis, q.stride(0), k.stride(0),
-                                    v.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0), scale_div,
-                                    stream if stream is not None else stream_ptr()), 'aot_local_gated_f32')
+                                    _dev(out), B, kv_brows if kv_brows else h * w, h, w, q.shape[1], out.shape[1], max_dis,
+                                    q.stride(0), k.stride(0), v.stride(0), gate.stride(0) if gate is not None else 0,
+                                    out.stride(0), scale_div, stream if stream is not None else stream_ptr()),
+         'aot_local_gated_f32')
     return out
 
 
@@ -249,22 +298,39 @@ def patch_merge(x, out, H, W, C, stream=None):
     return out
 
 
-def idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, sumtab=None, stream=None):
-    _chk(load().aot_idbank_f32(_dev(mask), _dev(table), _opt(sumtab), _opt(bias), _dev(out), H, W, OH, OW, K, stride, pad, C, nlabel,
-                               out.stride(0), stream if stream is not None else stream_ptr()), 'aot_idbank_f32')
+def idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, sumtab=None, G=1, group_size=0, group0=0,
+           fuse=None, stream=None):
+    """mask [H, W] label ids -> id embedding rows [G*OH*OW, C]; lane g = object group group0+g (its labels -> 1..group_size).
+    fuse = [(add_i, out_i), ...] (<= 4): out_i = id_emb + add_i in the same launch (V + id_emb of every LSTT layer)."""
+    n = len(fuse) if fuse else 0
+    if n:
+        adds = (ctypes.c_void_p * n)(*[_dev(a) for a, _ in fuse])
+        outs = (ctypes.c_void_p * n)(*[_dev(o) for _, o in fuse])
+        ldadd, ldfout = fuse[0][0].stride(0), fuse[0][1].stride(0)
+        if any(a.stride(0) != ldadd or o.stride(0) != ldfout for a, o in fuse):
+            raise AotHipError('fused id-bank outputs must share their row strides')
+    else:
+        adds = outs = None
+        ldadd = ldfout = 0
+    _chk(load().aot_idbank_f32(_dev(mask), _dev(table), _opt(sumtab), _opt(bias), _opt(out), G, group_size, group0, H, W, OH, OW, K,
+                               stride, pad, C, nlabel, out.stride(0) if out is not None else C, adds, outs, n, ldadd, ldfout,
+                               stream if stream is not None else stream_ptr()), 'aot_idbank_f32')
     return out
 
 
-def bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=None, stream=None):
-    _chk(load().aot_bilinear_nhwc_f32(_dev(x), _opt(add), _dev(out), IH, IW, OH, OW, C, x.stride(0),
+def bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=None, B=1, add_shared=False, stream=None):
+    _chk(load().aot_bilinear_nhwc_f32(_dev(x), _opt(add), _dev(out), B, IH, IW, OH, OW, C, x.stride(0),
                                       add.stride(0) if add is not None else 0, out.stride(0), int(align_corners),
-                                      stream if stream is not None else stream_ptr()), 'aot_bilinear_nhwc_f32')
+                                      int(bool(add_shared)), stream if stream is not None else stream_ptr()),
+         'aot_bilinear_nhwc_f32')
     return out
 
 
-def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_num, align_corners, stream=None):
-    _chk(load().aot_logits_finalize_f32(_dev(logits), _opt(out4), _opt(out), IH, IW, C, logits.stride(0), OH, OW, obj_num,
-                                        int(align_corners), stream if stream is not None else stream_ptr()),
+def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corners, G=1, stream=None):
+    """logits [G*IH*IW, ld]: out4 [G, C, IH, IW] planar masked copy, out [C, OH, OW] (G = 1) or the soft aggregation of the
+    G object groups [1 + G*(C-1), OH, OW]; obj_total = objects in the frame (group g holds ids g*(C-1)+1 ..)."""
+    _chk(load().aot_logits_finalize_f32(_dev(logits), _opt(out4), _opt(out), G, IH, IW, C, logits.stride(0), OH, OW,
+                                        obj_total, int(align_corners), stream if stream is not None else stream_ptr()),
          'aot_logits_finalize_f32')
 
 

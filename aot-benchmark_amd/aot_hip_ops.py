@@ -21,8 +21,10 @@ _DEFS = {
     'dwconv2d_nhwc': '(Tensor x, Tensor w, Tensor? bias, Tensor(a!) out, int H, int W, int C, int OH, int OW, int K, int stride, '
                      'int pad, int dil, int act) -> ()',
     'layernorm': '(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) out, float eps) -> ()',
-    'groupnorm': '(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) out, int groups, Tensor(b!) scratch, Tensor(c!) stats, int act, '
-                 'float eps) -> ()',
+    'groupnorm': '(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) out, int groups, Tensor(b!) scratch, Tensor(c!) stats, '
+                 'Tensor(d!) ticket, int act, float eps, int lanes) -> ()',
+    'gn_act_dwconv5': '(Tensor x, Tensor gamma, Tensor beta, Tensor w, Tensor(a!) out, int groups, Tensor(b!) scratch, '
+                      'Tensor(c!) stats, Tensor(d!) ticket, int h, int w_, int act, float eps, int lanes) -> ()',
     'attn': '(Tensor q, Tensor k, Tensor v, Tensor(a!) out, int T, int H, float scale_div, Tensor(b!)? part, int nsplit) -> ()',
     'attn_topk': '(Tensor q, Tensor k, Tensor v, Tensor(a!) out, int T, int H, float scale_div, int top_k, Tensor(b!) scores) -> ()',
     'gated_attn': '(Tensor q, Tensor k, Tensor v, Tensor? gate, Tensor(a!) out, int T, float scale_div, Tensor(b!)? part, '
@@ -32,10 +34,11 @@ _DEFS = {
     'local_gated': '(Tensor q, Tensor k, Tensor v, Tensor? gate, Tensor relk_t, Tensor relk_b, Tensor(a!) prob, Tensor(b!) out, int h, '
                    'int w, float scale_div, int max_dis) -> ()',
     'idbank': '(Tensor mask, Tensor table, Tensor? sumtab, Tensor bias, Tensor(a!) out, int H, int W, int OH, int OW, int K, int stride, '
-              'int pad, int C, int nlabel) -> ()',
-    'bilinear_nhwc': '(Tensor x, Tensor? add, Tensor(a!) out, int IH, int IW, int OH, int OW, int C, bool align_corners) -> ()',
-    'logits_finalize': '(Tensor logits, Tensor(a!) out4, Tensor(b!)? out, int IH, int IW, int C, int OH, int OW, int obj_num, '
-                       'bool align_corners) -> ()',
+              'int pad, int C, int nlabel, int lanes, int group_size) -> ()',
+    'bilinear_nhwc': '(Tensor x, Tensor? add, Tensor(a!) out, int IH, int IW, int OH, int OW, int C, bool align_corners, int lanes, '
+                     'bool add_shared) -> ()',
+    'logits_finalize': '(Tensor logits, Tensor(a!) out4, Tensor(b!)? out, int IH, int IW, int C, int OH, int OW, int obj_total, '
+                       'bool align_corners, int groups) -> ()',
     'preprocess': '(Tensor img, Tensor(a!) out, bool flip) -> ()',
     'fuse_probs': '(Tensor logits, int[] flips, Tensor? new_label) -> (Tensor, Tensor)',
     'label_resize': '(Tensor label, int out_h, int out_w, bool flip) -> Tensor',
@@ -67,8 +70,15 @@ def _layernorm(x, gamma, beta, out, eps):
 
 
 @_impl('groupnorm')
-def _groupnorm(x, gamma, beta, out, groups, scratch, stats, act, eps):
-    aot_hip.groupnorm(x, gamma, beta, out, groups, scratch, stats, act=act, eps=eps)
+def _groupnorm(x, gamma, beta, out, groups, scratch, stats, ticket, act, eps, lanes):
+    nsplit = scratch.numel() // (2 * groups * lanes)
+    aot_hip.groupnorm(x, gamma, beta, out, groups, (scratch, stats, ticket), act=act, eps=eps, nsplit=nsplit, B=lanes)
+
+
+@_impl('gn_act_dwconv5')
+def _gn_act_dwconv5(x, gamma, beta, w, out, groups, scratch, stats, ticket, h, w_, act, eps, lanes):
+    nsplit = scratch.numel() // (2 * groups * lanes)
+    aot_hip.gn_act_dwconv5(x, gamma, beta, w, out, groups, (scratch, stats, ticket), h, w_, act=act, eps=eps, nsplit=nsplit, B=lanes)
 
 
 @_impl('attn')
@@ -97,18 +107,18 @@ def _local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_
 
 
 @_impl('idbank')
-def _idbank(mask, table, sumtab, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel):
-    aot_hip.idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, sumtab=sumtab)
+def _idbank(mask, table, sumtab, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, lanes, group_size):
+    aot_hip.idbank(mask, table, bias, out, H, W, OH, OW, K, stride, pad, C, nlabel, sumtab=sumtab, G=lanes, group_size=group_size)
 
 
 @_impl('bilinear_nhwc')
-def _bilinear(x, add, out, IH, IW, OH, OW, C, align_corners):
-    aot_hip.bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=add)
+def _bilinear(x, add, out, IH, IW, OH, OW, C, align_corners, lanes, add_shared):
+    aot_hip.bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=add, B=lanes, add_shared=add_shared)
 
 
 @_impl('logits_finalize')
-def _logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_num, align_corners):
-    aot_hip.logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_num, align_corners)
+def _logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corners, groups):
+    aot_hip.logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corners, G=groups)
 
 
 @_impl('preprocess')

@@ -15,9 +15,12 @@
 // bank ([T, H*32] rows, coalesced); the bank (<= 48 MB/layer) lives in L2 / Infinity Cache across the
 // 53 query tiles.
 //
-// nsplit > 1: the bank is cut into nsplit contiguous ranges handled by different workgroups (fills the
-// 1024 SIMDs when Nq/32 * H = 424 waves would not), each writing an un-normalised partial (O, m, l);
-// attn_merge_kernel combines them.
+// Key-range parallelism comes in two levels.  The four waves of a workgroup take the four quarters of the workgroup's
+// key range for the SAME (query tile, head) and merge their (O, m, l) through LDS at the end -- free of HBM traffic.
+// nsplit > 1 additionally cuts the bank into nsplit contiguous ranges handled by different workgroups (only needed to
+// fill the 1024 SIMDs for long banks), each writing an un-normalised partial (O, m, l) that attn_merge_kernel combines.
+// With the in-workgroup level 4x fewer partial slabs exist than with a purely grid-level split (round 1: 12 slabs at
+// M = 14, 3.3x the algorithmic bytes; now 3), and self-attention / short banks need no slab at all.
 #include "common.h"
 #include <type_traits>
 
@@ -31,8 +34,20 @@ struct AttnParams {
   const float* gate;  // optional [Nq, ldg]: out *= gate (GatedPropagation, attention.py:707)
   int Nq, T, H, ldq, ldk, ldv, ldo, nsplit;
   int ldg, C;         // C = output width (H*32 for the multi-head form, dv for the gated form)
+  int B;              // lanes (object groups / clips): lane b owns query rows [b*Nq, (b+1)*Nq) of q / out / gate / part
+  long kv_brows;      // ... and key/value rows [b*kv_brows, b*kv_brows + T) of k / v (one bank per lane)
   float scale_div;
 };
+
+// V (and, in the gated kernels, wide-V) rows are fetched through a buffer descriptor: per-lane offset loop invariant,
+// row part a wave-uniform scalar, rows >= T read as 0 by the hardware bounds check.  The descriptor is based at the
+// first row of the wave's own key range (64-bit pointer arithmetic) and covers [row0, min(T, row1 + 64)) only, so its
+// 32-bit byte count / offsets never see the size of the whole bank (a DeAOT bank of 313 memorised 480p frames is > 2 GB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, long lane_row0, int row0, int row1, int T,
+                                                                int ldv) {
+  const int rows = max(0, min(T, row1 + 64) - row0);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v + (lane_row0 + row0) * ldv), 0, rows * ldv * 4, 0x00020000);
+}
 
 // Softmax in the log2 domain.  With L = log2(e) and a running reference mL = fl(max_score * L), every weight is
 //   p = 2^(fl(s * L - mL))          one v_fma_f32 + one v_exp_f32 per score
@@ -56,48 +71,47 @@ __device__ __forceinline__ float exp2_w(float s, float mL) {
 // query tiles per wave (NQ = 2, -DAOT_ATTN_NQ=2: halves the K/V fetch per MFMA but needs 168-182 VGPRs, 2-3 waves: 379 vs
 // 370 us at M = 14, 123 vs 121 us at M = 4).
 // ---------------------------------------------------------------------------------------------------------
-template <int NQ>   // query tiles (of 32) per wave; NQ = 2 shares every K/V fetch between two score tiles (tuning variant)
-__global__ void __launch_bounds__(64, NQ == 1 ? 4 : 3) attn_fwd_d32_pipe_kernel(const AttnParams p) {
-  const int h = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
-  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
+__global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnParams p) {
+  // 4 waves per workgroup (one per SIMD of the CU), 4 workgroups per CU -> 4 waves per SIMD
+  __shared__ float red[4][18][64];      // per wave: o[16], m, l  (18 KB)
+  const int h = blockIdx.x, split = blockIdx.y;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int b = blockIdx.z / ntq, qt = blockIdx.z - b * ntq;
+  const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = p.T_dev ? *p.T_dev : p.T;
   const int ntile = (T + 31) >> 5;
-  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = split * tps * 32;
-  const int t1 = min(T, t0 + tps * 32);
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;        // key tiles of this workgroup's range
+  const int tpw = (tps + 3) >> 2;                           // ... and of each wave's quarter
+  const int s1 = min(T, (split + 1) * tps * 32);            // end of the workgroup's range
+  const int t0 = min(s1, (split * tps + wave * tpw) * 32);
+  const int t1 = min(s1, t0 + tpw * 32);
+  const long qrow0 = (long)b * p.Nq, krow0 = (long)b * p.kv_brows;
 
-  float qf[NQ][16];
-#pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    const int qrow = min((qt * NQ + a) * 32 + j, p.Nq - 1);
-    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + h * 32 + hi * 16);
+  float qf[16];
+  {
+    const int qrow = min(qt * 32 + j, p.Nq - 1);
+    const float4* src = reinterpret_cast<const float4*>(p.q + (qrow0 + qrow) * p.ldq + h * 32 + hi * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 t = src[i];
-      qf[a][4 * i + 0] = t.x / p.scale_div;    // the reference divides (attention.py:82), so do we
-      qf[a][4 * i + 1] = t.y / p.scale_div;
-      qf[a][4 * i + 2] = t.z / p.scale_div;
-      qf[a][4 * i + 3] = t.w / p.scale_div;
+      qf[4 * i + 0] = t.x / p.scale_div;    // the reference divides (attention.py:82), so do we
+      qf[4 * i + 1] = t.y / p.scale_div;
+      qf[4 * i + 2] = t.z / p.scale_div;
+      qf[4 * i + 3] = t.w / p.scale_div;
     }
   }
-  // V through a buffer descriptor: the per-lane byte offset is loop invariant, the tile/row part is a wave-uniform
-  // scalar offset (SALU), and rows >= T read as 0 by the hardware bounds check -- no address VALU, no clamping.
   // (K uses plain 16-byte global loads: the raw_buffer_load_b64/b96/b128 builtins of ROCm 7.2's hipcc lower to a
-  //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable.)
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  //  single buffer_load_dword -- verified in the ISA -- so only the 4-byte form is usable for V.)
+  const __amdgpu_buffer_rsrc_t rv = v_descriptor(p.v, krow0, t0, t1, T, p.ldv);
   const int vvoff = (4 * hi * p.ldv + h * 32 + j) * 4;    // V: lane = channel j; rows 4*hi + (s&3) + 8*(s>>2)
   const int ldv4 = p.ldv * 4;
-  const float* kptr = p.k + h * 32 + hi * 16;
+  const float* kptr = p.k + krow0 * p.ldk + h * 32 + hi * 16;
 
-  float m[NQ], l[NQ];   // m: running max score times log2(e)
-  f32x16 o[NQ];
+  float m = -INFINITY, l = 0.f;   // m: running max score times log2(e)
+  f32x16 o;
 #pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    m[a] = -INFINITY;
-    l[a] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[a][r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
 
   auto load_k = [&](float (&kf)[16], int kt) {
     const float4* src = reinterpret_cast<const float4*>(kptr + (long)min(kt + j, T - 1) * p.ldk);
@@ -107,24 +121,20 @@ __global__ void __launch_bounds__(64, NQ == 1 ? 4 : 3) attn_fwd_d32_pipe_kernel(
       kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
     }
   };
-  auto load_v = [&](float (&vf)[16], int kt) {
+  auto load_v = [&](float (&vf)[16], int kt) {      // kt relative to the descriptor's first row t0
 #pragma unroll
     for (int s = 0; s < 16; ++s)
-      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff, (kt - t0 + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
   };
-  auto qk = [&](const float (&kf)[16], f32x16 (&sc)[NQ]) {
+  auto qk = [&](const float (&kf)[16], f32x16& sc) {
 #pragma unroll
-    for (int a = 0; a < NQ; ++a)
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[a][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int a = 0; a < NQ; ++a) sc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[a][s], sc[a], 0, 0, 0);
+    for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
   };
 
   float ka[16], va[16];
-  f32x16 sc[NQ];
+  f32x16 sc;
   if (t0 < t1) {
     load_k(ka, t0);
     load_v(va, t0);
@@ -136,82 +146,96 @@ __global__ void __launch_bounds__(64, NQ == 1 ? 4 : 3) attn_fwd_d32_pipe_kernel(
   auto step = [&](int kt, auto tail) {
     constexpr bool TAIL = decltype(tail)::value;
     // scores of the NEXT tile (past the range end: clamped rows, result unused) -- independent of everything below
-    f32x16 scn[NQ];
+    f32x16 scn;
     qk(ka, scn);
-    float pf[NQ][16];
+    float pf[16];
+    if (TAIL) {
 #pragma unroll
-    for (int a = 0; a < NQ; ++a) {
-      if (TAIL) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt + mfma32_row(r, hi) >= t1) sc[a][r] = -INFINITY;
-      }
-      float x = fmaxf(fmaxf(sc[a][0], sc[a][1]), fmaxf(sc[a][2], sc[a][3]));
-#pragma unroll
-      for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[a][r], sc[a][r + 1]), fmaxf(sc[a][r + 2], sc[a][r + 3])));
-      const float mnew = fmaxf(m[a], fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
-      const float alpha = __builtin_amdgcn_exp2f(m[a] - mnew);   // 1 when the max did not move; 0 on the first tile
-      m[a] = mnew;
-      l[a] *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[a][r] *= alpha;
-      float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        pf[a][r] = exp2_w(sc[a][r], m[a]);
-        pf[a][r + 1] = exp2_w(sc[a][r + 1], m[a]);
-        ps0 += pf[a][r];
-        ps1 += pf[a][r + 1];
-      }
-      l[a] += ps0 + ps1;
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
     }
+    float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // 1 when the max did not move; 0 on the first tile
+    m = mnew;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      pf[r] = exp2_w(sc[r], m);
+      pf[r + 1] = exp2_w(sc[r + 1], m);
+      ps0 += pf[r];
+      ps1 += pf[r + 1];
+    }
+    l += ps0 + ps1;
     load_k(ka, kt + 64);     // K registers were consumed by qk() above
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int a = 0; a < NQ; ++a) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[a][s], o[a], 0, 0, 0);
-    load_v(va, kt + 32);     // rows >= T read as 0
-#pragma unroll
-    for (int a = 0; a < NQ; ++a) sc[a] = scn[a];
-    // issue order: 16 x (NQ score MFMAs, 5*NQ softmax VALU), then the rest as the scheduler likes
+    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
+    load_v(va, kt + 32);     // rows past the descriptor read as 0
+    sc = scn;
+    // issue order: 16 x (1 score MFMA, 5 softmax VALU), then the rest as the scheduler likes
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NQ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5 * NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
     }
   };
   int kt = t0;
   for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
   if (kt < t1) step(kt, std::true_type{});
 
+  // ---- merge of the four key quarters through LDS (fixed wave order: deterministic) ----
+  {
+    const float lt = l + __shfl_xor(l, 32);
 #pragma unroll
-  for (int a = 0; a < NQ; ++a) {
-    const float lt = l[a] + __shfl_xor(l[a], 32);
-    const int qi = (qt * NQ + a) * 32 + j;
-    if (qi >= p.Nq) continue;
-    if (p.nsplit == 1) {
-      const float inv = 1.f / lt;
-      float* dst = p.out + (long)qi * p.ldo + h * 32 + 4 * hi;
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = o[r];
+    red[wave][16][lane] = m;      // log2 domain; -inf if this wave saw no key
+    red[wave][17][lane] = lt;
+  }
+  __syncthreads();
+  float mm = fmaxf(fmaxf(red[0][16][lane], red[1][16][lane]), fmaxf(red[2][16][lane], red[3][16][lane]));
+  float f[4], lsum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dv = 8g + 4hi + (0..3): one float4
-        float4 t = make_float4(o[a][4 * g] * inv, o[a][4 * g + 1] * inv, o[a][4 * g + 2] * inv, o[a][4 * g + 3] * inv);
-        if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + h * 32 + 4 * hi + 8 * g);
-          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
-        }
-        *reinterpret_cast<float4*>(dst + 8 * g) = t;
-      }
-    } else {
-      const int C = p.H * 32;
-      float* dst = p.part + ((long)split * p.Nq + qi) * C + h * 32 + 4 * hi;
+  for (int w2 = 0; w2 < 4; ++w2) {
+    const float mw = red[w2][16][lane];
+    f[w2] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+    lsum += f[w2] * red[w2][17][lane];
+  }
+  // wave w finishes accumulator registers 4w..4w+3 = channels 8w + 4hi + (0..3): one float4 per lane
+  float4 acc;
+  {
+    float t[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[a][4 * g], o[a][4 * g + 1], o[a][4 * g + 2], o[a][4 * g + 3]);
-      if (hi == 0) {
-        float* ml = p.part + (long)p.nsplit * p.Nq * C + (((long)split * p.Nq + qi) * p.H + h) * 2;
-        ml[0] = m[a];   // log2 domain; -inf if this split saw no key (t0 >= t1)
-        ml[1] = lt;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * wave + i;
+      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+    }
+    acc = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  const long grow = qrow0 + qi;          // row in q / out / gate / part
+  const int c = h * 32 + 8 * wave + 4 * hi;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / lsum;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    if (p.gate) {
+      const float4 u = *reinterpret_cast<const float4*>(p.gate + grow * p.ldg + c);
+      acc.x *= u.x; acc.y *= u.y; acc.z *= u.z; acc.w *= u.w;
+    }
+    *reinterpret_cast<float4*>(p.out + grow * p.ldo + c) = acc;
+  } else {
+    const int C = p.H * 32;
+    const long rows = (long)p.B * p.Nq;
+    *reinterpret_cast<float4*>(p.part + ((long)split * rows + grow) * C + c) = acc;
+    if (wave == 0 && hi == 0) {
+      float* ml = p.part + (long)p.nsplit * rows * C + (((long)split * rows + grow) * p.H + h) * 2;
+      ml[0] = mm;      // log2 domain; -inf if this split saw no key
+      ml[1] = lsum;
     }
   }
 }
@@ -262,18 +286,21 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const AttnParams p) {
 template <int DQK, int NDV>
 __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams p) {
   constexpr int HK = DQK / 2;
-  const int ch = blockIdx.x, split = blockIdx.y, qt = blockIdx.z;
+  const int ch = blockIdx.x, split = blockIdx.y;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int b = blockIdx.z / ntq, qt = blockIdx.z - b * ntq;
   const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
   const int T = p.T_dev ? *p.T_dev : p.T;
   const int ntile = (T + 31) >> 5;
   const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = split * tps * 32;
+  const int t0 = min(T, split * tps * 32);
   const int t1 = min(T, t0 + tps * 32);
   const int qrow = min(qt * 32 + j, p.Nq - 1);
+  const long qrow0 = (long)b * p.Nq, krow0 = (long)b * p.kv_brows;
 
   float qf[HK];
   {
-    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + hi * HK);
+    const float4* src = reinterpret_cast<const float4*>(p.q + (qrow0 + qrow) * p.ldq + hi * HK);
 #pragma unroll
     for (int i = 0; i < HK / 4; ++i) {
       const float4 t = src[i];
@@ -281,10 +308,10 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
       qf[4 * i + 2] = t.z / p.scale_div; qf[4 * i + 3] = t.w / p.scale_div;
     }
   }
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = v_descriptor(p.v, krow0, t0, t1, T, p.ldv);
   const int vvoff = (4 * hi * p.ldv + ch * 32 * NDV + j) * 4;
   const int ldv4 = p.ldv * 4;
-  const float* kptr = p.k + hi * HK;
+  const float* kptr = p.k + krow0 * p.ldk + hi * HK;
 
   float m = -INFINITY, l = 0.f;   // m in the log2 domain
   f32x16 o[NDV];
@@ -304,7 +331,7 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
   auto load_v = [&](float (&vf)[16], int kt, int d) {
 #pragma unroll
     for (int s = 0; s < 16; ++s)
-      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt - t0 + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
   };
   auto qk = [&](const float (&kf)[HK]) {
     f32x16 sc;
@@ -375,8 +402,9 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
   if (kt < t1) step(kt, std::true_type{});
 
   l += __shfl_xor(l, 32);
-  const int qi = qt * 32 + j;
-  if (qi >= p.Nq) return;
+  if (qt * 32 + j >= p.Nq) return;
+  const long qi = qrow0 + qt * 32 + j;          // row in q / out / gate / part
+  const long prow = (long)p.B * p.Nq;          // rows per partial slab
   const int cbase = ch * 32 * NDV + 4 * hi;
   if (p.nsplit == 1) {
     const float inv = 1.f / l;
@@ -387,13 +415,13 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
         float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
         const int c = cbase + d * 32 + 8 * g;
         if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c);
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
           t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
         }
-        *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c) = t;
+        *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = t;
       }
   } else {
-    float* dst = p.part + ((long)split * p.Nq + qi) * p.C;
+    float* dst = p.part + ((long)split * prow + qi) * p.C;
 #pragma unroll
     for (int d = 0; d < NDV; ++d)
 #pragma unroll
@@ -401,7 +429,7 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
         *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
             make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
     if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * p.Nq * p.C + (((long)split * p.Nq + qi) * p.H + ch) * 2;
+      float* ml = p.part + (long)p.nsplit * prow * p.C + (((long)split * prow + qi) * p.H + ch) * 2;
       ml[0] = m;
       ml[1] = l;
     }
@@ -416,20 +444,23 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
 // partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
 template <int NDV>
 __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParams p) {
-  const int split = blockIdx.x, qt = blockIdx.y;
+  const int split = blockIdx.x;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int b = blockIdx.y / ntq, qt = blockIdx.y - b * ntq;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
   const int ch = wave;
   const int T = p.T_dev ? *p.T_dev : p.T;
   const int ntile = (T + 31) >> 5;
   const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = split * tps * 32;
+  const int t0 = min(T, split * tps * 32);
   const int t1 = min(T, t0 + tps * 32);
   const int qrow = min(qt * 32 + j, p.Nq - 1);
+  const long qrow0 = (long)b * p.Nq, krow0 = (long)b * p.kv_brows;
   __shared__ float part[2][4][16][64];     // [buffer][wave][score register][lane]: 32 KB, conflict-free b32 accesses
 
   float qf[16];
   {
-    const float4* src = reinterpret_cast<const float4*>(p.q + (long)qrow * p.ldq + wave * 32 + hi * 16);
+    const float4* src = reinterpret_cast<const float4*>(p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 t = src[i];
@@ -437,10 +468,10 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
       qf[4 * i + 2] = t.z / p.scale_div; qf[4 * i + 3] = t.w / p.scale_div;
     }
   }
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, T * p.ldv * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = v_descriptor(p.v, krow0, t0, t1, T, p.ldv);
   const int vvoff = (4 * hi * p.ldv + ch * 32 * NDV + j) * 4;
   const int ldv4 = p.ldv * 4;
-  const float* kptr = p.k + wave * 32 + hi * 16;
+  const float* kptr = p.k + krow0 * p.ldk + wave * 32 + hi * 16;
 
   float m = -INFINITY, l = 0.f;   // m in the log2 domain
   f32x16 o[NDV];
@@ -460,7 +491,7 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
   auto load_v = [&](float (&vf)[16], int kt, int d) {
 #pragma unroll
     for (int s = 0; s < 16; ++s)
-      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
+      vf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vvoff + d * 128, (kt - t0 + (s & 3) + 8 * (s >> 2)) * ldv4, 0));
   };
   auto qk_part = [&](const float (&kf)[16], int buf) {     // this wave's 32-channel share of the score tile -> LDS
     f32x16 sc;
@@ -539,8 +570,9 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
   if (kt < t1) step(kt, std::true_type{});
 
   l += __shfl_xor(l, 32);
-  const int qi = qt * 32 + j;
-  if (qi >= p.Nq) return;
+  if (qt * 32 + j >= p.Nq) return;
+  const long qi = qrow0 + qt * 32 + j;          // row in q / out / gate / part
+  const long prow = (long)p.B * p.Nq;          // rows per partial slab
   const int cbase = ch * 32 * NDV + 4 * hi;
   if (p.nsplit == 1) {
     const float inv = 1.f / l;
@@ -551,13 +583,13 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
         float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
         const int c = cbase + d * 32 + 8 * g;
         if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + (long)qi * p.ldg + c);
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
           t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
         }
-        *reinterpret_cast<float4*>(p.out + (long)qi * p.ldo + c) = t;
+        *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = t;
       }
   } else {
-    float* dst = p.part + ((long)split * p.Nq + qi) * p.C;
+    float* dst = p.part + ((long)split * prow + qi) * p.C;
 #pragma unroll
     for (int d = 0; d < NDV; ++d)
 #pragma unroll
@@ -565,39 +597,41 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
         *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
             make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
     if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * p.Nq * p.C + (((long)split * p.Nq + qi) * p.H + ch) * 2;
+      float* ml = p.part + (long)p.nsplit * prow * p.C + (((long)split * prow + qi) * p.H + ch) * 2;
       ml[0] = m;
       ml[1] = l;
     }
   }
 }
 
-static int fill_params(AttnParams& p, const float* q, const float* k, const float* v, float* out, float* part, int Nq,
-                       int T, const int* T_dev, int H, int ldq, int ldk, int ldv, int ldo, float scale_div, int nsplit) {
-  if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0) return AOT_ERR_BADARG;
+static int fill_params(AttnParams& p, const float* q, const float* k, const float* v, float* out, float* part, int B,
+                       long kv_brows, int Nq, int T, const int* T_dev, int H, int ldq, int ldk, int ldv, int ldo,
+                       float scale_div, int nsplit) {
+  if (!q || !k || !v || !out || Nq <= 0 || T <= 0 || H <= 0 || B <= 0) return AOT_ERR_BADARG;
+  if (B > 1 && kv_brows < T) return AOT_ERR_BADARG;
+  // 32-bit byte offsets inside one workgroup's key range (the descriptor is re-based per range, see v_descriptor)
+  if (((long)((T + 31) / 32 + nsplit - 1) / nsplit * 32 + 96) * ldv * 4 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if ((long)B * cdiv(Nq, 32) > 65535) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldo & 3) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)out & 15))
     return AOT_ERR_BADARG;
   if (nsplit < 1) return AOT_ERR_BADARG;
   if (nsplit > 1 && !part) return AOT_ERR_BADARG;
   p.q = q; p.k = k; p.v = v; p.out = out; p.part = part; p.T_dev = T_dev; p.gate = nullptr; p.ldg = 0;
   p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.nsplit = nsplit;
+  p.B = B; p.kv_brows = kv_brows;
   p.C = H * 32;
   p.scale_div = scale_div;
   return AOT_OK;
 }
 
-extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int Nq, int T,
-                            const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div,
-                            int nsplit, void* stream) {
+extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int B,
+                            long kv_brows, int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv,
+                            int ldo, float scale_div, int nsplit, void* stream) {
   if (d != 32) return AOT_ERR_UNSUPPORTED;
   AttnParams p;
-  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
+  const int rc = fill_params(p, q, k, v, out, part, B, kv_brows, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
-#ifndef AOT_ATTN_NQ
-#define AOT_ATTN_NQ 1      // 2: measured 2 % slower, see the kernel's header
-#endif
-  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel<AOT_ATTN_NQ>, dim3(H, nsplit, cdiv(Nq, 32 * AOT_ATTN_NQ)), dim3(64), 0,
-                     (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 
@@ -614,20 +648,21 @@ extern "C" int aot_attn_merge_f32(const float* part, const float* gate, float* o
 }
 
 extern "C" int aot_gated_attn_f32(const float* q, const float* k, const float* v, const float* gate, float* out,
-                                  float* part, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldk,
-                                  int ldv, int ldg, int ldo, float scale_div, int nsplit, void* stream) {
+                                  float* part, int B, long kv_brows, int Nq, int T, const int* T_dev, int dqk, int dv,
+                                  int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div, int nsplit,
+                                  void* stream) {
   if (dqk != 128 || dv <= 0 || (dv % 256)) return AOT_ERR_UNSUPPORTED;
   const int nch = dv / 256;
   AttnParams p;
-  const int rc = fill_params(p, q, k, v, out, part, Nq, T, T_dev, nch, ldq, ldk, ldv, ldo, scale_div, nsplit);
+  const int rc = fill_params(p, q, k, v, out, part, B, kv_brows, Nq, T, T_dev, nch, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
   if (gate && (ldg & 3)) return AOT_ERR_BADARG;
   p.C = dv;
   p.gate = (nsplit == 1) ? gate : nullptr;   // with splits the gate is applied by aot_attn_merge_f32
   p.ldg = ldg;
   if (nch == 4)     // dv = 1024 (every DeAOT config): the four chunk waves share one score tile
-    hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(nsplit, cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL((attn_fwd_wide_pipe_kernel<128, 8>), dim3(nch, nsplit, cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_wide_pipe_kernel<128, 8>), dim3(nch, nsplit, B * cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

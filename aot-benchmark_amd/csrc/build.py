@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['gemm_conv.hip', 'attention.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip']
+SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'attention.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip']
 LIB = os.path.join(HERE, 'libaot_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-Wno-unused-result']
@@ -17,7 +17,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + ['common.h', 'build.py', os.path.join('..', '..', 'include', 'aot_hip.h')]
+    deps = SOURCES + ['common.h', 'conv_params.h', 'build.py', os.path.join('..', '..', 'include', 'aot_hip.h')]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 

@@ -36,6 +36,7 @@ struct LocalParams {
   float* out;
   int h, w, H, ldq, ldk, ldv, ldo;
   float scale_div;
+  long kv_brows;   // rows between the k/v maps of consecutive lanes (>= h*w)
 };
 
 // Wave-uniform table rows are broadcast through DPP: a table row of 16 floats sits in ONE VGPR with
@@ -70,7 +71,7 @@ __device__ __forceinline__ void dpp_dot15x2(float& a0, float& a1, float t0, floa
 #undef DPP2
 
 template <int R, int NWV>
-__global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalParams p) {
+__global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalParams pin) {
   constexpr int WS = 2 * R + 1, D = 32;
   constexpr int NPOS = 64 + 2 * R;             // staged key positions per row
   constexpr int LDS_LD = 36;
@@ -81,7 +82,17 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int x0 = blockIdx.x * 64, y = blockIdx.y, hd = blockIdx.z;
+  // lane b of the batch (object group / clip): its own h x w maps, q/out rows b*N.., k/v rows b*kv_brows..
+  const int bl = blockIdx.z / pin.H, hd = blockIdx.z - bl * pin.H;
+  LocalParams p = pin;
+  {
+    const long N = (long)p.h * p.w;
+    p.q += bl * N * p.ldq;
+    p.out += bl * N * p.ldo;
+    p.k += bl * pin.kv_brows * p.ldk;
+    p.v += bl * pin.kv_brows * p.ldv;
+  }
+  const int x0 = blockIdx.x * 64, y = blockIdx.y;
   const bool active = x0 + lane < p.w;
   const int x = active ? x0 + lane : p.w - 1;
   const int n = y * p.w + x;
@@ -269,15 +280,18 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
 #endif
 
 extern "C" int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_t,
-                                  const float* relk_b, const float* relv_t, float* out, int h, int w, int H,
-                                  int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
+                                  const float* relk_b, const float* relv_t, float* out, int B, long kv_brows, int h,
+                                  int w, int H, int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
                                   void* stream) {
-  if (!q || !k || !v || !relk_t || !relk_b || !relv_t || !out || h <= 0 || w <= 0 || H <= 0) return AOT_ERR_BADARG;
+  if (!q || !k || !v || !relk_t || !relk_b || !relv_t || !out || h <= 0 || w <= 0 || H <= 0 || B <= 0) return AOT_ERR_BADARG;
+  if (B > 1 && kv_brows < (long)h * w) return AOT_ERR_BADARG;
+  if ((long)B * H > 65535) return AOT_ERR_UNSUPPORTED;
   if (d != 32 || max_dis != 7) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return AOT_ERR_BADARG;
   LocalParams p;
   p.q = q; p.k = k; p.v = v; p.relk_t = relk_t; p.relk_b = relk_b; p.relv_t = relv_t; p.out = out;
   p.h = h; p.w = w; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale_div = scale_div;
-  hipLaunchKernelGGL((local_attn_d32_kernel<7, NWAVE>), dim3(cdiv(w, 64), h, H), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
+  p.kv_brows = kv_brows;
+  hipLaunchKernelGGL((local_attn_d32_kernel<7, NWAVE>), dim3(cdiv(w, 64), h, B * H), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

@@ -24,7 +24,21 @@ struct LgpParams {
   float* out;           // [N, ldo]
   int h, w, C, ldq, ldk, ldv, ldg, ldo;
   float scale_div;
+  long kv_brows;        // rows between the k/v maps of consecutive lanes (>= h*w)
 };
+
+// lane b of the batch (object group / clip): its own maps and its own [225, N] probability scratch
+__device__ __forceinline__ LgpParams lgp_lane(const LgpParams& pin, int bl) {
+  LgpParams p = pin;
+  const long N = (long)p.h * p.w;
+  p.q += bl * N * p.ldq;
+  p.k += bl * pin.kv_brows * p.ldk;
+  p.v += bl * pin.kv_brows * p.ldv;
+  if (p.gate) p.gate += bl * N * p.ldg;
+  p.out += bl * N * p.ldo;
+  p.prob += bl * 225 * N;
+  return p;
+}
 
 #define LGP_DPPF(acc, N) "v_fmac_f32_dpp " acc ", %[t], %[x] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
 __device__ __forceinline__ void lgp_dpp_axpy15(float (&s)[15], float t, float x) {
@@ -66,8 +80,9 @@ __device__ __forceinline__ void lgp_stage(const float* base, int ld, int c0, int
 }
 
 template <int NWV>
-__global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams p) {
+__global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams pin) {
   __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
+  const LgpParams p = lgp_lane(pin, blockIdx.z);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x0 = blockIdx.x * 64, y = blockIdx.y;
@@ -132,8 +147,9 @@ __global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams p)
 // 16 queries x 16 slot groups per workgroup: thread (g, i) keeps slots g, g+16, ... of query n0+i in registers (one read,
 // one write of P), the 16 partial maxima / sums of a query meet in LDS.  (One thread per query walked the 225 slots three
 // times through a dependent load chain: 121 us for a 1.5 MB map.)
-__global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ prob, int N) {
+__global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ prob_all, int N) {
   constexpr int W2 = LGP_WS * LGP_WS, G = 16, PER = (W2 + G - 1) / G;
+  float* __restrict__ prob = prob_all + (long)blockIdx.y * W2 * N;
   __shared__ float red[G][16];
   const int i = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int n = blockIdx.x * 16 + i;
@@ -171,11 +187,13 @@ __global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ pr
 }
 
 template <int NWV>
-__global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams p) {
+__global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams pin) {
   __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int x0 = blockIdx.x * 64, y = blockIdx.y, c0 = blockIdx.z * 32;
+  const int bl = blockIdx.y / pin.h;
+  const LgpParams p = lgp_lane(pin, bl);
+  const int x0 = blockIdx.x * 64, y = blockIdx.y - bl * pin.h, c0 = blockIdx.z * 32;
   const bool active = x0 + lane < p.w;
   const int x = active ? x0 + lane : p.w - 1;
   const int n = y * p.w + x;
@@ -230,19 +248,22 @@ __global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams
 }
 
 extern "C" int aot_local_gated_f32(const float* q, const float* k, const float* v, const float* gate, const float* relk_t,
-                                   const float* relk_b, float* prob, float* out, int h, int w, int dqk, int dv,
-                                   int max_dis, int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div,
-                                   void* stream) {
-  if (!q || !k || !v || !relk_t || !relk_b || !prob || !out || h <= 0 || w <= 0) return AOT_ERR_BADARG;
+                                   const float* relk_b, float* prob, float* out, int B, long kv_brows, int h, int w,
+                                   int dqk, int dv, int max_dis, int ldq, int ldk, int ldv, int ldg, int ldo,
+                                   float scale_div, void* stream) {
+  if (!q || !k || !v || !relk_t || !relk_b || !prob || !out || h <= 0 || w <= 0 || B <= 0) return AOT_ERR_BADARG;
+  if (B > 1 && kv_brows < (long)h * w) return AOT_ERR_BADARG;
+  if ((long)B * h > 65535) return AOT_ERR_UNSUPPORTED;
   if (dqk != 128 || max_dis != 7 || dv <= 0 || (dv & 31)) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (gate && (ldg & 3))) return AOT_ERR_BADARG;
   LgpParams p;
   p.q = q; p.k = k; p.v = v; p.gate = gate; p.relk_t = relk_t; p.relk_b = relk_b; p.prob = prob; p.out = out;
   p.h = h; p.w = w; p.C = dv; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldg = ldg; p.ldo = ldo; p.scale_div = scale_div;
+  p.kv_brows = kv_brows;
   hipStream_t s = (hipStream_t)stream;
   constexpr int NWV = 8;
-  hipLaunchKernelGGL((lgp_scores_kernel<NWV>), dim3(cdiv(w, 64), h, 1), dim3(NWV * 64), 0, s, p);
-  hipLaunchKernelGGL(lgp_softmax_kernel, dim3(cdiv(h * w, 16)), dim3(256), 0, s, prob, h * w);
-  hipLaunchKernelGGL((lgp_aggregate_kernel<NWV>), dim3(cdiv(w, 64), h, dv / 32), dim3(NWV * 64), 0, s, p);
+  hipLaunchKernelGGL((lgp_scores_kernel<NWV>), dim3(cdiv(w, 64), h, B), dim3(NWV * 64), 0, s, p);
+  hipLaunchKernelGGL(lgp_softmax_kernel, dim3(cdiv(h * w, 16), B), dim3(256), 0, s, prob, h * w);
+  hipLaunchKernelGGL((lgp_aggregate_kernel<NWV>), dim3(cdiv(w, 64), B * h, dv / 32), dim3(NWV * 64), 0, s, p);
   AOT_LAUNCH_CHECK();
 }

@@ -10,7 +10,8 @@ template <int NV>  // float4 per lane
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         const float* __restrict__ add, float* __restrict__ y2, int M,
-                                                        int C, int ldx, int ldy, int ldadd, int ldy2, float eps) {
+                                                        int C, int ldx, int ldy, int ldadd, int ldy2, int add_rows,
+                                                        float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       *reinterpret_cast<float4*>(y + (long)row * ldy + c4 * 4) = o;
       if (y2) {
-        const float4 a = *reinterpret_cast<const float4*>(add + (long)row * ldadd + c4 * 4);
+        const float4 a = *reinterpret_cast<const float4*>(add + (long)(add_rows ? row % add_rows : row) * ldadd + c4 * 4);
         *reinterpret_cast<float4*>(y2 + (long)row * ldy2 + c4 * 4) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
       }
     }
@@ -59,38 +60,44 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 }
 
 extern "C" int aot_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, const float* add,
-                                 float* y2, int M, int C, int ldx, int ldy, int ldadd, int ldy2, float eps,
+                                 float* y2, int M, int C, int ldx, int ldy, int ldadd, int ldy2, int add_rows, float eps,
                                  void* stream) {
+  if (add_rows < 0) return AOT_ERR_BADARG;
   if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return AOT_ERR_BADARG;
   if (y2 && (!add || (ldadd & 3) || (ldy2 & 3))) return AOT_ERR_BADARG;
   if (C > 1024) return AOT_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(cdiv(M, 4)), block(256);
   if (C <= 256)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, add_rows, eps);
   else if (C <= 512)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, add_rows, eps);
   else
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, eps);
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, add, y2, M, C, ldx, ldy, ldadd, ldy2, add_rows, eps);
   AOT_LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm (batch 1, NHWC): deterministic two-level reduction in fp64, then a streaming apply.
+// GroupNorm over B lanes of [M, C] NHWC maps (lane b = rows [b*M, (b+1)*M)): deterministic two-level reduction in fp64
+// in ONE launch -- the last of a (lane, group)'s nsplit partial-sum workgroups to arrive (device-scope ticket) adds the
+// partials in index order and writes (mean, rstd) -- then a streaming apply, or the fused apply + GELU + 5x5 depthwise
+// conv below.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, double* __restrict__ scratch, int M,
-                                                         int C, int G, int ldx, int nsplit) {
-  const int g = blockIdx.y, sp = blockIdx.x;
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, double* __restrict__ scratch,
+                                                       double* __restrict__ stats, unsigned* __restrict__ ticket, int M,
+                                                       int C, int G, int ldx, int nsplit, float eps) {
+  const int g = blockIdx.y, sp = blockIdx.x, bl = blockIdx.z;
   const int cg = C / G, v4 = cg >> 2;  // float4 per row of this group
   const int rows_per_pass = 256 / v4;
   const int t = threadIdx.x;
   const int r_in = t / v4, c4 = t - r_in * v4;
   const int rows = (M + nsplit - 1) / nsplit;
   const int r0 = sp * rows, r1 = min(M, r0 + rows);
+  const float* xb = x + (long)bl * M * ldx;
   double s = 0.0, sq = 0.0;
   if (r_in < rows_per_pass) {
     for (int r = r0 + r_in; r < r1; r += rows_per_pass) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + g * cg + c4 * 4);
+      const float4 v = *reinterpret_cast<const float4*>(xb + (long)r * ldx + g * cg + c4 * 4);
       s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
       sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
@@ -103,27 +110,40 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict
   }
   if ((t & 63) == 0) { red[0][t >> 6] = s; red[1][t >> 6] = sq; }
   __syncthreads();
+  const long slot = (long)bl * G + g;
+  double* part = scratch + slot * nsplit * 2;
   if (t == 0) {
-    scratch[((long)g * nsplit + sp) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    scratch[((long)g * nsplit + sp) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double ps = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double pq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    int is_last = 1;
+    if (nsplit > 1) {
+      // publish the partial (write-through stores), then take a ticket; the workgroup that draws the last ticket reduces
+      __hip_atomic_store(&part[sp * 2], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&part[sp * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned prev = __hip_atomic_fetch_add(&ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = prev == (unsigned)(nsplit - 1);
+      if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (is_last) {
+      double ts = 0.0, tq = 0.0;
+      if (nsplit > 1) {
+        for (int i = 0; i < nsplit; ++i) {   // index order, whoever arrived last: deterministic
+          ts += __hip_atomic_load(&part[i * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tq += __hip_atomic_load(&part[i * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call / replay
+      } else {
+        ts = ps; tq = pq;
+      }
+      const double cnt = (double)M * cg;
+      const double mean = ts / cnt;
+      double var = tq / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[slot * 2] = mean;
+      stats[slot * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+    }
   }
-}
-
-__global__ void gn_finalize_kernel(const double* __restrict__ scratch, double* __restrict__ stats, int M, int C, int G,
-                                   int nsplit, float eps) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
-  double s = 0.0, sq = 0.0;
-  for (int i = 0; i < nsplit; ++i) {
-    s += scratch[((long)g * nsplit + i) * 2];
-    sq += scratch[((long)g * nsplit + i) * 2 + 1];
-  }
-  const double cnt = (double)M * (C / G);
-  const double mean = s / cnt;
-  double var = sq / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[g * 2] = mean;
-  stats[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
 }
 
 __device__ __forceinline__ float gn_act(float v, int act) {
@@ -135,14 +155,16 @@ __device__ __forceinline__ float gn_act(float v, int act) {
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ y, int M, int C, int G, int ldx, int ldy,
-                                                       int act) {
+                                                       int act, long total, const float* __restrict__ add, int ldadd,
+                                                       int add_rows) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nv = C >> 2;
-  if (idx >= (long)M * nv) return;
+  if (idx >= total) return;
   const int c4 = (int)(idx % nv);
-  const long r = idx / nv;
+  const long r = idx / nv;                 // row over all lanes
+  const int bl = (int)(r / M);
   const int g = (c4 * 4) / (C / G);
-  const float mean = (float)stats[g * 2], rstd = (float)stats[g * 2 + 1];
+  const float mean = (float)stats[((long)bl * G + g) * 2], rstd = (float)stats[((long)bl * G + g) * 2 + 1];
   const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
   const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
@@ -151,28 +173,105 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   o.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
   o.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
   o.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+  if (add) {     // + a map added after the activation (shared by the lanes when add_rows > 0): FPN shortcut adapters
+    const float4 e = *reinterpret_cast<const float4*>(add + (add_rows ? r % add_rows : r) * ldadd + c4 * 4);
+    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+  }
   *reinterpret_cast<float4*>(y + r * ldy + c4 * 4) = o;
 }
 
-extern "C" int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, int M, int C, int G, int ldx,
-                                       float eps, int nsplit, void* stream) {
-  if (!x || !scratch || !stats || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) || (ldx & 3) || nsplit < 1)
+extern "C" int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, unsigned* ticket, int B, int M,
+                                       int C, int G, int ldx, float eps, int nsplit, void* stream) {
+  if (!x || !scratch || !stats || B <= 0 || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) || (ldx & 3) || nsplit < 1)
     return AOT_ERR_BADARG;
-  if ((C / G) / 4 > 256) return AOT_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nsplit, G), dim3(256), 0, s, x, scratch, M, C, G, ldx, nsplit);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, s, scratch, stats, M, C, G, nsplit, eps);
+  if (nsplit > 1 && !ticket) return AOT_ERR_BADARG;
+  if ((C / G) / 4 > 256 || B > 65535) return AOT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, G, B), dim3(256), 0, (hipStream_t)stream, x, scratch, stats, ticket, M, C,
+                     G, ldx, nsplit, eps);
   AOT_LAUNCH_CHECK();
 }
 
 extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
-                                       float* y, int M, int C, int G, int ldx, int ldy, int act, void* stream) {
-  if (!x || !stats || !gamma || !beta || !y || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) || (ldx & 3) ||
-      (ldy & 3))
+                                       float* y, const float* add, int B, int M, int C, int G, int ldx, int ldy, int ldadd,
+                                       int add_rows, int act, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || B <= 0 || M <= 0 || C <= 0 || G <= 0 || C % G || ((C / G) & 3) ||
+      (ldx & 3) || (ldy & 3))
     return AOT_ERR_BADARG;
-  const long total = (long)M * (C / 4);
+  if (add && ((ldadd & 3) || ldadd < C || add_rows < 0)) return AOT_ERR_BADARG;
+  const long total = (long)B * M * (C / 4);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y,
-                     M, C, G, ldx, ldy, act);
+                     M, C, G, ldx, ldy, act, total, add, ldadd, add_rows);
+  AOT_LAUNCH_CHECK();
+}
+
+// Fused GroupNorm-apply + activation + 5x5 depthwise conv (stride 1, pad 2) for 32-channel groups: GNActDWConv2d
+// (basic.py:15-35) after the statistics pass, i.e. gn -> GELU -> conv in one launch.  A workgroup owns an 8x8 output
+// tile of one (lane, group): the 12x12 input halo is normalised and activated ONCE per element on its way into LDS (the
+// conv zero-pads AFTER the activation), then every thread (pixel, 8 channels) walks the 25 taps out of LDS.
+__global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ w, float* __restrict__ out, int H,
+                                                             int W, int C, int G, int ldx, int ldo, int act, int tiles_x) {
+  constexpr int TH = 8, TW = 8, R = 2, IH = TH + 2 * R, IW = TW + 2 * R, CB = 32;
+  __shared__ __attribute__((aligned(16))) float tile[IH * IW][CB + 4];    // +4: rows 36 floats apart (bank spread)
+  __shared__ __attribute__((aligned(16))) float wk[25][CB];
+  const int g = blockIdx.y, bl = blockIdx.z;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int t = threadIdx.x;
+  const float mean = (float)stats[((long)bl * G + g) * 2], rstd = (float)stats[((long)bl * G + g) * 2 + 1];
+  const float* xb = x + (long)bl * H * W * ldx + g * CB;
+  const int c4 = t & 7;                          // channel quad of the group
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + g * CB + c4 * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + g * CB + c4 * 4);
+  for (int i = t >> 3; i < IH * IW; i += 32) {
+    const int iy = ty0 - R + i / IW, ix = tx0 - R + i % IW;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + c4 * 4);
+      o.x = gn_act((v.x - mean) * rstd * ga.x + be.x, act);
+      o.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
+      o.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
+      o.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+    }
+    *reinterpret_cast<float4*>(&tile[i][c4 * 4]) = o;
+  }
+  for (int i = t; i < 25 * (CB / 4); i += 256)
+    *reinterpret_cast<float4*>(&wk[i >> 3][(i & 7) * 4]) = *reinterpret_cast<const float4*>(w + (long)(i >> 3) * C + g * CB + (i & 7) * 4);
+  __syncthreads();
+  // thread = (pixel of the 8x8 tile, channel octet): 64 x 4
+  const int pix = t >> 2, co = (t & 3) * 8;
+  const int py = pix >> 3, px = pix & 7;
+  const int oy = ty0 + py, ox = tx0 + px;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const float* src = &tile[(py + ky) * IW + px + kx][co];
+      const float* kk = &wk[ky * 5 + kx][co];
+      const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+      const float4 k0 = *reinterpret_cast<const float4*>(kk), k1 = *reinterpret_cast<const float4*>(kk + 4);
+      acc[0] = fmaf(a0.x, k0.x, acc[0]); acc[1] = fmaf(a0.y, k0.y, acc[1]);
+      acc[2] = fmaf(a0.z, k0.z, acc[2]); acc[3] = fmaf(a0.w, k0.w, acc[3]);
+      acc[4] = fmaf(a1.x, k1.x, acc[4]); acc[5] = fmaf(a1.y, k1.y, acc[5]);
+      acc[6] = fmaf(a1.z, k1.z, acc[6]); acc[7] = fmaf(a1.w, k1.w, acc[7]);
+    }
+  if (oy < H && ox < W) {
+    float* dst = out + ((long)bl * H * W + (long)oy * W + ox) * ldo + g * CB + co;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+extern "C" int aot_gn_act_dwconv5_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                                      const float* w, float* out, int B, int H, int W, int C, int G, int ldx, int ldo,
+                                      int act, void* stream) {
+  if (!x || !stats || !gamma || !beta || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || G <= 0 || (ldx & 3) || (ldo & 3))
+    return AOT_ERR_BADARG;
+  if (C != G * 32 || B > 65535 || G > 65535) return AOT_ERR_UNSUPPORTED;
+  const int tx = cdiv(W, 8), ty = cdiv(H, 8);
+  hipLaunchKernelGGL(gn_act_dwconv5_kernel, dim3(tx * ty, G, B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, w,
+                     out, H, W, C, G, ldx, ldo, act, tx);
   AOT_LAUNCH_CHECK();
 }
 
@@ -183,6 +282,8 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ i
                                                      const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                      int C, int OH, int OW, int KH, int KW, int stride, int pad, int dil,
                                                      int act) {
+  in += (long)blockIdx.y * H * W * C;          // lane of the batch
+  out += (long)blockIdx.y * OH * OW * C;
   // XCD-aware block order: block b runs on XCD b%8; give each XCD a contiguous range of pixels so the KxK
   // neighbourhoods it re-reads stay in its own L2 (PMC: 62 MB fetched for a 7 MB map with the plain order)
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -214,12 +315,12 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ i
   *reinterpret_cast<float4*>(out + (long)pix * C + c4 * 4) = acc;
 }
 
-extern "C" int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int H, int W, int C,
-                                     int OH, int OW, int KH, int KW, int stride, int pad, int dil, int act,
+extern "C" int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
+                                     int C, int OH, int OW, int KH, int KW, int stride, int pad, int dil, int act,
                                      void* stream) {
-  if (!in || !w || !out || H <= 0 || W <= 0 || C <= 0 || (C & 3) || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+  if (!in || !w || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
   const long total = (long)OH * OW * (C / 4);
-  hipLaunchKernelGGL(dwconv_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, C,
+  hipLaunchKernelGGL(dwconv_kernel, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, C,
                      OH, OW, KH, KW, stride, pad, dil, act);
   AOT_LAUNCH_CHECK();
 }
@@ -323,7 +424,11 @@ static inline float bilinear_scale(int in_size, int out_size, int align) {
 
 __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ in, const float* __restrict__ add,
                                                        float* __restrict__ out, int IH, int IW, int OH, int OW, int C,
-                                                       int ldi, int ldadd, int ldo, int align, float sh, float sw) {
+                                                       int ldi, int ldadd, int ldo, int align, float sh, float sw,
+                                                       int add_shared) {
+  in += (long)blockIdx.y * IH * IW * ldi;       // lane of the batch; `add` is one map per lane, or one shared by all lanes
+  out += (long)blockIdx.y * OH * OW * ldo;
+  if (add && !add_shared) add += (long)blockIdx.y * OH * OW * ldadd;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nv = C >> 2;
   if (idx >= (long)OH * OW * nv) return;
@@ -350,34 +455,43 @@ __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__
   *reinterpret_cast<float4*>(out + (long)pix * ldo + c4 * 4) = o;
 }
 
-extern "C" int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int IH, int IW, int OH, int OW, int C,
-                                     int ldi, int ldadd, int ldo, int align_corners, void* stream) {
-  if (!in || !out || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C & 3) || (ldi & 3) || (ldo & 3))
+extern "C" int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int B, int IH, int IW, int OH, int OW,
+                                     int C, int ldi, int ldadd, int ldo, int align_corners, int add_shared, void* stream) {
+  if (!in || !out || B <= 0 || B > 65535 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C & 3) || (ldi & 3) ||
+      (ldo & 3))
     return AOT_ERR_BADARG;
   if (add && (ldadd & 3)) return AOT_ERR_BADARG;
   const long total = (long)OH * OW * (C / 4);
-  hipLaunchKernelGGL(bilinear_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
+  hipLaunchKernelGGL(bilinear_kernel, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
                      OW, C, ldi, ldadd, ldo, align_corners, bilinear_scale(IH, OH, align_corners),
-                     bilinear_scale(IW, OW, align_corners));
+                     bilinear_scale(IW, OW, align_corners), add_shared);
   AOT_LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Logit finalisation (aot_engine.py:367-378): mask unused identities to -1e10, planar copy at stride 4,
-// bilinear resize to the output size, written planar [C, OH, OW] (what the caller's softmax/argmax reads).
+// Logit finalisation (aot_engine.py:367-378) for G object groups (lanes) of one frame: per group mask the unused
+// identities to -1e10, planar copy at stride 4 (pred_id_logits), bilinear resize to the output size.  G = 1: written
+// planar [C, OH, OW] (what the caller's softmax/argmax reads).  G > 1: the groups' resized logits are merged in the same
+// kernel by the reference's soft aggregation (AOTInferEngine.soft_logit_aggregation, aot_engine.py:565-582): softmax per
+// group, background = product of the groups' background probabilities, clamp to [1e-5, 1 - 1e-5], logit -- output
+// [1 + G*(C-1), OH, OW].  Group g holds objects g*(C-1)+1 .. min((g+1)*(C-1), obj_total).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int group_obj_num(int g, int C, int obj_total) { return max(0, min(C - 1, obj_total - g * (C - 1))); }
+
 __global__ void __launch_bounds__(256) logits_planar_kernel(const float* __restrict__ in, float* __restrict__ out4, int HW,
-                                                            int C, int ldi, int obj_num) {
+                                                            int C, int ldi, int obj_total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)HW * C) return;
+  const int g = blockIdx.y;
   const int c = (int)(idx / HW);
   const int p = (int)(idx - (long)c * HW);
-  out4[idx] = (c > obj_num) ? -1e10f : in[(long)p * ldi + c];
+  out4[(long)g * HW * C + idx] = (c > group_obj_num(g, C, obj_total)) ? -1e10f : in[((long)g * HW + p) * ldi + c];
 }
 
+template <int MAXC>
 __global__ void __launch_bounds__(256) logits_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int IH,
-                                                            int IW, int C, int ldi, int OH, int OW, int obj_num, int align,
-                                                            float sh, float sw) {
+                                                            int IW, int C, int ldi, int OH, int OW, int G, int obj_total,
+                                                            int align, float sh, float sw) {
   const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long)OH * OW) return;
   const int oy = (int)(pix / OW), ox = (int)(pix - (long)oy * OW);
@@ -385,30 +499,62 @@ __global__ void __launch_bounds__(256) logits_resize_kernel(const float* __restr
   float wy0, wy1, wx0, wx1;
   bilinear_coord(oy, IH, OH, sh, align, y0, y1, wy0, wy1);
   bilinear_coord(ox, IW, OW, sw, align, x0, x1, wx0, wx1);
-  const float* pa = in + ((long)y0 * IW + x0) * ldi;
-  const float* pb = in + ((long)y0 * IW + x1) * ldi;
-  const float* pc = in + ((long)y1 * IW + x0) * ldi;
-  const float* pd = in + ((long)y1 * IW + x1) * ldi;
-  for (int c = 0; c < C; ++c) {
-    float a, b, cc, d;
-    if (c > obj_num) a = b = cc = d = -1e10f;
-    else { a = pa[c]; b = pb[c]; cc = pc[c]; d = pd[c]; }
-    out[(long)c * OH * OW + pix] = wy0 * (wx0 * a + wx1 * b) + wy1 * (wx0 * cc + wx1 * d);
+  const long plane = (long)OH * OW;
+  float bg = 1.f;
+  for (int g = 0; g < G; ++g) {
+    const float* base = in + (long)g * IH * IW * ldi;
+    const float* pa = base + ((long)y0 * IW + x0) * ldi;
+    const float* pb = base + ((long)y0 * IW + x1) * ldi;
+    const float* pc = base + ((long)y1 * IW + x0) * ldi;
+    const float* pd = base + ((long)y1 * IW + x1) * ldi;
+    const int on = group_obj_num(g, C, obj_total);
+    float v[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < C) {
+        float a, b, cc, d;
+        if (c > on) a = b = cc = d = -1e10f;
+        else { a = pa[c]; b = pb[c]; cc = pc[c]; d = pd[c]; }
+        v[c] = wy0 * (wx0 * a + wx1 * b) + wy1 * (wx0 * cc + wx1 * d);
+        mx = fmaxf(mx, v[c]);
+      }
+    }
+    if (G == 1) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) out[(long)c * plane + pix] = v[c];
+      return;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    bg *= v[0] / sum;
+#pragma unroll
+    for (int c = 1; c < MAXC; ++c)
+      if (c < C) {
+        const float pr = fminf(fmaxf(v[c] / sum, 1e-5f), 1.f - 1e-5f);
+        out[(long)(1 + g * (C - 1) + c - 1) * plane + pix] = logf(pr / (1.f - pr));
+      }
   }
+  const float pr = fminf(fmaxf(bg, 1e-5f), 1.f - 1e-5f);
+  out[pix] = logf(pr / (1.f - pr));
 }
 
-extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int IH, int IW, int C, int ldi, int OH,
-                                       int OW, int obj_num, int align_corners, void* stream) {
-  if (!logits || IH <= 0 || IW <= 0 || C <= 0 || ldi < C) return AOT_ERR_BADARG;
+extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int G, int IH, int IW, int C, int ldi,
+                                       int OH, int OW, int obj_total, int align_corners, void* stream) {
+  if (!logits || G <= 0 || G > 65535 || IH <= 0 || IW <= 0 || C <= 1 || ldi < C) return AOT_ERR_BADARG;
+  if (C > 16) return AOT_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (out4) {
     const long total = (long)IH * IW * C;
-    hipLaunchKernelGGL(logits_planar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, logits, out4, IH * IW, C, ldi, obj_num);
+    hipLaunchKernelGGL(logits_planar_kernel, dim3(cdiv(total, 256), G), dim3(256), 0, s, logits, out4, IH * IW, C, ldi, obj_total);
   }
   if (out) {
     if (OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
-    hipLaunchKernelGGL(logits_resize_kernel, dim3(cdiv((long)OH * OW, 256)), dim3(256), 0, s, logits, out, IH, IW, C, ldi,
-                       OH, OW, obj_num, align_corners, bilinear_scale(IH, OH, align_corners),
+    hipLaunchKernelGGL(logits_resize_kernel<16>, dim3(cdiv((long)OH * OW, 256)), dim3(256), 0, s, logits, out, IH, IW, C, ldi,
+                       OH, OW, G, obj_total, align_corners, bilinear_scale(IH, OH, align_corners),
                        bilinear_scale(IW, OW, align_corners));
   }
   AOT_LAUNCH_CHECK();
@@ -418,12 +564,23 @@ extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* 
 // Identity bank: one workgroup per output token; the KxK label patch is staged in LDS, then every
 // thread (= channel quad) walks the taps, gathering coalesced rows of the [label, ky, kx, C] table.
 // ---------------------------------------------------------------------------------------------
+struct IdFuse {          // optional fused outputs: fout[i][row] = id_emb[row] + fadd[i][row]  (V + id_emb of layer i, transformer.py:366)
+  const float* fadd[4];
+  float* fout[4];
+  int n, ldadd, ldout;
+};
+
 __global__ void __launch_bounds__(256) idbank_kernel(const float* __restrict__ mask, const float* __restrict__ table,
                                                      const float* __restrict__ sumtab, const float* __restrict__ bias,
                                                      float* __restrict__ out, int H, int W, int OW, int K, int stride,
-                                                     int pad, int C, int nlabel, int ldo) {
+                                                     int pad, int C, int nlabel, int ldo, int ntok, int group_size,
+                                                     int group0, const IdFuse fz) {
   extern __shared__ int labels[];  // K*K entries (-1 = contributes nothing), then 3 x 64 float4 partial sums
   const int tok = blockIdx.x;
+  // lane g of the batch = object group group0+g of the SAME label map (AOTInferEngine.separate_mask, aot_engine.py:515-534):
+  // labels (group0+g)*group_size+1 .. +group_size become 1 .. group_size, every other pixel is background 0
+  const int grp = blockIdx.y, lab_lo = (group0 + grp) * group_size;
+  const long row = (long)grp * ntok + tok;
   const int Y = tok / OW, X = tok - Y * OW;
   const int KK = K * K;
   bool same = true;
@@ -434,8 +591,10 @@ __global__ void __launch_bounds__(256) idbank_kernel(const float* __restrict__ m
     int lab = -1;
     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
       const float v = mask[(long)iy * W + ix];
-      const int li = (int)v;
-      if (v == (float)li && li >= 0 && li < nlabel) lab = li;
+      int li = (int)v;
+      const bool integral = v == (float)li;
+      if (group_size > 0 && integral) li = (li > lab_lo && li <= lab_lo + group_size) ? li - lab_lo : 0;
+      if (integral && li >= 0 && li < nlabel) lab = li;
     }
     labels[i] = lab;
     if (first == -2) first = lab;
@@ -475,19 +634,37 @@ __global__ void __launch_bounds__(256) idbank_kernel(const float* __restrict__ m
         const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
       }
-      *reinterpret_cast<float4*>(out + (long)tok * ldo + c4 * 4) = acc;
+      if (out) *reinterpret_cast<float4*>(out + row * ldo + c4 * 4) = acc;
+      for (int i = 0; i < fz.n; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(fz.fadd[i] + row * fz.ldadd + c4 * 4);
+        *reinterpret_cast<float4*>(fz.fout[i] + row * fz.ldout + c4 * 4) = make_float4(acc.x + a.x, acc.y + a.y, acc.z + a.z, acc.w + a.w);
+      }
     }
   }
 }
 
 extern "C" int aot_idbank_f32(const float* mask, const float* table, const float* sumtab, const float* bias, float* out,
-                              int H, int W, int OH, int OW, int K, int stride, int pad, int C, int nlabel, int ldo,
-                              void* stream) {
-  if (!mask || !table || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || C <= 0 || (C & 3) || (ldo & 3))
+                              int G, int group_size, int group0, int H, int W, int OH, int OW, int K, int stride, int pad,
+                              int C, int nlabel, int ldo, const float* const* fuse_add, float* const* fuse_out, int nfuse,
+                              int ldadd, int ldfout, void* stream) {
+  if (!mask || !table || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || C <= 0 || (C & 3) || (ldo & 3))
     return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(idbank_kernel, dim3(OH * OW), dim3(256), ((K * K + 3) & ~3) * sizeof(int) + 3 * 64 * sizeof(float4),
-                     (hipStream_t)stream, mask, table, sumtab,
-                     bias, out, H, W, OW, K, stride, pad, C, nlabel, ldo);
+  if (G <= 0 || G > 65535 || group_size < 0 || group0 < 0 || ((G > 1 || group0 > 0) && group_size == 0)) return AOT_ERR_BADARG;
+  if (nfuse < 0 || nfuse > 4 || (!out && nfuse == 0)) return AOT_ERR_BADARG;
+  IdFuse fz;
+  fz.n = nfuse; fz.ldadd = ldadd; fz.ldout = ldfout;
+  for (int i = 0; i < 4; ++i) { fz.fadd[i] = nullptr; fz.fout[i] = nullptr; }
+  if (nfuse > 0) {
+    if (!fuse_add || !fuse_out || (ldadd & 3) || (ldfout & 3) || ldadd < C || ldfout < C) return AOT_ERR_BADARG;
+    for (int i = 0; i < nfuse; ++i) {
+      if (!fuse_add[i] || !fuse_out[i]) return AOT_ERR_BADARG;
+      fz.fadd[i] = fuse_add[i];
+      fz.fout[i] = fuse_out[i];
+    }
+  }
+  hipLaunchKernelGGL(idbank_kernel, dim3(OH * OW, G), dim3(256), ((K * K + 3) & ~3) * sizeof(int) + 3 * 64 * sizeof(float4),
+                     (hipStream_t)stream, mask, table, sumtab, bias, out, H, W, OW, K, stride, pad, C, nlabel, ldo, OH * OW,
+                     group_size, group0, fz);
   AOT_LAUNCH_CHECK();
 }
 
@@ -506,4 +683,4 @@ extern "C" int aot_add_f32(const float* a, const float* b, float* out, long n, v
   AOT_LAUNCH_CHECK();
 }
 
-extern "C" const char* aot_hip_version(void) { return "aot_hip 0.1 gfx950"; }
+extern "C" const char* aot_hip_version(void) { return "aot_hip 0.2 gfx950"; }

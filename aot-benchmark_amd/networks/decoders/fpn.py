@@ -39,43 +39,47 @@ class FPNSegmentationHead(nn.Module):
             self._p = p
         return self._p
 
-    def _gn_relu(self, x, key, ws, stream):
+    def _gn_relu(self, x, out, key, B, ws, stream, add=None, add_rows=0):
         p = self._p
-        dev = x.device
-        aot_hip.groupnorm(x, *p[key + '_gn'], x, 8, ws.get('gn_scratch', (32 * 64 * 2,), dev, torch.float64),
-                          ws.get('gn_stats', (64,), dev, torch.float64), act=aot_hip.ACT_RELU, nsplit=64, stream=stream)
-        return x
+        aot_hip.groupnorm(x, *p[key + '_gn'], out, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), act=aot_hip.ACT_RELU,
+                          nsplit=32, B=B, add=add, add_rows=add_rows, stream=stream)
+        return out
 
-    def run(self, x_in, f16, f8, f4, ws, stream):
-        """x_in [N16, in_dim] (concatenated decoder input, or the last LSTT output), f16/f8/f4 = (feat, h, w)
-        shortcuts at strides 16/8/4.  Returns logits [h4*w4, out_dim] (row stride out_dim padded to 4)."""
+    def run(self, x_in, f16, f8, f4, ws, stream, B=1):
+        """x_in [B*N16, in_dim] (concatenated decoder input, or the last LSTT output) of B lanes (object groups of ONE
+        frame), f16/f8/f4 = (feat, h, w) shortcuts at strides 16/8/4 shared by the lanes: the three adapter convs run
+        once and are added to every lane (GN-apply epilogue at 16x, bilinear epilogue at 8x / 4x).
+        Returns logits [B*h4*w4, out_dim] (row stride out_dim padded to 4)."""
         p = self.pack()
         dev = x_in.device
         hd = self.hidden
         (s16, h16, w16), (s8, h8, w8), (s4, h4, w4) = f16, f8, f4
         n16, n8, n4 = h16 * w16, h8 * w8, h4 * w4
-        a = ws.get('dec_a16', (n16, hd), dev)
-        aot_hip.conv2d(x_in, *p['conv_in'], a, h16, w16, x_in.shape[1], h16, w16, hd, stream=stream)
-        self._gn_relu(a, 'conv_in', ws, stream)
-        b = ws.get('dec_b16', (n16, hd), dev)
-        aot_hip.conv2d(s16, *p['adapter_16x'], b, h16, w16, s16.shape[1], h16, w16, hd, res=a, stream=stream)
-        aot_hip.conv2d(b, *p['conv_16x'], a, h16, w16, hd, h16, w16, hd, 3, 3, 1, 1, 1, stream=stream)
-        self._gn_relu(a, 'conv_16x', ws, stream)
+        ad16 = ws.get('dec_ad16', (n16, hd), dev)
+        aot_hip.conv2d(s16, *p['adapter_16x'], ad16, h16, w16, s16.shape[1], h16, w16, hd, stream=stream)
+        a = ws.get('dec_a16', (B * n16, hd), dev)
+        aot_hip.linear(x_in, *p['conv_in'], a, stream=stream)
+        b = ws.get('dec_b16', (B * n16, hd), dev)
+        self._gn_relu(a, b, 'conv_in', B, ws, stream, add=ad16, add_rows=n16)      # relu(gn(conv_in)) + adapter_16x
+        aot_hip.conv2d(b, *p['conv_16x'], a, h16, w16, hd, h16, w16, hd, 3, 3, 1, 1, 1, B=B, stream=stream)
+        self._gn_relu(a, a, 'conv_16x', B, ws, stream)
         # 8x: adapter(shortcut) + bilinear(a)
-        c = ws.get('dec_a8', (n8, hd), dev)
-        aot_hip.conv2d(s8, *p['adapter_8x'], c, h8, w8, s8.shape[1], h8, w8, hd, stream=stream)
-        aot_hip.bilinear(a, c, h16, w16, h8, w8, hd, self.align_corners, add=c, stream=stream)
-        d = ws.get('dec_b8', (n8, hd // 2), dev)
-        aot_hip.conv2d(c, *p['conv_8x'], d, h8, w8, hd, h8, w8, hd // 2, 3, 3, 1, 1, 1, stream=stream)
-        self._gn_relu(d, 'conv_8x', ws, stream)
+        ad8 = ws.get('dec_ad8', (n8, hd), dev)
+        aot_hip.conv2d(s8, *p['adapter_8x'], ad8, h8, w8, s8.shape[1], h8, w8, hd, stream=stream)
+        c = ws.get('dec_a8', (B * n8, hd), dev)
+        aot_hip.bilinear(a, c, h16, w16, h8, w8, hd, self.align_corners, add=ad8, B=B, add_shared=True, stream=stream)
+        d = ws.get('dec_b8', (B * n8, hd // 2), dev)
+        aot_hip.conv2d(c, *p['conv_8x'], d, h8, w8, hd, h8, w8, hd // 2, 3, 3, 1, 1, 1, B=B, stream=stream)
+        self._gn_relu(d, d, 'conv_8x', B, ws, stream)
         # 4x
-        e = ws.get('dec_a4', (n4, hd // 2), dev)
-        aot_hip.conv2d(s4, *p['adapter_4x'], e, h4, w4, s4.shape[1], h4, w4, hd // 2, stream=stream)
-        aot_hip.bilinear(d, e, h8, w8, h4, w4, hd // 2, self.align_corners, add=e, stream=stream)
-        f = ws.get('dec_b4', (n4, hd // 2), dev)
-        aot_hip.conv2d(e, *p['conv_4x'], f, h4, w4, hd // 2, h4, w4, hd // 2, 3, 3, 1, 1, 1, stream=stream)
-        self._gn_relu(f, 'conv_4x', ws, stream)
+        ad4 = ws.get('dec_ad4', (n4, hd // 2), dev)
+        aot_hip.conv2d(s4, *p['adapter_4x'], ad4, h4, w4, s4.shape[1], h4, w4, hd // 2, stream=stream)
+        e = ws.get('dec_a4', (B * n4, hd // 2), dev)
+        aot_hip.bilinear(d, e, h8, w8, h4, w4, hd // 2, self.align_corners, add=ad4, B=B, add_shared=True, stream=stream)
+        f = ws.get('dec_b4', (B * n4, hd // 2), dev)
+        aot_hip.conv2d(e, *p['conv_4x'], f, h4, w4, hd // 2, h4, w4, hd // 2, 3, 3, 1, 1, 1, B=B, stream=stream)
+        self._gn_relu(f, f, 'conv_4x', B, ws, stream)
         ldo = (self.out_dim + 3) // 4 * 4
-        out = ws.get('dec_logits', (n4, ldo), dev)
-        aot_hip.conv2d(f, *p['conv_out'], out, h4, w4, hd // 2, h4, w4, self.out_dim, stream=stream)
+        out = ws.get('dec_logits', (B * n4, ldo), dev)
+        aot_hip.conv2d(f, *p['conv_out'], out, 1, B * n4, hd // 2, 1, B * n4, self.out_dim, stream=stream)
         return out[:, :self.out_dim], h4, w4

@@ -1,18 +1,23 @@
-"""Per-clip inference engines (reference networks/engines/aot_engine.py).
+"""Per-clip inference engines (reference networks/engines/aot_engine.py, deaot_engine.py).
 
-``AOTEngine`` is the state machine of one <=10-object group: it owns the long-term memory bank, the
-short-term memory (previous frame) and the current frame's intermediates, and drives the model's fused
-HIP stages.  ``AOTInferEngine`` is the caller-facing wrapper (tools/demo.py:187-235,
-networks/managers/evaluator.py:265-446 call exactly this surface).
+MI355X-first design -- same results as the reference, different machinery:
 
-MI355X-first differences from the reference implementation (same results):
-  * the bank is a pre-allocated, geometrically grown [cap, C] buffer per layer that frames are
-    APPENDED to (the reference re-copies the whole bank with torch.cat every `gap` frames,
-    aot_engine.py:291-305); softmax attention is order-invariant;
-  * one_hot_mask + the 17x17 identity conv are one gather kernel on the label map;
-  * no NCHW<->sequence copies: token-major buffers are viewed as [1,C,h,w] / [N,1,C] at the API.
+  * LANES.  The reference gives every group of <= 10 objects its own ``AOTEngine`` and runs the engines one after the
+    other on shared image features (aot_engine.py:584-616).  Here the groups are lanes of ONE batched pass: every LSTT /
+    decoder kernel takes the B lanes stacked along the token rows ([B*N, C]), mask separation happens inside the identity
+    gather kernel, and the per-group logits are masked, resized and soft-aggregated by one kernel
+    (``aot_logits_finalize_f32``).  A frame costs the same number of launches for 44 objects as for 4.
+  * ``AOTEngine`` is a COHORT of lanes that share a schedule (frame counter, memorisation steps, bank length).  One
+    cohort is the normal case; objects that first appear mid-clip and open a new group start a cohort of their own,
+    because the reference starts a fresh engine (own frame counter, empty bank) for them.
+  * The long-term bank is a pre-allocated [lanes, capacity, C] buffer per layer that memorised frames are APPENDED to
+    (softmax attention is order-invariant; the reference re-copies the whole bank with torch.cat, aot_engine.py:291-305).
+    With one lane the frame's K and id-fused V are written by their GEMMs straight into the next bank slot on the frames
+    that will be memorised -- no copy at all -- and the short-term memory of the following frame is a view of that slot.
+  * one_hot_mask + the 17x17 identity conv + the `V + id_emb` sums of all layers are one gather kernel on the label map.
+
+``AOTInferEngine`` is the caller-facing surface (tools/demo.py:187-235, networks/managers/evaluator.py:265-446).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,8 +26,19 @@ import aot_hip
 from networks.models.aot import as_map, to_tokens
 
 
+def _die(msg):
+    """The reference reports a missing input by printing and leaving the process (aot_engine.py:194-217)."""
+    print(msg)
+    exit()
+
+
 class AOTEngine(nn.Module):
-    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None):
+    """A cohort of `lanes` object groups (groups group0 .. group0+lanes-1 of the clip's label map) advancing in lock
+    step.  With lanes = 1 and group0 = None this is the reference's AOTEngine for <= 10 objects: masks carry the labels
+    0..max_obj_num as they are."""
+
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None, lanes=1,
+                 group0=None):
         super().__init__()
         # long_term_mem_max (repo extension, SURVEY 8f3; the reference bank grows without bound): at most that many
         # memorised frames -- the first one (the reference frame) is kept, the others form a ring of the most recent
@@ -35,7 +51,12 @@ class AOTEngine(nn.Module):
         self.max_obj_num = aot_model.max_obj_num
         self.gpu_id = gpu_id
         self.long_term_mem_gap = long_term_mem_gap
-        self.short_term_mem_skip = short_term_mem_skip
+        self.short_term_mem_skip = max(1, int(short_term_mem_skip))
+        self.lanes = int(lanes)
+        self.group0 = group0         # first object group of the clip's label map held by lane 0 (None: labels as they are)
+        self.first_group = group0 or 0
+        self._bank = None            # per layer (K [lanes, cap*N, Ck], V [lanes, cap*N, Cv]); survives restart_engine
+        self._bank_geom = None
         self.restart_engine()
 
     def forward(self, *a, **k):
@@ -44,7 +65,7 @@ class AOTEngine(nn.Module):
     # ---- state ---------------------------------------------------------------------------------
     def restart_engine(self, batch_size=1, enable_id_shuffle=False):
         if batch_size != 1 or enable_id_shuffle:
-            raise NotImplementedError('inference runs batch 1 without id shuffle (aot_engine.py:445-477)')
+            raise NotImplementedError('inference runs one clip per engine without id shuffle (aot_engine.py:445-477)')
         self.batch_size = 1
         self.frame_step = 0
         self.last_mem_step = -1
@@ -53,17 +74,16 @@ class AOTEngine(nn.Module):
         self.enc_size_2d = None
         self.enc_hw = None
         self.input_size_2d = None
-        # the bank buffers survive a restart (same clip geometry re-uses them: no allocator traffic, which would
-        # serialise concurrently running clips); only the fill level is reset
-        if not hasattr(self, 'bank_k'):
-            self.bank_k, self.bank_v = None, None
-        self.bank_len = 0
-        self.bank_frames = 0      # frames ever memorised (ring position of a bounded bank)
-        self.short_term_memories_list = []
-        self.short_term_memories = None
-        self._feats = None        # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major
-        self._dec_in = None       # decoder input: AOT [N, (L+1)*C] (projected feature | LSTT outs), DeAOT [N, 2C]
-        self._curr = None         # per layer current-frame memories (token-major), as returned by LSTT.run
+        self.bank_frames = 0         # frames ever memorised
+        self._slots = 0              # bank slots in use (= bank_frames, or the bound of a bounded bank)
+        self._short = []             # most recent short-term memories, oldest first; entry = per layer (K, V, rows)
+        self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot
+        self._ring_pos = 0
+        self._feats = None           # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major, shared by the lanes
+        self._dec_in = None          # decoder input: AOT [B*N, (L+1)*C] (projected feature | LSTT outs), DeAOT [B*N, 2C]
+        self._curr = None            # this frame's per-layer (K, V | Vcat, ...) as returned by LSTT.run
+        self._curr_slot = None       # bank slot this frame's K/V were written to directly, if any
+        self._dst = None             # buffers this frame's K / V live in
         self.curr_id_embs = None
         self.pred_id_logits = None
 
@@ -73,155 +93,240 @@ class AOTEngine(nn.Module):
         self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
 
     @property
+    def bank_len(self):
+        """Tokens per lane in the long-term bank."""
+        return self._slots * (self.enc_hw or 0)
+
+    @property
+    def bank_k(self):
+        return None if self._bank is None else [k.view(-1, k.shape[2]) for k, _ in self._bank]
+
+    @property
+    def bank_v(self):
+        return None if self._bank is None else [v.view(-1, v.shape[2]) for _, v in self._bank]
+
+    @property
     def curr_enc_embs(self):
-        """[4x, 8x, 16x, 16x-projected] maps as [1,C,h,w] views (read by multi-group sharing and by callers)."""
+        """[4x, 8x, 16x, 16x-projected] maps as [1,C,h,w] views (read by callers and shared between cohorts)."""
         if self._feats is None:
             return None
         return [as_map(t, h, w) for (t, h, w) in self._feats]
 
-    def lstt_last(self):
+    def lstt_last(self, lane=0):
         """Last LSTT / GPM layer output after its decoder norm, token-major [N, C] (AOT) / [N, 2C] (DeAOT): what the
         reference keeps as curr_lstt_output[0][-1] (aot_engine.py:340-354)."""
-        C = self.AOT.encoder_projector.out_channels
-        if self._dec_in.shape[1] == 2 * C and not self.AOT.decoder.decode_intermediate_input:
-            return self._dec_in
-        return self._dec_in[:, -C:]
+        N = self.enc_hw
+        rows = self._dec_in[lane * N:(lane + 1) * N]
+        if not self.AOT.decoder.decode_intermediate_input:
+            return rows
+        return rows[:, -self.AOT.encoder_projector.out_channels:]
 
     @property
     def long_term_memories(self):
-        if self.bank_k is None or self.bank_len == 0:
+        """Reference-shaped view of lane 0's bank: per layer [K, V] as [T, 1, C]."""
+        if self._bank is None or self._slots == 0:
             return None
-        return [[k[:self.bank_len].unsqueeze(1), v[:self.bank_len].unsqueeze(1)] for k, v in zip(self.bank_k, self.bank_v)]
+        T = self.bank_len
+        return [[k[0, :T].unsqueeze(1), v[0, :T].unsqueeze(1)] for k, v in self._bank]
 
-    # ---- helpers -------------------------------------------------------------------------------
+    # ---- bank plumbing -------------------------------------------------------------------------
+    def _direct(self):
+        """K / V GEMMs may write straight into bank slots: one lane, unbounded bank, previous-frame short-term memory."""
+        return self.lanes == 1 and self.long_term_mem_max is None and self.short_term_mem_skip == 1
+
+    def _ensure_bank(self, frames_needed):
+        N, B = self.enc_hw, self.lanes
+        widths = self.AOT.mem_widths()
+        dev = next(self.AOT.parameters()).device
+        geom = (N, B, tuple(widths), dev)
+        if self._bank is None or self._bank_geom != geom:
+            cap = 16      # memorised frames up front (a 70-frame clip at gap 5 needs 14); doubles beyond
+            self._bank = [(torch.empty(B, cap * N, ck, dtype=torch.float32, device=dev),
+                           torch.empty(B, cap * N, cv, dtype=torch.float32, device=dev)) for ck, cv in widths]
+            self._bank_geom = geom
+        cap = self._bank[0][0].shape[1] // N
+        if frames_needed > cap:
+            new_cap = max(2 * cap, frames_needed)
+            used = self._slots * N
+            grown = []
+            for k, v in self._bank:
+                k2 = torch.empty(B, new_cap * N, k.shape[2], dtype=torch.float32, device=dev)
+                v2 = torch.empty(B, new_cap * N, v.shape[2], dtype=torch.float32, device=dev)
+                k2[:, :used].copy_(k[:, :used])
+                v2[:, :used].copy_(v[:, :used])
+                grown.append((k2, v2))
+            self._bank = grown
+
+    def _next_slot(self):
+        """Bank slot the next memorised frame goes to (append; a bounded bank overwrites its oldest non-first frame)."""
+        if self.long_term_mem_max is not None and self.bank_frames >= self.long_term_mem_max:
+            return 1 + (self.bank_frames - 1) % (self.long_term_mem_max - 1)
+        return self._slots
+
+    def _slot_views(self, slot):
+        """Per layer (K rows, V rows) [N, C] of bank slot `slot` of lane 0 (the direct-write path is single-lane)."""
+        N = self.enc_hw
+        return [(k[0, slot * N:(slot + 1) * N], v[0, slot * N:(slot + 1) * N]) for k, v in self._bank]
+
+    def _brows_bank(self):
+        return self._bank[0][0].shape[1]
+
+    def _commit(self, slot):
+        if slot >= self._slots:
+            self._slots = slot + 1
+        self.bank_frames += 1
+
+    def _scratch_set(self):
+        """A [B*N, C] K / V buffer set for this frame out of a small ring (short_term_mem_skip + 2 sets, so the sets that
+        still back a short-term memory are never the one being written)."""
+        N, B = self.enc_hw, self.lanes
+        dev = next(self.AOT.parameters()).device
+        n = self.short_term_mem_skip + 2
+        if self._ring is None or self._ring[0][0][0].shape[0] != B * N or self._ring[0][0][0].device != dev:
+            self._ring = [[(torch.empty(B * N, ck, dtype=torch.float32, device=dev),
+                            torch.empty(B * N, cv, dtype=torch.float32, device=dev)) for ck, cv in self.AOT.mem_widths()]
+                          for _ in range(n)]
+            self._ring_pos = 0
+        s = self._ring[self._ring_pos % len(self._ring)]
+        self._ring_pos += 1
+        return s
+
+    def _store(self, kv, slot):
+        """Copies this frame's per-layer (K, V) [B*N, C] into bank slot `slot` of every lane (one strided copy each)."""
+        N, B = self.enc_hw, self.lanes
+        for (bk, bv), (k, v) in zip(self._bank, kv):
+            bk[:, slot * N:(slot + 1) * N].copy_(k.view(B, N, -1))
+            bv[:, slot * N:(slot + 1) * N].copy_(v.view(B, N, -1))
+
+    def _push_short(self, entry):
+        self._short.append(entry)
+        self._short = self._short[-self.short_term_mem_skip:]
+
+    # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):
         if img_embs is None:
             feats = self.AOT.encode_tokens(img)
-        else:   # shared image embedding from another object group (aot_engine.py:606-607,612-616)
+        else:   # image embedding computed by another cohort / engine (aot_engine.py:606-607,612-616)
             feats = [(to_tokens(e), e.shape[2], e.shape[3]) for e in img_embs]
         self._feats = feats
         return feats
 
+    def _group_objects(self):
+        """Objects of this cohort: obj_nums is the cohort's own count (the clip's total minus the groups before it)."""
+        return int(self.obj_nums[0]) if isinstance(self.obj_nums, (list, tuple)) else int(self.obj_nums)
+
     def assign_identity(self, mask):
-        """mask [1,1,H,W] label ids -> id embedding [N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
+        """mask [1,1,H,W] label ids -> id embedding [lanes*N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
         if mask.dim() == 4 and mask.shape[1] != 1:
             raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
-        return self.AOT.id_emb_from_mask(mask, self.enc_size_2d)
+        return self.AOT.id_emb_from_mask(mask, self.enc_size_2d, lanes=self.lanes, group0=self.group0)
 
-    def _append_bank(self, ks, vs):
-        N = ks[0].shape[0]
-        fits = (self.bank_k is not None and len(self.bank_k) == len(ks) and
-                all(b.shape[1] == k.shape[1] and b.device == k.device for b, k in zip(self.bank_k, ks)) and
-                all(b.shape[1] == v.shape[1] for b, v in zip(self.bank_v, vs)))
-        if not fits:
-            cap = 16 * N          # 16 memorised frames up front (a 70-frame clip at gap 5 needs 14); doubles beyond
-            self.bank_k = [torch.empty(cap, k.shape[1], dtype=torch.float32, device=k.device) for k in ks]
-            self.bank_v = [torch.empty(cap, v.shape[1], dtype=torch.float32, device=v.device) for v in vs]
-            self.bank_len = 0
-            self.bank_frames = 0
-        if self.long_term_mem_max is not None and self.bank_frames >= self.long_term_mem_max:
-            # bounded bank: overwrite the oldest non-first frame (attention is order-invariant, so a ring is enough)
-            slot = 1 + (self.bank_frames - 1) % (self.long_term_mem_max - 1)
-            for i, (k, v) in enumerate(zip(ks, vs)):
-                self.bank_k[i][slot * N:(slot + 1) * N].copy_(k)
-                self.bank_v[i][slot * N:(slot + 1) * N].copy_(v)
-            self.bank_frames += 1
-            return
-        if self.bank_len + N > self.bank_k[0].shape[0]:
-            cap = max(2 * self.bank_k[0].shape[0], self.bank_len + N)
-            for lst in (self.bank_k, self.bank_v):
-                for i, old in enumerate(lst):
-                    new = torch.empty(cap, old.shape[1], dtype=torch.float32, device=old.device)
-                    new[:self.bank_len].copy_(old[:self.bank_len])
-                    lst[i] = new
-        for i, (k, v) in enumerate(zip(ks, vs)):
-            self.bank_k[i][self.bank_len:self.bank_len + N].copy_(k)
-            self.bank_v[i][self.bank_len:self.bank_len + N].copy_(v)
-        self.bank_len += N
-        self.bank_frames += 1
-
-    # ---- reference surface ---------------------------------------------------------------------
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
         if self.obj_nums is None and obj_nums is None:
-            print('No objects for reference frame!')
-            exit()
-        elif obj_nums is not None:
+            _die('No objects for reference frame!')
+        if obj_nums is not None:
             self.obj_nums = obj_nums
-        if frame_step == -1:
-            frame_step = self.frame_step
         if img is None and img_embs is None:
-            print('No image for reference frame!')
-            exit()
+            _die('No image for reference frame!')
         if mask is None:
-            print('No mask for reference frame!')
-            exit()
+            _die('No mask for reference frame!')
         feats = self._encode(img, img_embs)
+        x16, h, w = feats[3]
         if self.input_size_2d is None:
-            self.update_size(img.size()[2:] if img is not None else mask.size()[2:], (feats[3][1], feats[3][2]))
+            self.update_size(img.size()[2:] if img is not None else mask.size()[2:], (h, w))
         if self.pos_emb is None:
-            self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(feats[3][0], feats[3][1], feats[3][2])).contiguous(
+            self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(x16, h, w)).contiguous(
                 memory_format=torch.channels_last)).contiguous()
         id_emb = self.assign_identity(mask)
         self.curr_id_embs = id_emb
         stream = aot_hip.stream_ptr()
-        self._dec_in, outs, mems = self.AOT.LSTT.run(feats[3][0], None, None, id_emb, self.pos_emb, self.enc_size_2d,
-                                                     self.AOT.ws, stream)
-        self._curr = list(mems)
-        self._append_bank([m[2][0] for m in mems], [m[2][1] for m in mems])
+        # the reference frame memorises itself (aot_engine.py:243-251): K and the id-fused V go to the next bank slot
+        slot = self._next_slot()
+        self._ensure_bank(slot + 1)
+        direct = self._direct()
+        dst = self._slot_views(slot) if direct else self._scratch_set()
+        self._dec_in, mems = self.AOT.LSTT.run(x16, None, None, id_emb, self.pos_emb, self.enc_size_2d, self.AOT.ws, stream,
+                                               B=self.lanes, dst=dst)
+        self._curr = mems
+        if not direct:
+            self._store(dst, slot)
+        self._commit(slot)
+        self._curr_slot = None
+        self._dst = dst
         self.last_mem_step = self.frame_step
-        st = [(m[3][0], m[3][1]) for m in mems]
-        self.short_term_memories_list = [st]
-        self.short_term_memories = st
+        rows = self._brows_bank() if direct else self.enc_hw
+        self._short = [[(k, v, rows) for k, v in dst]]
 
     def match_propogate_one_frame(self, img=None, img_embs=None):
         self.frame_step += 1
         feats = self._encode(img, img_embs)
         stream = aot_hip.stream_ptr()
-        lm = list(zip(self.bank_k, self.bank_v))
-        self._dec_in, outs, mems = self.AOT.LSTT.run(feats[3][0], lm, self.short_term_memories, None, self.pos_emb,
-                                                     self.enc_size_2d, self.AOT.ws, stream, t_long=self.bank_len)
-        self._curr = list(mems)
+        T, brows = self.bank_len, self._brows_bank()
+        long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+        # a frame that update_memory will memorise gets its K / V written straight into its bank slot
+        self._curr_slot = None
+        if self._direct() and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            slot = self._next_slot()
+            self._ensure_bank(slot + 1)
+            if self._bank[0][0].shape[1] != brows:       # the bank was re-allocated: refresh the views
+                brows = self._brows_bank()
+                long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+            self._curr_slot = slot
+            dst = self._slot_views(slot)
+        else:
+            dst = self._scratch_set()
+        self._dst = dst
+        self._dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, self._short[0], None, self.pos_emb, self.enc_size_2d,
+                                               self.AOT.ws, stream, B=self.lanes, dst=dst)
+        self._curr = mems
+
+    def decode_stride4(self):
+        """Runs the decoder for the cohort's lanes: stride-4 logits [lanes*h4*w4, max_obj+1] (a scratch view), h4, w4."""
+        f4, f8, f16, _ = self._feats
+        return self.AOT.decoder.run(self._dec_in, f16, f8, f4, self.AOT.ws, aot_hip.stream_ptr(), B=self.lanes)
 
     def decode_current_logits(self, output_size=None):
-        stream = aot_hip.stream_ptr()
-        f4, f8, f16, _ = self._feats
-        dec = self.AOT.decoder
-        logits, h4, w4 = dec.run(self._dec_in, f16, f8, f4, self.AOT.ws, stream)
-        nc = logits.shape[1]
-        dev = logits.device
-        obj_num = int(self.obj_nums[0])
-        out4 = torch.empty(1, nc, h4, w4, dtype=torch.float32, device=dev)
-        out = None
-        if output_size is not None:
-            oh, ow = int(output_size[0]), int(output_size[1])
-            out = torch.empty(1, nc, oh, ow, dtype=torch.float32, device=dev)
-            aot_hip.logits_finalize(logits, out4, out, h4, w4, nc, oh, ow, obj_num, self.align_corners, stream=stream)
-        else:
-            aot_hip.logits_finalize(logits, out4, None, h4, w4, nc, 0, 0, obj_num, self.align_corners, stream=stream)
-        self.pred_id_logits = out4
-        return out if out is not None else out4
+        """Single-cohort form of the reference call (aot_engine.py:356-380)."""
+        logits, h4, w4 = self.decode_stride4()
+        return _finalize(self, [self], logits, h4, w4, output_size, aot_hip.stream_ptr())
 
     def update_long_term_memory(self, new_long_term_memories):
-        """Reference signature (aot_engine.py:291-305): list over layers of [K, V] ([N,1,C]); appended."""
-        self._append_bank([to_tokens(m[0]) for m in new_long_term_memories],
-                          [to_tokens(m[1]) for m in new_long_term_memories])
+        """Reference signature (aot_engine.py:291-305): list over layers of [K, V] ([N,1,C]), lane 0; appended."""
+        slot = self._next_slot()
+        self._ensure_bank(slot + 1)
+        self._store([(to_tokens(m[0]).contiguous(), to_tokens(m[1]).contiguous()) for m in new_long_term_memories], slot)
+        self._commit(slot)
 
     def update_short_term_memory(self, curr_mask, curr_id_emb=None, skip_long_term_update=False):
-        if curr_id_emb is None:
-            curr_id_emb = self.assign_identity(curr_mask)
-        else:
-            curr_id_emb = to_tokens(curr_id_emb)
-        self.curr_id_embs = curr_id_emb
+        if curr_id_emb is not None:
+            raise NotImplementedError('pre-computed identity embeddings: pass the label map, the gather is fused')
+        if curr_mask.dim() == 4 and curr_mask.shape[1] != 1:
+            raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
         stream = aot_hip.stream_ptr()
-        fused = [self.AOT.LSTT.layers[i].update_memory_kv(m, curr_id_emb, self.AOT.ws, stream)
-                 for i, m in enumerate(self._curr)]
-        self.short_term_memories_list.append(fused)
-        self.short_term_memories_list = self.short_term_memories_list[-self.short_term_mem_skip:]
-        self.short_term_memories = self.short_term_memories_list[0]
+        dst = self._dst
+        self.AOT.update_memory_values(self._curr, curr_mask, self.enc_size_2d, self.lanes, self.group0,
+                                      [d[1] for d in dst], stream)
+        in_bank = self._curr_slot is not None
+        rows = self._brows_bank() if in_bank else self.enc_hw
+        self._push_short([(k, v, rows) for k, v in dst])
         if self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
             if not skip_long_term_update:
-                self._append_bank([f[0] for f in fused], [f[1] for f in fused])
+                if in_bank:
+                    self._commit(self._curr_slot)
+                else:
+                    slot = self._next_slot()
+                    self._ensure_bank(slot + 1)
+                    self._store(dst, slot)
+                    self._commit(slot)
+            elif in_bank:
+                # the slot is not kept: move this frame's K / V out before the next memorised frame overwrites it
+                keep = self._scratch_set()
+                for (k2, v2), (k, v) in zip(keep, dst):
+                    k2.copy_(k[:self.enc_hw])
+                    v2.copy_(v[:self.enc_hw])
+                self._short[-1] = [(k, v, self.enc_hw) for k, v in keep]
             self.last_mem_step = self.frame_step
+        self._curr_slot = None
 
     def predict_current_mask(self, output_size=None, return_prob=False):
         if output_size is None:
@@ -233,113 +338,182 @@ class AOTEngine(nn.Module):
         return pred_mask, torch.softmax(logits, dim=1)
 
 
+def _finalize(owner, cohorts, logits, h4, w4, output_size, stream):
+    """Masks unused ids, writes pred_id_logits ([G, C, h4, w4]) and the output-size logits of all G lanes: plain logits for
+    one group, the reference's soft aggregation (aot_engine.py:565-582) for several -- one kernel either way.  The cohorts
+    hold consecutive object groups; every group but the last is full, so the object count of the lanes in view is the sum
+    of the cohorts' counts."""
+    nc = logits.shape[1]
+    G = sum(c.lanes for c in cohorts)
+    dev = logits.device
+    objects = sum(c._group_objects() for c in cohorts)
+    out4 = torch.empty(G, nc, h4, w4, dtype=torch.float32, device=dev)
+    out = None
+    oh = ow = 0
+    if output_size is not None:
+        oh, ow = int(output_size[0]), int(output_size[1])
+        out = torch.empty(1, nc if G == 1 else 1 + G * (nc - 1), oh, ow, dtype=torch.float32, device=dev)
+    aot_hip.logits_finalize(logits, out4, out, h4, w4, nc, oh, ow, objects, owner.align_corners, G=G, stream=stream)
+    g = 0
+    for c in cohorts:
+        c.pred_id_logits = out4[g:g + c.lanes]
+        g += c.lanes
+    if out is not None:
+        return out
+    if G == 1:
+        return out4
+    raise NotImplementedError('stride-4 aggregation of several object groups: pass an output_size')
+
+
 class DeAOTEngine(AOTEngine):
     """reference networks/engines/deaot_engine.py:9-56.  The memory layout differences of DeAOT ([K 128 | V 512 | ID_V 512]
-    per token, only ID_V refreshed at update time) live in GatedPropagationModule.update_memory_kv / run; the state
-    machine is the same."""
+    per token, only ID_V refreshed at update time) live in the model (DeAOT.update_memory_values / mem_widths) and in
+    GatedPropagationModule.run; the state machine is the same."""
+
+
+class _GroupView:
+    """What callers read from `engine.aot_engines[g]` (reference: one AOTEngine per object group): a window on lane `lane`
+    of a cohort."""
+
+    def __init__(self, cohort, lane):
+        self._c, self._lane = cohort, lane
+
+    def __getattr__(self, name):
+        return getattr(self._c, name)
+
+    @property
+    def pred_id_logits(self):
+        p = self._c.pred_id_logits
+        return None if p is None else p[self._lane:self._lane + 1]
+
+    def lstt_last(self):
+        return self._c.lstt_last(self._lane)
 
 
 class AOTInferEngine(nn.Module):
-    """Caller-facing engine (reference aot_engine.py:485-635): one AOTEngine per group of max_aot_obj_num
-    objects, created lazily; the image embedding is computed once per frame and shared."""
+    """Caller-facing engine (reference aot_engine.py:485-635) for any number of objects."""
 
-    engine_cls = AOTEngine
+    cohort_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
                  long_term_mem_max=None):
         super().__init__()
-        self.long_term_mem_max = long_term_mem_max       # bounded bank per object group (repo extension)
         self.cfg = aot_model.cfg
         self.AOT = aot_model
-        if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
-            self.max_aot_obj_num = aot_model.max_obj_num
-        else:
-            self.max_aot_obj_num = max_aot_obj_num
+        if max_aot_obj_num is not None and max_aot_obj_num < aot_model.max_obj_num:
+            raise NotImplementedError('groups narrower than the identity bank (max_aot_obj_num < MODEL_MAX_OBJ_NUM)')
+        self.max_aot_obj_num = aot_model.max_obj_num
         self.gpu_id = gpu_id
         self.long_term_mem_gap = long_term_mem_gap
         self.short_term_mem_skip = short_term_mem_skip
-        self.aot_engines = []
+        self.long_term_mem_max = long_term_mem_max       # bounded bank per object group (repo extension)
+        self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
+        self._cohorts = []
+        self._spare = []             # cohorts of the previous clip: their bank buffers are re-used (no allocator traffic)
         self.restart_engine()
 
+    # ---- reference attributes ------------------------------------------------------------------
+    @property
+    def aot_engines(self):
+        return [_GroupView(c, i) for c in self._cohorts for i in range(c.lanes)]
+
     def restart_engine(self):
-        del (self.aot_engines)
-        self.aot_engines = []
+        self._spare = self._cohorts + self._spare
+        self._cohorts = []
         self.obj_nums = None
+        self.input_size_2d = self.enc_size_2d = self.enc_hw = None
 
-    def separate_mask(self, mask, obj_nums):
-        if mask is None:
-            return [None] * len(self.aot_engines)
-        if len(self.aot_engines) == 1:
-            return [mask], [obj_nums]
-        separated_obj_nums = [self.max_aot_obj_num for _ in range(len(self.aot_engines))]
-        if obj_nums % self.max_aot_obj_num > 0:
-            separated_obj_nums[-1] = obj_nums % self.max_aot_obj_num
-        if len(mask.size()) == 3 or mask.size()[0] == 1:
-            separated_masks = []
-            for idx in range(len(self.aot_engines)):
-                start_id = idx * self.max_aot_obj_num + 1
-                end_id = (idx + 1) * self.max_aot_obj_num
-                fg_mask = ((mask >= start_id) & (mask <= end_id)).float()
-                separated_masks.append((fg_mask * mask - start_id + 1) * fg_mask)
-            return separated_masks, separated_obj_nums
-        raise NotImplementedError('probability-map masks (aot_engine.py:536-545) are not on the scoped path')
+    def _new_cohort(self, lanes, group0):
+        for i, c in enumerate(self._spare):
+            if c.lanes == lanes and c.first_group == group0:
+                self._spare.pop(i)
+                c.restart_engine()
+                return c
+        c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip, self.long_term_mem_max,
+                            lanes=lanes, group0=group0)
+        c.eval()
+        return c
 
-    def soft_logit_aggregation(self, all_logits):
-        """aot_engine.py:565-582.  Identity for <=10 objects (the scoped configs); the multi-group merge is
-        host-side torch plumbing for now."""
-        if len(all_logits) == 1:
-            return all_logits[0]
-        fg_probs, bg_probs = [], []
-        for logit in all_logits:
-            prob = torch.softmax(logit, dim=1)
-            bg_probs.append(prob[:, 0:1])
-            fg_probs.append(prob[:, 1:1 + self.max_aot_obj_num])
-        bg_prob = torch.prod(torch.cat(bg_probs, dim=1), dim=1, keepdim=True)
-        merged_prob = torch.cat([bg_prob] + fg_probs, dim=1).clamp(1e-5, 1 - 1e-5)
-        return torch.logit(merged_prob)
+    def _groups_needed(self, obj_nums):
+        return max(-(-int(obj_nums) // self.max_aot_obj_num), 1)
+
+    def _set_counts(self):
+        """Every cohort learns how many of the clip's objects fall into its lanes.  With a single group the label map is
+        used as it is (labels beyond max_obj_num contribute nothing, utils/image.py:69-74); with several, every group sees
+        the other groups' pixels as background (separate_mask, aot_engine.py:515-534)."""
+        k = self.max_aot_obj_num
+        single = sum(c.lanes for c in self._cohorts) == 1
+        for c in self._cohorts:
+            c.obj_nums = [max(0, min(self.obj_nums - c.first_group * k, c.lanes * k))]
+            c.group0 = None if single else c.first_group
 
     def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
-        if isinstance(obj_nums, list):
+        if isinstance(obj_nums, (list, tuple)):
             obj_nums = obj_nums[0]
-        self.obj_nums = obj_nums
-        aot_num = max(np.ceil(obj_nums / self.max_aot_obj_num), 1)
-        while aot_num > len(self.aot_engines):
-            new_engine = self.engine_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
-                                         self.long_term_mem_max)
-            new_engine.eval()
-            self.aot_engines.append(new_engine)
-        separated_masks, separated_obj_nums = self.separate_mask(mask, obj_nums)
+        self.obj_nums = int(obj_nums)
+        have = sum(c.lanes for c in self._cohorts)
+        need = self._groups_needed(self.obj_nums)
+        if need > have:      # first frame: one cohort for every group; later: the groups opened by new objects
+            self._cohorts.append(self._new_cohort(need - have, have))
+        self._set_counts()
         img_embs = None
-        for aot_engine, separated_mask, separated_obj_num in zip(self.aot_engines, separated_masks,
-                                                                 separated_obj_nums):
-            aot_engine.add_reference_frame(img, separated_mask, obj_nums=[separated_obj_num], frame_step=frame_step,
-                                           img_embs=img_embs)
+        for c in self._cohorts:
+            c.add_reference_frame(img, mask, frame_step=frame_step, obj_nums=c.obj_nums, img_embs=img_embs)
             if img_embs is None:
-                img_embs = aot_engine.curr_enc_embs
-        self.update_size()
+                img_embs = c.curr_enc_embs
+        first = self._cohorts[0]
+        self.input_size_2d, self.enc_size_2d, self.enc_hw = first.input_size_2d, first.enc_size_2d, first.enc_hw
 
     def match_propogate_one_frame(self, img=None):
         img_embs = None
-        for aot_engine in self.aot_engines:
-            aot_engine.match_propogate_one_frame(img, img_embs=img_embs)
+        for c in self._cohorts:
+            c.match_propogate_one_frame(img, img_embs=img_embs)
             if img_embs is None:
-                img_embs = aot_engine.curr_enc_embs
+                img_embs = c.curr_enc_embs
 
     def decode_current_logits(self, output_size=None):
-        all_logits = [e.decode_current_logits(output_size) for e in self.aot_engines]
-        return self.soft_logit_aggregation(all_logits)
+        stream = aot_hip.stream_ptr()
+        if len(self._cohorts) == 1:
+            logits, h4, w4 = self._cohorts[0].decode_stride4()
+        else:       # several cohorts: their stride-4 logits are gathered lane after lane into one buffer
+            parts = []
+            for c in self._cohorts:
+                lg, h4, w4 = c.decode_stride4()
+                parts.append((lg.clone(), h4, w4))          # the decoder's output scratch is shared by the cohorts
+            h4, w4 = parts[0][1], parts[0][2]
+            buf = torch.empty(sum(p[0].shape[0] for p in parts), parts[0][0].stride(0), dtype=torch.float32,
+                              device=parts[0][0].device)
+            r = 0
+            for lg, _, _ in parts:
+                buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
+                r += lg.shape[0]
+            logits = buf[:, :parts[0][0].shape[1]]
+        return _finalize(self, self._cohorts, logits, h4, w4, output_size, stream)
 
     def update_memory(self, curr_mask, skip_long_term_update=False):
-        separated_masks, _ = self.separate_mask(curr_mask, self.obj_nums)
-        for aot_engine, separated_mask in zip(self.aot_engines, separated_masks):
-            aot_engine.update_short_term_memory(separated_mask, skip_long_term_update=skip_long_term_update)
+        for c in self._cohorts:
+            c.update_short_term_memory(curr_mask, skip_long_term_update=skip_long_term_update)
+
+    # reference helpers kept for callers that use them directly (aot_engine.py:515-582) -----------
+    def separate_mask(self, mask, obj_nums):
+        """Label map -> per-group label maps (the engine itself never materialises them: the identity gather kernel
+        separates on the fly)."""
+        n = self._groups_needed(obj_nums)
+        if n == 1:
+            return [mask], [obj_nums]
+        k = self.max_aot_obj_num
+        counts = [k] * (n - 1) + [obj_nums - k * (n - 1)]
+        outs = []
+        for g in range(n):
+            inside = (mask > g * k) & (mask <= (g + 1) * k)
+            outs.append(torch.where(inside, mask - g * k, torch.zeros_like(mask)))
+        return outs, counts
 
     def update_size(self):
-        self.input_size_2d = self.aot_engines[0].input_size_2d
-        self.enc_size_2d = self.aot_engines[0].enc_size_2d
-        self.enc_hw = self.aot_engines[0].enc_hw
+        first = self._cohorts[0]
+        self.input_size_2d, self.enc_size_2d, self.enc_hw = first.input_size_2d, first.enc_size_2d, first.enc_hw
 
 
 class DeAOTInferEngine(AOTInferEngine):
     """reference networks/engines/deaot_engine.py:59-94."""
-    engine_cls = DeAOTEngine
+    cohort_cls = DeAOTEngine

@@ -18,23 +18,24 @@ _SIMDS = 1024                 # 256 CUs x 4 SIMDs; one 32-query x 1-head (or 1-c
 _OCC_EFF = (0.8, 0.9, 0.97, 0.99, 1.0)   # measured MFMA-pipe fill at 1..5 resident waves per SIMD
 
 
-def attn_splits(nq, units, t, occ=4, c0=3.0):
-    """How many key ranges to cut the bank into (csrc/attention.hip).
+def attn_splits(nq, units, t, occ=4, c0=3.0, wg_waves=1):
+    """How many key ranges to cut the bank into at GRID level (csrc/attention.hip).
 
-    The kernel is bound by the MFMA pipe of each SIMD, so its run time is the MAKESPAN over SIMDs: (waves per SIMD,
+    The kernels are bound by the MFMA pipe of each SIMD, so their run time is the MAKESPAN over SIMDs: (waves per SIMD,
     rounded up) x (key tiles per wave + a fixed per-wave cost c0, in key-tile units).  Measured on MI355X
-    (scratch/mb_attn_sweep.py, N=1674, 8 heads): the time follows this model within a few % for every bank size; the
-    minima are the split counts that land just under a whole number of waves per SIMD -- 7 (371 of 384 slots per XCD)
-    and 12 (636 of 640) -- and 16 splits (6.6 -> 7 waves per SIMD for 46 tiles each) is 20% slower than 12.
-    ``units`` = heads (multi-head form) or value chunks (gated form); ``occ`` = resident waves per SIMD of the kernel
-    (4 for the d=32 kernel; 1 for the wide gated kernel, where extra waves just queue)."""
-    waves1 = ((nq + 31) // 32) * units
+    (N=1674, 8 heads): the time follows this model within a few % for every bank size; the minima are the totals
+    that land just under a whole number of waves per SIMD.  ``nq`` = query rows over all lanes, ``units`` = heads
+    (multi-head form) or value chunks (gated form); ``wg_waves`` = waves of a workgroup that split the workgroup's key
+    range among themselves and merge in LDS (4 for the d=32 kernel: the total key split is 4 x the returned value; 1 for
+    the gated kernels); ``occ`` = resident waves per SIMD (4 for the d=32 kernel; 1 for the wide gated kernel, where
+    extra waves just queue)."""
+    waves1 = ((nq + 31) // 32) * units * wg_waves
     tiles = (t + 31) // 32
     best, best_cost = 1, None
-    for ns in range(1, max(1, min(16, tiles // 4)) + 1):
+    for ns in range(1, max(1, min(16 // wg_waves, tiles // (4 * wg_waves))) + 1):
         k = -(-waves1 * ns // _SIMDS)
         eff = _OCC_EFF[min(k, occ, 5) - 1] if occ > 1 else 1.0
-        cost = k * (-(-tiles // ns) + c0) / eff + (0.15 * ns if ns > 1 else 0.0)   # + merge pass over ns partials
+        cost = k * (-(-tiles // (ns * wg_waves)) + c0) / eff + (0.15 * ns * wg_waves if ns > 1 else 0.0)   # + merge pass
         if best_cost is None or cost < best_cost * 0.999:
             best, best_cost = ns, cost
     return best
@@ -64,9 +65,9 @@ class MultiheadAttention(nn.Module):
             self.linear_V = nn.Linear(d_model, d_model)
         self.projection = nn.Linear(d_model, d_model)
 
-    def core(self, q, k, v, out, t, ws, stream, t_dev=None):
-        """q [Nq, C], k/v [>=t, C] token-major -> out [Nq, C] (pre-projection)."""
-        nq = q.shape[0]
+    def core(self, q, k, v, out, t, ws, stream, t_dev=None, B=1, kv_brows=0):
+        """q [B*Nq, C], k/v token-major (lane b: rows b*kv_brows .. + t) -> out [B*Nq, C] (pre-projection)."""
+        nq = q.shape[0] // B
         scale_div = self.T
         if self.max_mem_len_ratio > 0:
             ratio = float(t) / nq
@@ -74,13 +75,17 @@ class MultiheadAttention(nn.Module):
                 scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
         if 0 < self.top_k < t:
             scores = ws.get('attn_scores', (self.num_head * nq * ((t + 3) // 4 * 4),), q.device)
-            aot_hip.attention_topk(q, k, v, out, t, self.num_head, scale_div, self.top_k, scores, stream=stream)
+            for b in range(B):       # the sparse form is a long-video knob; lanes one at a time
+                kb, vb = k[b * kv_brows:], v[b * kv_brows:]
+                aot_hip.attention_topk(q[b * nq:(b + 1) * nq], kb, vb, out[b * nq:(b + 1) * nq], t, self.num_head,
+                                       scale_div, self.top_k, scores, stream=stream)
             return out
-        ns = attn_splits(nq, self.num_head, t)
+        ns = attn_splits(nq * B, self.num_head, t, wg_waves=4)
         part = None
-        if ns > 1:
-            part = ws.get('attn_part', (ns * nq * (self.d_model + 2 * self.num_head),), q.device)
-        aot_hip.attention(q, k, v, out, t, self.num_head, scale_div, part=part, nsplit=ns, T_dev=t_dev, stream=stream)
+        if ns > 1:      # one slab set sized for the largest grid split (4): no per-bank-size allocations
+            part = ws.get('attn_part', (4 * B * nq * (self.d_model + 2 * self.num_head),), q.device)
+        aot_hip.attention(q, k, v, out, t, self.num_head, scale_div, part=part, nsplit=ns, T_dev=t_dev, B=B,
+                          kv_brows=kv_brows, stream=stream)
         return out
 
 
@@ -114,11 +119,11 @@ class MultiheadLocalAttention(nn.Module):
                                                      self.relative_emb_v, self.num_head, self.max_dis)
         return self._packed
 
-    def core(self, q, k, v, out, size_2d, stream):
+    def core(self, q, k, v, out, size_2d, stream, B=1, kv_brows=0):
         relk_w, relk_b, relv_t = self.pack()
         h, w = size_2d
         aot_hip.local_attention(q, k, v, relk_w, relk_b, relv_t, out, h, w, self.num_head, self.T,
-                                max_dis=self.max_dis, stream=stream)
+                                max_dis=self.max_dis, B=B, kv_brows=kv_brows, stream=stream)
         return out
 
 
@@ -132,8 +137,10 @@ class GatedPropagation(nn.Module):
         super().__init__()
         if num_head != 1:
             raise NotImplementedError('DeAOT configs use a single head (configs/models/default_deaot.py:14-15)')
-        if use_dis or top_k > 0 or max_mem_len_ratio > 0:
-            raise NotImplementedError('default-off eval knobs (attention.py:597-600) are not built')
+        if use_dis:
+            raise NotImplementedError('use_dis is a default-off knob no reference config enables (attention.py:697-698)')
+        self.max_mem_len_ratio = float(max_mem_len_ratio)     # eval-time Q rescale for long banks, attention.py:674-679
+        self.top_k = int(top_k)                               # eval-time sparse softmax, attention.py:689-693
         self.expand_d_vu = int(d_vu * expand_ratio)
         self.d_vu, self.d_qk, self.num_head = d_vu, d_qk, num_head
         self.hidden_dim = self.expand_d_vu // num_head
@@ -161,23 +168,36 @@ class GatedPropagation(nn.Module):
             self._p = p
         return self._p
 
-    def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None):
-        """(softmax((q/T) k^T) v) * gate : q [Nq,128], k [>=t,128], v [>=t,E], gate/out [Nq,E]."""
-        nq = q.shape[0]
-        ns = attn_splits(nq, out.shape[1] // 256, t, occ=1, c0=1.0)
+    def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None, B=1, kv_brows=0):
+        """(softmax((q/T) k^T) v) * gate : q [B*Nq,128], k [.,128], v [.,E], gate/out [B*Nq,E]; lane b reads rows
+        b*kv_brows .. + t of k/v."""
+        nq = q.shape[0] // B
+        scale_div = self.T
+        if self.max_mem_len_ratio > 0:       # Q *= log(ratio)/log(max ratio), folded into the divisor (attention.py:674-679)
+            ratio = float(t) / nq
+            if ratio > self.max_mem_len_ratio:
+                scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
+        if 0 < self.top_k < t:
+            return self._core_topk(q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows)
+        ns = attn_splits(nq * B, out.shape[1] // 256, t, occ=1, c0=1.0)
         part = None
         if ns > 1:
-            part = ws.get('gattn_part', (ns * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)
-        aot_hip.gated_attention(q, k, v, gate, out, t, self.T, part=part, nsplit=ns, T_dev=t_dev, stream=stream)
+            part = ws.get('gattn_part', (16 * B * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)
+        aot_hip.gated_attention(q, k, v, gate, out, t, scale_div, part=part, nsplit=ns, T_dev=t_dev, B=B, kv_brows=kv_brows,
+                                stream=stream)
         return out
 
-    def tail(self, raw, out, size_2d, ws, stream, res=None):
+    def _core_topk(self, q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows):
+        # the sparse kernel (csrc/attn_topk.hip) is built for heads of width 32; the gated form has ONE 128-wide head
+        raise NotImplementedError('top_k of GatedPropagation (attention.py:689-693) is not built; max_mem_len_ratio is')
+
+    def tail(self, raw, out, size_2d, ws, stream, res=None, B=1):
         """projection(dw_conv(raw)) (+ res): attention.py:709-710."""
         p = self.pack()
         h, w = size_2d
         E = raw.shape[1]
         tmp = ws.get('gp_dw', (raw.shape[0], E), raw.device)
-        aot_hip.dwconv2d(raw, p['dw'], None, tmp, h, w, E, h, w, 5, 1, 2, 1, stream=stream)
+        aot_hip.dwconv2d(raw, p['dw'], None, tmp, h, w, E, h, w, 5, 1, 2, 1, B=B, stream=stream)
         aot_hip.linear(tmp, p['proj_w'], p['proj_b'], out, res=res, stream=stream)
         return out
 
@@ -214,12 +234,12 @@ class LocalGatedPropagation(nn.Module):
             self._p = p
         return self._p
 
-    def core(self, q, k, v, gate, out, size_2d, ws, stream):
+    def core(self, q, k, v, gate, out, size_2d, ws, stream, B=1, kv_brows=0):
         p = self.pack()
         h, w = size_2d
-        prob = ws.get('lgp_prob', (self.window_size * self.window_size * h * w,), q.device)
-        aot_hip.local_gated(q, k, v, gate, p['relk_t'], p['relk_b'], prob, out, h, w, self.T, max_dis=self.max_dis,
-                            stream=stream)
+        prob = ws.get('lgp_prob', (B * self.window_size * self.window_size * h * w,), q.device)
+        aot_hip.local_gated(q, k, v, gate, p['relk_t'], p['relk_b'], prob, out, h, w, self.T, max_dis=self.max_dis, B=B,
+                            kv_brows=kv_brows, stream=stream)
         return out
 
     tail = GatedPropagation.tail

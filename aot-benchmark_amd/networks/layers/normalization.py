@@ -5,6 +5,8 @@ bias once, at ``prepare()`` time, so no kernel is ever launched for it."""
 import torch
 from torch import nn
 
+from aot_hip import attach_wt
+
 
 class FrozenBatchNorm2d(nn.Module):
     def __init__(self, n, epsilon=1e-5):
@@ -38,7 +40,7 @@ def fold_conv_bn(conv, bn=None, pad_cin=None):
     ldb = (cout + 3) // 4 * 4
     out = torch.zeros(kh * kw * cin, ldb, dtype=torch.float32, device=w.device)
     out[:, :cout] = wk.float()
-    return out, b.float().contiguous()
+    return attach_wt(out, cin), b.float().contiguous()
 
 
 def fold_dwconv_bn(conv, bn=None):
@@ -56,4 +58,5 @@ def fold_dwconv_bn(conv, bn=None):
 
 def linear_t(lin):
     """nn.Linear -> (W^T [in, out] fp32 contiguous, bias)."""
-    return lin.weight.detach().t().contiguous().float(), (None if lin.bias is None else lin.bias.detach().float().contiguous())
+    return (attach_wt(lin.weight.detach().t().contiguous().float()),
+            (None if lin.bias is None else lin.bias.detach().float().contiguous()))

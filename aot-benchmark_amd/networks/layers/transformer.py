@@ -1,10 +1,15 @@
-"""LSTT stack of AOT (reference networks/layers/transformer.py:33-140, 258-372).
+"""LSTT stack of AOT and GPM stack of DeAOT (reference networks/layers/transformer.py:33-140, 143-255, 258-372, 501-670).
 
-Per-layer launch sequence on the HIP path (token-major [N, C] activations, N = h*w):
+Every activation is token-major [B*N, C]: B LANES stacked along the rows -- the object groups of one frame (each group of
+<= 10 objects is an independent pass over the SAME image features, reference AOTInferEngine, aot_engine.py:584-616) run
+as one batch through every kernel instead of one engine after the other.  Memories are (tensor, rows-between-lanes)
+pairs, so a lane's keys can live in its bank slot or in a stacked scratch buffer.
+
+Per-layer launch sequence of the AOT block (N = h*w):
   LN1 (+pos, two outputs) -> [Q|K] GEMM, V GEMM -> flash self-attention -> projection GEMM (+residual)
   LN2 -> linear_Q GEMM -> flash long-term attention over the bank  +  fused windowed short-term attention
-  (both write halves of one [N, 512] buffer) -> one K=512 GEMM = proj_lt + proj_st (+residual)
-  LN3 -> linear1 GEMM -> GroupNorm(32)+GELU -> 5x5 depthwise conv -> linear2 GEMM (+residual)
+  (both write halves of one [B*N, 512] buffer) -> one K=512 GEMM = proj_lt + proj_st (+residual)
+  LN3 -> linear1 GEMM -> GroupNorm statistics -> [GN-apply + GELU + 5x5 depthwise conv] -> linear2 GEMM (+residual)
 """
 import torch
 from torch import nn
@@ -71,78 +76,87 @@ class LongShortTermTransformerBlock(nn.Module):
         return p
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
-    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, t_long=None):
-        """x [N, C(ld)] token-major.  long_mem = (K, V) token-major [>=T, C] with T = t_long;
-        short_mem = (K, V) [N, C].  Returns (out [N,C], curr_K, curr_V, global (K,V,T), local (K,V))."""
+    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+        """x [B*N, C(ld)] token-major (B lanes).  long_mem = (K, V, T, kv_brows): lane b's bank = rows b*kv_brows .. + T;
+        short_mem = (K, V, kv_brows).  dst = (k_out, v_out) [B*N, C] buffers for this frame's K (= linear_Q output) and, on
+        a reference frame, the id-fused V (e.g. the lane's bank slot); allocated when None.
+        Returns (out [B*N,C], curr_K, curr_V (normed input), fused_V or None)."""
         p = self.pack()
-        N, C = x.shape
+        M, C = x.shape
+        N = M // B
         dev = x.device
         h, w = size_2d
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # tensors that outlive this call
 
         # self-attention
-        x1 = ws.get('x1', (N, C), dev)
-        x1p = ws.get('x1p', (N, C), dev)
-        aot_hip.layernorm(x, *p['norm1'], x1, add=pos, out2=x1p, stream=stream)
-        qk = ws.get('sa_qk', (N, 2 * C), dev)
+        x1 = ws.get('x1', (M, C), dev)
+        x1p = ws.get('x1p', (M, C), dev)
+        aot_hip.layernorm(x, *p['norm1'], x1, add=pos, out2=x1p, add_rows=N, stream=stream)
+        qk = ws.get('sa_qk', (M, 2 * C), dev)
         aot_hip.linear(x1p, p['sa_qk_w'], p['sa_qk_b'], qk, stream=stream)
-        sv = ws.get('sa_v', (N, C), dev)
+        sv = ws.get('sa_v', (M, C), dev)
         aot_hip.linear(x1, p['sa_v_w'], p['sa_v_b'], sv, stream=stream)
-        so = ws.get('sa_o', (N, C), dev)
-        self.self_attn.core(qk[:, :C], qk[:, C:], sv, so, N, ws, stream)
-        xa = ws.get('xa', (N, C), dev)
+        so = ws.get('sa_o', (M, C), dev)
+        self.self_attn.core(qk[:, :C], qk[:, C:], sv, so, N, ws, stream, B=B, kv_brows=N)
+        xa = ws.get('xa', (M, C), dev)
         aot_hip.linear(so, p['sa_o_w'], p['sa_o_b'], xa, res=x, stream=stream)
 
         # long + short term attention
-        x2 = new(N, C)                                            # curr_V (normed input, transformer.py:333)
+        x2 = new(M, C)                                            # curr_V (normed input, transformer.py:333)
         aot_hip.layernorm(xa, *p['norm2'], x2, stream=stream)
-        qc = new(N, C)                                            # curr_Q == curr_K (:331-332)
+        qc = dst[0] if dst is not None else new(M, C)             # curr_Q == curr_K (:331-332)
         aot_hip.linear(x2, p['q_w'], p['q_b'], qc, stream=stream)
+        fused_v = None
         if id_emb is not None:                                    # reference frame: memorise itself (:337-341)
-            gk, gv = qc, self.fuse_kv_2d(x2, id_emb, ws, stream)
-            lk, lv, t = gk, gv, N
+            fused_v = self.fuse_kv_2d(x2, id_emb, ws, stream, out=dst[1] if dst is not None else None)
+            gk, gv, t, g_brows = qc, fused_v, N, N
+            lk, lv, l_brows = qc, fused_v, N
         else:
-            gk, gv = long_mem
-            lk, lv = short_mem
-            t = t_long if t_long is not None else gk.shape[0]
-        cat = ws.get('lst_cat', (N, 2 * C), dev)
-        self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream)
-        self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream)
-        xb = ws.get('xb', (N, C), dev)
+            gk, gv, t, g_brows = long_mem
+            lk, lv, l_brows = short_mem
+        cat = ws.get('lst_cat', (M, 2 * C), dev)
+        self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream, B=B, kv_brows=g_brows)
+        self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream, B=B, kv_brows=l_brows)
+        xb = ws.get('xb', (M, C), dev)
         aot_hip.linear(cat, p['lst_w'], p['lst_b'], xb, res=xa, stream=stream)
 
-        # feed-forward: linear1 -> GN(32)+GELU -> dw5x5 -> linear2
-        x3 = ws.get('x3', (N, C), dev)
+        # feed-forward: linear1 -> GN(32) statistics -> [GN-apply + GELU + dw5x5] -> linear2
+        x3 = ws.get('x3', (M, C), dev)
         aot_hip.layernorm(xb, *p['norm3'], x3, stream=stream)
         F1 = self.dim_ff
-        f = ws.get('ffn_a', (N, F1), dev)
+        f = ws.get('ffn_a', (M, F1), dev)
         aot_hip.linear(x3, p['w1'], p['b1'], f, stream=stream)
-        g = ws.get('ffn_b', (N, F1), dev)
-        aot_hip.groupnorm(f, *p['gn'], g, 32, ws.get('gn_scratch', (32 * 64 * 2,), dev, torch.float64),
-                          ws.get('gn_stats', (64,), dev, torch.float64), act=aot_hip.ACT_GELU, nsplit=32, stream=stream)
-        aot_hip.dwconv2d(g, p['dw'], None, f, h, w, F1, h, w, 5, 1, 2, 1, stream=stream)
-        out = ws.get('layer_out_%d' % id(self), (N, C), dev)
-        aot_hip.linear(f, p['w2'], p['b2'], out, res=xb, stream=stream)
-        return out, qc, x2, (gk, gv, t), (lk, lv)
+        g = ws.get('ffn_b', (M, F1), dev)
+        if F1 == 32 * 32:
+            aot_hip.gn_act_dwconv5(f, *p['gn'], p['dw'], g, 32, aot_hip.gn_buffers(ws, dev, B, 32, 8), h, w,
+                                   act=aot_hip.ACT_GELU, nsplit=8, B=B, stream=stream)
+        else:       # generic widths: GN-apply + GELU, then the depthwise conv
+            aot_hip.groupnorm(f, *p['gn'], g, 32, aot_hip.gn_buffers(ws, dev, B, 32, 8), act=aot_hip.ACT_GELU, nsplit=8,
+                              B=B, stream=stream)
+            f2 = ws.get('ffn_c', (M, F1), dev)
+            aot_hip.dwconv2d(g, p['dw'], None, f2, h, w, F1, h, w, 5, 1, 2, 1, B=B, stream=stream)
+            g = f2
+        out = ws.get('layer_out_%d' % id(self), (M, C), dev)
+        aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
+        return out, qc, x2, fused_v
 
-    def fuse_kv_2d(self, v, id_emb, ws, stream):
+    def fuse_kv_2d(self, v, id_emb, ws, stream, out=None, summed=None):
+        """linear_V(V + id_emb) (transformer.py:364-367).  `summed` = V + id_emb already formed (fused id-bank launch)."""
         p = self.pack()
-        N, C = v.shape
-        tmp = ws.get('fuse_tmp', (N, C), v.device)
-        aot_hip.add(v, id_emb, tmp, stream=stream)
-        out = torch.empty(N, C, dtype=torch.float32, device=v.device)
-        aot_hip.linear(tmp, p['v_w'], p['v_b'], out, stream=stream)
+        M, C = v.shape
+        if summed is None:
+            summed = ws.get('fuse_tmp', (M, C), v.device)
+            aot_hip.add(v, id_emb, summed, stream=stream)
+        if out is None:
+            out = torch.empty(M, C, dtype=torch.float32, device=v.device)
+        aot_hip.linear(summed, p['v_w'], p['v_b'], out, stream=stream)
         return out
-
-    def update_memory_kv(self, mem, id_emb, ws, stream):
-        """Engine hook after the frame's mask is known (aot_engine.py:317-327): (curr_K, curr_V) -> memorised (K, V)."""
-        ck, cv = mem[0], mem[1]
-        return ck, self.fuse_kv_2d(cv, id_emb, ws, stream)
 
     def fuse_key_value_id(self, key, value, id_emb):
         """Reference API (transformer.py:364-367): K unchanged, V <- linear_V(V + id_emb); [N,1,C] tensors."""
         n, b, c = value.shape
-        v2 = self.fuse_kv_2d(value.reshape(n * b, c), id_emb.reshape(n * b, c).contiguous(), self._ws(), aot_hip.stream_ptr())
+        v2 = self.fuse_kv_2d(value.reshape(n * b, c).contiguous(), id_emb.reshape(n * b, c).contiguous(), self._ws(),
+                             aot_hip.stream_ptr())
         return key, v2.view(n, b, c)
 
     def _ws(self):
@@ -171,21 +185,22 @@ class LongShortTermTransformer(nn.Module):
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, t_long=None):
-        """Runs the stack on the projected encoder feature x0 [N, C].  Returns (dec_in, outs, mems): dec_in is the
-        decoder's concatenated input [N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0, blocks 1.. = the layer
-        outputs after their decoder norm (transformer.py:124-135), written in place so the concat is never a copy."""
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+        """Runs the stack for B lanes on the projected encoder feature x0 [N, C] (shared by the lanes).  Returns
+        (dec_in, mems): dec_in is the decoder's concatenated input [B*N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0,
+        blocks 1.. = the layer outputs after their decoder norm (transformer.py:124-135), written in place so the concat is
+        never a copy; mems[i] = (curr_K, curr_V, fused_V | None) of layer i."""
         N, C = x0.shape
         L = self.num_layers
-        out_cat = torch.empty(N, (L + 1) * C, dtype=torch.float32, device=x0.device)
-        out_cat[:, :C].copy_(x0)
+        out_cat = torch.empty(B * N, (L + 1) * C, dtype=torch.float32, device=x0.device)
+        out_cat.view(B, N, (L + 1) * C)[:, :, :C].copy_(x0)      # the same image feature for every lane
         x = out_cat[:, :C]
-        outs, mems = [], []
+        mems = []
         for i, layer in enumerate(self.layers):
-            x, ck, cv, glob, loc = layer.run(x, long_mems[i] if long_mems is not None else None,
-                                             short_mems[i] if short_mems is not None else None,
-                                             id_emb, pos, size_2d, ws, stream, t_long)
-            mems.append((ck, cv, glob, loc))
+            x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
+                                      short_mems[i] if short_mems is not None else None,
+                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None)
+            mems.append((ck, cv, fv))
             is_last = i == L - 1
             norm = None
             if self.decoder_norms is not None:
@@ -193,13 +208,18 @@ class LongShortTermTransformer(nn.Module):
                     norm = self.decoder_norms[-1]
                 elif not is_last and self.return_intermediate and self.intermediate_norm:
                     norm = self.decoder_norms[i]
-            dst = out_cat[:, (i + 1) * C:(i + 2) * C]
+            d = out_cat[:, (i + 1) * C:(i + 2) * C]
             if norm is not None:
-                aot_hip.layernorm(x, norm.weight, norm.bias, dst, stream=stream)
+                aot_hip.layernorm(x, norm.weight, norm.bias, d, stream=stream)
             else:
-                dst.copy_(x)
-            outs.append(dst)
-        return out_cat, outs, mems
+                d.copy_(x)
+        return out_cat, mems
+
+    def update_values(self, mems, id_sums, ws, stream, dst=None):
+        """Memory update of every layer once the frame's mask is known (aot_engine.py:307-338): V <- linear_V(V + id_emb)
+        with the sums V + id_emb already formed by the fused id-bank launch.  dst[i] = where layer i's fused V goes."""
+        return [self.layers[i].fuse_kv_2d(m[1], None, ws, stream, out=dst[i] if dst is not None else None, summed=id_sums[i])
+                for i, m in enumerate(mems)]
 
 
 class GatedPropagationModule(nn.Module):
@@ -269,68 +289,65 @@ class GatedPropagationModule(nn.Module):
             aot_hip.linear(id_emb, p['idv_w_id'], None, dst, res=tmp, act=aot_hip.ACT_SILU, stream=stream)
         return vcat
 
-    def update_memory_kv(self, mem, id_emb, ws, stream):
-        """deaot_engine.py:29-45: only ID_V is refreshed with the new identity embedding; K, V stay."""
-        ck, vcat, xi = mem[0], mem[1], mem[4]
-        return ck, self.fuse_id_into(vcat, xi, id_emb, ws, stream)
-
-    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, t_long=None):
-        """X [N, 2D] = [tgt | tgt_id] (tgt_id = 0 into layer 0).  Returns (X_out, curr_K, curr_Vcat, glob, loc, curr_ID_V)."""
+    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+        """X [B*N, 2D] = [tgt | tgt_id] (tgt_id = 0 into layer 0), B lanes.  long_mem = (K, Vcat, T, kv_brows), short_mem =
+        (K, Vcat, kv_brows); dst = (k_out [B*N, d_att], vcat_out [B*N, 2E]) for this frame's K and [V | ID_V].
+        Returns (X_out, curr_K, curr_Vcat, curr_ID_V_input)."""
         p = self.pack()
-        N = X.shape[0]
+        M = X.shape[0]
+        N = M // B
         D, E, da = self.d_model, self.expand_d_model, self.d_att
         dev = X.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        x1 = ws.get('gpm_x1', (N, D), dev)
+        x1 = ws.get('gpm_x1', (M, D), dev)
         aot_hip.layernorm(X[:, :D], *p['norm1'], x1, stream=stream)
-        qc = new(N, da)                                                     # curr_Q == curr_K (:597)
+        qc = dst[0] if dst is not None else new(M, da)                      # curr_Q == curr_K (:597)
         aot_hip.linear(x1, p['q_w'], p['q_b'], qc, stream=stream)
-        vcat = new(N, 2 * E)                                                # [curr_V | ID_V]
+        vcat = dst[1] if dst is not None else new(M, 2 * E)                 # [curr_V | ID_V]
         aot_hip.linear(x1, p['v_w'], p['v_b'], vcat[:, :E], act=aot_hip.ACT_SILU, stream=stream)
         if self.layer_idx == 0:                                             # U = [silu(U) | 1] (:602-606)
             nbuf = len(ws._bufs)
-            U = ws.get('gpm_U0', (N, 2 * E), dev)
+            U = ws.get('gpm_U0', (M, 2 * E), dev)
             if len(ws._bufs) != nbuf:          # freshly allocated: set the constant half once
                 U[:, E:].fill_(1.0)
             aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
             xi = None
         else:                                                               # U = silu([U | linear_ID_U(LN(tgt_id))]) (:608-611)
-            xi = new(N, D)
+            xi = new(M, D)
             aot_hip.layernorm(X[:, D:], *p['id_norm1'], xi, stream=stream)
-            U = ws.get('gpm_U', (N, 2 * E), dev)
+            U = ws.get('gpm_U', (M, 2 * E), dev)
             aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
             aot_hip.linear(xi, p['idu_w'], p['idu_b'], U[:, E:], act=aot_hip.ACT_SILU, stream=stream)
         if id_emb is not None:                                              # reference frame (:613-620)
             self.fuse_id_into(vcat, xi, id_emb, ws, stream)
-            gk, gv, t = qc, vcat, N
-            lk, lv = qc, vcat
+            gk, gv, t, g_brows = qc, vcat, N, N
+            lk, lv, l_brows = qc, vcat, N
         else:
-            gk, gv = long_mem
-            lk, lv = short_mem
-            t = t_long if t_long is not None else gk.shape[0]
-        raw = ws.get('gpm_raw', (N, 2 * E), dev)
-        self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream)
-        Xm = ws.get('gpm_Xm', (N, 2 * D), dev)
-        self.long_term_attn.tail(raw, Xm, size_2d, ws, stream, res=X)      # X + lt
-        self.short_term_attn.core(qc, lk, lv, U, raw, size_2d, ws, stream)
-        self.short_term_attn.tail(raw, Xm, size_2d, ws, stream, res=Xm)     # + st   (:633-641)
+            gk, gv, t, g_brows = long_mem
+            lk, lv, l_brows = short_mem
+        raw = ws.get('gpm_raw', (M, 2 * E), dev)
+        self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream, B=B, kv_brows=g_brows)
+        Xm = ws.get('gpm_Xm', (M, 2 * D), dev)
+        self.long_term_attn.tail(raw, Xm, size_2d, ws, stream, res=X, B=B)      # X + lt
+        self.short_term_attn.core(qc, lk, lv, U, raw, size_2d, ws, stream, B=B, kv_brows=l_brows)
+        self.short_term_attn.tail(raw, Xm, size_2d, ws, stream, res=Xm, B=B)     # + st   (:633-641)
         # self gated propagation on [LN(tgt) | LN(tgt_id)]  (:643-653)
-        z = ws.get('gpm_z', (N, 2 * D), dev)
+        z = ws.get('gpm_z', (M, 2 * D), dev)
         aot_hip.layernorm(Xm[:, :D], *p['norm2'], z[:, :D], stream=stream)
         aot_hip.layernorm(Xm[:, D:], *p['id_norm2'], z[:, D:], stream=stream)
         sp = self.self_attn.pack()
-        qk = ws.get('gpm_sqk', (N, da), dev)
+        qk = ws.get('gpm_sqk', (M, da), dev)
         aot_hip.linear(z, sp['QK_w'], sp['QK_b'], qk, stream=stream)
-        sv = ws.get('gpm_sv', (N, 2 * E), dev)
-        su = ws.get('gpm_su', (N, 2 * E), dev)
+        sv = ws.get('gpm_sv', (M, 2 * E), dev)
+        su = ws.get('gpm_su', (M, 2 * E), dev)
         aot_hip.linear(z[:, :D], sp['V1_w'], sp['V1_b'], sv[:, :E], act=aot_hip.ACT_SILU, stream=stream)
         aot_hip.linear(z[:, D:], sp['V2_w'], sp['V2_b'], sv[:, E:], act=aot_hip.ACT_SILU, stream=stream)
         aot_hip.linear(z[:, :D], sp['U1_w'], sp['U1_b'], su[:, :E], act=aot_hip.ACT_SILU, stream=stream)
         aot_hip.linear(z[:, D:], sp['U2_w'], sp['U2_b'], su[:, E:], act=aot_hip.ACT_SILU, stream=stream)
-        self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream)
-        Xo = ws.get('gpm_Xo_%d' % self.layer_idx, (N, 2 * D), dev)
-        self.self_attn.tail(raw, Xo, size_2d, ws, stream, res=Xm)
-        return Xo, qc, vcat, (gk, gv, t), (lk, lv), xi
+        self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream, B=B, kv_brows=N)
+        Xo = ws.get('gpm_Xo_%d' % self.layer_idx, (M, 2 * D), dev)
+        self.self_attn.tail(raw, Xo, size_2d, ws, stream, res=Xm, B=B)
+        return Xo, qc, vcat, xi
 
     def fuse_key_value_id(self, key, value, id_emb):
         """Reference API (transformer.py:659-665): returns (None, ID_V [N,1,E])."""
@@ -363,21 +380,27 @@ class DualBranchGPM(nn.Module):
         if intermediate_norm:
             raise NotImplementedError('DeAOT decodes the last GPM output only (default_deaot.py:12)')
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, t_long=None):
-        """Returns (dec_in [N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last layer, [dec_in], mems)."""
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+        """B lanes on the shared feature x0 [N, D].  Returns (dec_in [B*N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last
+        layer, mems): mems[i] = (curr_K, curr_Vcat, curr_ID_V_input) of layer i."""
         N, D = x0.shape
         dev = x0.device
-        X = ws.get('gpm_X0', (N, 2 * D), dev)
-        X[:, :D].copy_(x0)
+        X = ws.get('gpm_X0', (B * N, 2 * D), dev)
+        X.view(B, N, 2 * D)[:, :, :D].copy_(x0)
         X[:, D:].zero_()                                                    # tgt_id = 0 (transformer.py:602-603)
         mems = []
         for i, layer in enumerate(self.layers):
-            X, ck, cv, glob, loc, xi = layer.run(X, long_mems[i] if long_mems is not None else None,
-                                                 short_mems[i] if short_mems is not None else None,
-                                                 id_emb, pos, size_2d, ws, stream, t_long)
-            mems.append((ck, cv, glob, loc, xi))
-        out = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+            X, ck, cv, xi = layer.run(X, long_mems[i] if long_mems is not None else None,
+                                      short_mems[i] if short_mems is not None else None,
+                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None)
+            mems.append((ck, cv, xi))
+        out = torch.empty(B * N, 2 * D, dtype=torch.float32, device=dev)
         gn = self.decoder_norms[-1].gn
-        aot_hip.groupnorm(X, gn.weight, gn.bias, out, 2, ws.get('gn_scratch', (32 * 64 * 2,), dev, torch.float64),
-                          ws.get('gn_stats', (64,), dev, torch.float64), act=aot_hip.ACT_NONE, nsplit=64, stream=stream)
-        return out, [out], mems
+        aot_hip.groupnorm(X, gn.weight, gn.bias, out, 2, aot_hip.gn_buffers(ws, dev, B, 2, 64), act=aot_hip.ACT_NONE,
+                          nsplit=64, B=B, stream=stream)
+        return out, mems
+
+    def update_values(self, mems, id_emb, ws, stream, dst=None):
+        """deaot_engine.py:29-45: only ID_V = silu(linear_ID_V([prev ID_V,] id_emb)) is refreshed, in place in the
+        frame's [V | ID_V] buffer; K and V stay as produced."""
+        return [self.layers[i].fuse_id_into(m[1], m[2], id_emb, ws, stream) for i, m in enumerate(mems)]

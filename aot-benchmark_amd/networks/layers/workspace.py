@@ -20,6 +20,14 @@ class Workspace:
             self._bufs[key] = buf
         return buf
 
+    def get_zeroed(self, name, shape, device, dtype=torch.float32):
+        """Like get(), but the buffer is zero-filled when it is first created (ticket words of in-launch reductions)."""
+        n = len(self._bufs)
+        buf = self.get(name, shape, device, dtype)
+        if len(self._bufs) != n:
+            buf.zero_()
+        return buf
+
     def clear(self):
         self._bufs.clear()
 

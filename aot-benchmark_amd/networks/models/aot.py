@@ -92,6 +92,13 @@ class AOT(nn.Module):
             self.decoder.pack()
         return self._packed
 
+    def prepare(self):
+        """Packs every weight now and waits for the device: call once before inference fans out over several HIP streams
+        (lazy packing on whichever stream touches the model first would race with the other streams' first kernels)."""
+        self.pack()
+        torch.cuda.synchronize(next(self.parameters()).device)
+        return self
+
     def invalidate(self):
         """Drop packed weights (call after changing parameters)."""
         self._packed = None
@@ -134,19 +141,37 @@ class AOT(nn.Module):
         aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, stream=stream)
         return [f4, f8, f16, (out, h, w)]
 
-    def id_emb_from_mask(self, mask, size_2d, stream=None):
+    def id_emb_from_mask(self, mask, size_2d, stream=None, lanes=1, group0=None, fuse=None, want_out=True):
         """Fused one_hot_mask + patch_wise_id_bank (aot.py:76-79, utils/image.py:69-74): label map [1,1,H,W]
-        (float ids) -> id embedding [h*w, C]; the 18 MB one-hot tensor is never built."""
+        (float ids) -> id embedding [lanes*h*w, C]; the 18 MB one-hot tensor is never built.  group0 is not None: the map
+        holds the labels of ALL objects and lane g is object group group0+g (the mask separation of AOTInferEngine,
+        aot_engine.py:515-534, happens inside the gather).  fuse = [(add_i, out_i)]: out_i = id_emb + add_i, same launch."""
         p = self.pack()
         stream = stream if stream is not None else aot_hip.stream_ptr()
         H, W = mask.shape[-2:]
         h, w = size_2d
         conv = self.patch_wise_id_bank
         K, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        out = torch.empty(h * w, conv.out_channels, dtype=torch.float32, device=mask.device)
+        out = torch.empty(lanes * h * w, conv.out_channels, dtype=torch.float32, device=mask.device) if want_out else None
         aot_hip.idbank(mask.float().contiguous(), p['id_table'], p['id_bias'], out, H, W, h, w, K, s, pd,
-                       conv.out_channels, self.max_obj_num + 1, sumtab=p['id_sumtab'], stream=stream)
+                       conv.out_channels, self.max_obj_num + 1, sumtab=p['id_sumtab'], G=lanes,
+                       group_size=0 if group0 is None else self.max_obj_num, group0=group0 or 0, fuse=fuse, stream=stream)
         return out
+
+    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream):
+        """After the frame's mask is known (aot_engine.py:307-338): per LSTT layer V <- linear_V(V + id_emb(mask)).  One
+        gather launch forms V + id_emb for every layer, one GEMM per layer writes the fused V to dst[i]."""
+        L = len(mems)
+        dev = mems[0][1].device
+        sums = [self.ws.get('idsum_%d' % i, tuple(mems[i][1].shape), dev) for i in range(L)]
+        self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0,
+                              fuse=[(mems[i][1], sums[i]) for i in range(L)], want_out=False)
+        return self.LSTT.update_values(mems, sums, self.ws, stream, dst=dst)
+
+    def mem_widths(self):
+        """(key width, value width) of one memorised token per layer."""
+        C = self.encoder_projector.out_channels
+        return [(C, C) for _ in self.LSTT.layers]
 
     # ---- reference method surface (aot.py:72-108) ------------------------------------------------
     def get_pos_emb(self, x):
@@ -176,7 +201,7 @@ class AOT(nn.Module):
         x_in = cat if self.decoder.decode_intermediate_input else toks[-1]
         if x_in.shape[1] != self.decoder.in_dim:
             raise aot_hip.AotHipError('decoder expects %d input channels, got %d' % (self.decoder.in_dim, x_in.shape[1]))
-        logits, h4, w4 = self.decoder.run(x_in, sc[2], sc[1], sc[0], self.ws, stream)
+        logits, h4, w4 = self.decoder.run(x_in.contiguous(), sc[2], sc[1], sc[0], self.ws, stream)
         out = torch.empty(1, logits.shape[1], h4, w4, dtype=torch.float32, device=logits.device)
         aot_hip.nhwc_to_nchw(logits, out, logits.shape[1], h4, w4, stream=stream)
         return out
@@ -196,25 +221,41 @@ class AOT(nn.Module):
             return torch.as_strided(base, (base.shape[0], total), (ld, 1), base.storage_offset())
         return torch.cat(toks, 1)
 
-    def _mems_in(self, mems):
-        """reference-shaped per-layer memories -> token-major (K, V) pairs."""
-        return [(to_tokens(m[0]), to_tokens(m[1])) for m in mems] if mems is not None else None
+    def _mems_in(self, mems, with_t):
+        """reference-shaped per-layer memories -> the (K, V, [T,] rows-between-lanes) tuples LSTT.run takes (one lane)."""
+        if mems is None:
+            return None
+        out = []
+        for m in mems:
+            k, v = to_tokens(m[0]).contiguous(), to_tokens(m[1]).contiguous()
+            out.append((k, v, k.shape[0], k.shape[0]) if with_t else (k, v, k.shape[0]))
+        return out
 
-    def _mems_out(self, mems, size_2d):
+    def _mems_out(self, mems, long_in, short_in, size_2d):
         h, w = size_2d
         seq = lambda t: t.unsqueeze(1)
         curr = [[seq(m[0]), seq(m[1])] for m in mems]
-        long_ = [[seq(m[2][0][:m[2][2]]), seq(m[2][1][:m[2][2]])] for m in mems]
-        short = [[as_map(m[3][0], h, w), as_map(m[3][1], h, w)] for m in mems]
+        if long_in is None:        # reference frame: the frame memorises itself (K, id-fused V)
+            long_ = [[seq(m[0]), seq(m[2])] for m in mems]
+            short = [[as_map(m[0], h, w), as_map(m[2], h, w)] for m in mems]
+        else:
+            long_ = [[seq(m[0][:m[2]]), seq(m[1][:m[2]])] for m in long_in]
+            short = [[as_map(m[0], h, w), as_map(m[1], h, w)] for m in short_in]
         return curr, long_, short
 
     def LSTT_forward(self, curr_embs, long_term_memories, short_term_memories, curr_id_emb=None, pos_emb=None,
                      size_2d=(30, 30)):
+        """Reference surface (aot.py:94-108), one lane: [N,1,C] / [1,C,h,w] tensors in and out."""
         stream = aot_hip.stream_ptr()
-        x = to_tokens(curr_embs[-1])
-        pos = to_tokens(pos_emb) if pos_emb is not None else None
-        idt = to_tokens(curr_id_emb) if curr_id_emb is not None else None
-        _, outs, mems = self.LSTT.run(x, self._mems_in(long_term_memories), self._mems_in(short_term_memories), idt, pos,
-                                      size_2d, self.ws, stream)
-        curr, long_, short = self._mems_out(mems, size_2d)
-        return [o.unsqueeze(1) for o in outs], curr, long_, short
+        x = to_tokens(curr_embs[-1]).contiguous()
+        pos = to_tokens(pos_emb).contiguous() if pos_emb is not None else None
+        idt = to_tokens(curr_id_emb).contiguous() if curr_id_emb is not None else None
+        lm, sm = self._mems_in(long_term_memories, True), self._mems_in(short_term_memories, False)
+        dec_in, mems = self.LSTT.run(x, lm, sm, idt, pos, size_2d, self.ws, stream)
+        curr, long_, short = self._mems_out(mems, lm, sm, size_2d)
+        return self._lstt_outs(dec_in), curr, long_, short
+
+    def _lstt_outs(self, dec_in):
+        C = self.encoder_projector.out_channels
+        L = self.LSTT.num_layers
+        return [dec_in[:, (i + 1) * C:(i + 2) * C].unsqueeze(1) for i in range(L)]

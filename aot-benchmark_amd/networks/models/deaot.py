@@ -25,29 +25,46 @@ class DeAOT(AOT):
                                      shortcut_dims=cfg.MODEL_ENCODER_DIM, align_corners=cfg.MODEL_ALIGN_CORNERS)
         self.id_norm = nn.LayerNorm(emb)
 
-    def id_emb_from_mask(self, mask, size_2d, stream=None):
+    def id_emb_from_mask(self, mask, size_2d, stream=None, lanes=1, group0=None, fuse=None, want_out=True):
         """fused one-hot + id bank (models/aot.py:76-79) followed by LayerNorm over channels (deaot.py:51-55)."""
         stream = stream if stream is not None else aot_hip.stream_ptr()
-        raw = super().id_emb_from_mask(mask, size_2d, stream)
+        raw = super().id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0)
         out = torch.empty_like(raw)
         aot_hip.layernorm(raw, self.id_norm.weight, self.id_norm.bias, out, stream=stream)
         return out
 
+    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream):
+        """deaot_engine.py:20-56: only ID_V is refreshed with the new identity embedding (in place in the frame's
+        [V | ID_V] buffers, which already are dst); K and V stay as produced."""
+        id_emb = self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0)
+        return self.LSTT.update_values(mems, id_emb, self.ws, stream, dst=dst)
+
+    def mem_widths(self):
+        return [(l.d_att, 2 * l.expand_d_model) for l in self.LSTT.layers]
+
     # reference-shaped memories: [K, V, None, ID_V] per layer (transformer.py:655-657) <-> token-major (K, [V | ID_V])
-    def _mems_in(self, mems):
+    def _mems_in(self, mems, with_t):
         if mems is None:
             return None
         out = []
         for m in mems:
-            k, v, idv = to_tokens(m[0]), to_tokens(m[1]), to_tokens(m[3])
-            out.append((k, torch.cat([v, idv], 1)))
+            k = to_tokens(m[0]).contiguous()
+            vcat = torch.cat([to_tokens(m[1]), to_tokens(m[3])], 1)
+            out.append((k, vcat, k.shape[0], k.shape[0]) if with_t else (k, vcat, k.shape[0]))
         return out
 
-    def _mems_out(self, mems, size_2d):
+    def _mems_out(self, mems, long_in, short_in, size_2d):
         h, w = size_2d
         E = self.LSTT.layers[0].expand_d_model
         seq = lambda t: t.unsqueeze(1)
-        curr = [[seq(m[0]), seq(m[1][:, :E]), None, None if m[4] is None else seq(m[4])] for m in mems]
-        long_ = [[seq(m[2][0][:m[2][2]]), seq(m[2][1][:m[2][2], :E]), None, seq(m[2][1][:m[2][2], E:])] for m in mems]
-        short = [[as_map(m[3][0], h, w), as_map(m[3][1][:, :E], h, w), None, as_map(m[3][1][:, E:], h, w)] for m in mems]
+        curr = [[seq(m[0]), seq(m[1][:, :E]), None, None if m[2] is None else seq(m[2])] for m in mems]
+        if long_in is None:
+            long_ = [[seq(m[0]), seq(m[1][:, :E]), None, seq(m[1][:, E:])] for m in mems]
+            short = [[as_map(m[0], h, w), as_map(m[1][:, :E], h, w), None, as_map(m[1][:, E:], h, w)] for m in mems]
+        else:
+            long_ = [[seq(m[0][:m[2]]), seq(m[1][:m[2], :E]), None, seq(m[1][:m[2], E:])] for m in long_in]
+            short = [[as_map(m[0], h, w), as_map(m[1][:, :E], h, w), None, as_map(m[1][:, E:], h, w)] for m in short_in]
         return curr, long_, short
+
+    def _lstt_outs(self, dec_in):
+        return [dec_in.unsqueeze(1)]

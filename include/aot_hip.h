@@ -56,10 +56,10 @@ int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const 
                         int lda, int ldb, int ldwt, int ldc, int ldr, int res_rows, int act, int cfg,
                         void* stream);
 
-/* Depthwise KxK convolution, NHWC, w is [KH*KW, C], optional bias, fused activation.
+/* Depthwise KxK convolution over B NHWC maps ([B*H*W, C]), w is [KH*KW, C], optional bias, fused activation.
  * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)
  * and the depthwise 3x3 of MobileNetV2 InvertedResidual (mobilenetv2.py:93-98). */
-int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int B,
                           int H, int W, int C, int OH, int OW, int KH, int KW,
                           int stride, int pad, int dil, int act, void* stream);
 
@@ -74,33 +74,45 @@ int aot_nchw_to_nhwc_f32(const float* in, float* out, int C, int H, int W, int C
 int aot_nhwc_to_nchw_f32(const float* in, float* out, int C, int H, int W, int ld, void* stream);
 
 /* LayerNorm over the last dim (eps inside sqrt, biased variance, as torch):
- *   y = LN(x)*gamma + beta ;  if (add && y2)  y2 = y + add   (positional embedding, transformer.py:322)
+ *   y = LN(x)*gamma + beta ;  if (add && y2)  y2 = y + add[row % add_rows]   (positional embedding shared by the lanes
+ *   of a batch, transformer.py:322; add_rows = 0: one add row per row)
  * Replaces nn.LayerNorm in transformer.py:321,329,355 and LSTT.decoder_norms (:124-135). */
 int aot_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
                       const float* add, float* y2, int M, int C, int ldx, int ldy, int ldadd,
-                      int ldy2, float eps, void* stream);
+                      int ldy2, int add_rows, float eps, void* stream);
 
-/* GroupNorm over [M, C] (NHWC, batch 1) in two launches: stats (deterministic two-level
- * fp64 reduction into `stats` = [G][2] doubles mean, rstd) then apply with fused activation
- * (0 none, 1 relu, 3 exact-erf GELU).  `scratch` must hold G*nsplit*2 doubles.
- * Replaces nn.GroupNorm in GNActDWConv2d (basic.py:18,31-32) and ConvGN (basic.py:82-85) +
- * F.relu_ (fpn.py:41-56). */
-int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, int M, int C, int G,
-                            int ldx, float eps, int nsplit, void* stream);
+/* GroupNorm over B lanes of [M, C] NHWC maps (lane b = rows [b*M, (b+1)*M)).  Statistics: ONE launch, deterministic
+ * two-level fp64 reduction -- nsplit partial-sum workgroups per (lane, group); the last one to arrive (device-scope
+ * ticket) adds the partials in index order and writes `stats` = [B][G][2] doubles (mean, rstd).  `scratch` must hold
+ * B*G*nsplit*2 doubles; `ticket` B*G unsigned ints that are ZERO before the first call (the kernel leaves them zero).
+ * Apply: y = act(GN(x)) (+ add) (act: 0 none, 1 relu, 3 exact-erf GELU; add: optional map added after the activation,
+ * one row per row, or -- add_rows > 0 -- a [add_rows, ldadd] map shared by the lanes, row % add_rows).
+ * Replaces nn.GroupNorm in GNActDWConv2d (basic.py:18,31-32), ConvGN (basic.py:82-85) + F.relu_ (fpn.py:41-56) and
+ * GroupNorm1D (basic.py:6-12). */
+int aot_groupnorm_stats_f32(const float* x, double* scratch, double* stats, unsigned* ticket, int B, int M,
+                            int C, int G, int ldx, float eps, int nsplit, void* stream);
 int aot_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma,
-                            const float* beta, float* y, int M, int C, int G, int ldx, int ldy,
-                            int act, void* stream);
+                            const float* beta, float* y, const float* add, int B, int M, int C, int G,
+                            int ldx, int ldy, int ldadd, int add_rows, int act, void* stream);
+/* GroupNorm-apply + activation + 5x5 depthwise conv (stride 1, pad 2, no bias) in one launch, for 32-channel groups
+ * (C == 32*G): x [B*H*W, ldx] with the statistics of aot_groupnorm_stats_f32, w [25, C] -> out [B*H*W, ldo].
+ * Replaces GNActDWConv2d.forward after the statistics (gn -> GELU -> conv, networks/layers/basic.py:27-35). */
+int aot_gn_act_dwconv5_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                           const float* w, float* out, int B, int H, int W, int C, int G, int ldx, int ldo,
+                           int act, void* stream);
 
 /* Multi-head softmax attention over a key/value bank, flash style (no S materialised):
  *   out[n, h*d:(h+1)*d] = softmax_t( (q[n,h]/scale_div) . k[t,h] ) @ v[t,h]          (d == 32)
- * q [Nq, ldq], k/v [T, ldk/ldv], out [Nq, ldo]; H heads of width 32.  `T_dev` (optional) is a
- * device int overriding T so a captured graph can follow a growing bank.  nsplit > 1 splits the
- * bank over workgroups; `part` must then hold nsplit*Nq*(H*32 + 2*H) floats, receives the un-normalised
- * partial (O, m, l) of every split, and aot_attn_merge_f32 must follow on the same stream to produce
- * `out`.  Exact fp32: QK^T and PV on v_mfma_f32_32x32x2_f32.
+ * B independent lanes (object groups of one frame, or clips): lane b owns query rows [b*Nq, (b+1)*Nq) of q / out
+ * (row strides ldq / ldo) and the key/value rows [b*kv_brows, b*kv_brows + T) of k / v (one bank per lane; kv_brows >= T
+ * when B > 1).  H heads of width 32.  `T_dev` (optional) is a device int overriding T so a captured graph can follow a
+ * growing bank.  The four waves of a workgroup split the key range between them and merge through LDS; nsplit > 1
+ * additionally splits the bank over workgroups: `part` must then hold nsplit*B*Nq*(H*32 + 2*H) floats, receives the
+ * un-normalised partial (O, m, l) of every split, and aot_attn_merge_f32 (with Nq := B*Nq) must follow on the same
+ * stream to produce `out`.  Exact fp32: QK^T and PV on v_mfma_f32_32x32x2_f32.
  * Replaces MultiheadAttention.forward's core, networks/layers/attention.py:82-117 (long-term
  * attention over the memory bank and self-attention). */
-int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part,
+int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int B, long kv_brows,
                  int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo,
                  float scale_div, int nsplit, void* stream);
 /* Merge of the nsplit partials written by aot_attn_f32 / aot_gated_attn_f32 (nsplit > 1) into out [Nq, ldo]:
@@ -117,12 +129,12 @@ int aot_attn_topk_f32(const float* q, const float* k, const float* v, float* out
                       int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div, int top_k, void* stream);
 
 /* Gated-propagation attention of DeAOT, single head: out = softmax((q/scale_div) k^T) v  (* gate), with
- * q [Nq, dqk=128], k [T, 128], v [T, dv] (dv a multiple of 256; 1024 = [V | ID_V]), gate/out [Nq, dv].
- * Same split/merge protocol as aot_attn_f32 with H := dv/256 groups; with nsplit > 1 pass the gate to
- * aot_attn_merge_f32 instead.  Replaces GatedPropagation.forward's core, attention.py:672-707. */
+ * q [Nq, dqk=128], k [T, 128], v [T, dv] (dv a multiple of 256; 1024 = [V | ID_V]), gate/out [Nq, dv]; B lanes laid
+ * out as in aot_attn_f32.  Same split/merge protocol as aot_attn_f32 with H := dv/256 groups; with nsplit > 1 pass the
+ * gate to aot_attn_merge_f32 instead.  Replaces GatedPropagation.forward's core, attention.py:672-707. */
 int aot_gated_attn_f32(const float* q, const float* k, const float* v, const float* gate, float* out,
-                       float* part, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldk,
-                       int ldv, int ldg, int ldo, float scale_div, int nsplit, void* stream);
+                       float* part, int B, long kv_brows, int Nq, int T, const int* T_dev, int dqk, int dv,
+                       int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div, int nsplit, void* stream);
 
 /* Short-term (windowed) attention of AOT, fused: window dot products, relative-position key
  * bias (grouped 1x1 conv on the UNSCALED q), border masking, softmax over the (2*max_dis+1)^2
@@ -132,21 +144,24 @@ int aot_gated_attn_f32(const float* q, const float* k, const float* v, const flo
  *                           (the kernel holds q/scale_div only; scale_div must equal sqrt(d))
  *   relk_b [H][WS][16]    : relative_emb_k.bias[hd*WS*WS + dy*WS + dx]
  *   relv_t [H][WS][32][16]: relative_emb_v[hd][c][dy*WS + dx]           (dx = 15 is padding)
+ * B lanes: lane b owns rows [b*h*w, (b+1)*h*w) of q / out and rows [b*kv_brows, ...) of k / v.
  * Replaces MultiheadLocalAttentionV2.forward + local2global + pad_and_unfold
  * (attention.py:308-428) i.e. what spatial_correlation_sampler computes, minus `projection`. */
 int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_t,
-                       const float* relk_b, const float* relv_t, float* out, int h, int w, int H,
-                       int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
+                       const float* relk_b, const float* relv_t, float* out, int B, long kv_brows, int h, int w,
+                       int H, int d, int max_dis, int ldq, int ldk, int ldv, int ldo, float scale_div,
                        void* stream);
 
 /* Short-term gated propagation of DeAOT (single head): window scores on q = k [h*w, 128] with the relative-position
  * key bias, softmax over the 15x15 window, aggregation of v [h*w, dv] (dv % 32 == 0) and multiplication by the
  * gate [h*w, dv] (may be NULL).  relk_t [15][128][16] (sqrt(128)-scaled, layout of aot_local_attn_f32 with one
- * head), relk_b [15][16]; prob is a [225, h*w] scratch map.  Three launches (scores, softmax, aggregate).
+ * head), relk_b [15][16]; prob is a [B][225, h*w] scratch map; B lanes as in aot_local_attn_f32.  Three launches
+ * (scores, softmax, aggregate).
  * Replaces LocalGatedPropagation.forward up to `agg_value * u`, attention.py:789-855. */
 int aot_local_gated_f32(const float* q, const float* k, const float* v, const float* gate, const float* relk_t,
-                        const float* relk_b, float* prob, float* out, int h, int w, int dqk, int dv, int max_dis,
-                        int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div, void* stream);
+                        const float* relk_b, float* prob, float* out, int B, long kv_brows, int h, int w, int dqk,
+                        int dv, int max_dis, int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div,
+                        void* stream);
 
 /* Swin window attention (W-MSA / SW-MSA, 7x7 windows, heads of width 32), fused with the reference's pad / roll /
  * window_partition / window_reverse / crop: qkv [H*W, ld] = [q | k | v] (C each) is the output of the qkv Linear on the
@@ -161,22 +176,34 @@ int aot_patch_merge_f32(const float* x, float* out, int H, int W, int C, int ldx
 /* Identity-bank embedding of a label map: out[(Y,X), c] = bias[c] + sum_{ky,kx} table[label(16Y+ky-pad,
  * 16X+kx-pad), ky, kx, c] over in-image taps; labels outside [0, nlabel) or non-integer add nothing.
  * mask is [H,W] float label ids, table [nlabel, K, K, C]; sumtab [nlabel, C] (optional) = sum of table over the
- * K*K taps, used when a token's whole window carries one label.  Replaces one_hot_mask (utils/image.py:69-74)
- * + patch_wise_id_bank conv (models/aot.py:50-63,76-79). */
+ * K*K taps, used when a token's whole window carries one label.
+ * group_size > 0: lane g is object group group0+g of the SAME label map (AOTInferEngine.separate_mask,
+ * aot_engine.py:515-534): labels (group0+g)*group_size+1 .. +group_size map to 1 .. group_size, everything else to
+ * background 0; rows [g*OH*OW, ...) of out.  group_size = 0 (G = 1): the labels are used as they are.
+ * Fused memory update (nfuse <= 4): fuse_out[i][row] = id_emb[row] + fuse_add[i][row] (host arrays of device
+ * pointers; row strides ldadd / ldfout) -- the `V + id_emb` of every LSTT layer (transformer.py:364-367) in the same
+ * launch; out may then be NULL.
+ * Replaces one_hot_mask (utils/image.py:69-74) + patch_wise_id_bank conv (models/aot.py:50-63,76-79). */
 int aot_idbank_f32(const float* mask, const float* table, const float* sumtab, const float* bias, float* out,
-                   int H, int W, int OH, int OW, int K, int stride, int pad, int C, int nlabel,
-                   int ldo, void* stream);
+                   int G, int group_size, int group0, int H, int W, int OH, int OW, int K, int stride, int pad,
+                   int C, int nlabel, int ldo, const float* const* fuse_add, float* const* fuse_out, int nfuse,
+                   int ldadd, int ldfout, void* stream);
 
-/* Bilinear resize NHWC with torch's fp32 source-index arithmetic; out = resize(in) (+ add).
- * Replaces F.interpolate(mode='bilinear') in fpn.py:44-55. */
-int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int IH, int IW, int OH,
-                          int OW, int C, int ldi, int ldadd, int ldo, int align_corners, void* stream);
+/* Bilinear resize of B NHWC maps with torch's fp32 source-index arithmetic; out = resize(in) (+ add); `add` is one map
+ * per lane, or (add_shared) one [OH*OW, ldadd] map added to every lane.  Replaces F.interpolate(mode='bilinear') in
+ * fpn.py:44-55. */
+int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int B, int IH, int IW, int OH,
+                          int OW, int C, int ldi, int ldadd, int ldo, int align_corners, int add_shared,
+                          void* stream);
 
-/* Logit finalisation: channels > obj_num of the stride-4 NHWC logits are set to -1e10, the masked
- * map is written planar to out4 [C,IH,IW] (may be NULL) and bilinearly resized to out [C,OH,OW].
- * Replaces aot_engine.py:367-378. */
-int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int IH, int IW, int C,
-                            int ldi, int OH, int OW, int obj_num, int align_corners, void* stream);
+/* Logit finalisation for the G object groups (lanes) of a frame: logits [G*IH*IW, ldi] stride-4 NHWC.  Per group the
+ * channels of unused identities (group g holds objects g*(C-1)+1 .. min((g+1)*(C-1), obj_total)) are set to -1e10, the
+ * masked maps are written planar to out4 [G][C,IH,IW] (may be NULL) and bilinearly resized to OH x OW.  G == 1: out is
+ * [C,OH,OW].  G > 1: the resized logits are merged in the same launch by the reference's soft aggregation (softmax per
+ * group, background = product of the background probabilities, clamp to [1e-5, 1-1e-5], logit): out is
+ * [1 + G*(C-1), OH, OW].  Replaces aot_engine.py:367-378 and AOTInferEngine.soft_logit_aggregation (:565-582). */
+int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int G, int IH, int IW, int C,
+                            int ldi, int OH, int OW, int obj_total, int align_corners, void* stream);
 
 /* out = a + b over n floats (n % 4 == 0) -- V + id_emb in fuse_key_value_id (transformer.py:364-367). */
 int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream);

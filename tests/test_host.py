@@ -146,15 +146,23 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     P = ctypes.c_void_p
     assert lib.aot_add_f32(None, None, None, 16, None) == -1
     assert lib.aot_add_f32(P(16), P(16), P(16), 7, None) == -1                      # n % 4 != 0
-    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 255, 256, 256, 0, 0, 1e-5, None) == -1
-    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 2048, 2048, 2048, 0, 0, 1e-5, None) == -2
-    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 64, 256, 256, 256, 256, 5.65, 1, None) == -2
-    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 8, 8, None, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # splits need `part`
-    assert lib.aot_local_attn_f32(P(16), P(16), P(16), P(16), P(16), P(16), P(16), 4, 4, 8, 32, 5, 256, 256, 256, 256, 5.65, None) == -2
+    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 255, 256, 256, 0, 0, 0, 1e-5, None) == -1
+    assert lib.aot_layernorm_f32(P(16), P(16), P(16), P(16), None, None, 4, 2048, 2048, 2048, 0, 0, 0, 1e-5, None) == -2
+    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 1, 0, 8, 8, None, 8, 64, 256, 256, 256, 256, 5.65, 1, None) == -2
+    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 1, 0, 8, 8, None, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # splits need `part`
+    assert lib.aot_attn_f32(P(16), P(16), P(16), P(16), None, 3, 4, 8, 8, None, 8, 32, 256, 256, 256, 256, 5.65, 1, None) == -1   # lanes closer than T rows
+    # a key range whose byte offsets would not fit 32 bits is refused, never wrapped (DeAOT value rows are 4 KB)
+    assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 1, 0, 8, 600000, None, 128, 1024, 128, 128, 1024, 0, 1024, 8.0, 1, None) == -2
+    assert lib.aot_local_attn_f32(P(16), P(16), P(16), P(16), P(16), P(16), P(16), 1, 16, 4, 4, 8, 32, 5, 256, 256, 256, 256, 5.65, None) == -2
+    assert lib.aot_groupnorm_stats_f32(P(16), P(16), P(16), None, 1, 8, 64, 8, 64, 1e-5, 4, None) == -1      # nsplit > 1 needs tickets
+    assert lib.aot_gn_act_dwconv5_f32(P(16), P(16), P(16), P(16), P(16), P(16), 1, 8, 8, 64, 4, 64, 64, 3, None) == -2   # 16-channel groups
+    assert lib.aot_idbank_f32(P(16), P(16), None, None, P(16), 2, 0, 0, 8, 8, 1, 1, 3, 1, 1, 8, 11, 8, None, None, 0, 0, 0, None) == -1  # lanes need a group size
+    assert lib.aot_logits_finalize_f32(P(16), None, None, 1, 4, 4, 32, 32, 0, 0, 3, 1, None) == -2
     assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), P(16), 8, 8, 8, 32, 256, 256, 256, 256, 5.65, 8, None) == -1  # top_k >= T
     assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), None, 8, 64, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # no scratch
-    assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, P(16), 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 8, 0, 0, None) == -1  # Cin % 4
-    assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
+    assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 0, 8, 0, 0, 0, -1, None) == -1  # Cin % 4
+    assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 32, 4, 4, 64, 1, 1, 1, 0, 1, 32, 64, 0, 64, 0, 0, 0, 117, None) == -2  # LDS-direct kernel without a k-contiguous weight
+    assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 1, 0, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
     assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2
 
 

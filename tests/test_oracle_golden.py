@@ -67,7 +67,8 @@ def test_oracle_multi_group_matches_reference(case):
             got = extra['merged_%d' % t]
             assert got.shape == ref.shape == (1 + 10 * len(eng.aot_engines),) + ref.shape[1:]
             # logit() of a clamped probability: the slope is 1/p(1-p) <= 1e5 at the clamp, so compare probabilities too
-            assert np.abs(got - ref).max() < 2e-3
+            mid = (ref > -6.9) & (ref < 6.9)                # 1e-3 < p < 1 - 1e-3: away from the clamp the logits themselves agree
+            assert np.abs(got - ref)[mid].max() < 2e-3 and np.abs(got - ref).max() < 5e-2
             assert np.abs(1 / (1 + np.exp(-got)) - 1 / (1 + np.exp(-ref))).max() < 1e-5
 
 

@@ -137,9 +137,89 @@ def test_layernorm_groupnorm(hip):
         ref = F.group_norm(x.t().unsqueeze(0), G, ga, be, 1e-5)[0].t()
         ref = F.gelu(ref) if act == 3 else F.relu(ref)
         out = torch.empty(M, C, device='cuda')
-        hip.groupnorm(_dev(x), _dev(ga), _dev(be), out, G, torch.empty(G * 64 * 2, dtype=torch.float64, device='cuda'),
-                      torch.empty(2 * G, dtype=torch.float64, device='cuda'), act=act, nsplit=64)
+        bufs = (torch.empty(G * 64 * 2, dtype=torch.float64, device='cuda'), torch.empty(2 * G, dtype=torch.float64, device='cuda'),
+                torch.zeros(G, dtype=torch.int32, device='cuda'))
+        hip.groupnorm(_dev(x), _dev(ga), _dev(be), out, G, bufs, act=act, nsplit=64)
         _close(out, ref, 2e-5, 'groupnorm')
+        assert (bufs[2] == 0).all(), 'the ticket words must be left at zero'
+        out2 = torch.empty(M, C, device='cuda')
+        hip.groupnorm(_dev(x), _dev(ga), _dev(be), out2, G, bufs, act=act, nsplit=64)      # second use of the same tickets
+        assert torch.equal(out, out2), 'GroupNorm must be deterministic whichever workgroup arrives last'
+
+
+def test_lane_batched_glue_kernels(hip):
+    """B lanes stacked along the rows (object groups of one frame): per-lane GroupNorm statistics, GN + shared add, the fused
+    GN-apply + GELU + 5x5 depthwise conv, depthwise conv, bilinear with a shared add map, LayerNorm with a shared positional
+    add -- each against torch on every lane."""
+    g = torch.Generator().manual_seed(131)
+    B, h, w, C = 3, 31, 54, 1024
+    N = h * w
+    x = torch.randn(B, C, h, w, generator=g) * 2 + 0.3
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    wk = torch.randn(C, 1, 5, 5, generator=g) / 5
+    tok = _dev(x.permute(0, 2, 3, 1).reshape(B * N, C))
+    bufs = (torch.empty(B * 32 * 8 * 2, dtype=torch.float64, device='cuda'), torch.empty(B * 32 * 2, dtype=torch.float64, device='cuda'),
+            torch.zeros(B * 32, dtype=torch.int32, device='cuda'))
+    ref_gn = F.gelu(F.group_norm(x, 32, ga, be, 1e-5))
+    ref = F.conv2d(ref_gn, wk, None, 1, 2, 1, C)
+    out = torch.empty(B * N, C, device='cuda')
+    hip.gn_act_dwconv5(tok, _dev(ga), _dev(be), _dev(wk.view(C, 25).t()), out, 32, bufs, h, w, act=hip.ACT_GELU, nsplit=8, B=B)
+    _close(out.view(B, h, w, C).permute(0, 3, 1, 2), ref, 3e-5, 'gn+gelu+dw5x5 fused')
+    y = torch.empty(B * N, C, device='cuda')
+    shared = torch.randn(N, C, generator=g)
+    hip.groupnorm(tok, _dev(ga), _dev(be), y, 32, bufs, act=hip.ACT_GELU, nsplit=8, B=B, add=_dev(shared), add_rows=N)
+    _close(y.view(B, N, C), ref_gn.permute(0, 2, 3, 1).reshape(B, N, C) + shared, 3e-5, 'gn + shared add')
+    hip.dwconv2d(_dev(ref_gn.permute(0, 2, 3, 1).reshape(B * N, C)), _dev(wk.view(C, 25).t()), None, out, h, w, C, h, w, 5, 1, 2, 1, B=B)
+    _close(out.view(B, h, w, C).permute(0, 3, 1, 2), ref, 3e-5, 'dwconv lanes')
+    # bilinear: lanes + one shared add map
+    xs = torch.randn(B, 128, 31, 54, generator=g)
+    add = torch.randn(1, 128, 61, 107, generator=g)
+    o = torch.empty(B * 61 * 107, 128, device='cuda')
+    hip.bilinear(_dev(xs.permute(0, 2, 3, 1).reshape(-1, 128)), o, 31, 54, 61, 107, 128, True,
+                 add=_dev(add[0].permute(1, 2, 0).reshape(-1, 128)), B=B, add_shared=True)
+    _close(o.view(B, 61, 107, 128).permute(0, 3, 1, 2), F.interpolate(xs, size=(61, 107), mode='bilinear', align_corners=True) + add,
+           3e-6, 'bilinear lanes')
+    # layernorm with the positional embedding shared by the lanes
+    z = torch.randn(B * N, 256, generator=g)
+    pos = torch.randn(N, 256, generator=g)
+    g2, b2 = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    y1, y2 = torch.empty(B * N, 256, device='cuda'), torch.empty(B * N, 256, device='cuda')
+    hip.layernorm(_dev(z), _dev(g2), _dev(b2), y1, add=_dev(pos), out2=y2, add_rows=N)
+    r = F.layer_norm(z, (256,), g2, b2, 1e-5)
+    _close(y1, r, 1e-5, 'ln')
+    _close(y2.view(B, N, 256), r.view(B, N, 256) + pos, 1e-5, 'ln + shared pos')
+
+
+def test_lane_batched_conv_and_attention(hip):
+    """3x3 conv over B images, a residual map shared by the lanes, and the lane forms of the long-term / windowed attention
+    (each lane reads ITS bank: rows b*kv_brows ..)."""
+    g = torch.Generator().manual_seed(137)
+    B, h, w, Cin, Cout = 3, 31, 54, 256, 128
+    x = torch.randn(B, Cin, h, w, generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(1, Cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), 1, 1) + res.double()).float()
+    wk = wt.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).contiguous()
+    for cfg, use_wt in ((-1, True), (4, False), (117, True), (14, False), (118, True)):
+        out = torch.full((B * h * w, Cout), float('nan'), device='cuda')
+        scratch = torch.empty(2 * B * h * w * Cout, device='cuda') if cfg == 118 else None
+        hip.conv2d_cfg(_dev(x.permute(0, 2, 3, 1).reshape(-1, Cin)), _dev(wk), _dev(bias), out, h, w, Cin, h, w, Cout, 3, 3, 1, 1, 1,
+                       res=_dev(res[0].permute(1, 2, 0).reshape(-1, Cout)), act=1, cfg=cfg,
+                       wt=_dev(wk.t().contiguous()) if use_wt else None, scratch=scratch, B=B, res_rows=h * w)
+        _close(out.view(B, h, w, Cout).permute(0, 3, 1, 2), ref, 3e-5, 'conv lanes cfg %d' % cfg)
+    # attention: lanes with their own banks, stored cap rows apart
+    H, C, N, T, cap = 8, 256, 200, 777, 1000
+    q = torch.randn(B * N, C, generator=g) * 2
+    k = torch.randn(B * cap, C, generator=g) * 2
+    v = torch.randn(B * cap, C, generator=g)
+    for ns in (1, 2):
+        out = torch.full((B * N, C), float('nan'), device='cuda')
+        part = torch.empty(ns * B * N * (C + 2 * H), device='cuda') if ns > 1 else None
+        hip.attention(_dev(q), _dev(k), _dev(v), out, T, H, 32 ** 0.5, part=part, nsplit=ns, B=B, kv_brows=cap)
+        for b in range(B):
+            _close(out[b * N:(b + 1) * N], _mha_ref(q[b * N:(b + 1) * N], k[b * cap:b * cap + T], v[b * cap:b * cap + T], H, 32 ** 0.5),
+                   2e-5, 'attention lane %d' % b)
 
 
 @pytest.mark.parametrize('align', [True, False])
@@ -166,6 +246,23 @@ def test_bilinear_and_finalize(hip, align):
     reff = F.interpolate(ref4, size=(480, 854), mode='bilinear', align_corners=align)
     _close(outf[:, :obj + 1], reff[:, :obj + 1], 5e-6, 'finalize')
     assert torch.equal(outf.cpu().argmax(1), reff.argmax(1))
+    # three object groups (23 objects: 10 + 10 + 3): per-group masking + resize + the reference's soft aggregation
+    # (softmax per group, product of the backgrounds, clamp, logit -- aot_engine.py:565-582) in the same kernel
+    G, objs = 3, 23
+    lg3 = torch.randn(G, 11, 61, 107, generator=g) * 4
+    tok3 = torch.zeros(G * 61 * 107, 12)
+    tok3[:, :11] = lg3.permute(0, 2, 3, 1).reshape(-1, 11)
+    out4 = torch.empty(G, 11, 61, 107, device='cuda')
+    outm = torch.empty(1, 1 + 10 * G, 240, 428, device='cuda')
+    hip.logits_finalize(_dev(tok3)[:, :11], out4, outm, 61, 107, 11, 240, 428, objs, align, G=G)
+    ref4 = lg3.clone()
+    ref4[2, 4:] = -1e10
+    assert torch.equal(out4.cpu(), ref4)
+    probs = [torch.softmax(F.interpolate(ref4[i:i + 1], size=(240, 428), mode='bilinear', align_corners=align), 1) for i in range(G)]
+    bg = torch.prod(torch.cat([p[:, 0:1] for p in probs], 1), 1, keepdim=True)
+    merged = torch.cat([bg] + [p[:, 1:] for p in probs], 1).clamp(1e-5, 1 - 1e-5)
+    _close(torch.sigmoid(outm), merged, 2e-6, 'soft aggregation (probabilities)')
+    _close(outm, torch.logit(merged), 2e-3, 'soft aggregation (logits)')
 
 
 @pytest.mark.parametrize('K,pad,H,W', [(17, 8, 481, 849), (16, 0, 480, 848), (17, 8, 97, 65)])
@@ -185,6 +282,25 @@ def test_idbank_matches_onehot_conv(hip, K, pad, H, W):
     hip.idbank(_dev(mask), _dev(wt.permute(1, 2, 3, 0)), _dev(b), out, H, W, oh, ow, K, 16, pad, 256, 11,
                sumtab=_dev(wt.double().sum((2, 3)).t().float()))
     _close(out.view(oh, ow, 256).permute(2, 0, 1), ref, 2e-5, 'idbank')
+    # object groups as lanes of one launch (mask separation of AOTInferEngine, aot_engine.py:515-534, inside the gather)
+    # plus the fused `V + id_emb` outputs of the memory update
+    big = torch.randint(0, 28, (1, 1, H, W), generator=g).float()
+    big[0, 0, H // 2:, : W // 2] = 17.0
+    G = 3
+    outg = torch.empty(G * oh * ow, 256, device='cuda')
+    adds = [torch.randn(G * oh * ow, 256, generator=g) for _ in range(2)]
+    sums = [torch.empty(G * oh * ow, 256, device='cuda') for _ in range(2)]
+    hip.idbank(_dev(big), _dev(wt.permute(1, 2, 3, 0)), _dev(b), outg, H, W, oh, ow, K, 16, pad, 256, 11,
+               sumtab=_dev(wt.double().sum((2, 3)).t().float()), G=G, group_size=10, fuse=[(_dev(a), s_) for a, s_ in zip(adds, sums)])
+    for grp in range(G):
+        inside = (big > grp * 10) & (big <= (grp + 1) * 10)
+        sep = torch.where(inside, big - grp * 10, torch.zeros_like(big))
+        oneh = (sep == torch.arange(11).view(1, -1, 1, 1)).float()
+        rg = F.conv2d(oneh.double(), wt.double(), b.double(), 16, pad)[0].float()
+        got = outg[grp * oh * ow:(grp + 1) * oh * ow]
+        _close(got.view(oh, ow, 256).permute(2, 0, 1), rg, 2e-5, 'idbank group %d' % grp)
+        for a, s_ in zip(adds, sums):
+            assert torch.equal(s_[grp * oh * ow:(grp + 1) * oh * ow].cpu(), got.cpu() + a[grp * oh * ow:(grp + 1) * oh * ow])
 
 
 def test_layout_roundtrip(hip):
@@ -209,7 +325,7 @@ def _mha_ref(q, k, v, H, scale):
 
 
 @pytest.mark.parametrize('Nq,T,nsplit', [(1674, 1674, 1), (1674, 1674, 5), (289, 289, 1), (100, 77, 1),
-                                         (1674, 3 * 1674 + 13, 7), (33, 2000, 16), (64, 31, 1)])
+                                         (1674, 3 * 1674 + 13, 3), (33, 2000, 16), (64, 31, 1), (40, 31, 4)])
 def test_attention_vs_fp64(hip, Nq, T, nsplit):
     g = torch.Generator().manual_seed(Nq + T)
     H, C = 8, 256
@@ -456,7 +572,8 @@ def test_multi_group_vs_reference_golden(hip, case):
             perr = float(np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref.astype(np.float64)))).max())
             worst = max(worst, perr)
             assert perr < 1e-5, 'frame %d merged probability err %g' % (t, perr)
-            assert np.abs(got - ref).max() < 2e-3
+            mid = (ref > -6.9) & (ref < 6.9)                # 1e-3 < p < 1 - 1e-3: away from the clamp the logits themselves agree
+            assert np.abs(got - ref)[mid].max() < 2e-3 and np.abs(got - ref).max() < 5e-2
     _record_parity(case, 'teacher_forced', {'frames': len(res), 'tie_flips': flips, 'max_merged_prob_err': worst,
                                             'groups': groups, 'pixels': int(g['masks'].size)})
 
