@@ -23,6 +23,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import aot_hip
+from networks.engines.graphs import FrameGraphs, ptr_key
+from networks.layers.workspace import Workspace
 from networks.models.aot import as_map, to_tokens
 
 
@@ -38,8 +40,15 @@ class AOTEngine(nn.Module):
     0..max_obj_num as they are."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None, lanes=1,
-                 group0=None):
+                 group0=None, graph=False):
         super().__init__()
+        # graph=True: the launch sequence of every stage (match / decode / memory update) is captured once per engine
+        # state as a hipGraph and replayed (engines/graphs.py).  What decode_current_logits returns is then a buffer that
+        # belongs to the graph: valid until the next decode of this engine (the reference returns a fresh tensor).
+        self.use_graph = bool(graph)
+        self._graphs = None
+        self._static = {}            # staged copies of caller-owned inputs (image, label map): stable addresses for replay
+        self._arena = Workspace()    # tensors that live from one stage of a frame to the next (curr_V, decoder input)
         # long_term_mem_max (repo extension, SURVEY 8f3; the reference bank grows without bound): at most that many
         # memorised frames -- the first one (the reference frame) is kept, the others form a ring of the most recent
         if long_term_mem_max is not None and long_term_mem_max < 2:
@@ -57,6 +66,7 @@ class AOTEngine(nn.Module):
         self.first_group = group0 or 0
         self._bank = None            # per layer (K [lanes, cap*N, Ck], V [lanes, cap*N, Cv]); survives restart_engine
         self._bank_geom = None
+        self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot; survives too
         self.restart_engine()
 
     def forward(self, *a, **k):
@@ -77,8 +87,7 @@ class AOTEngine(nn.Module):
         self.bank_frames = 0         # frames ever memorised
         self._slots = 0              # bank slots in use (= bank_frames, or the bound of a bounded bank)
         self._short = []             # most recent short-term memories, oldest first; entry = per layer (K, V, rows)
-        self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot
-        self._ring_pos = 0
+        self._ring_pos = 0           # (the ring buffers themselves are kept: same addresses clip after clip)
         self._feats = None           # [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major, shared by the lanes
         self._dec_in = None          # decoder input: AOT [B*N, (L+1)*C] (projected feature | LSTT outs), DeAOT [B*N, 2C]
         self._curr = None            # this frame's per-layer (K, V | Vcat, ...) as returned by LSTT.run
@@ -202,6 +211,21 @@ class AOTEngine(nn.Module):
         self._short.append(entry)
         self._short = self._short[-self.short_term_mem_skip:]
 
+    # ---- hipGraph replay -----------------------------------------------------------------------
+    def _gx(self):
+        if self._graphs is None:
+            self._graphs = FrameGraphs(next(self.AOT.parameters()).device)
+        return self._graphs
+
+    def _stage(self, name, t):
+        """Copies a caller-owned input into a buffer with a stable address (one per name and shape), fp32."""
+        key = (name, tuple(t.shape))
+        buf = self._static.get(key)
+        if buf is None:
+            buf = self._static[key] = torch.empty(tuple(t.shape), dtype=torch.float32, device=t.device)
+        buf.copy_(t)
+        return buf
+
     # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):
         if img_embs is None:
@@ -246,7 +270,7 @@ class AOTEngine(nn.Module):
         direct = self._direct()
         dst = self._slot_views(slot) if direct else self._scratch_set()
         self._dec_in, mems = self.AOT.LSTT.run(x16, None, None, id_emb, self.pos_emb, self.enc_size_2d, self.AOT.ws, stream,
-                                               B=self.lanes, dst=dst)
+                                               B=self.lanes, dst=dst, keep=self._arena)
         self._curr = mems
         if not direct:
             self._store(dst, slot)
@@ -259,26 +283,33 @@ class AOTEngine(nn.Module):
 
     def match_propogate_one_frame(self, img=None, img_embs=None):
         self.frame_step += 1
-        feats = self._encode(img, img_embs)
-        stream = aot_hip.stream_ptr()
-        T, brows = self.bank_len, self._brows_bank()
-        long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+        T = self.bank_len
         # a frame that update_memory will memorise gets its K / V written straight into its bank slot
         self._curr_slot = None
         if self._direct() and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
             slot = self._next_slot()
-            self._ensure_bank(slot + 1)
-            if self._bank[0][0].shape[1] != brows:       # the bank was re-allocated: refresh the views
-                brows = self._brows_bank()
-                long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+            self._ensure_bank(slot + 1)          # (may re-allocate the bank: the views below are taken afterwards)
             self._curr_slot = slot
             dst = self._slot_views(slot)
         else:
             dst = self._scratch_set()
+        brows = self._brows_bank()
+        long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+        short = self._short[0]
         self._dst = dst
-        self._dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, self._short[0], None, self.pos_emb, self.enc_size_2d,
-                                               self.AOT.ws, stream, B=self.lanes, dst=dst)
-        self._curr = mems
+
+        def launch(img_, embs_):
+            feats = self._encode(img_, embs_)
+            dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, short, None, self.pos_emb, self.enc_size_2d, self.AOT.ws,
+                                             aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena)
+            return feats, dec_in, mems
+
+        if self.use_graph:
+            src = self._stage('img', img) if img_embs is None else None
+            key = ptr_key('match', src, img_embs, long_m, short, dst, self.pos_emb, self.lanes, self.enc_size_2d)
+            self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
+        else:
+            self._feats, self._dec_in, self._curr = launch(img, img_embs)
 
     def decode_stride4(self):
         """Runs the decoder for the cohort's lanes: stride-4 logits [lanes*h4*w4, max_obj+1] (a scratch view), h4, w4."""
@@ -287,8 +318,7 @@ class AOTEngine(nn.Module):
 
     def decode_current_logits(self, output_size=None):
         """Single-cohort form of the reference call (aot_engine.py:356-380)."""
-        logits, h4, w4 = self.decode_stride4()
-        return _finalize(self, [self], logits, h4, w4, output_size, aot_hip.stream_ptr())
+        return _decode(self, [self], output_size)
 
     def update_long_term_memory(self, new_long_term_memories):
         """Reference signature (aot_engine.py:291-305): list over layers of [K, V] ([N,1,C]), lane 0; appended."""
@@ -302,22 +332,32 @@ class AOTEngine(nn.Module):
             raise NotImplementedError('pre-computed identity embeddings: pass the label map, the gather is fused')
         if curr_mask.dim() == 4 and curr_mask.shape[1] != 1:
             raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
-        stream = aot_hip.stream_ptr()
-        dst = self._dst
-        self.AOT.update_memory_values(self._curr, curr_mask, self.enc_size_2d, self.lanes, self.group0,
-                                      [d[1] for d in dst], stream)
+        dst, curr = self._dst, self._curr
         in_bank = self._curr_slot is not None
+        memorise = self.frame_step - self.last_mem_step >= self.long_term_mem_gap
+        store_slot = None
+        if memorise and not skip_long_term_update and not in_bank:
+            store_slot = self._next_slot()
+            self._ensure_bank(store_slot + 1)
+
+        def launch(mask_):
+            self.AOT.update_memory_values(curr, mask_, self.enc_size_2d, self.lanes, self.group0, [d[1] for d in dst],
+                                          aot_hip.stream_ptr())
+            if store_slot is not None:
+                self._store(dst, store_slot)
+
+        if self.use_graph:
+            src = self._stage('mask', curr_mask)
+            key = ptr_key('update', src, curr, dst, store_slot, [b[0] for b in self._bank] if store_slot is not None else None,
+                          self.lanes, self.group0, self.enc_size_2d)
+            self._gx().run(key, lambda: launch(src))
+        else:
+            launch(curr_mask)
         rows = self._brows_bank() if in_bank else self.enc_hw
         self._push_short([(k, v, rows) for k, v in dst])
-        if self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+        if memorise:
             if not skip_long_term_update:
-                if in_bank:
-                    self._commit(self._curr_slot)
-                else:
-                    slot = self._next_slot()
-                    self._ensure_bank(slot + 1)
-                    self._store(dst, slot)
-                    self._commit(slot)
+                self._commit(self._curr_slot if in_bank else store_slot)
             elif in_bank:
                 # the slot is not kept: move this frame's K / V out before the next memorised frame overwrites it
                 keep = self._scratch_set()
@@ -339,10 +379,10 @@ class AOTEngine(nn.Module):
 
 
 def _finalize(owner, cohorts, logits, h4, w4, output_size, stream):
-    """Masks unused ids, writes pred_id_logits ([G, C, h4, w4]) and the output-size logits of all G lanes: plain logits for
-    one group, the reference's soft aggregation (aot_engine.py:565-582) for several -- one kernel either way.  The cohorts
-    hold consecutive object groups; every group but the last is full, so the object count of the lanes in view is the sum
-    of the cohorts' counts."""
+    """Masks unused ids and writes the stride-4 planar logits ([G, C, h4, w4]) and the output-size logits of all G lanes:
+    plain logits for one group, the reference's soft aggregation (aot_engine.py:565-582) for several -- one kernel either
+    way.  The cohorts hold consecutive object groups; every group but the last is full, so the object count of the lanes
+    in view is the sum of the cohorts' counts.  Returns (out4, out | None)."""
     nc = logits.shape[1]
     G = sum(c.lanes for c in cohorts)
     dev = logits.device
@@ -354,13 +394,46 @@ def _finalize(owner, cohorts, logits, h4, w4, output_size, stream):
         oh, ow = int(output_size[0]), int(output_size[1])
         out = torch.empty(1, nc if G == 1 else 1 + G * (nc - 1), oh, ow, dtype=torch.float32, device=dev)
     aot_hip.logits_finalize(logits, out4, out, h4, w4, nc, oh, ow, objects, owner.align_corners, G=G, stream=stream)
+    return out4, out
+
+
+def _decode(owner, cohorts, output_size):
+    """decode_current_logits of one or several cohorts (aot_engine.py:356-380, 618-628): decoder, id masking, resize and
+    group aggregation.  One cohort in graph mode: a single replay."""
+    first = cohorts[0]
+    if output_size is not None:
+        output_size = (int(output_size[0]), int(output_size[1]))
+
+    def launch():
+        stream = aot_hip.stream_ptr()
+        if len(cohorts) == 1:
+            logits, h4, w4 = first.decode_stride4()
+        else:       # several cohorts: their stride-4 logits are gathered lane after lane into one buffer
+            parts = []
+            for c in cohorts:
+                lg, h4, w4 = c.decode_stride4()
+                parts.append(lg.clone())                    # the decoder's output scratch is shared by the cohorts
+            buf = torch.empty(sum(p.shape[0] for p in parts), parts[0].stride(0), dtype=torch.float32, device=parts[0].device)
+            r = 0
+            for lg in parts:
+                buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
+                r += lg.shape[0]
+            logits = buf[:, :parts[0].shape[1]]
+        return _finalize(owner, cohorts, logits, h4, w4, output_size, stream)
+
+    if len(cohorts) == 1 and first.use_graph:
+        key = ptr_key('decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
+                      first._group_objects())
+        out4, out = first._gx().run(key, launch)
+    else:
+        out4, out = launch()
     g = 0
     for c in cohorts:
         c.pred_id_logits = out4[g:g + c.lanes]
         g += c.lanes
     if out is not None:
         return out
-    if G == 1:
+    if out4.shape[0] == 1:
         return out4
     raise NotImplementedError('stride-4 aggregation of several object groups: pass an output_size')
 
@@ -396,8 +469,9 @@ class AOTInferEngine(nn.Module):
     cohort_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
-                 long_term_mem_max=None):
+                 long_term_mem_max=None, graph=False):
         super().__init__()
+        self.use_graph = bool(graph)    # replay captured hipGraphs per engine state (see AOTEngine.__init__, engines/graphs.py)
         self.cfg = aot_model.cfg
         self.AOT = aot_model
         if max_aot_obj_num is not None and max_aot_obj_num < aot_model.max_obj_num:
@@ -430,7 +504,7 @@ class AOTInferEngine(nn.Module):
                 c.restart_engine()
                 return c
         c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip, self.long_term_mem_max,
-                            lanes=lanes, group0=group0)
+                            lanes=lanes, group0=group0, graph=self.use_graph)
         c.eval()
         return c
 
@@ -472,23 +546,7 @@ class AOTInferEngine(nn.Module):
                 img_embs = c.curr_enc_embs
 
     def decode_current_logits(self, output_size=None):
-        stream = aot_hip.stream_ptr()
-        if len(self._cohorts) == 1:
-            logits, h4, w4 = self._cohorts[0].decode_stride4()
-        else:       # several cohorts: their stride-4 logits are gathered lane after lane into one buffer
-            parts = []
-            for c in self._cohorts:
-                lg, h4, w4 = c.decode_stride4()
-                parts.append((lg.clone(), h4, w4))          # the decoder's output scratch is shared by the cohorts
-            h4, w4 = parts[0][1], parts[0][2]
-            buf = torch.empty(sum(p[0].shape[0] for p in parts), parts[0][0].stride(0), dtype=torch.float32,
-                              device=parts[0][0].device)
-            r = 0
-            for lg, _, _ in parts:
-                buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
-                r += lg.shape[0]
-            logits = buf[:, :parts[0][0].shape[1]]
-        return _finalize(self, self._cohorts, logits, h4, w4, output_size, stream)
+        return _decode(self, self._cohorts, output_size)
 
     def update_memory(self, curr_mask, skip_long_term_update=False):
         for c in self._cohorts:

@@ -76,17 +76,23 @@ class LongShortTermTransformerBlock(nn.Module):
         return p
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
-    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
         """x [B*N, C(ld)] token-major (B lanes).  long_mem = (K, V, T, kv_brows): lane b's bank = rows b*kv_brows .. + T;
         short_mem = (K, V, kv_brows).  dst = (k_out, v_out) [B*N, C] buffers for this frame's K (= linear_Q output) and, on
-        a reference frame, the id-fused V (e.g. the lane's bank slot); allocated when None.
+        a reference frame, the id-fused V (e.g. the lane's bank slot); allocated when None.  keep = the caller's arena
+        (a Workspace) for the tensors that outlive this call; None: fresh tensors.
         Returns (out [B*N,C], curr_K, curr_V (normed input), fused_V or None)."""
         p = self.pack()
         M, C = x.shape
         N = M // B
         dev = x.device
         h, w = size_2d
-        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # tensors that outlive this call
+        tag = id(self)
+
+        def new(name, *s):            # tensors that outlive this call
+            if keep is not None:
+                return keep.get('%s_%d' % (name, tag), s, dev)
+            return torch.empty(s, dtype=torch.float32, device=dev)
 
         # self-attention
         x1 = ws.get('x1', (M, C), dev)
@@ -102,9 +108,9 @@ class LongShortTermTransformerBlock(nn.Module):
         aot_hip.linear(so, p['sa_o_w'], p['sa_o_b'], xa, res=x, stream=stream)
 
         # long + short term attention
-        x2 = new(M, C)                                            # curr_V (normed input, transformer.py:333)
+        x2 = new('x2', M, C)                                      # curr_V (normed input, transformer.py:333)
         aot_hip.layernorm(xa, *p['norm2'], x2, stream=stream)
-        qc = dst[0] if dst is not None else new(M, C)             # curr_Q == curr_K (:331-332)
+        qc = dst[0] if dst is not None else new('qc', M, C)       # curr_Q == curr_K (:331-332)
         aot_hip.linear(x2, p['q_w'], p['q_b'], qc, stream=stream)
         fused_v = None
         if id_emb is not None:                                    # reference frame: memorise itself (:337-341)
@@ -185,21 +191,25 @@ class LongShortTermTransformer(nn.Module):
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
         """Runs the stack for B lanes on the projected encoder feature x0 [N, C] (shared by the lanes).  Returns
         (dec_in, mems): dec_in is the decoder's concatenated input [B*N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0,
         blocks 1.. = the layer outputs after their decoder norm (transformer.py:124-135), written in place so the concat is
         never a copy; mems[i] = (curr_K, curr_V, fused_V | None) of layer i."""
         N, C = x0.shape
         L = self.num_layers
-        out_cat = torch.empty(B * N, (L + 1) * C, dtype=torch.float32, device=x0.device)
+        if keep is not None:
+            out_cat = keep.get('lstt_out_cat', (B * N, (L + 1) * C), x0.device)
+        else:
+            out_cat = torch.empty(B * N, (L + 1) * C, dtype=torch.float32, device=x0.device)
         out_cat.view(B, N, (L + 1) * C)[:, :, :C].copy_(x0)      # the same image feature for every lane
         x = out_cat[:, :C]
         mems = []
         for i, layer in enumerate(self.layers):
             x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
                                       short_mems[i] if short_mems is not None else None,
-                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None)
+                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
+                                      keep=keep)
             mems.append((ck, cv, fv))
             is_last = i == L - 1
             norm = None
@@ -289,7 +299,7 @@ class GatedPropagationModule(nn.Module):
             aot_hip.linear(id_emb, p['idv_w_id'], None, dst, res=tmp, act=aot_hip.ACT_SILU, stream=stream)
         return vcat
 
-    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
         """X [B*N, 2D] = [tgt | tgt_id] (tgt_id = 0 into layer 0), B lanes.  long_mem = (K, Vcat, T, kv_brows), short_mem =
         (K, Vcat, kv_brows); dst = (k_out [B*N, d_att], vcat_out [B*N, 2E]) for this frame's K and [V | ID_V].
         Returns (X_out, curr_K, curr_Vcat, curr_ID_V_input)."""
@@ -298,12 +308,16 @@ class GatedPropagationModule(nn.Module):
         N = M // B
         D, E, da = self.d_model, self.expand_d_model, self.d_att
         dev = X.device
-        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+
+        def new(name, *s):            # tensors that outlive this call (keep = the caller's arena)
+            if keep is not None:
+                return keep.get('gpm_%s_%d' % (name, self.layer_idx), s, dev)
+            return torch.empty(s, dtype=torch.float32, device=dev)
         x1 = ws.get('gpm_x1', (M, D), dev)
         aot_hip.layernorm(X[:, :D], *p['norm1'], x1, stream=stream)
-        qc = dst[0] if dst is not None else new(M, da)                      # curr_Q == curr_K (:597)
+        qc = dst[0] if dst is not None else new('qc', M, da)                    # curr_Q == curr_K (:597)
         aot_hip.linear(x1, p['q_w'], p['q_b'], qc, stream=stream)
-        vcat = dst[1] if dst is not None else new(M, 2 * E)                 # [curr_V | ID_V]
+        vcat = dst[1] if dst is not None else new('vcat', M, 2 * E)               # [curr_V | ID_V]
         aot_hip.linear(x1, p['v_w'], p['v_b'], vcat[:, :E], act=aot_hip.ACT_SILU, stream=stream)
         if self.layer_idx == 0:                                             # U = [silu(U) | 1] (:602-606)
             nbuf = len(ws._bufs)
@@ -313,7 +327,7 @@ class GatedPropagationModule(nn.Module):
             aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
             xi = None
         else:                                                               # U = silu([U | linear_ID_U(LN(tgt_id))]) (:608-611)
-            xi = new(M, D)
+            xi = new('xi', M, D)
             aot_hip.layernorm(X[:, D:], *p['id_norm1'], xi, stream=stream)
             U = ws.get('gpm_U', (M, 2 * E), dev)
             aot_hip.linear(x1, p['u_w'], p['u_b'], U[:, :E], act=aot_hip.ACT_SILU, stream=stream)
@@ -380,7 +394,7 @@ class DualBranchGPM(nn.Module):
         if intermediate_norm:
             raise NotImplementedError('DeAOT decodes the last GPM output only (default_deaot.py:12)')
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None):
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
         """B lanes on the shared feature x0 [N, D].  Returns (dec_in [B*N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last
         layer, mems): mems[i] = (curr_K, curr_Vcat, curr_ID_V_input) of layer i."""
         N, D = x0.shape
@@ -392,9 +406,13 @@ class DualBranchGPM(nn.Module):
         for i, layer in enumerate(self.layers):
             X, ck, cv, xi = layer.run(X, long_mems[i] if long_mems is not None else None,
                                       short_mems[i] if short_mems is not None else None,
-                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None)
+                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
+                                      keep=keep)
             mems.append((ck, cv, xi))
-        out = torch.empty(B * N, 2 * D, dtype=torch.float32, device=dev)
+        if keep is not None:
+            out = keep.get('gpm_dec_in', (B * N, 2 * D), dev)
+        else:
+            out = torch.empty(B * N, 2 * D, dtype=torch.float32, device=dev)
         gn = self.decoder_norms[-1].gn
         aot_hip.groupnorm(X, gn.weight, gn.bias, out, 2, aot_hip.gn_buffers(ws, dev, B, 2, 64), act=aot_hip.ACT_NONE,
                           nsplit=64, B=B, stream=stream)

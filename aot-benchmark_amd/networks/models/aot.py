@@ -135,7 +135,7 @@ class AOT(nn.Module):
         x, h, w = top
         emb = self.encoder_projector.out_channels
         if out_cat is None:
-            out = torch.empty(h * w, emb, dtype=torch.float32, device=img.device)
+            out = self.ws.get('enc_proj16', (h * w, emb), img.device)     # per-stream scratch, like the encoder maps
         else:
             out = out_cat[:, :emb]
         aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, stream=stream)
@@ -190,7 +190,7 @@ class AOT(nn.Module):
 
     def encode_image(self, img):
         f4, f8, f16, top = self.encode_tokens(img)
-        return [as_map(t.clone(), h, w) for (t, h, w) in (f4, f8, f16)] + [as_map(top[0], top[1], top[2])]
+        return [as_map(t.clone(), h, w) for (t, h, w) in (f4, f8, f16, top)]      # callers own what this API returns
 
     def decode_id_logits(self, lstt_emb, shortcuts):
         stream = aot_hip.stream_ptr()

@@ -58,7 +58,7 @@ def gather_stats(stats, world):
     return torch.stack(out).cpu()
 
 
-def build_model(device):
+def build_model(device, graph=False):
     from networks.engines import build_engine
     from networks.models import build_vos_model
     from utils.synth import synth_state_dict
@@ -68,7 +68,7 @@ def build_model(device):
     model.load_state_dict(sd)
     model = model.to(device).eval()
     engine = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
-                          long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP)
+                          long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP, graph=graph)
     return cfg, model, engine, sd
 
 
@@ -178,7 +178,7 @@ def attention_roofline(engine, clip, device):
             'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n)}
 
 
-def jf_vs_reference(device):
+def jf_vs_reference(device, graph=False):
     """J&F of this engine's FREE-RUNNING masks against the real reference's masks on the committed golden clip of
     BASELINE config 2 (tests/golden/c2_r50_aotl_70.npz: R50-AOTL, 481x849, 10 objects, 69 propagated frames)."""
     import numpy as np
@@ -188,7 +188,7 @@ def jf_vs_reference(device):
     if not os.path.exists(gp):
         return None
     gold = np.load(gp)['masks']
-    cfg, model, engine, _ = build_model(device)
+    cfg, model, engine, _ = build_model(device, graph)
     frames, mask, objs, _ = synth_clip(0, gold.shape[0] + 1, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
     engine.restart_engine()
     engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
@@ -280,6 +280,9 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=3 * (CLIP_FRAMES - 1), help='propagated frames timed per GPU (default: one full 70-frame clip per stream)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--streams', type=int, default=3, help='clips processed concurrently per GPU (one HIP stream each)')
+    ap.add_argument('--graph', type=int, default=1, choices=[0, 1],
+                    help='1 (default): the engines replay one captured hipGraph per frame stage and engine state '
+                         '(networks/engines/graphs.py); 0: every kernel launched from the host')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (default); gloo only with --dry-run')
@@ -336,7 +339,7 @@ def main(argv=None):
     else:
         from networks.engines import build_engine
         from utils.synth import synth_clip
-        cfg, model, engine, sd = build_model(device)
+        cfg, model, engine, sd = build_model(device, bool(args.graph))
         gap = cfg.TEST_LONG_TERM_MEM_GAP
         if hasattr(model, 'prepare'):
             model.prepare()        # pack the weights once, before the clips fan out over streams
@@ -345,7 +348,7 @@ def main(argv=None):
             frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
             clips.append((frames, mask, objs))
         engines = [engine] + [build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
-                                           long_term_mem_gap=gap) for _ in range(S - 1)]
+                                           long_term_mem_gap=gap, graph=bool(args.graph)) for _ in range(S - 1)]
         streams = [torch.cuda.Stream(device) for _ in range(S)]
         lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
 
@@ -406,13 +409,16 @@ def main(argv=None):
 
         roof = None
         if rank == 0 and not args.no_roofline and not dry:
+            # the instrumented pass launches every kernel from the host (events cannot sit inside a replayed graph)
+            probe = engines[0] if not args.graph else build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model,
+                                                                    gpu_id=device.index or 0, long_term_mem_gap=gap)
             with torch.cuda.stream(streams[0]):
-                roof = attention_roofline(engines[0], clips[0], device)
+                roof = attention_roofline(probe, clips[0], device)
 
     base = jf = None
     if rank == 0 and not dry:
         with torch.no_grad():
-            jf = jf_vs_reference(device)
+            jf = jf_vs_reference(device, bool(args.graph))
         if not args.no_cpu_baseline:
             base = cpu_baseline(sd)          # rank 0 only, after the timed region; the other ranks wait at the barrier
     if world > 1:
@@ -433,6 +439,7 @@ def main(argv=None):
                        'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
                        'single_stream': single,
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
+                       'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
                        'timed_region': 'wall clock (barrier + device sync on both sides) over the propagated frames '
                                        'only: windows of consecutive frames spread over the 70-frame clip so that the '

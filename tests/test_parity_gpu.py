@@ -874,6 +874,67 @@ def test_concurrent_clips_on_two_streams(hip):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('name,nobj,size', [('aott', 2, (97, 129)), ('r50_aotl', 10, (241, 321)), ('deaott', 3, (97, 129)),
+                                            ('aott', 13, (97, 129))])
+def test_graph_replay_bit_identical(hip, name, nobj, size):
+    """graph=True (engines/graphs.py): every stage of a frame is captured once per engine state as a hipGraph and replayed.
+    Two clips back to back on two engines that run interleaved on their own streams: clip 1 captures (and replays),
+    clip 2 only replays the graphs of clip 1 -- logits must be BIT-identical to the eager engine's, the second clip must
+    add no capture, and the state walk of a clip must be covered by replays."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state(name)
+    model = model.cuda().eval()
+    model.prepare()
+    osz = (size[0] - 1, size[1] - 1)
+    mk = lambda g: build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=2, graph=g)
+    clips = [synth_clip(k, 8, size, osz, nobj, device='cuda') for k in (3, 4, 5, 6)]
+
+    def frame(e, img):
+        e.match_propogate_one_frame(img)
+        lg = e.decode_current_logits(osz)
+        e.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=e.input_size_2d, mode='nearest'))
+        return lg.clone(), e.aot_engines[0].pred_id_logits.clone()
+
+    def run_clip(e, clip):
+        fr, m, ob, _ = clip
+        e.restart_engine()
+        e.add_reference_frame(fr[0], m, ob, frame_step=0)
+        return [frame(e, fr[t]) for t in range(1, len(fr))]
+
+    with torch.no_grad():
+        eager = mk(False)
+        want = [run_clip(eager, c) for c in clips]
+        torch.cuda.synchronize()
+        engs, sts = [mk(True), mk(True)], [torch.cuda.Stream(), torch.cuda.Stream()]
+        got = [None] * 4
+        caps = []
+        for rnd in range(2):                      # engine i runs clips i and i + 2, the two engines interleaved frame by frame
+            outs = [[], []]
+            for i in range(2):
+                fr, m, ob, _ = clips[2 * rnd + i]
+                with torch.cuda.stream(sts[i]):
+                    engs[i].restart_engine()
+                    engs[i].add_reference_frame(fr[0], m, ob, frame_step=0)
+            for t in range(1, 8):
+                for i in range(2):
+                    with torch.cuda.stream(sts[i]):
+                        outs[i].append(frame(engs[i], clips[2 * rnd + i][0][t]))
+            for i in range(2):
+                got[2 * rnd + i] = outs[i]
+            caps.append([sum(c._gx().captures for c in e._cohorts) for e in engs])
+        torch.cuda.synchronize()
+    for k in range(4):
+        for t, ((a, a4), (b, b4)) in enumerate(zip(want[k], got[k])):
+            assert torch.equal(a, b), 'clip %d frame %d: graph replay differs from eager (max %g)' % (
+                k, t + 1, (a - b).abs().max().item())
+            assert torch.equal(a4, b4)
+    assert caps[1] == caps[0], 'the second clip captured new graphs: %s -> %s' % (caps[0], caps[1])
+    for e in engs:
+        g = e._cohorts[0]._gx()
+        assert g.captures <= 3 * 7 and g.replays == 2 * 3 * 7
+
+
 def test_reference_api_surface(hip):
     """the reference's model-level methods keep working on reference-shaped tensors (aot.py:72-108)."""
     from oracle.aot_oracle import OracleModel, one_hot_mask

@@ -14,12 +14,12 @@ nf, fetch = total(sys.argv[1], 'FETCH_SIZE')
 nw, write = total(sys.argv[2], 'WRITE_SIZE')
 N, C, H = 1674, 256, 8
 rec = {'kernel': kern,
-       'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a second pass --pmc WRITE_SIZE) -- python scratch/pmc_attn_mix.py  (the 414 attention launches of one 70-frame bench clip, default stream)',
+       'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a second pass --pmc WRITE_SIZE) -- python tools/dev/pmc_attn_mix.py  (the 414 attention launches of one 70-frame bench clip, default stream)',
        'launches': nf, 'launches_write_pass': nw, 'FETCH_SIZE_KB_total': fetch, 'WRITE_SIZE_KB_total': write,
        'fetch_correction': 'x2 on gfx950 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a wide coalesced stream)',
        'bytes_per_launch': {'fetch_corrected': 2 * fetch * 1024 / max(nf, 1), 'write': write * 1024 / max(nw, 1)}}
 rec['traffic_bytes_per_launch'] = rec['bytes_per_launch']['fetch_corrected'] + rec['bytes_per_launch']['write']
-rec['note'] = ('fabric-side counters (Infinity Cache hits included); the split-KV partial slabs (nsplit*N*(C+2H) floats written, read '
-               'back by attn_merge_kernel) and K/V re-streaming by the 53 query tiles account for the excess over the algorithmic bytes')
+rec['note'] = ('fabric-side counters (Infinity Cache hits included); K/V re-streaming by the 53 query tiles and the grid-level '
+               'split partial slabs (<= 4*N*(C+2H) floats, merged by attn_merge_kernel) account for the excess over the algorithmic bytes')
 json.dump(rec, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(rec, indent=1))

@@ -1,7 +1,7 @@
 """Per-shape microbenchmark of the implicit-GEMM conv for every conv/linear of the R50-AOTL 480p frame.
-usage: python scratch/mb_gemm.py [cfgs e.g. -1,0,1,2]"""
+usage: python tools/dev/mb_gemm.py [cfgs e.g. -1,0,1,2]"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
 if len(sys.argv) > 2: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])

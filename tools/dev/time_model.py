@@ -1,5 +1,5 @@
 import sys, os, time, importlib
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, torch.nn.functional as F
 from networks.models import build_vos_model
