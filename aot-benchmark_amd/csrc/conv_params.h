@@ -14,7 +14,10 @@ struct ConvParams {
   int lda, ldb, ldwt, ldc, ldr, res_rows, M, K, act;
 };
 
-// LDS-direct kernel (gemm_lds.hip).  variant: 0 = 128x64 tile, 1 = 64x64 tile.  ksplit > 1 cuts K into ksplit slices
+// LDS-direct kernel (gemm_lds.hip).  variant: 0 = 128x64 tile, 1 = 64x64 tile (two DMA steps ahead); 2 / 3 = 64x64 with
+// three / four steps ahead, 4 / 5 = 128x64 with three / four (for shapes with about one workgroup per CU).  ksplit > 1 cuts K into ksplit slices
 // whose fp32 partial tiles go to `scratch` ([ksplit][M][Cout] floats) and are summed in slice order by a second launch.
 int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s);
 bool gemm_lds_eligible(const ConvParams& p);
+// variant 6 / 7 = the lean 64x64 / 128x64 kernel (buffer-DMA addressing, interleaved issue; see gemm_lds.hip)
+bool gemm_lean_eligible(const ConvParams& p);

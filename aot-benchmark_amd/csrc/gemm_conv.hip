@@ -472,25 +472,25 @@ static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
   AOT_LAUNCH_CHECK();
 }
 
-// Kernel choice (cfg < 0): a table read off the sweep of tools/dev/gemm_check.hip on MI355X (profiles/r02_gemm_sweep.txt;
-// every kernel family on every conv / linear shape of the R50-AOTL frame, one clip and three lanes stacked):
-//   * register-staged 64x64x32 LDS kernel (cfg 4): >= 512 tiles of 64x64, and everything the other kernels cannot take
-//     (stem, MobileNet channel counts); 128x32 tiles for Cout <= 32;
-//   * LDS-direct 64x64 tile kernel (gemm_lds.hip, cfg 117): KxK convs with >= 192 tiles (the filter tap is wave-uniform per
-//     k-step there: 10-40 % faster than the per-lane tap arithmetic of the register-staged loader), and the mid-sized 1x1
-//     shapes with K = 512 or Cout >= 1024 (192 <= tiles < 512);
+// Kernel choice (cfg < 0): a table read off the sweeps of tools/dev/gemm_check.hip on MI355X (profiles/r02_gemm_sweep.txt,
+// profiles/r02f_gemm_sweep_lean.txt; every kernel family on every conv / linear shape of the R50-AOTL frame, one clip and
+// three lanes stacked):
+//   * lean LDS-direct 64x64 tile kernel (gemm_lds.hip, cfg 197): everything with Cin % 32 == 0 and >= 192 tiles of 64x64 --
+//     15-25 % faster than both older tile kernels on every such shape (buffer-DMA addressing, fragment reads and DMA
+//     pieces placed between the MFMAs);
+//   * register-staged 64x64x32 LDS kernel (cfg 4): what the lean kernel cannot take (stem, MobileNet channel counts);
+//     128x32 tiles for Cout <= 32;
 //   * wave-independent kernels with in-block split-K (cfg 1x: 32x32 waves, cfg 2x: 64x32 waves): the stride-16 maps
-//     (M = 1674 per lane), where neither LDS-tiled kernel -- with or without split-K slabs -- beats them.
+//     (M = 1674 per lane) with fewer than 192 tiles, where no LDS-tiled kernel -- with or without split-K slabs --
+//     beats them.
 static int auto_cfg(const ConvParams& p, long scratch_floats) {
   (void)scratch_floats;
   const bool direct_ok = (p.Cin % 32 == 0) && (p.K % 32 == 0);
-  const bool lds_ok = gemm_lds_eligible(p);
   const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const bool kxk = p.KH * p.KW > 1;
   if (p.Cout <= 32) return 3;
-  if (kxk && lds_ok && tiles64 >= 192 && !(tiles64 < 400 && p.K >= 2048 && p.Cout >= 256)) return 116 + 1;
+  if (tiles64 >= 192 && gemm_lean_eligible(p)) return 196 + 1;
   if (tiles64 >= 512 || !direct_ok) return 4;
-  if (!kxk && lds_ok && tiles64 >= 192 && p.K <= 512 && (p.K == 512 || p.Cout >= 1024)) return 116 + 1;
   if (kxk && tiles64 < 192 && p.K >= 1024) return 24;
   const long tiles32 = (long)cdiv(p.M, 32) * cdiv(p.Cout, 32);
   const int nslab = p.K / 32;

@@ -137,17 +137,17 @@ class SwinTransformer(nn.Module):
         self._pe = None
 
     def run(self, img, ws, stream):
-        """img [1,3,H,W] (H, W multiples of 4; the 16-aligned evaluator sizes are) -> [(feat, h, w)] x 3."""
+        """img [1,3,H,W] -> [(feat, h, w)] x 3.  Sides that are not multiples of the 4x4 patch are zero-padded on the
+        right / bottom (PatchEmbed.forward, swin_transformer.py:501-509): the implicit-GEMM loader reads taps beyond the
+        image as zeros, so the padding is just the rounded-up output size."""
         _, _, H, W = img.shape
-        if H % 4 or W % 4:
-            raise NotImplementedError('Swin patch embedding: pad H, W to multiples of 4 (reference :474-481)')
         dev = img.device
         if self._pe is None:
             self._pe = (fold_conv_bn(self.patch_embed.proj, pad_cin=4), _ln(self.patch_embed.norm))
         (pw, pb), (g, b) = self._pe
         x4 = ws.get('img_nhwc4', (H * W, 4), dev)
         aot_hip.nchw_to_nhwc(img, x4, 3, H, W, 4, stream=stream)
-        h, w = H // 4, W // 4
+        h, w = -(-H // 4), -(-W // 4)
         C = self.embed_dim
         x = ws.get('sw_x_%d_0' % C, (h * w, C), dev)
         aot_hip.conv2d(x4, pw, pb, x, H, W, 4, h, w, C, 4, 4, 4, 0, 1, stream=stream)

@@ -8,11 +8,13 @@ new-object merge and the label feedback to every augmentation's engine -- is res
 Config keys read (same names as configs/default.py of the reference): TEST_FLIP, TEST_MULTISCALE, TEST_MAX_SHORT_EDGE,
 TEST_MAX_LONG_EDGE, TEST_LONG_TERM_MEM_GAP, TEST_SHORT_TERM_MEM_SKIP, MODEL_ALIGN_CORNERS, MODEL_ENGINE.
 """
+import os
+
 import torch
 
 import aot_hip
 from networks.engines import build_engine
-from utils.image import restrict_size
+from utils.image import restrict_size, save_mask
 
 
 class SequenceEvaluator:
@@ -45,11 +47,14 @@ class SequenceEvaluator:
         return self.engines[i]
 
     @torch.no_grad()
-    def run(self, frames, labels, obj_nums):
+    def run(self, frames, labels, obj_nums, save_dir=None, names=None, obj_idx=None):
         """frames: list of [H, W, 3] uint8/float32 device images (values 0..255, the dataset's channel order);
         labels: {frame_idx: [H, W] label map} -- frame 0 is required, later entries inject new objects
         (evaluator.py:336-338,362-392); obj_nums: {frame_idx: int} objects annotated so far at that frame.
-        Returns the list of predicted label maps [H, W] (float) for frames 1.. ."""
+        Returns the list of predicted label maps [H, W] (float) for frames 1.. .
+        save_dir: the predictions are also written as palette PNGs `<save_dir>/<names[t]>.png` once the sequence is
+        done (outside the per-frame loop, as the reference does: evaluator.py:448-466,500-505); obj_idx = the dataset's
+        object ids of the dense ids 0..n (the reference's squeeze index), or None."""
         H, W = frames[0].shape[:2]
         augs = self.augmentations(H, W)
         for e in self.engines:
@@ -87,4 +92,10 @@ class SequenceEvaluator:
             else:
                 for i, (nh, nw, flip) in enumerate(augs):                   # (:394-408)
                     self._engine(i).update_memory(aot_hip.label_resize(augl[i], nh, nw, flip))
+        if save_dir is not None:
+            os.makedirs(save_dir, exist_ok=True)
+            writers = [save_mask(p, os.path.join(save_dir, '%s.png' % (names[t] if names is not None else '%05d' % t)),
+                                 obj_idx) for t, p in enumerate(preds, start=1)]
+            for w in writers:
+                w.join()
         return preds

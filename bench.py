@@ -285,6 +285,7 @@ def main(argv=None):
                          '(networks/engines/graphs.py); 0: every kernel launched from the host')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-jf', action='store_true', help='skip the J&F pass on the committed reference clip (tuning runs)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (default); gloo only with --dry-run')
     ap.add_argument('--dry-run', action='store_true', help='launcher / sharding / gather plumbing only, no device work (CPU tests)')
     args = ap.parse_args(argv)
@@ -417,8 +418,9 @@ def main(argv=None):
 
     base = jf = None
     if rank == 0 and not dry:
-        with torch.no_grad():
-            jf = jf_vs_reference(device, bool(args.graph))
+        if not args.no_jf:
+            with torch.no_grad():
+                jf = jf_vs_reference(device, bool(args.graph))
         if not args.no_cpu_baseline:
             base = cpu_baseline(sd)          # rank 0 only, after the timed region; the other ranks wait at the barrier
     if world > 1:

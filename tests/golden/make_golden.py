@@ -161,6 +161,54 @@ def make_transforms():
         refdriver._leave()
 
 
+def make_swin_ragged():
+    """The REAL reference's Swin-B trunk (networks/encoders/swin/swin_transformer.py) on an input whose sides are not
+    multiples of 4 -- the zero padding of PatchEmbed.forward (:501-509), odd token grids in PatchMerging (:341-345) and
+    padded windows at every stage.  Stage outputs are stored subsampled."""
+    net, _, _ = refdriver.build_reference('swinb_aotl')
+    net.load_state_dict(synth_state_dict(net.state_dict()))
+    x = torch.randn(1, 3, 98, 131, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        feats = net.encoder(x)
+    out = {'x': x.numpy()}
+    for i, f in enumerate(feats):
+        out['shape_%d' % i] = np.array(f.shape)
+        out['feat_%d' % i] = f[0, ::3].numpy()              # every third channel
+    np.savez_compressed(os.path.join(HERE, 'swin_ragged.npz'), **out)
+    print('swin_ragged', [tuple(f.shape) for f in feats], flush=True)
+
+
+def make_image_utils():
+    """Golden for the result writers (utils/image.py:6-105) from the REAL reference module: its palette table,
+    label2colormap of every id, and a palette PNG written by its _save_mask (decoded again: pixel ids + palette), with
+    and without the squeeze-index remap."""
+    import tempfile
+    from PIL import Image
+    refdriver._enter()
+    try:
+        import utils.image as rim
+        lab = (np.arange(37 * 53).reshape(37, 53) % 256).astype(np.uint8)
+        small = (np.arange(20 * 30).reshape(20, 30) % 5).astype(np.uint8)
+        sq = [0, 7, 3, 21, 200]
+        out = {'palette': np.array(rim._palette, dtype=np.uint8), 'label': lab, 'colormap': rim.label2colormap(lab),
+               'small': small, 'squeeze_idx': np.array(sq)}
+        with tempfile.TemporaryDirectory() as d:
+            for tag, m, s_ in (('plain', lab, None), ('squeezed', small, sq)):
+                pth = os.path.join(d, tag + '.png')
+                rim._save_mask(m.copy(), pth, s_)
+                im = Image.open(pth)
+                out['png_%s_ids' % tag] = np.array(im)
+                out['png_%s_palette' % tag] = np.array(im.getpalette(), dtype=np.uint8)
+                out['png_%s_mode' % tag] = np.array([ord(ch) for ch in im.mode], dtype=np.uint8)
+        img = np.linspace(0, 1, 3 * 20 * 30, dtype=np.float32).reshape(3, 20, 30)
+        col = rim.label2colormap(small).transpose(2, 0, 1).astype(np.float32) / 255.
+        out['overlay_img'], out['overlay'] = img, rim.masked_image(img, col, small).astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, 'image_utils.npz'), **out)
+        print('image_utils', {k: v.shape for k, v in out.items()}, flush=True)
+    finally:
+        refdriver._leave()
+
+
 def make_configs():
     """Every attribute of every model preset of the reference (configs/models/*.py) -> tests/golden/model_configs.json."""
     import importlib
@@ -181,6 +229,14 @@ def main():
     if not sys.argv[1:] or 'configs' in sys.argv[1:]:
         make_configs()
         if sys.argv[1:] == ['configs']:
+            return
+    if not sys.argv[1:] or 'swin_ragged' in sys.argv[1:]:
+        make_swin_ragged()
+        if sys.argv[1:] == ['swin_ragged']:
+            return
+    if not sys.argv[1:] or 'image_utils' in sys.argv[1:]:
+        make_image_utils()
+        if sys.argv[1:] == ['image_utils']:
             return
     if not sys.argv[1:] or 'transforms' in sys.argv[1:]:
         make_transforms()

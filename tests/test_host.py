@@ -177,3 +177,27 @@ def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
         assert hasattr(torch.ops.aot_hip, n)
     with pytest.raises(NotImplementedError):        # a CPU tensor never silently falls back
         torch.ops.aot_hip.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), torch.empty(4, 8), 1e-5)
+
+
+def test_result_writers_match_reference(tmp_path):
+    """utils/image.py result writers against the REAL reference module (tests/golden/image_utils.npz, made by
+    make_golden.make_image_utils): the palette table, label2colormap for every id, the overlay blend, and palette PNGs
+    decoded again (ids, palette, mode), with and without the squeeze-index remap (utils/image.py:6-105)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from utils import image as im
+    g = np.load(os.path.join(GOLD, 'image_utils.npz'))
+    assert im.davis_palette() == g['palette'].tolist()
+    assert np.array_equal(im.label2colormap(g['label']), g['colormap'])
+    col = im.label2colormap(g['small']).transpose(2, 0, 1).astype(np.float32) / 255.
+    assert np.array_equal(im.masked_image(g['overlay_img'], col, g['small']).astype(np.float32), g['overlay'])
+    for tag, m, sq in (('plain', g['label'], None), ('squeezed', g['small'], g['squeeze_idx'].tolist())):
+        p = str(tmp_path / (tag + '.png'))
+        im.save_mask(torch.from_numpy(m.copy()), p, sq, wait=True)
+        got = Image.open(p)
+        assert got.mode == ''.join(chr(c) for c in g['png_%s_mode' % tag])
+        assert np.array_equal(np.array(got), g['png_%s_ids' % tag])
+        assert np.array_equal(np.array(got.getpalette(), dtype=np.uint8), g['png_%s_palette' % tag])
+    x = torch.arange(24).view(2, 3, 4)
+    assert torch.equal(im.flip_tensor(x, 2), x.index_select(2, torch.arange(3, -1, -1)))

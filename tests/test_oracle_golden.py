@@ -172,3 +172,20 @@ def test_cubic_resize_restatement_vs_torch_bicubic():
                               align_corners=False)[0].permute(1, 2, 0).numpy()
             assert np.abs(a - b).max() < tol
     assert np.array_equal(cv2_cubic_resize(smooth, 120, 213), smooth)
+
+
+def test_oracle_swin_ragged_input_matches_reference():
+    """Swin-B trunk on a 98x131 input (sides not multiples of the 4x4 patch): the REAL reference's zero padding in
+    PatchEmbed (swin_transformer.py:501-509), odd token grids in PatchMerging and padded windows at every stage --
+    tests/golden/swin_ragged.npz (make_golden.make_swin_ragged)."""
+    import os
+    from oracle.aot_oracle import swin_features
+    g = np.load(os.path.join(GOLD, 'swin_ragged.npz'))
+    _, _, sd = synth_model_state('swinb_aotl')
+    with torch.no_grad():
+        feats = swin_features(sd, torch.from_numpy(g['x']))
+    assert len(feats) in (3, 4)
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g['shape_%d' % i])
+        ref = g['feat_%d' % i]
+        assert np.abs(f[0, ::3].numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -71,6 +71,51 @@ def test_conv2d(hip, H, W, Cin, Cout, K, s, p, d, act, res):
         assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
 
 
+@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', [
+    (61, 107, 128, 128, 3, 1, 1, 1, 1, False, 1),     # 3x3, 204 tiles (auto dispatch picks the lean kernel)
+    (61, 107, 128, 128, 3, 2, 1, 1, 1, True, 1),      # stride-2 3x3 + residual
+    (61, 107, 256, 512, 1, 2, 0, 1, 0, False, 1),     # 1x1 stride-2 downsample
+    (64, 66, 64, 256, 1, 1, 0, 1, 1, True, 1),        # K = 64: two k-steps per tile, residual + relu
+    (31, 54, 1024, 256, 1, 1, 0, 1, 0, True, 3),      # three lanes on a shared residual map (row m % res_rows)
+    (33, 35, 96, 96, 3, 1, 2, 2, 3, False, 1),        # dilation 2, Cout = 96 (ragged column tile), GELU
+    (17, 19, 32, 40, 3, 1, 1, 1, 0, False, 1),        # tiny map: fewer tiles than workgroups, ragged rows and columns
+    (9, 9, 64, 64, 1, 1, 0, 1, 0, True, 2),           # residual map smaller than a tile (general modulo path)
+])
+@pytest.mark.parametrize('cfg', [197, 213, 198, 216])
+def test_conv2d_lean_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, cfg):
+    """The lean LDS-direct tile kernels forced by configuration (197: 64x64, 213: 128x64, 198 / 216: the same with K split in
+    2 / 8 slices through a scratch slab): buffer-descriptor addressing with out-of-range offsets for padding taps, rows
+    >= M and columns >= Cout; B lanes with a shared residual map; every epilogue."""
+    g = torch.Generator().manual_seed(H * 131 + Cout + B)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    OH, OW = ref.shape[2:]
+    r = torch.randn(1, Cout, OH, OW, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    ref = {0: ref, 1: F.relu(ref), 3: F.gelu(ref)}[act].float()
+    ks = (cfg - 100) % 16
+    if (K * K * Cin // 32) % ks:
+        pytest.skip('K / 32 not divisible by the split')
+    ldb = (Cout + 3) // 4 * 4
+    wk = torch.zeros(K * K * Cin, ldb)
+    wk[:, :Cout] = w.permute(2, 3, 1, 0).reshape(K * K * Cin, Cout)
+    wk = _dev(wk)
+    wt = wk.t().contiguous()
+    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
+    out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+    rt = _dev(r[0].permute(1, 2, 0).reshape(OH * OW, Cout)) if res else None
+    scratch = torch.empty(ks * B * OH * OW * Cout, device='cuda') if ks > 1 else None
+    hip.conv2d_cfg(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, cfg=cfg, wt=wt,
+                   scratch=scratch, B=B, res_rows=OH * OW if res else 0)
+    got = out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    _close(got, ref, 2e-5 * max(1.0, ref.abs().max().item()), 'lean conv cfg %d' % cfg)
+    if ldb > Cout:
+        assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+
+
 def test_linear_strided_views(hip):
     """column slices of wider buffers as A, C and residual (how the LSTT avoids concat/split copies)."""
     g = torch.Generator().manual_seed(5)
@@ -593,6 +638,27 @@ def test_swin_encoder_full_size_vs_oracle(hip):
         _close(a, b, 2e-4, 'swin stage')
 
 
+def test_swin_encoder_ragged_input_vs_reference_golden(hip):
+    """Swin-B trunk on a 98x131 input: sides that are not multiples of the 4x4 patch are zero-padded by the patch
+    embedding (swin_transformer.py:501-509; here: the implicit-GEMM loader's bounds check) -- against the REAL
+    reference's stage outputs (tests/golden/swin_ragged.npz)."""
+    import os
+    from common import GOLD
+    from networks.models.aot import as_map
+    g = np.load(os.path.join(GOLD, 'swin_ragged.npz'))
+    cfg, model, sd = synth_model_state('swinb_aotl')
+    model = model.cuda().eval()
+    import aot_hip
+    with torch.no_grad():
+        feats = model.encoder.run(torch.from_numpy(g['x']).cuda().contiguous(), model.ws, aot_hip.stream_ptr())
+    assert len(feats) == 3
+    for i, (f, h, w) in enumerate(feats):
+        assert (1, f.shape[1], h, w) == tuple(g['shape_%d' % i])
+        ref = g['feat_%d' % i]
+        got = as_map(f, h, w)[0, ::3].cpu().numpy()
+        assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_free_running_bank_growth_vs_oracle(hip):
     """gap=1: the bank grows every frame through a capacity doubling; compares the HIP engine with the oracle
     frame by frame on the oracle's masks (14 propagated frames, AOTT)."""
@@ -746,7 +812,7 @@ def test_fuse_probs_and_label_resize_vs_torch(hip, A, nc, H, W, newobj):
 
 
 @pytest.mark.parametrize('flip,ms', [(False, (1,)), (True, (1.3, 1.0))])
-def test_sequence_evaluator_vs_oracle(hip, flip, ms):
+def test_sequence_evaluator_vs_oracle(hip, flip, ms, tmp_path):
     """The evaluator loop end to end on the device vs the oracle's restatement of evaluator.py:265-446:
     multi-scale + flip test-time augmentation, probability fusion, a new object injected at frame 2, label feedback."""
     from networks.managers.evaluator import SequenceEvaluator
@@ -768,7 +834,15 @@ def test_sequence_evaluator_vs_oracle(hip, flip, ms):
     labels, nums = {0: lab0, 2: lab2}, {0: 2, 2: 3}
     ref = sequence_eval(OracleModel('aott', sd), frames, labels, nums, flip=flip, multiscale=ms, long_term_mem_gap=2)
     ev = SequenceEvaluator(cfg, model)
-    got = ev.run([torch.from_numpy(f).cuda() for f in frames], {t: torch.from_numpy(l).cuda() for t, l in labels.items()}, nums)
+    got = ev.run([torch.from_numpy(f).cuda() for f in frames], {t: torch.from_numpy(l).cuda() for t, l in labels.items()}, nums,
+                 save_dir=str(tmp_path), names=['f%d' % t for t in range(4)], obj_idx=[0, 5, 9, 12])
+    from PIL import Image
+    from utils.image import davis_palette
+    for t in (1, 2, 3):      # the written palette PNGs decode to the predictions with the dataset's object ids
+        png = Image.open(str(tmp_path / ('f%d.png' % t)))
+        lut = np.array([0, 5, 9, 12], np.uint8)
+        assert png.mode == 'P' and png.getpalette() == davis_palette()
+        assert np.array_equal(np.array(png), lut[got[t - 1].cpu().numpy().astype(np.uint8)])
     assert len(got) == len(ref) == 3 and len(ev.engines) == len(ms) * (2 if flip else 1)
     for t, (g_, (rl, rp)) in enumerate(zip(got, ref), start=1):
         top2 = torch.topk(rp, 2, 0)[0]

@@ -41,6 +41,9 @@ struct Shape { const char* name; int H, W, Cin, Cout, K, s, cnt; };
 
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  // `gemm_check list 7:117:1,22:117:1` : only the listed (shape index : cfg : batch) launches, five times each, no check --
+  // the dispatches a `rocprofv3 --pmc` pass should see
+  const char* only = (argc > 2 && !strcmp(argv[1], "list")) ? argv[2] : nullptr;
   const Shape shapes[] = {
       {"l1.c1 64>64", 121, 213, 64, 64, 1, 1, 1},       {"l1.c1 256>64", 121, 213, 256, 64, 1, 1, 2},
       {"l1.c2 3x3 64", 121, 213, 64, 64, 3, 1, 3},      {"l1.c3 64>256", 121, 213, 64, 256, 1, 1, 4},
@@ -54,11 +57,45 @@ int main(int argc, char** argv) {
       {"lstt 512>256", 31, 54, 512, 256, 1, 1, 3},      {"dec ad8 512>256", 61, 107, 512, 256, 1, 1, 1},
       {"dec c8 3x3 256>128", 61, 107, 256, 128, 3, 1, 1}, {"dec ad4 256>128", 121, 213, 256, 128, 1, 1, 1},
       {"dec c4 3x3 128", 121, 213, 128, 128, 3, 1, 1},  {"ragged 3x3 d2", 17, 19, 32, 96, 3, 1, 0}};
-  const int cfgs[] = {-1, 4, 117, 12, 14, 18, 24};     // auto, 64x64 register-staged, lds 64x64, wave-independent x in-block split-K 2/4/8, 64x32 waves x4
+  // auto | 64x64 register-staged | LDS-direct 64x64 (2 / 3 DMA steps ahead) | lean 64x64 | lean 128x64 | lean 64x64 with
+  // split-K 2 / 4 | lean 128x64 with split-K 2 / 4 | wave-independent kernels (in-block split-K 4 / 8, 64x32 waves x4)
+  const int cfgs[] = {-1, 4, 117, 133, 197, 213, 198, 200, 214, 216, 14, 18, 24};
   const long scratch_floats = 48L << 20;
   float* scratch;
   CK(hipMalloc(&scratch, scratch_floats * 4));
-  double tot_us[8][2] = {}, tot_gf[2] = {};
+  if (only) {
+    for (const char* q = only; *q;) {
+      int si, c, B;
+      if (sscanf(q, "%d:%d:%d", &si, &c, &B) != 3) { printf("bad list entry %s\n", q); return 1; }
+      const Shape& sh = shapes[si];
+      const int pad = sh.K / 2;
+      const int OH = (sh.H + 2 * pad - (sh.K - 1) - 1) / sh.s + 1, OW = (sh.W + 2 * pad - (sh.K - 1) - 1) / sh.s + 1;
+      const long M = (long)B * OH * OW;
+      const int KK = sh.K * sh.K * sh.Cin;
+      std::vector<float> hin((size_t)B * sh.H * sh.W * sh.Cin), hw((size_t)KK * sh.Cout);
+      unsigned seed = 777u + si;
+      auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((int)(seed >> 9) - (1 << 22)) * (1.f / (1 << 22)); };
+      for (auto& v : hin) v = rnd();
+      for (auto& v : hw) v = rnd() * 0.1f;
+      float *din, *dw, *dwt, *dout;
+      CK(hipMalloc(&din, hin.size() * 4)); CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&dwt, hw.size() * 4));
+      CK(hipMalloc(&dout, (size_t)M * sh.Cout * 4));
+      CK(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dwt, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));     // (values do not matter here)
+      int rc = 0;
+      for (int i = 0; i < 5; ++i)
+        rc = aot_conv2d_nhwc_f32(din, dw, dwt, nullptr, nullptr, dout, scratch, scratch_floats, B, sh.H, sh.W, sh.Cin, OH, OW,
+                                 sh.Cout, sh.K, sh.K, sh.s, pad, 1, sh.Cin, sh.Cout, KK, sh.Cout, 0, 0, 1, c, 0);
+      CK(hipDeviceSynchronize());
+      printf("%s cfg %d batch %d: rc %d, M %ld K %d N %d\n", sh.name, c, B, rc, M, KK, sh.Cout);
+      hipFree(din); hipFree(dw); hipFree(dwt); hipFree(dout);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    return 0;
+  }
+  double tot_us[16][2] = {}, tot_gf[2] = {};
   for (int B = 1; B <= 3; B += 2) {
     printf("==== batch %d ====\n%-20s %7s %5s %5s %8s |", B, "shape", "M", "K", "N", "GF");
     for (int c : cfgs) printf(" cfg%4d us   TF |", c);
