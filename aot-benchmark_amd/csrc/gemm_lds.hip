@@ -347,6 +347,28 @@ __device__ __forceinline__ void fetch_frags(f32x4 (&a)[BMB][4], f32x4 (&b)[4], c
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
 }
+// raw buffer descriptor (stride 0) as four scalars, for the inline-asm buffer loads / stores of the epilogue
+__device__ __forceinline__ i32x4 raw_desc(const void* base, long bytes) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  i32x4 d;
+  d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+  d[2] = __builtin_amdgcn_readfirstlane(base ? (int)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL) : 0);
+  d[3] = 0x00020000;
+  return d;
+}
+// asynchronous (the compiler does not see them as memory operations: the callers place the vmcnt waits).  The s_nop covers
+// the "VALU writes an SGPR -> vector-memory instruction reads it" hazard (5 wait states), which hipcc cannot insert for an
+// instruction hidden in inline asm: under register pressure it restores the descriptor from spill lanes with v_readlane
+// right in front of the asm (seen in the KxK kernel: the load then went out with a stale base address).
+__device__ __forceinline__ float buf_load(const i32x4& desc, int voff) {
+  float v;
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(desc));
+  return v;
+}
+__device__ __forceinline__ void buf_store(const i32x4& desc, int voff, float v) {
+  asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(desc) : "memory");
+}
 template <int IMM>
 __device__ __forceinline__ void fetch_one(f32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
@@ -424,6 +446,16 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (int)((long)p.Cout * p.ldwt * 4), 0x00020000);
+
+  // epilogue operands through descriptors too (offset 0x80000000 = masked: loads give 0, stores are dropped), so that
+  // the number of vector-memory instructions a tile end issues is FIXED and the counted waits below stay exact
+  const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
+  const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
+  const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
+  constexpr bool PREFETCH_EPI = BMB == 1;      // residual + bias of a tile are fetched under its last k-step (64x64 tile only:
+                                               // the 128x64 tile has no registers to spare for them)
+  const bool fused_epi = ksplit == 1;
+  const int n_res = (fused_epi && p.res) ? 16 * BMB : 0, n_bias = (fused_epi && p.bias) ? 1 : 0;
 
   // ---- issue side --------------------------------------------------------------------------------------------------
   int is_i = 0, is_kt = 0;
@@ -529,6 +561,32 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   int c_i = 0, c_kt = 0;
+  int stores_pending = 0;      // vector stores the previous step's epilogue issued (they count on vmcnt like the DMAs)
+  float rv[BMB][16], bv = 0.f;
+  // residual rows: row (m % res_rows) of a map shared by the lanes -- one modulo per tile, then a conditional subtract per
+  // element (maps smaller than a tile take the general modulo)
+  auto epi_loads = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int n = it.bn * BN + wn + l31;
+    const bool col_ok = n < p.Cout;
+    const int m0 = it.bm * BM;
+    if (n_bias) bv = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
+    if (n_res) {
+      const int rr0 = p.res_rows ? m0 % p.res_rows : m0;
+#pragma unroll
+      for (int x = 0; x < BMB; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = wm + 32 * x + mfma32_row(r, half);
+          int rr = rr0 + dm;
+          if (p.res_rows) {
+            if (p.res_rows >= BM) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+            else rr %= p.res_rows;
+          }
+          rv[x][r] = buf_load(desc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB);
+        }
+    }
+  };
   auto epilogue = [&]() __attribute__((always_inline)) {
     const Item it = item_of(c_i);
     const int n = it.bn * BN + wn + l31;
@@ -537,7 +595,7 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] += acc[1][r]; acc[1][r] = 0.f; }
     }
-    if (ksplit > 1) {
+    if (!fused_epi) {        // split-K: the partial tile goes to its slab (plain stores: the next step waits for all of them)
       float* dst = scratch + (long)(it.kt0 / nk) * p.M * p.Cout;
 #pragma unroll
       for (int x = 0; x < BMB; ++x)
@@ -549,39 +607,30 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
         }
       return;
     }
-    const float bv = (col_ok && p.bias) ? p.bias[n] : 0.f;
-    const int m0 = it.bm * BM;
-    // residual rows: row (m % res_rows) of a map shared by the lanes -- one modulo per tile, then a conditional subtract per
-    // element (maps smaller than a tile take the general modulo).  All residual loads of the tile are issued before the
-    // first is used: from clamped addresses, without a branch between them.
-    float rv[BMB][16];
-    if (p.res) {
-      const int rr0 = p.res_rows ? m0 % p.res_rows : m0;
-      const int nc = col_ok ? n : 0;
+    if (!PREFETCH_EPI) epi_loads();
+    // the tile's residual and bias have arrived: with the prefetch they are older than the DMA pieces of step ss+3 (which
+    // may stay in flight), without it they are the youngest instructions
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(PREFETCH_EPI ? LPW : 0, 15));
+    if (n_bias) asm volatile("" : "+v"(bv));
+    if (n_res) {
 #pragma unroll
       for (int x = 0; x < BMB; ++x)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = wm + 32 * x + mfma32_row(r, half);
-          int rr = rr0 + dm;
-          if (p.res_rows) {
-            if (p.res_rows >= BM) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
-            else rr %= p.res_rows;
-          }
-          rr = (m0 + dm < p.M) ? rr : 0;
-          rv[x][r] = p.res[(long)rr * p.ldr + nc];
-        }
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[x][r]));
     }
+    const int m0 = it.bm * BM;
 #pragma unroll
     for (int x = 0; x < BMB; ++x)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + 32 * x + mfma32_row(r, half);
-        float v = acc[x][r] + bv;
-        if (p.res) v += rv[x][r];
-        if (col_ok && m < p.M) p.out[(long)m * p.ldc + n] = apply_act(v, p.act);
+        float v = acc[x][r];
+        if (n_bias) v += bv;
+        if (n_res) v += rv[x][r];
+        buf_store(desc_out, (col_ok && m < p.M) ? (m * p.ldc + n) * 4 : (int)OOB, apply_act(v, p.act));
         acc[x][r] = 0.f;
       }
+    stores_pending = 16 * BMB;
   };
   constexpr int NM = 16 * BMB;              // MFMAs of one step
   constexpr int NR = 4 * BMB + 4;           // fragment reads of one step
@@ -630,11 +679,36 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
   __builtin_amdgcn_s_barrier();
   fetch(I0{}, I0{});
   // step ss (ring stage U = ss % 4, register set U % 2): steps ss+1 and ss+2 are in flight on entry
+#ifdef AOT_LEAN_TIMING      // developer build (tools/dev/gemm_check): where does a step spend its cycles?
+  unsigned long long tm_wait = 0, tm_bar = 0, tm_body = 0, tm_prev = 0, tm_steps = 0;
+#endif
   auto step = [&](auto U) __attribute__((always_inline)) -> void {
     constexpr int u = decltype(U)::value;
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 0));       // step ss+1 has landed; this wave's fragment reads of step ss too
+#ifdef AOT_LEAN_TIMING
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+    // step ss+1 has landed (and this wave's fragment reads of step ss): everything but the youngest LPW vector-memory
+    // instructions -- plus the stores of a tile the previous step finished, which are younger than the DMA waited for
+    if (stores_pending) {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW + 16 * BMB, 0));
+      stores_pending = 0;
+    } else {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 0));
+    }
+#ifdef AOT_LEAN_TIMING
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+#endif
     __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 is free
+#ifdef AOT_LEAN_TIMING
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+    tm_wait += t2 - t1; tm_bar += t3 - t2;
+    if (tm_prev) tm_body += t1 - tm_prev;
+    tm_prev = t3; ++tm_steps;
+#endif
     landed(std::integral_constant<int, u & 1>{});
+    if (PREFETCH_EPI && fused_epi && c_kt == nk - 1) epi_loads();   // last k-step of the tile: its residual and bias, now
     static_for<NM>([&](auto I) __attribute__((always_inline)) -> void {
       mfma_one(std::integral_constant<int, u & 1>{}, I);
       filler(U, I);
@@ -654,6 +728,12 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
     if (ss + 3 < total) step(I3{});
   }
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
+#ifdef AOT_LEAN_TIMING
+  if (tid == 0 && ksplit == 1 && scratch) {
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(scratch);
+    atomicAdd(c + 0, tm_wait); atomicAdd(c + 1, tm_bar); atomicAdd(c + 2, tm_body); atomicAdd(c + 3, tm_steps);
+  }
+#endif
 }
 
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels
@@ -722,6 +802,7 @@ bool gemm_lds_eligible(const ConvParams& p) {
 // the lean kernel addresses both operands through buffer descriptors with 32-bit byte offsets
 bool gemm_lean_eligible(const ConvParams& p) {
   return gemm_lds_eligible(p) && (long)p.B * p.H * p.W * p.lda * 4 < 0x7fffffffL && (long)p.Cout * p.ldwt * 4 < 0x7fffffffL &&
+         (long)p.M * p.ldc * 4 < 0x7fffffffL && (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL) &&
          ((uintptr_t)p.in & 15) == 0;
 }
 

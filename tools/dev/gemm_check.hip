@@ -40,6 +40,7 @@ __global__ void naive_conv(const float* in, const float* w, const float* bias, c
 struct Shape { const char* name; int H, W, Cin, Cout, K, s, cnt; };
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   // `gemm_check list 7:117:1,22:117:1` : only the listed (shape index : cfg : batch) launches, five times each, no check --
   // the dispatches a `rocprofv3 --pmc` pass should see
@@ -84,11 +85,20 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dwt, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));     // (values do not matter here)
       int rc = 0;
+      CK(hipMemset(scratch, 0, 64));
       for (int i = 0; i < 5; ++i)
         rc = aot_conv2d_nhwc_f32(din, dw, dwt, nullptr, nullptr, dout, scratch, scratch_floats, B, sh.H, sh.W, sh.Cin, OH, OW,
                                  sh.Cout, sh.K, sh.K, sh.s, pad, 1, sh.Cin, sh.Cout, KK, sh.Cout, 0, 0, 1, c, 0);
       CK(hipDeviceSynchronize());
       printf("%s cfg %d batch %d: rc %d, M %ld K %d N %d\n", sh.name, c, B, rc, M, KK, sh.Cout);
+#ifdef AOT_LEAN_TIMING
+      {   // cycle split of the lean kernel's steps (wave 0 of every workgroup, summed over the five launches)
+        unsigned long long t[4];
+        CK(hipMemcpy(t, scratch, 32, hipMemcpyDeviceToHost));
+        if (t[3]) printf("   per step (s_memtime cycles, %llu steps): DMA/LDS wait %.0f, barrier %.0f, body %.0f\n", t[3],
+                         (double)t[0] / t[3], (double)t[1] / t[3], (double)t[2] / t[3]);
+      }
+#endif
       hipFree(din); hipFree(dw); hipFree(dwt); hipFree(dout);
       while (*q && *q != ',') ++q;
       if (*q == ',') ++q;
