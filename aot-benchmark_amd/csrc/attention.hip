@@ -58,6 +58,39 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 // costs ~20 VALU instructions per score; 16 scores per lane and tile made that as expensive as the tile's 32 MFMAs.)
 // Masked scores (-inf) and the initial mL = -inf give 2^-inf = 0 exactly; no clamps needed.
 #define AOT_LOG2E 1.44269502162933349609375f
+// A/B switches of the softmax step (tools/dev/mb_attn.py on MI355X, M = 14 / 8: plain 364 / 220 us; max3 359 / 219; max3 +
+// packed 350 / 216; any variant unrolled by two to drop the score-tile copy 369-390 / 223-231 -- the larger loop body costs
+// more than the nine v_mov it saves).  All variants give bit-identical results.
+#ifndef AOT_ATT_UNROLL2
+#define AOT_ATT_UNROLL2 0
+#endif
+#ifndef AOT_ATT_MAX3
+#define AOT_ATT_MAX3 1
+#endif
+#ifndef AOT_ATT_PK
+#define AOT_ATT_PK 1
+#endif
+#ifndef AOT_ATT_VPM
+#define AOT_ATT_VPM 4
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max of three in ONE instruction (same NaN rule as fmaxf: a NaN operand is ignored)
+// packed fp32: two values per lane and instruction (hipcc scalarises most <2 x float> arithmetic next to MFMA operands)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ float exp2_w(float s, float mL) {
   return __builtin_amdgcn_exp2f(fmaf(s, AOT_LOG2E, -mL));
 }
@@ -134,33 +167,65 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
   };
 
   float ka[16], va[16];
-  f32x16 sc;
+  f32x16 sa, sb;      // score tiles: the step of tile i reads one and fills the other with tile i+1
   if (t0 < t1) {
     load_k(ka, t0);
     load_v(va, t0);
-    qk(ka, sc);
+    qk(ka, sa);
     load_k(ka, t0 + 32);
   }
   // One straight-line step (no branches, so the scheduler can interleave the next tile's score MFMAs with this tile's
   // softmax VALU work).  TAIL = the last, possibly partial tile of the range: keys >= t1 are masked to -inf.
-  auto step = [&](int kt, auto tail) {
+  // VALU budget: on gfx950 a v_mfma_f32_32x32x2_f32 runs on the fp32 vector ALUs, so VALU work does NOT hide under it
+  // (tools/dev/mfma_filler.hip: +5-6 cycles per VALU instruction beside the chain, +11 per v_exp_f32, at any occupancy) --
+  // every instruction of the softmax comes straight out of the MFMA rate.  Hence: v_max3_f32 for the tile maximum (inline
+  // asm: fmaxf() adds a canonicalising v_max per MFMA output) and packed fp32 (v_pk_fma / v_pk_add / v_pk_mul: two values
+  // per lane and instruction) for the exponent arguments, the row sums and the rescale: 103 -> 80 VALU instructions per tile.
+  auto step = [&](int kt, f32x16& sc, f32x16& scn, auto tail) {
     constexpr bool TAIL = decltype(tail)::value;
     // scores of the NEXT tile (past the range end: clamped rows, result unused) -- independent of everything below
-    f32x16 scn;
     qk(ka, scn);
-    float pf[16];
     if (TAIL) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
     }
+#if AOT_ATT_MAX3
+    float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                    max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
+#else
     float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
 #pragma unroll
     for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+#endif
     const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // 1 when the max did not move; 0 on the first tile
     m = mnew;
     l *= alpha;
+    float pf[16];
+#if AOT_ATT_PK
+    {
+      const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = pk_mul(f32x2{o[r], o[r + 1]}, al2);
+        o[r] = t[0];
+        o[r + 1] = t[1];
+      }
+    }
+    const f32x2 L2 = {AOT_LOG2E, AOT_LOG2E}, nm2 = {-m, -m};
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 s2 = {sc[r], sc[r + 1]};
+      const f32x2 t2 = pk_fma(s2, L2, nm2);      // fl(s * log2(e) - mL) per element, as exp2_w()
+      pf[r] = __builtin_amdgcn_exp2f(t2[0]);
+      pf[r + 1] = __builtin_amdgcn_exp2f(t2[1]);
+      const f32x2 p2 = {pf[r], pf[r + 1]};
+      ps += p2;
+    }
+    l += ps[0] + ps[1];
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] *= alpha;
     float ps0 = 0.f, ps1 = 0.f;
@@ -172,21 +237,36 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
       ps1 += pf[r + 1];
     }
     l += ps0 + ps1;
+#endif
     load_k(ka, kt + 64);     // K registers were consumed by qk() above
 #pragma unroll
     for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
     load_v(va, kt + 32);     // rows past the descriptor read as 0
-    sc = scn;
-    // issue order: 16 x (1 score MFMA, 5 softmax VALU), then the rest as the scheduler likes
+    // issue order: 16 x (1 score MFMA, a few softmax VALU), then the rest as the scheduler likes
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, AOT_ATT_VPM, 0);
     }
   };
   int kt = t0;
-  for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
-  if (kt < t1) step(kt, std::true_type{});
+#if AOT_ATT_UNROLL2
+  for (; kt + 64 < t1; kt += 64) {
+    step(kt, sa, sb, std::false_type{});
+    step(kt + 32, sb, sa, std::false_type{});
+  }
+#else
+  for (; kt + 64 < t1; kt += 32) {
+    step(kt, sa, sb, std::false_type{});
+    sa = sb;
+  }
+#endif
+  if (kt + 32 < t1) {          // two tiles left
+    step(kt, sa, sb, std::false_type{});
+    step(kt + 32, sb, sa, std::true_type{});
+  } else if (kt < t1) {        // one
+    step(kt, sa, sb, std::true_type{});
+  }
 
   // ---- merge of the four key quarters through LDS (fixed wave order: deterministic) ----
   {
