@@ -34,6 +34,7 @@ _SIGS = {
     'aot_fuse_probs_f32': [_P] * 5 + [_I] * 5 + [_P],
     'aot_label_resize_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_attn_topk_f32': [_P] * 5 + [_I] * 8 + [_F, _I, _P],
+    'aot_gated_attn_topk_f32': [_P] * 6 + [_I] * 9 + [_F, _I, _P],
     'aot_gated_attn_f32': [_P] * 6 + [_I, _L, _I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I, _L] + [_I] * 9 + [_F, _P],
     'aot_local_gated_f32': [_P] * 8 + [_I, _L] + [_I] * 10 + [_F, _P],
@@ -235,6 +236,16 @@ def attention_topk(q, k, v, out, T, H, scale_div, top_k, scores, stream=None):
     _chk(load().aot_attn_topk_f32(_dev(q), _dev(k), _dev(v), _dev(out), _dev(scores), q.shape[0], T, H, 32, q.stride(0),
                                   k.stride(0), v.stride(0), out.stride(0), scale_div, top_k,
                                   stream if stream is not None else stream_ptr()), 'aot_attn_topk_f32')
+    return out
+
+
+def gated_attention_topk(q, k, v, gate, out, T, scale_div, top_k, scores, stream=None):
+    """Top-k sparse gated attention (GatedPropagation top_k > 0): q [Nq,128], k [T,128], v [T,dv], gate/out [Nq,dv];
+    scores is scratch of Nq*((T+3)&~3) floats."""
+    _chk(load().aot_gated_attn_topk_f32(_dev(q), _dev(k), _dev(v), _opt(gate), _dev(out), _dev(scores), q.shape[0], T,
+                                        q.shape[1], out.shape[1], q.stride(0), k.stride(0), v.stride(0),
+                                        gate.stride(0) if gate is not None else 0, out.stride(0), scale_div, top_k,
+                                        stream if stream is not None else stream_ptr()), 'aot_gated_attn_topk_f32')
     return out
 
 

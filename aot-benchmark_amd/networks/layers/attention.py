@@ -188,8 +188,15 @@ class GatedPropagation(nn.Module):
         return out
 
     def _core_topk(self, q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows):
-        # the sparse kernel (csrc/attn_topk.hip) is built for heads of width 32; the gated form has ONE 128-wide head
-        raise NotImplementedError('top_k of GatedPropagation (attention.py:689-693) is not built; max_mem_len_ratio is')
+        """top_k > 0 (attention.py:689-693): scores materialised once, radix select of the k-th largest per query row, ordered
+        gather of the selected [V | ID_V] rows, gate fused (csrc/attn_topk.hip); lanes one at a time."""
+        nq = q.shape[0] // B
+        scores = ws.get('gattn_scores', (nq * ((t + 3) // 4 * 4),), q.device)
+        for b in range(B):
+            rows = slice(b * nq, (b + 1) * nq)
+            aot_hip.gated_attention_topk(q[rows], k[b * kv_brows:], v[b * kv_brows:], gate[rows] if gate is not None else None,
+                                         out[rows], t, scale_div, self.top_k, scores, stream=stream)
+        return out
 
     def tail(self, raw, out, size_2d, ws, stream, res=None, B=1):
         """projection(dw_conv(raw)) (+ res): attention.py:709-710."""

@@ -19,6 +19,11 @@ class DeAOT(AOT):
             lt_dropout=cfg.TRAIN_LSTT_LT_DROPOUT, st_dropout=cfg.TRAIN_LSTT_ST_DROPOUT,
             droppath_lst=cfg.TRAIN_LSTT_DROPPATH_LST, droppath_scaling=cfg.TRAIN_LSTT_DROPPATH_SCALING,
             intermediate_norm=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, return_intermediate=True)
+        # long-video knobs of GatedPropagation (attention.py:674-679,689-693): constructor arguments nobody sets in the
+        # reference; reached here through the same two optional config keys as AOT's
+        for layer in self.LSTT.layers:
+            layer.long_term_attn.top_k = int(getattr(cfg, 'MODEL_LT_TOP_K', -1))
+            layer.long_term_attn.max_mem_len_ratio = float(getattr(cfg, 'MODEL_LT_MAX_MEM_LEN_RATIO', -1))
         decoder_indim = emb * (cfg.MODEL_LSTT_NUM * 2 + 1) if cfg.MODEL_DECODER_INTERMEDIATE_LSTT else emb * 2
         self.decoder = build_decoder(decoder, in_dim=decoder_indim, out_dim=cfg.MODEL_MAX_OBJ_NUM + 1,
                                      decode_intermediate_input=cfg.MODEL_DECODER_INTERMEDIATE_LSTT, hidden_dim=emb,

@@ -128,6 +128,14 @@ int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq,
 int aot_attn_topk_f32(const float* q, const float* k, const float* v, float* out, float* scores, int Nq, int T,
                       int H, int d, int ldq, int ldk, int ldv, int ldo, float scale_div, int top_k, void* stream);
 
+/* Top-k sparse form of aot_gated_attn_f32 (GatedPropagation with top_k > 0, networks/layers/attention.py:689-693): one head
+ * of width d = 128, value / gate / out of width dv (a multiple of 4, <= 2048).  `scores` is caller-owned scratch of
+ * Nq*((T+3)&~3) floats.  0 < top_k < T required.  Among scores EQUAL to the k-th largest the first ones in key order are
+ * taken (torch.topk leaves that choice open); the summation order is fixed, so the result is reproducible. */
+int aot_gated_attn_topk_f32(const float* q, const float* k, const float* v, const float* gate, float* out, float* scores,
+                            int Nq, int T, int d, int dv, int ldq, int ldk, int ldv, int ldg, int ldo, float scale_div,
+                            int top_k, void* stream);
+
 /* Gated-propagation attention of DeAOT, single head: out = softmax((q/scale_div) k^T) v  (* gate), with
  * q [Nq, dqk=128], k [T, 128], v [T, dv] (dv a multiple of 256; 1024 = [V | ID_V]), gate/out [Nq, dv]; B lanes laid
  * out as in aot_attn_f32.  Same split/merge protocol as aot_attn_f32 with H := dv/256 groups; with nsplit > 1 pass the

@@ -322,8 +322,9 @@ def dwconv5(x, sd, p, size_2d):
     return x.reshape(B, C, h * w).permute(2, 0, 1)
 
 
-def gated_propagation(sd, p, Q, K, V, U, size_2d, H, use_linear, d_att):
-    """GatedPropagation.forward, attention.py:636-712."""
+def gated_propagation(sd, p, Q, K, V, U, size_2d, H, use_linear, d_att, max_mem_len_ratio=-1., top_k=-1):
+    """GatedPropagation.forward, attention.py:636-712.  Eval-time knobs: max_mem_len_ratio (:674-679) rescales Q for banks
+    longer than ratio x the query length; top_k (:689-693) keeps the k largest scores per row."""
     L, B, _ = Q.shape
     if use_linear:
         Q = K = _lin(Q, sd, p + '.linear_QK')                      # :649
@@ -339,10 +340,19 @@ def gated_propagation(sd, p, Q, K, V, U, size_2d, H, use_linear, d_att):
         V = silu(cat(_lin(V[..., :half], sd, p + '.linear_V1'), _lin(V[..., half:], sd, p + '.linear_V2')))
         U = silu(cat(_lin(U[..., :half], sd, p + '.linear_U1'), _lin(U[..., half:], sd, p + '.linear_U2')))
     Q = Q / (d_att ** 0.5)                                         # :672
+    if max_mem_len_ratio > 0:                                      # :674-679
+        mem_len_ratio = float(K.shape[0]) / Q.shape[0]
+        if mem_len_ratio > max_mem_len_ratio:
+            Q = Q * (math.log(mem_len_ratio) / math.log(max_mem_len_ratio))
     q = Q.view(-1, B, H, d_att).permute(1, 2, 0, 3)
     k = K.view(-1, B, H, d_att).permute(1, 2, 3, 0)
     v = V.view(-1, B, H, V.shape[-1] // H).permute(1, 2, 0, 3)
-    a = torch.softmax(q @ k, -1)                                   # :687,697
+    qk = q @ k                                                     # :687
+    if 0 < top_k < qk.shape[-1]:                                   # :689-693
+        top, idx = torch.topk(qk, k=top_k, dim=-1)
+        a = torch.zeros_like(qk).scatter_(-1, idx, torch.softmax(top, -1))
+    else:
+        a = torch.softmax(qk, -1)                                  # :697
     o = (a @ v).permute(2, 0, 1, 3).reshape(L, B, -1) * U          # :703-707
     o = dwconv5(o, sd, p + '.dw_conv.conv', size_2d)               # :709
     return _lin(o, sd, p + '.projection')                          # :710
@@ -487,7 +497,8 @@ class OracleModel:
         else:
             gK, gV, _, gIDV = long_mem
             lK, lV, _, lIDV = short_mem
-        lt = gated_propagation(sd, p + '.long_term_attn', cQ, gK, torch.cat([gV, gIDV], -1), U, size_2d, H, False, d_att)
+        lt = gated_propagation(sd, p + '.long_term_attn', cQ, gK, torch.cat([gV, gIDV], -1), U, size_2d, H, False, d_att,
+                               self.spec.get('lt_max_mem_len_ratio', -1.), self.spec.get('lt_top_k', -1))
         st = local_gated_propagation(sd, p + '.short_term_attn', lQ, lK, torch.cat([lV, lIDV], 1), U, size_2d, H, d_att)
         both = lt + st
         tgt = tgt + both[..., :D]

@@ -115,3 +115,26 @@ def mha_knob_inputs():
 
 MHA_KNOB_CASES = {'topk50': dict(top_k=50), 'topk1': dict(top_k=1), 'ratio4': dict(max_mem_len_ratio=4.),
                   'ratio4_topk200': dict(max_mem_len_ratio=4., top_k=200), 'dense': dict()}
+
+
+def gp_knob_inputs():
+    """Inputs of tests/golden/gp_knobs.npz (make_golden.make_gp_knobs): one 128-wide head, value / gate width 1024, a
+    13x11 query map against 900 memory tokens."""
+    g = torch.Generator().manual_seed(777)
+    h, w, Tk = 13, 11, 900
+    Q = torch.randn(h * w, 1, 128, generator=g) * 3.0
+    K = torch.randn(Tk, 1, 128, generator=g)
+    V = torch.randn(Tk, 1, 1024, generator=g)
+    U = torch.randn(h * w, 1, 1024, generator=g)
+    return Q, K, V, U, (h, w)
+
+
+GP_KNOB_CASES = {'topk40': dict(top_k=40), 'topk1': dict(top_k=1), 'ratio3': dict(max_mem_len_ratio=3.),
+                 'ratio3_topk300': dict(max_mem_len_ratio=3., top_k=300), 'dense': dict()}
+
+
+def gp_knob_state(module_state_dict):
+    """The keyed synthetic weights make_gp_knobs loaded into the reference module (key names prefixed 'gp_knobs.')."""
+    from utils.synth import synth_state_dict
+    keyed = synth_state_dict({'gp_knobs.' + k: v for k, v in module_state_dict.items()})
+    return {k[len('gp_knobs.'):]: v for k, v in keyed.items()}

@@ -102,6 +102,30 @@ def make_mha_knobs():
         refdriver._leave()
 
 
+def make_gp_knobs():
+    """Module-level golden for the long-video knobs of DeAOT's GatedPropagation (attention.py:674-679 max_mem_len_ratio,
+    :689-693 top_k): the REAL reference module (one head, d_att 128, use_linear=False) with seeded weights; inputs are
+    regenerated from the seed by the tests (tests/common.py: gp_knob_inputs, gp_knob_state)."""
+    refdriver._enter()
+    try:
+        from networks.layers.attention import GatedPropagation
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from common import GP_KNOB_CASES, gp_knob_inputs
+        Q, K, V, U, size_2d = gp_knob_inputs()
+        out = {'input_sums': np.array([t.double().sum().item() for t in (Q, K, V, U)])}
+        for name, kw in GP_KNOB_CASES.items():
+            m = GatedPropagation(d_qk=256, d_vu=512, num_head=1, use_linear=False, d_att=128, **kw).eval()
+            # keyed synthetic weights (a pure function of the key names: the tests rebuild them, nothing is stored)
+            keyed = synth_state_dict({'gp_knobs.' + k: v for k, v in m.state_dict().items()})
+            m.load_state_dict({k[len('gp_knobs.'):]: v for k, v in keyed.items()})
+            with torch.no_grad():
+                out[name] = m(Q, K, V, U, size_2d)[0].numpy()
+        np.savez_compressed(os.path.join(HERE, 'gp_knobs.npz'), **out)
+        print('gp_knobs', {k: v.shape for k, v in out.items() if not k.startswith('w.')}, flush=True)
+    finally:
+        refdriver._leave()
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -241,6 +265,10 @@ def main():
     if not sys.argv[1:] or 'transforms' in sys.argv[1:]:
         make_transforms()
         if sys.argv[1:] == ['transforms']:
+            return
+    if not sys.argv[1:] or 'gp_knobs' in sys.argv[1:]:
+        make_gp_knobs()
+        if sys.argv[1:] == ['gp_knobs']:
             return
     if not sys.argv[1:] or 'mha_knobs' in sys.argv[1:]:
         make_mha_knobs()

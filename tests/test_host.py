@@ -160,6 +160,8 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.aot_logits_finalize_f32(P(16), None, None, 1, 4, 4, 32, 32, 0, 0, 3, 1, None) == -2
     assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), P(16), 8, 8, 8, 32, 256, 256, 256, 256, 5.65, 8, None) == -1  # top_k >= T
     assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), None, 8, 64, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # no scratch
+    assert lib.aot_gated_attn_topk_f32(P(16), P(16), P(16), None, P(16), P(16), 8, 64, 64, 1024, 128, 128, 1024, 0, 1024, 11.3, 4, None) == -2  # d != 128
+    assert lib.aot_gated_attn_topk_f32(P(16), P(16), P(16), None, P(16), P(16), 8, 64, 128, 1024, 128, 128, 1024, 0, 1024, 11.3, 64, None) == -1  # top_k >= T
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 0, 8, 0, 0, 0, -1, None) == -1  # Cin % 4
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 32, 4, 4, 64, 1, 1, 1, 0, 1, 32, 64, 0, 64, 0, 0, 0, 117, None) == -2  # LDS-direct kernel without a k-contiguous weight
     assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 1, 0, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2

@@ -189,3 +189,22 @@ def test_oracle_swin_ragged_input_matches_reference():
         assert tuple(f.shape) == tuple(g['shape_%d' % i])
         ref = g['feat_%d' % i]
         assert np.abs(f[0, ::3].numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('case', ['topk40', 'topk1', 'ratio3', 'ratio3_topk300', 'dense'])
+def test_oracle_gated_propagation_knobs_match_reference(case):
+    """DeAOT's long-video knobs (attention.py:674-679 max_mem_len_ratio, :689-693 top_k) against the REAL reference module
+    GatedPropagation (one 128-wide head, value 1024): tests/golden/gp_knobs.npz (make_golden.make_gp_knobs)."""
+    import os
+    from common import GP_KNOB_CASES, gp_knob_inputs, gp_knob_state
+    from networks.layers.attention import GatedPropagation
+    from oracle.aot_oracle import gated_propagation
+    g = np.load(os.path.join(GOLD, 'gp_knobs.npz'))
+    Q, K, V, U, size_2d = gp_knob_inputs()
+    assert np.allclose(g['input_sums'], [t.double().sum().item() for t in (Q, K, V, U)], rtol=1e-12)
+    mod = GatedPropagation(d_qk=256, d_vu=512, num_head=1, use_linear=False, d_att=128)
+    sd = {'gp.' + k: v for k, v in gp_knob_state(mod.state_dict()).items()}
+    with torch.no_grad():
+        out = gated_propagation(sd, 'gp', Q, K, V, U, size_2d, 1, False, 128, **GP_KNOB_CASES[case])
+    ref = g[case]
+    assert np.abs(out.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())

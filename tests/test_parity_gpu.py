@@ -699,6 +699,53 @@ def test_attention_knobs_vs_reference_module(hip, case):
     _close(out, torch.from_numpy(g[case][:, 0]), 5e-6, case)
 
 
+@pytest.mark.parametrize('case', ['topk40', 'topk1', 'ratio3', 'ratio3_topk300', 'dense'])
+def test_gated_propagation_knobs_vs_reference_module(hip, case):
+    """DeAOT's long-video knobs (attention.py:674-679 max_mem_len_ratio, :689-693 top_k) through GatedPropagation.core + tail
+    (aot_gated_attn_topk_f32: one 128-wide head, value 1024, gate fused) against the REAL reference module's outputs
+    (tests/golden/gp_knobs.npz)."""
+    import os
+    from common import GOLD, GP_KNOB_CASES, gp_knob_inputs, gp_knob_state
+    from networks.layers.attention import GatedPropagation
+    from networks.layers.workspace import Workspace
+    g = np.load(os.path.join(GOLD, 'gp_knobs.npz'))
+    Q, K, V, U, size_2d = gp_knob_inputs()
+    m = GatedPropagation(d_qk=256, d_vu=512, num_head=1, use_linear=False, d_att=128, **GP_KNOB_CASES[case])
+    m.load_state_dict(gp_knob_state(m.state_dict()))
+    m = m.cuda().eval()
+    q, k, v, u = (_dev(t[:, 0]) for t in (Q, K, V, U))
+    ws = Workspace()
+    raw = torch.empty(q.shape[0], 1024, device='cuda')
+    out = torch.empty(q.shape[0], 512, device='cuda')
+    with torch.no_grad():
+        m.core(q, k, v, u, raw, k.shape[0], ws, hip.stream_ptr())
+        m.tail(raw, out, size_2d, ws, hip.stream_ptr())
+    ref = torch.from_numpy(g[case][:, 0])
+    _close(out, ref, 2e-5 * max(1.0, ref.abs().max().item()), case)
+
+
+@pytest.mark.parametrize('Nq,T,top_k,dv', [(300, 5000, 128, 1024), (1674, 2 * 1674 + 5, 1500, 1024), (33, 257, 256, 1024),
+                                           (64, 64, 3, 512), (40, 3000, 2999, 2048)])
+def test_gated_attention_topk_vs_fp64(hip, Nq, T, top_k, dv):
+    """aot_gated_attn_topk_f32 at larger / ragged shapes (the compaction list flushes several times at top_k > 1024; every key
+    but one at top_k = T - 1), through strided views, against an fp64 top-k softmax."""
+    g = torch.Generator().manual_seed(Nq + T)
+    q = torch.randn(Nq, 128, generator=g) * 2.0
+    kv = torch.randn(T + 3, 128 + dv + 8, generator=g)       # k and v are column slices of one wider buffer
+    gate = torch.randn(Nq, dv, generator=g)
+    qd, kvd, gd = _dev(q), _dev(kv), _dev(gate)
+    k, v = kvd[:T, :128], kvd[:T, 128:128 + dv]
+    out = torch.full((Nq, dv + 4), float('nan'), device='cuda')
+    scores = torch.empty(Nq * ((T + 3) // 4 * 4), device='cuda')
+    hip.gated_attention_topk(qd, k, v, gd, out[:, :dv], T, 128 ** 0.5, top_k, scores)
+    s = (q.double() / 128 ** 0.5) @ kv[:T, :128].double().t()
+    top, idx = torch.topk(s, top_k, dim=-1)
+    a = torch.zeros_like(s).scatter_(-1, idx, torch.softmax(top, -1))
+    ref = (a @ kv[:T, 128:128 + dv].double()) * gate.double()
+    _close(out[:, :dv], ref.float(), 3e-5 * max(1.0, ref.abs().max().item()), 'gated top-k')
+    assert torch.isnan(out[:, dv:]).all()
+
+
 @pytest.mark.parametrize('Nq,T,top_k', [(300, 5000, 128), (1674, 3 * 1674, 512), (33, 257, 256), (64, 64, 3)])
 def test_attention_topk_vs_oracle(hip, Nq, T, top_k):
     """aot_attn_topk_f32 at larger / ragged shapes, through strided views, against the oracle's mha_core."""
@@ -755,6 +802,31 @@ def test_long_video_knobs_engine_vs_oracle(hip, top_k, tol):
             ora.update_memory(fb, skip_long_term_update=skip)
     e0 = eng.aot_engines[0]
     assert e0.bank_len == 3 * e0.enc_hw
+
+
+@pytest.mark.parametrize('top_k,tol', [(-1, 2e-4), (60, 5e-2)])
+def test_long_video_knobs_deaot_engine_vs_oracle(hip, top_k, tol):
+    """The same knobs on DeAOT (GatedPropagation long-term attention) through the engine API, HIP vs oracle, frame by
+    frame on the oracle's masks (DeAOTT, gap 1): max_mem_len_ratio at the usual 2e-4; with top_k the bar is loose for the
+    reason given above (the cut is decided by fp32 rounding) -- that run checks the plumbing."""
+    from oracle.aot_oracle import SPECS, OracleEngine, OracleModel
+    from utils.synth import synth_clip
+    cfg, model, eng, sd = _hip_engine('deaott', gap=1, cfg_overrides=dict(MODEL_LT_TOP_K=top_k, MODEL_LT_MAX_MEM_LEN_RATIO=1.5))
+    spec = dict(SPECS['deaott'], lt_top_k=top_k, lt_max_mem_len_ratio=1.5)
+    ora = OracleEngine(OracleModel(spec, sd), long_term_mem_gap=1)
+    frames, mask, objs, out_size = synth_clip(12, 7, (97, 129), (96, 128), 3)
+    with torch.no_grad():
+        eng.add_reference_frame(frames[0].cuda(), mask.cuda(), objs, frame_step=0)
+        ora.add_reference_frame(frames[0], mask, objs)
+        for t in range(1, 7):
+            eng.match_propogate_one_frame(frames[t].cuda())
+            ora.match_propogate_one_frame(frames[t])
+            lg, lo = eng.decode_current_logits(out_size), ora.decode_current_logits(out_size)
+            _close(lg[:, :4], lo[:, :4], tol, 'frame %d logits' % t)
+            assert (torch.argmax(lg, 1).cpu() == torch.argmax(lo, 1)).float().mean().item() > 0.995
+            fb = F.interpolate(torch.argmax(lo, 1, keepdim=True).float(), size=ora.input_size_2d, mode='nearest')
+            eng.update_memory(fb.cuda())
+            ora.update_memory(fb)
 
 
 @pytest.mark.parametrize('H,W,OH,OW,flip,u8', [(480, 854, 481, 849, False, False), (480, 854, 625, 1105, True, False),
