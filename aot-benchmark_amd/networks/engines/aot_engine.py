@@ -484,6 +484,7 @@ class AOTInferEngine(nn.Module):
         self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
         self._cohorts = []
         self._spare = []             # cohorts of the previous clip: their bank buffers are re-used (no allocator traffic)
+        self._last_geom = None       # frame geometry of the previous clip (scratch is released when it changes)
         self.restart_engine()
 
     # ---- reference attributes ------------------------------------------------------------------
@@ -521,10 +522,22 @@ class AOTInferEngine(nn.Module):
             c.obj_nums = [max(0, min(self.obj_nums - c.first_group * k, c.lanes * k))]
             c.group0 = None if single else c.first_group
 
+    def _release_on_new_geometry(self, img):
+        """Scratch, banks and arenas are sized for one frame geometry and kept from clip to clip.  A sequence set with mixed
+        resolutions (YouTube-VOS, multi-scale testing) would otherwise keep one full set per geometry: when a clip starts
+        at a size different from the previous clip's, this engine's sets are dropped first.  (Not in graph mode: captured
+        graphs hold the addresses.)"""
+        geom = (tuple(img.shape[-2:]), img.device)
+        if self._last_geom is not None and geom != self._last_geom and not self.use_graph and not self._cohorts:
+            self._spare = []
+            self.AOT.ws.clear(stream=aot_hip.stream_ptr())
+        self._last_geom = geom
+
     def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
         if isinstance(obj_nums, (list, tuple)):
             obj_nums = obj_nums[0]
         self.obj_nums = int(obj_nums)
+        self._release_on_new_geometry(img)
         have = sum(c.lanes for c in self._cohorts)
         need = self._groups_needed(self.obj_nums)
         if need > have:      # first frame: one cohort for every group; later: the groups opened by new objects

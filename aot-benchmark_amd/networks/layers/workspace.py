@@ -28,8 +28,13 @@ class Workspace:
             buf.zero_()
         return buf
 
-    def clear(self):
-        self._bufs.clear()
+    def clear(self, stream=None):
+        """Drops every buffer (or only those of one raw stream handle): the next get() allocates again."""
+        if stream is None:
+            self._bufs.clear()
+        else:
+            for key in [k for k in self._bufs if k[4] == stream]:
+                del self._bufs[key]
 
     def nbytes(self):
         return sum(b.numel() * b.element_size() for b in self._bufs.values())

@@ -3,10 +3,13 @@ accepts {'state_dict': ...}, {'model': ...} or a raw dict, strips a leading 'mod
 import torch
 
 
-def load_network(net, pretrained_dir, gpu=None):
+def load_network(net, pretrained_dir, gpu=None, trusted=False):
+    """Only tensors are needed (a state_dict, optionally wrapped in {'state_dict': ...} / {'model': ...}), so the file is
+    read with weights_only=True: a downloaded checkpoint cannot run pickled code.  trusted=True restores torch's full
+    unpickler for old checkpoints that carry other objects next to the weights."""
     device = torch.device('cpu') if (gpu is None or gpu < 0 or not torch.cuda.is_available()) \
         else torch.device('cuda', gpu)
-    blob = torch.load(pretrained_dir, map_location='cpu', weights_only=False)
+    blob = torch.load(pretrained_dir, map_location='cpu', weights_only=not trusted)
     return load_state(net, blob, device)
 
 

@@ -1081,6 +1081,39 @@ def test_graph_replay_bit_identical(hip, name, nobj, size):
         assert g.captures <= 3 * 7 and g.replays == 2 * 3 * 7
 
 
+def test_scratch_released_when_clip_geometry_changes(hip):
+    """A sequence set with mixed resolutions must not keep one scratch set per geometry: starting a clip at a
+    new size drops this stream's buffers of the previous size, and going back reproduces the first clip bit for bit."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state('aott')
+    model = model.cuda().eval()
+    eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=2)
+
+    def run(size, k):
+        osz = (size[0] - 1, size[1] - 1)
+        fr, m, ob, _ = synth_clip(k, 4, size, osz, 2, device='cuda')
+        eng.restart_engine()
+        eng.add_reference_frame(fr[0], m, ob, frame_step=0)
+        outs = []
+        for t in range(1, 4):
+            eng.match_propogate_one_frame(fr[t])
+            lg = eng.decode_current_logits(osz)
+            eng.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=eng.input_size_2d, mode='nearest'))
+            outs.append(lg.clone())
+        return outs
+    with torch.no_grad():
+        a1 = run((97, 129), 1)
+        n1 = model.ws.nbytes()
+        run((129, 161), 2)
+        n2 = model.ws.nbytes()
+        a2 = run((97, 129), 1)
+        n3 = model.ws.nbytes()
+    assert n3 == n1 and n2 < 2.2 * n1, (n1, n2, n3)        # one geometry's worth at a time (129x161 is 1.65x the pixels)
+    for x, y in zip(a1, a2):
+        assert torch.equal(x, y)
+
+
 def test_reference_api_surface(hip):
     """the reference's model-level methods keep working on reference-shaped tensors (aot.py:72-108)."""
     from oracle.aot_oracle import OracleModel, one_hot_mask
