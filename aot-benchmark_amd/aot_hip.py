@@ -48,6 +48,24 @@ _SIGS = {
 
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 
+# Which kernel table aot_conv2d_nhwc_f32 uses when a caller leaves the choice open (cfg = -1): 'latency' = fastest launch on
+# its own (one clip at a time), 'throughput' = cheapest in SIMD time when several clips share the GPU (include/aot_hip.h).
+GEMM_TABLES = {'latency': -1, 'throughput': -2}
+_gemm_table = -1
+
+
+def set_gemm_table(name):
+    """Selects the dispatch table for all later conv2d / linear calls of this process; returns the previous name.  Engines
+    in graph mode key their captured graphs on it, so switching never replays a graph captured under the other table."""
+    global _gemm_table
+    prev = gemm_table()
+    _gemm_table = GEMM_TABLES[name]
+    return prev
+
+
+def gemm_table():
+    return 'throughput' if _gemm_table == -2 else 'latency'
+
 
 class AotHipError(RuntimeError):
     pass
@@ -122,7 +140,7 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
     _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), None, 0, B, H, W, Cin, OH,
                                     OW, Cout, KH, KW, stride, pad, dil, x.stride(0), w.stride(0),
                                     wt.stride(0) if wt is not None else 0, out.stride(0),
-                                    res.stride(0) if res is not None else 0, res_rows, act, cfg,
+                                    res.stride(0) if res is not None else 0, res_rows, act, _gemm_table if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 

@@ -17,6 +17,7 @@
 // fp32 MFMA issues once per 64 cycles per SIMD, so one ds_read_b32 per operand is far from the
 // LDS limit (section 3 of the guide: 4 LDS cycles per 4 MFMAs = 256 cycles).
 #include "conv_params.h"
+#include <cstdlib>
 
 template <int BM, int BN, int WM, int WN, int BK, bool IS1X1>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
@@ -483,13 +484,17 @@ static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
 //   * wave-independent kernels with in-block split-K (cfg 1x: 32x32 waves, cfg 2x: 64x32 waves): the stride-16 maps
 //     (M = 1674 per lane) with fewer than 192 tiles, where no LDS-tiled kernel -- with or without split-K slabs --
 //     beats them.
-static int auto_cfg(const ConvParams& p, long scratch_floats) {
+// Two tables.  LATENCY (cfg -1): the fastest kernel for each shape run on its own -- one clip at a time.  THROUGHPUT (cfg -2):
+// the kernel that costs the least SIMD time when several clips keep the chip saturated -- the wave-independent kernels win
+// the stride-16 shapes in isolation (more workgroups), but issue twice the VALU instructions per MFMA, and VALU work does not
+// hide under fp32 MFMAs: with three clips per GPU the lean tile kernel everywhere is +4..14 % frames/s.
+static int auto_cfg(const ConvParams& p, long scratch_floats, bool throughput) {
   (void)scratch_floats;
   const bool direct_ok = (p.Cin % 32 == 0) && (p.K % 32 == 0);
   const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const bool kxk = p.KH * p.KW > 1;
   if (p.Cout <= 32) return 3;
-  if (tiles64 >= 192 && gemm_lean_eligible(p)) return 196 + 1;
+  if (tiles64 >= (throughput ? 16 : 192) && gemm_lean_eligible(p)) return 196 + 1;
   if (tiles64 >= 512 || !direct_ok) return 4;
   if (kxk && tiles64 < 192 && p.K >= 1024) return 24;
   const long tiles32 = (long)cdiv(p.M, 32) * cdiv(p.Cout, 32);
@@ -519,7 +524,7 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
   const bool is1x1 = (KH == 1 && KW == 1 && pad == 0);
   hipStream_t s = (hipStream_t)stream;
   if (!scratch) scratch_floats = 0;
-  if (cfg < 0) cfg = auto_cfg(p, scratch_floats);
+  if (cfg < 0) cfg = auto_cfg(p, scratch_floats, cfg == -2);
   if (cfg >= 100) {      // LDS-direct kernel: variant (cfg - 100) / 16, split-K factor (cfg - 100) % 16
     const int variant = (cfg - 100) / 16, ks = (cfg - 100) % 16;
     if (ks > 1 && (long)ks * p.M * p.Cout > scratch_floats) return AOT_ERR_BADARG;

@@ -306,7 +306,8 @@ class AOTEngine(nn.Module):
 
         if self.use_graph:
             src = self._stage('img', img) if img_embs is None else None
-            key = ptr_key('match', src, img_embs, long_m, short, dst, self.pos_emb, self.lanes, self.enc_size_2d)
+            key = ptr_key('match', src, img_embs, long_m, short, dst, self.pos_emb, self.lanes, self.enc_size_2d,
+                          aot_hip.gemm_table())
             self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
         else:
             self._feats, self._dec_in, self._curr = launch(img, img_embs)
@@ -349,7 +350,7 @@ class AOTEngine(nn.Module):
         if self.use_graph:
             src = self._stage('mask', curr_mask)
             key = ptr_key('update', src, curr, dst, store_slot, [b[0] for b in self._bank] if store_slot is not None else None,
-                          self.lanes, self.group0, self.enc_size_2d)
+                          self.lanes, self.group0, self.enc_size_2d, aot_hip.gemm_table())
             self._gx().run(key, lambda: launch(src))
         else:
             launch(curr_mask)
@@ -423,7 +424,7 @@ def _decode(owner, cohorts, output_size):
 
     if len(cohorts) == 1 and first.use_graph:
         key = ptr_key('decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
-                      first._group_objects())
+                      first._group_objects(), aot_hip.gemm_table())
         out4, out = first._gx().run(key, launch)
     else:
         out4, out = launch()

@@ -44,8 +44,10 @@ const char* aot_hip_version(void);
  * (csrc/gemm_conv.hip).  bias / res may be NULL; res_rows = 0 means one residual row per output row, otherwise the
  * residual is a [res_rows, ldr] map shared by the images (row m % res_rows).  A linear layer is the 1x1 case with
  * B = 1, H = 1, W = M.  `scratch` (optional, scratch_floats floats) enables split-K for shapes with too few tiles
- * (partials summed in slice order: deterministic).  cfg < 0 = heuristic kernel choice; cfg >= 0 forces a kernel
- * configuration (tuning / tests; same results up to summation order).  Requires Cin % 4 == 0 and lda % 4 == 0.
+ * (partials summed in slice order: deterministic).  cfg = -1: kernel chosen for the lowest latency of this launch on
+ * its own (one clip at a time); cfg = -2: chosen for the lowest cost when several clips keep the chip busy (the lean
+ * tile kernel wherever it applies); cfg >= 0 forces a kernel configuration (tuning / tests).  Same results up to
+ * summation order.  Requires Cin % 4 == 0 and lda % 4 == 0.
  * Replaces: every nn.Conv2d + FrozenBatchNorm2d + ReLU of networks/encoders/resnet.py:34-54,
  * 140-157 and mobilenetv2.py (1x1 / 3x3), encoder_projector (models/aot.py:19-21,81-84),
  * the nn.Linear layers of networks/layers/transformer.py:321-359 and attention.py:76-79,119,
