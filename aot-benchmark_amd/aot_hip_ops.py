@@ -27,6 +27,8 @@ _DEFS = {
                       'Tensor(c!) stats, Tensor(d!) ticket, int h, int w_, int act, float eps, int lanes) -> ()',
     'attn': '(Tensor q, Tensor k, Tensor v, Tensor(a!) out, int T, int H, float scale_div, Tensor(b!)? part, int nsplit) -> ()',
     'attn_topk': '(Tensor q, Tensor k, Tensor v, Tensor(a!) out, int T, int H, float scale_div, int top_k, Tensor(b!) scores) -> ()',
+    'gated_attn_topk': '(Tensor q, Tensor k, Tensor v, Tensor? gate, Tensor(a!) out, int T, float scale_div, int top_k, '
+                       'Tensor(b!) scores) -> ()',
     'gated_attn': '(Tensor q, Tensor k, Tensor v, Tensor? gate, Tensor(a!) out, int T, float scale_div, Tensor(b!)? part, '
                   'int nsplit) -> ()',
     'local_attn': '(Tensor q, Tensor k, Tensor v, Tensor relk_w, Tensor relk_b, Tensor relv_t, Tensor(a!) out, int h, int w, int H, '
@@ -89,6 +91,11 @@ def _attn(q, k, v, out, T, H, scale_div, part, nsplit):
 @_impl('attn_topk')
 def _attn_topk(q, k, v, out, T, H, scale_div, top_k, scores):
     aot_hip.attention_topk(q, k, v, out, T, H, scale_div, top_k, scores)
+
+
+@_impl('gated_attn_topk')
+def _gated_attn_topk(q, k, v, gate, out, T, scale_div, top_k, scores):
+    aot_hip.gated_attention_topk(q, k, v, gate, out, T, scale_div, top_k, scores)
 
 
 @_impl('gated_attn')
