@@ -81,6 +81,11 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
   f32x2 r;
   asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -598,32 +603,40 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
     load_v(vb[1], kt, 1);
     f32x16 sc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)     // fixed wave order: every wave of the workgroup gets the same bits
-      sc[r] = ((part[buf][0][r][lane] + part[buf][1][r][lane]) + part[buf][2][r][lane]) + part[buf][3][r][lane];
+    for (int r = 0; r < 16; r += 2) {   // fixed wave order: every wave of the workgroup gets the same bits (two rows per v_pk_add)
+      const f32x2 p0 = {part[buf][0][r][lane], part[buf][0][r + 1][lane]}, p1 = {part[buf][1][r][lane], part[buf][1][r + 1][lane]};
+      const f32x2 p2 = {part[buf][2][r][lane], part[buf][2][r + 1][lane]}, p3 = {part[buf][3][r][lane], part[buf][3][r + 1][lane]};
+      const f32x2 t = pk_add(pk_add(pk_add(p0, p1), p2), p3);
+      sc[r] = t[0];
+      sc[r + 1] = t[1];
+    }
     qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of the softmax below
     if (TAIL) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
     }
-    float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+    // (same VALU diet as the d = 32 kernel: v_max3, packed fp32 -- fp32 MFMAs do not hide VALU work)
+    const float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                          max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
     const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);
     const bool moved = mnew > m;
     m = mnew;
     l *= alpha;
     float pf[16];
-    float ps0 = 0.f, ps1 = 0.f;
+    {
+      const f32x2 L2 = {AOT_LOG2E, AOT_LOG2E}, nm2 = {-m, -m};
+      f32x2 ps = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      pf[r] = exp2_w(sc[r], m);
-      pf[r + 1] = exp2_w(sc[r + 1], m);
-      ps0 += pf[r];
-      ps1 += pf[r + 1];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t2 = pk_fma(f32x2{sc[r], sc[r + 1]}, L2, nm2);
+        pf[r] = __builtin_amdgcn_exp2f(t2[0]);
+        pf[r + 1] = __builtin_amdgcn_exp2f(t2[1]);
+        ps += f32x2{pf[r], pf[r + 1]};
+      }
+      l += ps[0] + ps[1];
     }
-    l += ps0 + ps1;
     load_k(ka, kt + 64);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -631,10 +644,15 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
     }
     if (__any(moved)) {
+      const f32x2 al2 = {alpha, alpha};
 #pragma unroll
       for (int d = 0; d < NDV; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 t = pk_mul(f32x2{o[d][r], o[d][r + 1]}, al2);
+          o[d][r] = t[0];
+          o[d][r + 1] = t[1];
+        }
     }
 #pragma unroll
     for (int d = 0; d < NDV; ++d) {

@@ -274,6 +274,7 @@ class _DryClip:
 
 
 def main(argv=None):
+    global MODEL, IN_SIZE
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -283,6 +284,9 @@ def main(argv=None):
     ap.add_argument('--graph', type=int, default=1, choices=[0, 1],
                     help='1 (default): the engines replay one captured hipGraph per frame stage and engine state '
                          '(networks/engines/graphs.py); 0: every kernel launched from the host')
+    ap.add_argument('--model', default=MODEL, choices=['r50_aotl', 'r50_deaotl', 'swinb_deaotl', 'swinb_aotl', 'r101_aotl'],
+                    help='default: R50-AOTL = BASELINE configs[1], the configuration the metric is quoted on; swinb_deaotl = '
+                         'configs[2] (480x848 input).  The roofline and J&F legs belong to the default model only.')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-jf', action='store_true', help='skip the J&F pass on the committed reference clip (tuning runs)')
@@ -291,6 +295,12 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1:
         raise SystemExit('bench.py: --gpus and --steps must be >= 1')
+    default_model = args.model == MODEL
+    MODEL = args.model
+    if MODEL.startswith('swinb'):
+        IN_SIZE = (480, 848)          # align_corners = False models take multiples of 16 (video_transforms.py:640-655)
+    if not default_model:
+        args.no_roofline = args.no_jf = True
     if args.backend == 'gloo' and not args.dry_run:
         raise SystemExit('bench.py: the gloo backend is only for --dry-run (the hot path has no CPU fallback)')
 
@@ -444,8 +454,10 @@ def main(argv=None):
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'dry-run (no device work)' if dry else 'synthetic',
-            'config': {'workload': 'R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
-                                   '70 frames/clip, long-term gap 5 (configs[1])',
+            'config': {'workload': ('R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
+                                    '70 frames/clip, long-term gap 5 (configs[1])') if default_model else
+                                   '%s inference, 480p (%dx%d in, 480x854 out) 10-object synthetic clips, 70 frames/clip'
+                                   % (MODEL, IN_SIZE[0], IN_SIZE[1]),
                        'frames_per_clip': CLIP_FRAMES, 'clips_per_gpu': nclips_rank, 'streams_per_gpu': S,
                        'timed_M_mean': round(float(stats[:, 3].sum()) / total_frames, 2),
                        'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
