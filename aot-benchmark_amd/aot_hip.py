@@ -44,6 +44,14 @@ _SIGS = {
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
+    # training-side stages (csrc/train_ops.hip)
+    'aot_ce_loss_f32': [_P] * 6 + [_I, _I, _L, _L, _P],
+    'aot_ce_loss_bwd_f32': [_P] * 6 + [_I, _I, _L, _P],
+    'aot_soft_jaccard_f32': [_P] * 5 + [_I, _I, _L, _I, _F, _P],
+    'aot_soft_jaccard_bwd_f32': [_P] * 5 + [_I, _I, _L, _F, _P],
+    'aot_adamw_step_f32': [_P] * 4 + [_L] + [_F] * 5 + [_I, _F, _P],
+    'aot_ema_update_f32': [_P, _P, _L, _F, _P],
+    'aot_sumsq_accum_f64': [_P, _L, _P, _P],
 }
 
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
@@ -409,3 +417,66 @@ def label_resize(label, out_h, out_w, flip=False, stream=None):
     _chk(load().aot_label_resize_f32(_dev(label.contiguous()), _dev(out), H, W, out_h, out_w, int(bool(flip)),
                                      stream if stream is not None else stream_ptr()), 'aot_label_resize_f32')
     return out
+
+
+# ---- training-side stages (csrc/train_ops.hip; SURVEY 8f4 first slice) ------------------------------------------------
+def ce_loss(logits, labels, top_k=0, stream=None):
+    """logits [B,C,H,W] (contiguous), labels [B,H,W] fp32 ids (255 = ignore) -> (loss [B], saved state for ce_loss_bwd).
+    top_k > 0: mean of the top_k largest per-pixel losses of each sample; 0: mean over the valid pixels."""
+    B, C = logits.shape[:2]
+    P = logits[0, 0].numel()
+    dev = logits.device
+    loss_px = torch.empty(B, P, dtype=torch.float32, device=dev)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    thr = torch.empty(B, dtype=torch.int32, device=dev) if top_k > 0 else None
+    cnt = torch.empty(B, dtype=torch.float32, device=dev) if top_k <= 0 else None
+    _chk(load().aot_ce_loss_f32(_dev(logits), _dev(labels), _dev(loss_px), _dev(loss), _opt(thr), _opt(cnt), B, C, P, int(top_k),
+                                stream if stream is not None else stream_ptr()), 'aot_ce_loss_f32')
+    return loss, (loss_px, thr, cnt)
+
+
+def ce_loss_bwd(logits, labels, saved, gscale, stream=None):
+    """gscale [B] = upstream gradient / k (or / number of valid pixels) -> grad of the logits."""
+    loss_px, thr, _ = saved
+    B, C = logits.shape[:2]
+    grad = torch.empty_like(logits)
+    _chk(load().aot_ce_loss_bwd_f32(_dev(logits), _dev(labels), _dev(loss_px), _opt(thr), _dev(gscale), _dev(grad), B, C,
+                                    logits[0, 0].numel(), stream if stream is not None else stream_ptr()), 'aot_ce_loss_bwd_f32')
+    return grad
+
+
+def soft_jaccard(logits, labels, eps=1e-6, nchunk=64, stream=None):
+    B, C = logits.shape[:2]
+    P = logits[0, 0].numel()
+    dev = logits.device
+    part = torch.empty(B * nchunk * 16 * 3, dtype=torch.float64, device=dev)
+    sums = torch.empty(B, 16, 3, dtype=torch.float64, device=dev)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    _chk(load().aot_soft_jaccard_f32(_dev(logits), _dev(labels), _dev(part), _dev(sums), _dev(loss), B, C, P, nchunk, eps,
+                                     stream if stream is not None else stream_ptr()), 'aot_soft_jaccard_f32')
+    return loss, sums
+
+
+def soft_jaccard_bwd(logits, labels, sums, gout, eps=1e-6, stream=None):
+    B, C = logits.shape[:2]
+    grad = torch.empty_like(logits)
+    _chk(load().aot_soft_jaccard_bwd_f32(_dev(logits), _dev(labels), _dev(sums), _dev(gout), _dev(grad), B, C,
+                                         logits[0, 0].numel(), eps, stream if stream is not None else stream_ptr()),
+         'aot_soft_jaccard_bwd_f32')
+    return grad
+
+
+def adamw_step(p, g, m, v, lr, weight_decay, beta1, beta2, eps, step, gscale=1.0, stream=None):
+    _chk(load().aot_adamw_step_f32(_dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, weight_decay, beta1, beta2, eps, int(step),
+                                   gscale, stream if stream is not None else stream_ptr()), 'aot_adamw_step_f32')
+
+
+def ema_update(shadow, param, one_minus_decay, stream=None):
+    _chk(load().aot_ema_update_f32(_dev(shadow), _dev(param), shadow.numel(), one_minus_decay,
+                                   stream if stream is not None else stream_ptr()), 'aot_ema_update_f32')
+
+
+def sumsq_accum(x, out, stream=None):
+    """out (one fp64 element on the device) += sum(x^2)."""
+    _chk(load().aot_sumsq_accum_f64(_dev(x), x.numel(), _dev(out), stream if stream is not None else stream_ptr()),
+         'aot_sumsq_accum_f64')

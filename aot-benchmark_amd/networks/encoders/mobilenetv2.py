@@ -96,6 +96,16 @@ class MobileNetV2(nn.Module):
         features.append(ConvBNReLU(input_channel, self.last_channel, kernel_size=1, norm_layer=norm_layer))
         self.features = nn.Sequential(*features)
         self._stem = self._last = None
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at):
+        """reference mobilenetv2.py:240-247: stages = features[0:4], [4:7], [7:14], [14:]; freeze_at >= 1 stops the gradients of
+        the first conv block, freeze_at >= k+1 those of stage k."""
+        stages = [self.features[0:4], self.features[4:7], self.features[7:14], self.features[14:]]
+        frozen = ([self.features[0]] if freeze_at >= 1 else []) + [st for idx, st in enumerate(stages, start=2) if freeze_at >= idx]
+        for m in frozen:
+            for p in m.parameters():
+                p.requires_grad = False
 
     def run(self, img, ws, stream):
         """img [1,3,H,W] -> [(feat, h, w)] for the 4 stages features[0:4],[4:7],[7:14],[14:] (:210-224)."""

@@ -77,6 +77,16 @@ class ResNet(nn.Module):
         self.layer2 = self._make_layer(block, 128, layers[1], strides[1], dilations[1], BatchNorm)
         self.layer3 = self._make_layer(block, 256, layers[2], strides[2], dilations[2], BatchNorm)
         self._stem = None
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at):
+        """Stops gradients of the stem (freeze_at >= 1) and of layer{1,2,3} (freeze_at >= 2, 3, 4): reference resnet.py:168-175
+        (TRAIN_ENCODER_FREEZE_AT; decides which tensors the trainer's parameter groups hold)."""
+        frozen = ([self.conv1, self.bn1] if freeze_at >= 1 else []) + \
+                 [st for idx, st in enumerate((self.layer1, self.layer2, self.layer3), start=2) if freeze_at >= idx]
+        for m in frozen:
+            for p in m.parameters():
+                p.requires_grad = False
 
     def _make_layer(self, block, planes, blocks, stride, dilation, BatchNorm):
         downsample = None

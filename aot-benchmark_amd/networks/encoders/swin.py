@@ -168,8 +168,27 @@ class SwinTransformer(nn.Module):
         return feats
 
 
+def _freeze_stages(net, frozen_stages):
+    """reference swin_transformer.py:637-657: frozen_stages >= 0 stops the gradients of the patch embedding, >= 2 those of the
+    first frozen_stages - 1 stages -- except the patch-merging layer of the last of them, which stays trainable."""
+    if frozen_stages >= 0:
+        for p in net.patch_embed.parameters():
+            p.requires_grad = False
+    if frozen_stages >= 2:
+        last = None
+        for i in range(frozen_stages - 1):
+            last = net.layers[i]
+            for p in last.parameters():
+                p.requires_grad = False
+        if last is not None and last.downsample is not None:
+            for p in last.downsample.parameters():
+                p.requires_grad = True
+
+
 def build_swin_model(model_type, freeze_at=0):
     if model_type == 'swin_base':       # reference swin/build.py:11-27
-        return SwinTransformer(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7,
-                               out_indices=(0, 1, 2))
+        net = SwinTransformer(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7,
+                              out_indices=(0, 1, 2))
+        _freeze_stages(net, freeze_at)
+        return net
     raise NotImplementedError('Unknown model: %s' % model_type)

@@ -1,0 +1,52 @@
+"""Optimiser of the trainer (reference networks/managers/trainer.py:116-118,501-503): AdamW over named parameter groups and the
+global gradient-norm clip, with the element-wise work as device kernels (csrc/train_ops.hip)."""
+import torch
+
+import aot_hip
+
+
+class AdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction, no amsgrad) over the groups produced by
+    utils.learning.get_trainable_params ({'params', 'lr', 'weight_decay', 'name'})."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.param_groups = []
+        for g in params:
+            g = dict(g) if isinstance(g, dict) else {'params': [g]}
+            g.setdefault('lr', lr)
+            g.setdefault('weight_decay', weight_decay)
+            g.setdefault('betas', betas)
+            g.setdefault('eps', eps)
+            g.setdefault('name', '')
+            self.param_groups.append(g)
+        self.state = {}
+
+    def zero_grad(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                p.grad = None
+
+    def clip_grad_norm(self, max_norm):
+        """clip_grad_norm_(parameters, max_norm): returns (total L2 norm, factor the step multiplies the gradients by)."""
+        grads = [p.grad for g in self.param_groups for p in g['params'] if p.grad is not None]
+        if not grads:
+            return 0.0, 1.0
+        acc = torch.zeros(1, dtype=torch.float64, device=grads[0].device)
+        for gr in grads:
+            aot_hip.sumsq_accum(gr.contiguous(), acc)
+        total = float(acc.item()) ** 0.5
+        return total, min(1.0, max_norm / (total + 1e-6))
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        for g in self.param_groups:
+            b1, b2 = g['betas']
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
+                st['step'] += 1
+                aot_hip.adamw_step(p, p.grad.contiguous(), st['exp_avg'], st['exp_avg_sq'], g['lr'], g['weight_decay'], b1, b2,
+                                   g['eps'], st['step'], grad_scale)

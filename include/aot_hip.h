@@ -240,6 +240,37 @@ int aot_fuse_probs_f32(const float* logits, const float* new_label, float* fused
  * input size [OH, OW] (torch's legacy nearest index rule).  Replaces evaluator.py:375-386,399-408. */
 int aot_label_resize_f32(const float* src, float* dst, int H, int W, int OH, int OW, int flip, void* stream);
 
+/* ---- training-side stages (first slice; networks/layers/loss.py, utils/ema.py, trainer.py:116-118,501-503) ----
+ * logits [B, C, P] planar (the reference's [B,C,H,W], P = H*W), labels [B, P] fp32 class ids, 255 = ignore; C <= 16. */
+
+/* CrossEntropyLoss of the reference (loss.py:137-188) for B samples: loss_px [B,P] = per-pixel cross entropy (0 on ignored
+ * pixels); loss[b] = mean of the top_k largest per-pixel losses of sample b (hard-example mining, top_k > 0; thr[b] receives
+ * the order key of the k-th largest for the backward pass) or, with top_k = 0, the mean over the valid pixels (cnt[b] = their
+ * number). */
+int aot_ce_loss_f32(const float* logits, const float* labels, float* loss_px, float* loss, unsigned* thr, float* cnt, int B,
+                    int C, long P, long top_k, void* stream);
+/* grad [B,C,P] = gscale[b] * (softmax - onehot) on the pixels that entered loss[b] (thr given: per-pixel loss >= the k-th
+ * largest; thr = NULL: every valid pixel), 0 elsewhere.  gscale[b] = upstream gradient / k (or / cnt[b]). */
+int aot_ce_loss_bwd_f32(const float* logits, const float* labels, const float* loss_px, const unsigned* thr,
+                        const float* gscale, float* grad, int B, int C, long P, void* stream);
+
+/* SoftJaccordLoss of the reference (loss.py:119-137 = tversky_loss(alpha = beta = 1), :29-55): loss[b] = mean over the classes
+ * present in sample b of 1 - I / (I + FP + FN + eps) on the softmax probabilities of the valid pixels.  part is scratch of
+ * B*nchunk*16*3 doubles, sums [B,16,3] (I, sum p, sum g per class) is kept for the backward pass. */
+int aot_soft_jaccard_f32(const float* logits, const float* labels, double* part, double* sums, float* loss, int B, int C, long P,
+                         int nchunk, float eps, void* stream);
+int aot_soft_jaccard_bwd_f32(const float* logits, const float* labels, const double* sums, const float* gout, float* grad, int B,
+                             int C, long P, float eps, void* stream);
+
+/* One tensor of torch.optim.AdamW (decoupled weight decay, no amsgrad) at 1-based step `step`; gscale multiplies the
+ * gradient first (the clip_grad_norm_ factor, trainer.py:501-503). */
+int aot_adamw_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float weight_decay, float beta1,
+                       float beta2, float eps, int step, float gscale, void* stream);
+/* utils/ema.py:63-66: shadow -= one_minus_decay * (shadow - param). */
+int aot_ema_update_f32(float* shadow, const float* param, long n, float one_minus_decay, void* stream);
+/* out[0] += sum(x^2) in fp64 (one workgroup, fixed order): the gradient-norm reduction of clip_grad_norm_. */
+int aot_sumsq_accum_f64(const float* x, long n, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,30 @@ def gp_knob_state(module_state_dict):
     from utils.synth import synth_state_dict
     keyed = synth_state_dict({'gp_knobs.' + k: v for k, v in module_state_dict.items()})
     return {k[len('gp_knobs.'):]: v for k, v in keyed.items()}
+
+
+# training-side slice: loss cases of tests/golden/training_losses.npz (make_golden.make_training)
+LOSS_CASES = {
+    'ce_topk_start': dict(kind='ce', top_k=0.15, mining_steps=1000, step=0, seed=1),
+    'ce_topk_mid': dict(kind='ce', top_k=0.15, mining_steps=1000, step=400, seed=2),
+    'ce_topk_end': dict(kind='ce', top_k=0.15, mining_steps=1000, step=5000, seed=3),
+    'ce_mean': dict(kind='ce', top_k=None, mining_steps=1000, step=10, seed=4),
+    'jaccard': dict(kind='jac', step=0, seed=5),
+    'jaccard_missing_classes': dict(kind='jac', step=0, seed=6),
+}
+
+
+def loss_case_inputs(name):
+    """Three samples with 4 / 11 / 2 classes (objects + background, as aot_engine.py:406-412 slices them) of 37x53 pixels;
+    labels carry an ignore band (255); 'missing' leaves some classes without pixels."""
+    c = LOSS_CASES[name]
+    g = torch.Generator().manual_seed(9000 + c['seed'])
+    logits, labels = [], []
+    for C in (4, 11, 2):
+        logits.append(torch.randn(1, C, 37, 53, generator=g) * 2.0)
+        hi = C if 'missing' not in name else max(2, C // 2)
+        lab = torch.randint(0, hi, (1, 37, 53), generator=g).float()
+        lab[:, :3, :] = 255.
+        lab[:, 20:22, 10:30] = 255.
+        labels.append(lab)
+    return logits, labels

@@ -126,6 +126,74 @@ def make_gp_knobs():
         refdriver._leave()
 
 
+def make_training():
+    """Goldens for the training-side slice from the REAL reference: the two losses with their gradients
+    (networks/layers/loss.py, autograd), the learning-rate schedule and parameter groups (utils/learning.py) on the reference's
+    R50-AOTL parameter tree, and the EMA decay / update rule (utils/ema.py).  Inputs are regenerated from seeds by the tests
+    (tests/common.py: loss_case_inputs)."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import LOSS_CASES, loss_case_inputs
+    out = {}
+    net, _, cfg = refdriver.build_reference('r50_aotl')
+    refdriver._enter()
+    try:
+        from networks.layers.loss import CrossEntropyLoss, SoftJaccordLoss
+        from utils.learning import adjust_learning_rate, get_trainable_params
+        from utils.ema import ExponentialMovingAverage
+        for name, c in LOSS_CASES.items():
+            logits, labels = loss_case_inputs(name)
+            logits = [l.clone().requires_grad_(True) for l in logits]
+            if c['kind'] == 'ce':
+                fn = CrossEntropyLoss(c['top_k'], c['mining_steps'])
+            else:
+                fn = SoftJaccordLoss()
+            loss = fn(logits, [l.long() for l in labels], c['step'])
+            w = torch.arange(1, len(logits) + 1, dtype=torch.float32)          # distinct upstream gradients per sample
+            (loss * w).sum().backward()
+            out[name + '.loss'] = loss.detach().numpy()
+            for i, l in enumerate(logits):
+                out['%s.grad%d' % (name, i)] = l.grad.numpy()
+        # learning-rate schedule
+        class _Opt:
+            def __init__(self, names):
+                self.param_groups = [{'name': n, 'lr': 0., 'weight_decay': 0.07} for n in names]
+        names = ['encoder.layer1.0.conv1.weight', 'LSTT.layers.0.norm1.weight', 'patch_wise_id_bank.weight', 'decoder.conv_out.bias']
+        sched = []
+        for kw in (dict(p=0.9, max_itr=1000, warm_up_steps=50, min_lr=1e-5, encoder_lr_ratio=0.1),
+                   dict(p=0.9, max_itr=1000, warm_up_steps=50, min_lr=2e-5, encoder_lr_ratio=1.0, is_cosine_decay=True),
+                   dict(p=2.0, max_itr=900, warm_up_steps=90, min_lr=1e-5, encoder_lr_ratio=0.1, restart=3,
+                        freeze_params=['patch_wise_id_bank'])):
+            rows = []
+            for itr in (0, 1, 25, 49, 50, 51, 299, 300, 301, 500, 899, 999):
+                o = _Opt(names)
+                now = adjust_learning_rate(o, 2e-4, itr=itr, **kw)
+                rows.append([now] + [g['lr'] for g in o.param_groups] + [g['weight_decay'] for g in o.param_groups])
+            sched.append({'kw': kw, 'rows': rows})
+        groups = []
+        for use_frozen in (True, False):
+            gs = get_trainable_params(net, 2e-4, 0.07, use_frozen_bn=use_frozen,
+                                      exclusive_wd_dict={'relative_emb_k': 0.001, 'norm': 0.01}, no_wd_keys=['pos_emb', 'mask_token'])
+            groups.append([[g['name'], g['weight_decay']] for g in gs])
+        # EMA: decays of the first updates and the shadow of a 5-element vector after three updates
+        p = [torch.nn.Parameter(torch.arange(5, dtype=torch.float32))]
+        ema = ExponentialMovingAverage(p, decay=0.999)
+        decays, shadows = [], []
+        for t in range(1, 40):
+            with torch.no_grad():
+                p[0].add_(0.5 * t)
+            ema.update(p)
+            decays.append(min(0.999, (1 + ema.num_updates) / (10 + ema.num_updates)))
+            if t <= 3:
+                shadows.append(ema.shadow_params[0].clone().numpy().tolist())
+        with open(os.path.join(HERE, 'training.json'), 'w') as f:
+            json.dump({'schedule': sched, 'param_groups': groups, 'ema_decays': decays, 'ema_shadows': shadows}, f)
+    finally:
+        refdriver._leave()
+    np.savez_compressed(os.path.join(HERE, 'training_losses.npz'), **out)
+    print('training', {k: v.shape for k, v in out.items() if k.endswith('.loss')}, 'groups', len(groups[0]), flush=True)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -265,6 +333,10 @@ def main():
     if not sys.argv[1:] or 'transforms' in sys.argv[1:]:
         make_transforms()
         if sys.argv[1:] == ['transforms']:
+            return
+    if not sys.argv[1:] or 'training' in sys.argv[1:]:
+        make_training()
+        if sys.argv[1:] == ['training']:
             return
     if not sys.argv[1:] or 'gp_knobs' in sys.argv[1:]:
         make_gp_knobs()
