@@ -49,6 +49,8 @@ class AOTEngine(nn.Module):
         self._graphs = None
         self._static = {}            # staged copies of caller-owned inputs (image, label map): stable addresses for replay
         self._arena = Workspace()    # tensors that live from one stage of a frame to the next (curr_V, decoder input)
+        self._enc = None             # look-ahead encoder: two side streams (+ events, graph caches) used alternately
+        self._prefetched = None      # (image tensor, its token-major features, side-stream index) of prefetch_encode()
         # long_term_mem_max (repo extension; the reference bank grows without bound): at most that many
         # memorised frames -- the first one (the reference frame) is kept, the others form a ring of the most recent
         if long_term_mem_max is not None and long_term_mem_max < 2:
@@ -95,6 +97,7 @@ class AOTEngine(nn.Module):
         self._dst = None             # buffers this frame's K / V live in
         self.curr_id_embs = None
         self.pred_id_logits = None
+        self._prefetched = None
 
     def update_size(self, input_size, enc_size):
         self.input_size_2d = tuple(int(x) for x in input_size)
@@ -226,6 +229,44 @@ class AOTEngine(nn.Module):
         buf.copy_(t)
         return buf
 
+    # ---- look-ahead encoding -------------------------------------------------------------------
+    def prefetch_encode(self, img):
+        """Optional: starts the encoder of the NEXT frame on a side stream now, so that it runs beside this frame's attention
+        and decoder -- the encoder (a third of a frame's work) does not depend on the memory state, and one clip alone cannot
+        fill the chip.  The match_propogate_one_frame call that receives the SAME tensor picks the result up; any other call
+        ignores it.  Two side streams alternate, each with its own scratch (scratch is keyed by stream), so a frame's shortcut
+        features stay intact while the frame after next is being encoded.  Results are bit-identical to encoding in line.
+        MEASURED SLOWER on MI355X (bench.py --prefetch 1: one clip at a time 307 vs 378 fps): the two cross-stream event waits
+        per frame cost more than the overlap returns, so nothing calls it by default."""
+        dev = img.device
+        if self._enc is None:
+            self._enc = {'streams': [torch.cuda.Stream(dev), torch.cuda.Stream(dev)],
+                         'events': [torch.cuda.Event(), torch.cuda.Event()], 'graphs': [None, None], 'sel': 0}
+        e = self._enc
+        i = e['sel']
+        e['sel'] ^= 1
+        side = e['streams'][i]
+        side.wait_stream(torch.cuda.current_stream(dev))     # everything issued so far (incl. the last readers of this set)
+        img.record_stream(side)
+        with torch.cuda.stream(side):
+            if self.use_graph:
+                if e['graphs'][i] is None:
+                    e['graphs'][i] = FrameGraphs(dev)
+                src = self._stage('img_ahead%d' % i, img)
+                feats = e['graphs'][i].run(ptr_key('encode', src, aot_hip.gemm_table()), lambda: self.AOT.encode_tokens(src))
+            else:
+                feats = self.AOT.encode_tokens(img)
+            e['events'][i].record(side)
+        self._prefetched = (img, feats, i)
+
+    def _take_prefetched(self, img):
+        """Features of prefetch_encode(img) if that is the tensor being matched now (the current stream then waits for them)."""
+        pf, self._prefetched = self._prefetched, None
+        if pf is None or img is None or pf[0] is not img:
+            return None
+        torch.cuda.current_stream(img.device).wait_event(self._enc['events'][pf[2]])
+        return pf[1]
+
     # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):
         if img_embs is None:
@@ -298,16 +339,18 @@ class AOTEngine(nn.Module):
         short = self._short[0]
         self._dst = dst
 
+        ahead = self._take_prefetched(img) if img_embs is None else None
+
         def launch(img_, embs_):
-            feats = self._encode(img_, embs_)
+            feats = ahead if ahead is not None else self._encode(img_, embs_)
             dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, short, None, self.pos_emb, self.enc_size_2d, self.AOT.ws,
                                              aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena)
             return feats, dec_in, mems
 
         if self.use_graph:
-            src = self._stage('img', img) if img_embs is None else None
-            key = ptr_key('match', src, img_embs, long_m, short, dst, self.pos_emb, self.lanes, self.enc_size_2d,
-                          aot_hip.gemm_table())
+            src = self._stage('img', img) if (img_embs is None and ahead is None) else None
+            key = ptr_key('match', src, img_embs, [f[0] for f in ahead] if ahead is not None else None, long_m, short, dst,
+                          self.pos_emb, self.lanes, self.enc_size_2d, aot_hip.gemm_table())
             self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
         else:
             self._feats, self._dec_in, self._curr = launch(img, img_embs)
@@ -551,6 +594,11 @@ class AOTInferEngine(nn.Module):
                 img_embs = c.curr_enc_embs
         first = self._cohorts[0]
         self.input_size_2d, self.enc_size_2d, self.enc_hw = first.input_size_2d, first.enc_size_2d, first.enc_hw
+
+    def prefetch_encode(self, img):
+        """Optional look-ahead (see AOTEngine.prefetch_encode): call with the NEXT frame before matching the current one."""
+        if self._cohorts:
+            self._cohorts[0].prefetch_encode(img)
 
     def match_propogate_one_frame(self, img=None):
         img_embs = None

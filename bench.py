@@ -90,6 +90,7 @@ class StreamClip:
     def __init__(self, engine, stream, clip):
         self.engine, self.stream, self.clip = engine, stream, clip
         self.t = None
+        self.ahead = False      # encode frame t+1 on a side stream while frame t is matched (engine.prefetch_encode)
 
     def restart(self):
         """restart_engine + add_reference_frame: per-clip set-up, never inside the timed region (the reference's
@@ -101,8 +102,11 @@ class StreamClip:
         self.t = 1
 
     def step(self):
+        frames = self.clip[0]
         with torch.cuda.stream(self.stream):
-            one_frame(self.engine, self.clip[0][self.t])
+            if self.ahead and self.t + 1 < len(frames):
+                self.engine.prefetch_encode(frames[self.t + 1])
+            one_frame(self.engine, frames[self.t])
         self.t += 1
 
     def advance_to(self, t):
@@ -287,6 +291,10 @@ def main(argv=None):
     ap.add_argument('--model', default=MODEL, choices=['r50_aotl', 'r50_deaotl', 'swinb_deaotl', 'swinb_aotl', 'r101_aotl'],
                     help='default: R50-AOTL = BASELINE configs[1], the configuration the metric is quoted on; swinb_deaotl = '
                          'configs[2] (480x848 input).  The roofline and J&F legs belong to the default model only.')
+    ap.add_argument('--prefetch', type=int, default=0, choices=[0, 1],
+                    help='1: encode the next frame on a side stream while the current one is matched (engine.prefetch_encode).  '
+                         'Off by default: measured SLOWER on MI355X (one clip at a time 307 vs 378 fps, three clips 368 vs 503 -- '
+                         'the cross-stream event waits cost more than the overlap returns)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-jf', action='store_true', help='skip the J&F pass on the committed reference clip (tuning runs)')
@@ -362,6 +370,8 @@ def main(argv=None):
                                            long_term_mem_gap=gap, graph=bool(args.graph)) for _ in range(S - 1)]
         streams = [torch.cuda.Stream(device) for _ in range(S)]
         lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
+        for lane in lanes:
+            lane.ahead = args.prefetch == 1
 
         def set_clip(lane, j):
             lane.clip = clips[j]
@@ -417,7 +427,8 @@ def main(argv=None):
             for t in range(1, CLIP_FRAMES):
                 lanes[0].step()
             e1, f1, m1 = run_plan(lanes[:1], plan_windows(args.steps, 1), lambda pi, i: 0, collective=False)
-            single = {'fps': round(f1 / e1, 2), 'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency'}
+            single = {'fps': round(f1 / e1, 2), 'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency',
+                      'encoder_look_ahead': bool(lanes[0].ahead)}
             aot_hip.set_gemm_table('throughput')
 
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -465,6 +476,7 @@ def main(argv=None):
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': 'throughput' if S > 1 else 'latency',
+                       'encoder_look_ahead': bool(args.prefetch == 1),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
                        'timed_region': 'wall clock (barrier + device sync on both sides) over the propagated frames '
                                        'only: windows of consecutive frames spread over the 70-frame clip so that the '

@@ -1114,6 +1114,42 @@ def test_scratch_released_when_clip_geometry_changes(hip):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_prefetch_encode_bit_identical(hip, graph):
+    """engine.prefetch_encode(next frame): the encoder of frame t+1 runs on a side stream beside frame t's attention / decoder
+    (two alternating side streams, own scratch each).  Two clips back to back, eager and hipGraph mode: logits BIT-identical
+    to the same engine without look-ahead; a prefetch for a tensor that is then not the one matched is ignored."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state('r50_aotl')
+    model = model.cuda().eval()
+    model.prepare()
+    size, osz = (241, 321), (240, 320)
+    clips = [synth_clip(k, 8, size, osz, 4, device='cuda') for k in (21, 22)]
+
+    def run(ahead):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=2, graph=graph)
+        outs = []
+        for fr, m, ob, _ in clips:
+            eng.restart_engine()
+            eng.add_reference_frame(fr[0], m, ob, frame_step=0)
+            for t in range(1, len(fr)):
+                if ahead and t + 1 < len(fr):
+                    eng.prefetch_encode(fr[t + 1] if t != 3 else fr[1])      # at t = 3 a useless prefetch: must be ignored
+                if ahead and t == 1:
+                    pass                                                      # frame 1 itself was never prefetched: encoded in line
+                eng.match_propogate_one_frame(fr[t])
+                lg = eng.decode_current_logits(osz)
+                eng.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=eng.input_size_2d, mode='nearest'))
+                outs.append(lg.clone())
+        torch.cuda.synchronize()
+        return outs
+    with torch.no_grad():
+        plain, ahead = run(False), run(True)
+    for i, (a, b) in enumerate(zip(plain, ahead)):
+        assert torch.equal(a, b), 'frame %d differs with look-ahead encoding (max %g)' % (i, (a - b).abs().max().item())
+
+
 def test_reference_api_surface(hip):
     """the reference's model-level methods keep working on reference-shaped tensors (aot.py:72-108)."""
     from oracle.aot_oracle import OracleModel, one_hot_mask
