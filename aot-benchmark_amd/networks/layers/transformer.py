@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 import aot_hip
+from aot_hip import attach_wt
 from networks.layers.attention import (GatedPropagation, LocalGatedPropagation, MultiheadAttention,
                                        MultiheadLocalAttention)
 from networks.layers.basic import GNActDWConv2d, GroupNorm1D
@@ -54,7 +55,7 @@ class LongShortTermTransformerBlock(nn.Module):
         sa = self.self_attn
         wq, bq = linear_t(sa.linear_Q)
         wk, bk = linear_t(sa.linear_K)
-        p['sa_qk_w'] = torch.cat([wq, wk], 1).contiguous()          # [256, 512]: one GEMM for Q and K of (x1 + pos)
+        p['sa_qk_w'] = attach_wt(torch.cat([wq, wk], 1).contiguous())   # [256, 512]: one GEMM for Q and K of (x1 + pos)
         p['sa_qk_b'] = torch.cat([bq, bk]).contiguous()
         p['sa_v_w'], p['sa_v_b'] = linear_t(sa.linear_V)
         p['sa_o_w'], p['sa_o_b'] = linear_t(sa.projection)
@@ -62,7 +63,7 @@ class LongShortTermTransformerBlock(nn.Module):
         p['v_w'], p['v_b'] = linear_t(self.linear_V)
         wl, bl = linear_t(self.long_term_attn.projection)
         ws_, bs_ = linear_t(self.short_term_attn.projection)
-        p['lst_w'] = torch.cat([wl, ws_], 0).contiguous()           # [512, 256]: lt and st projections in one GEMM
+        p['lst_w'] = attach_wt(torch.cat([wl, ws_], 0).contiguous())    # [512, 256]: lt and st projections in one GEMM
         p['lst_b'] = (bl + bs_).contiguous()
         p['w1'], p['b1'] = linear_t(self.linear1)
         p['w2'], p['b2'] = linear_t(self.linear2)
@@ -270,13 +271,15 @@ class GatedPropagationModule(nn.Module):
             da = self.d_att * self.att_nhead
             p['q_w'], p['q_b'] = wqv[:, :da], bqv[:da].contiguous()   # column views of one packed matrix (ldb = 640)
             p['v_w'], p['v_b'] = wqv[:, da:], bqv[da:].contiguous()
+            if getattr(wqv, '_aot_wt', None) is not None:             # ... and the matching row blocks of its k-contiguous twin
+                p['q_w']._aot_wt, p['v_w']._aot_wt = wqv._aot_wt[:da], wqv._aot_wt[da:]
             p['u_w'], p['u_b'] = linear_t(self.linear_U)
             widv, p['idv_b'] = linear_t(self.linear_ID_V)
             if self.layer_idx == 0:
                 p['idv_w_id'] = widv
             else:
                 D = self.d_model
-                p['idv_w_prev'], p['idv_w_id'] = widv[:D].contiguous(), widv[D:].contiguous()
+                p['idv_w_prev'], p['idv_w_id'] = attach_wt(widv[:D].contiguous()), attach_wt(widv[D:].contiguous())
                 p['idu_w'], p['idu_b'] = linear_t(self.linear_ID_U)
                 p['id_norm1'] = _ln_params(self.id_norm1)
             for n in ('norm1', 'norm2', 'id_norm2'):
