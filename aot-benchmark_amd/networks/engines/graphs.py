@@ -35,6 +35,8 @@ def ptr_key(*items):
 
 
 class FrameGraphs:
+    MAX_GRAPHS = 2048      # states of a handful of clip geometries; beyond that everything is dropped and captured afresh
+
     def __init__(self, device):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
@@ -51,6 +53,8 @@ class FrameGraphs:
         time (tensors whose contents the replay has just refreshed)."""
         ent = self._g.get(key)
         if ent is None:
+            if len(self._g) >= self.MAX_GRAPHS:     # e.g. a re-allocated memory bank left every old key unreachable
+                self._g.clear()
             g = torch.cuda.CUDAGraph()
             # (capture_begin / capture_end directly: the torch.cuda.graph context manager also synchronises the device,
             #  runs the garbage collector and empties the allocator cache on entry -- per-capture costs that would stall

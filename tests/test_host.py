@@ -162,6 +162,14 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.aot_attn_topk_f32(P(16), P(16), P(16), P(16), None, 8, 64, 8, 32, 256, 256, 256, 256, 5.65, 4, None) == -1  # no scratch
     assert lib.aot_gated_attn_topk_f32(P(16), P(16), P(16), None, P(16), P(16), 8, 64, 64, 1024, 128, 128, 1024, 0, 1024, 11.3, 4, None) == -2  # d != 128
     assert lib.aot_gated_attn_topk_f32(P(16), P(16), P(16), None, P(16), P(16), 8, 64, 128, 1024, 128, 128, 1024, 0, 1024, 11.3, 64, None) == -1  # top_k >= T
+    # training-side stages: argument checks happen before any launch
+    assert lib.aot_ce_loss_f32(P(16), P(16), P(16), P(16), None, None, 1, 11, 100, 10, None) == -1       # top_k without thr
+    assert lib.aot_ce_loss_f32(P(16), P(16), P(16), P(16), P(16), None, 1, 17, 100, 10, None) == -2      # more than 16 classes
+    assert lib.aot_ce_loss_f32(P(16), P(16), P(16), P(16), P(16), None, 1, 11, 100, 101, None) == -1     # top_k > pixels
+    assert lib.aot_soft_jaccard_f32(P(16), P(16), None, P(16), P(16), 1, 11, 100, 8, 1e-6, None) == -1   # no scratch
+    assert lib.aot_adamw_step_f32(P(16), P(16), P(16), P(16), 10, 1e-3, 0.0, 0.9, 0.999, 1e-8, 0, 1.0, None) == -1   # steps count from 1
+    assert lib.aot_ema_update_f32(P(16), None, 10, 0.1, None) == -1
+    assert lib.aot_sumsq_accum_f64(P(16), 0, P(16), None) == -1
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 0, 8, 0, 0, 0, -1, None) == -1  # Cin % 4
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 32, 4, 4, 64, 1, 1, 1, 0, 1, 32, 64, 0, 64, 0, 0, 0, 117, None) == -2  # LDS-direct kernel without a k-contiguous weight
     assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 1, 0, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
