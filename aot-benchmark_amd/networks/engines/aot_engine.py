@@ -69,16 +69,147 @@ class AOTEngine(nn.Module):
         self._bank = None            # per layer (K [lanes, cap*N, Ck], V [lanes, cap*N, Cv]); survives restart_engine
         self._bank_geom = None
         self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot; survives too
+        self.losses = None           # built by the first forward() (training only)
         self.restart_engine()
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('training forward (aot_engine.py:33-108) is outside the scoped inference path')
+    # ---- training-step forward (aot_engine.py:33-108) -------------------------------------------
+    def _init_losses(self):
+        """aot_engine.py:110-125: 0.5 * hard-mined cross entropy + 0.5 * soft Jaccard; the auxiliary loss of the frames that
+        see their own mask fades out linearly over TRAIN_TOTAL_STEPS * TRAIN_AUX_LOSS_RATIO steps."""
+        from networks.layers.loss import CrossEntropyLoss, SoftJaccordLoss
+        cfg = self.cfg
+        self.losses = nn.ModuleList([CrossEntropyLoss(cfg.TRAIN_TOP_K_PERCENT_PIXELS,
+                                                      cfg.TRAIN_HARD_MINING_RATIO * cfg.TRAIN_TOTAL_STEPS),
+                                     SoftJaccordLoss()])
+        self.loss_weights = [0.5, 0.5]
+        self.aux_weight = cfg.TRAIN_AUX_LOSS_WEIGHT
+        self.aux_step = cfg.TRAIN_TOTAL_STEPS * cfg.TRAIN_AUX_LOSS_RATIO + 1e-5
+
+    def forward(self, all_frames, all_masks, batch_size, obj_nums, step=0, tf_board=False, use_prev_pred=False,
+                enable_prev_frame=False, use_prev_prob=False):
+        """The reference's training-step forward: all_frames [T*bs, 3, H, W] / all_masks [T*bs, 1, H, W], time-major
+        (reference frame, previous frame, current frames; trainer.py:452-455) -> (loss, per-frame masks [bs, H, W], per-frame
+        losses [bs], boards).  Frame 0 memorises its own mask, frames 1.. are propagated and feed their ground-truth mask
+        (or, use_prev_pred, their own prediction / probabilities) back; every frame is decoded and scored.
+
+        The samples of a batch are independent clips (every reference op on this path is per-sample), so they run here one
+        after the other through the single-lane per-frame path -- the same kernels as inference, with the per-frame encoder
+        instead of the reference's batched offline one.  This is the deterministic network: drop-path and dropout
+        (TRAIN_LSTT_*) are not applied, and the returned loss carries no autograd graph -- the model backward is not built
+        (DESIGN.md section 7), only the losses themselves differentiate (layers/loss.py)."""
+        if self.lanes != 1 or self.group0 is not None:
+            raise NotImplementedError('the training forward runs <= %d objects per sample on one lane' % self.max_obj_num)
+        if self.losses is None:
+            self._init_losses()
+        bs = int(batch_size)
+        if bs != self.batch_size:
+            raise ValueError('batch_size %d differs from restart_engine(%d, ...)' % (bs, self.batch_size))
+        T = all_frames.shape[0] // bs
+        if T < 3 or all_frames.shape[0] != T * bs or all_masks.shape[0] != T * bs:
+            raise ValueError('need >= 3 frames per sample, time-major: got %d frames / %d masks for batch %d'
+                             % (all_frames.shape[0], all_masks.shape[0], bs))
+        aux_weight = self.aux_weight * max(self.aux_step - step, 0.) / self.aux_step
+        frames = all_frames.view(T, bs, *all_frames.shape[1:])
+        masks = all_masks.view(T, bs, *all_masks.shape[1:]).float()
+        n_aux = 2 if enable_prev_frame else 1
+        losses = [[None] * bs for _ in range(T)]
+        preds = [[None] * bs for _ in range(T)]
+        for b in range(bs):
+            self._restart_clip()
+            self._sample = b
+            objs = int(obj_nums[b])
+            # with the identities shuffled the objects sit on arbitrary channels: nothing is masked by count until the
+            # channels are back in place (aot_engine.py:364-372)
+            count = [self.max_obj_num if self.enable_id_shuffle else objs]
+
+            def score(t):
+                loss, mask, prob = self._loss_and_mask(masks[t, b], objs, step, want_prob=use_prev_prob)
+                losses[t][b], preds[t][b] = loss, mask
+                return mask.view(1, 1, *mask.shape[-2:]).float() if not use_prev_prob else prob
+
+            def feed_back(t, pred):
+                self.update_short_term_memory(self._shuffled(pred if use_prev_pred else masks[t, b:b + 1]))
+
+            self.add_reference_frame(frames[0, b:b + 1], self._shuffled(masks[0, b:b + 1]), frame_step=0, obj_nums=count)
+            score(0)
+            t = 1
+            if enable_prev_frame:
+                self.set_prev_frame(frames[1, b:b + 1], self._shuffled(masks[1, b:b + 1]), frame_step=1)
+                score(1)
+                t = 2
+            while t < T:
+                self.match_propogate_one_frame(frames[t, b:b + 1])
+                pred = score(t)
+                if t < T - 1:
+                    feed_back(t, pred)
+                t += 1
+        self._sample = None
+        frame_loss = [torch.cat(l, 0) for l in losses]
+        frame_mask = [torch.cat(m, 0) for m in preds]
+        aux_loss = torch.cat(frame_loss[:n_aux], 0).mean(0)
+        pred_loss = torch.cat(frame_loss[n_aux:], 0).mean(0)
+        loss = aux_weight * aux_loss + pred_loss
+        return loss, frame_mask, frame_loss, {'image': {}, 'scalar': {}}
+
+    def _loss_and_mask(self, gt, objs, step, want_prob=False):
+        """generate_loss_mask of one sample (aot_engine.py:398-430): decode at the label size, put shuffled identities back,
+        score the first objs+1 channels.  gt [1, H, W].  Returns (loss [1], mask [1, H, W] long, prob [1, L, H, W] | None)."""
+        size = tuple(gt.shape[-2:])
+        logits = self.decode_current_logits(size)
+        if self.enable_id_shuffle:
+            perm = self.id_shuffle[self._sample]
+            logits = logits.index_select(1, perm)               # channel t <- the channel identity t was moved to
+            logits[:, objs + 1:] = -1e10
+            self.pred_id_logits = self.pred_id_logits.index_select(1, perm)
+            self.pred_id_logits[:, objs + 1:] = -1e10
+        scored = [logits[:, :objs + 1].contiguous()]
+        label = [gt.view(1, *size)]
+        loss = 0
+        for fn, wgt in zip(self.losses, self.loss_weights):
+            loss = loss + wgt * fn(scored, label, step)
+        mask, _, prob = aot_hip.fuse_probs(logits, [False], want_aug_labels=False, want_prob=want_prob)
+        return loss, mask.view(1, *size).long(), prob
+
+    def _shuffled(self, m):
+        """Moves the identities of a label map [1,1,H,W] or a probability map [1,L,H,W] of the current sample to their
+        shuffled channels (assign_identity's einsum, aot_engine.py:168-172); unchanged when the shuffle is off."""
+        if not self.enable_id_shuffle:
+            return m
+        perm = self.id_shuffle[self._sample]
+        if m.shape[1] != 1:
+            out = torch.empty_like(m)
+            out[:, perm] = m
+            return out
+        ids = m.long()
+        known = ids <= self.max_obj_num                           # (the ignore label stays what it is)
+        return torch.where(known, perm[ids.clamp(max=self.max_obj_num)], ids).float()
+
+    def set_prev_frame(self, img=None, mask=None, frame_step=1):
+        """aot_engine.py:253-289: a second frame that memorises its own mask (appended to the bank, becomes the short-term
+        memory) -- the reference-frame stage again at another frame counter."""
+        if img is None:
+            _die('No image for previous frame!')
+        if mask is None:
+            _die('No mask for previous frame!')
+        self.frame_step = frame_step
+        self.add_reference_frame(img, mask)
 
     # ---- state ---------------------------------------------------------------------------------
     def restart_engine(self, batch_size=1, enable_id_shuffle=False):
-        if batch_size != 1 or enable_id_shuffle:
-            raise NotImplementedError('inference runs one clip per engine without id shuffle (aot_engine.py:445-477)')
-        self.batch_size = 1
+        """batch_size > 1 and enable_id_shuffle only matter to forward() (trainer.py:457); the per-frame calls serve one clip.
+        The shuffle is one random permutation of the identities 1..max_obj_num per sample, background fixed
+        (utils/math.py:3-24)."""
+        self.batch_size = int(batch_size)
+        self.enable_id_shuffle = bool(enable_id_shuffle)
+        self.id_shuffle = None
+        self._sample = None
+        if self.enable_id_shuffle:
+            dev = next(self.AOT.parameters()).device
+            self.id_shuffle = [torch.cat([torch.zeros(1, dtype=torch.long, device=dev),
+                                          1 + torch.randperm(self.max_obj_num, device=dev)]) for _ in range(self.batch_size)]
+        self._restart_clip()
+
+    def _restart_clip(self):
         self.frame_step = 0
         self.last_mem_step = -1
         self.obj_nums = None
@@ -281,9 +412,8 @@ class AOTEngine(nn.Module):
         return int(self.obj_nums[0]) if isinstance(self.obj_nums, (list, tuple)) else int(self.obj_nums)
 
     def assign_identity(self, mask):
-        """mask [1,1,H,W] label ids -> id embedding [lanes*N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
-        if mask.dim() == 4 and mask.shape[1] != 1:
-            raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
+        """mask [1,1,H,W] label ids, or [1,max_obj_num+1,H,W] one-hot / probabilities (MODEL_USE_PREV_PROB) -> id embedding
+        [lanes*N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
         return self.AOT.id_emb_from_mask(mask, self.enc_size_2d, lanes=self.lanes, group0=self.group0)
 
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
@@ -372,10 +502,12 @@ class AOTEngine(nn.Module):
         self._commit(slot)
 
     def update_short_term_memory(self, curr_mask, curr_id_emb=None, skip_long_term_update=False):
+        """curr_mask: label map [1,1,H,W], or a probability map [1,max_obj_num+1,H,W] (one lane).  curr_id_emb, when given,
+        replaces the mask's identity embedding: [N, C] token-major as assign_identity returns it, or the reference's [N,1,C]."""
         if curr_id_emb is not None:
-            raise NotImplementedError('pre-computed identity embeddings: pass the label map, the gather is fused')
-        if curr_mask.dim() == 4 and curr_mask.shape[1] != 1:
-            raise NotImplementedError('probability-map identities (MODEL_USE_PREV_PROB) need a dense id conv; not built')
+            curr_id_emb = curr_id_emb.reshape(-1, curr_id_emb.shape[-1]).float().contiguous()
+            if curr_id_emb.shape[0] != self.lanes * self.enc_hw:
+                raise ValueError('curr_id_emb has %d tokens, the frame has %d' % (curr_id_emb.shape[0], self.lanes * self.enc_hw))
         dst, curr = self._dst, self._curr
         in_bank = self._curr_slot is not None
         memorise = self.frame_step - self.last_mem_step >= self.long_term_mem_gap
@@ -386,12 +518,14 @@ class AOTEngine(nn.Module):
 
         def launch(mask_):
             self.AOT.update_memory_values(curr, mask_, self.enc_size_2d, self.lanes, self.group0, [d[1] for d in dst],
-                                          aot_hip.stream_ptr())
+                                          aot_hip.stream_ptr(), id_emb=mask_ if curr_id_emb is not None else None)
             if store_slot is not None:
                 self._store(dst, store_slot)
 
+        if curr_id_emb is not None:
+            curr_mask = curr_id_emb
         if self.use_graph:
-            src = self._stage('mask', curr_mask)
+            src = self._stage('mask' if curr_id_emb is None else 'id_emb', curr_mask)
             key = ptr_key('update', src, curr, dst, store_slot, [b[0] for b in self._bank] if store_slot is not None else None,
                           self.lanes, self.group0, self.enc_size_2d, aot_hip.gemm_table())
             self._gx().run(key, lambda: launch(src))

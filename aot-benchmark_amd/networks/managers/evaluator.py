@@ -6,7 +6,7 @@ new-object merge and the label feedback to every augmentation's engine -- is res
 (``aot_hip.preprocess`` / ``fuse_probs`` / ``label_resize``), with frames and labels already resident on the GPU.
 
 Config keys read (same names as configs/default.py of the reference): TEST_FLIP, TEST_MULTISCALE, TEST_MAX_SHORT_EDGE,
-TEST_MAX_LONG_EDGE, TEST_LONG_TERM_MEM_GAP, TEST_SHORT_TERM_MEM_SKIP, MODEL_ALIGN_CORNERS, MODEL_ENGINE.
+TEST_MAX_LONG_EDGE, TEST_LONG_TERM_MEM_GAP, TEST_SHORT_TERM_MEM_SKIP, MODEL_ALIGN_CORNERS, MODEL_ENGINE, MODEL_USE_PREV_PROB.
 """
 import os
 
@@ -19,8 +19,10 @@ from utils.image import restrict_size, save_mask
 
 class SequenceEvaluator:
     def __init__(self, cfg, model, gpu_id=0):
-        if getattr(cfg, 'MODEL_USE_PREV_PROB', False):
-            raise NotImplementedError('MODEL_USE_PREV_PROB feeds probability maps back (evaluator.py:409-425); not built')
+        # MODEL_USE_PREV_PROB: every augmentation's engine gets its own class probabilities back instead of its label map
+        # (evaluator.py:409-425 -- as shipped that branch stops on an undefined name, `current_prob`; what it sets out to do
+        # is done here).  One object group only (see AOT.id_emb_from_mask).
+        self.use_prev_prob = bool(getattr(cfg, 'MODEL_USE_PREV_PROB', False))
         self.cfg = cfg
         self.model = model
         self.gpu = gpu_id
@@ -89,6 +91,12 @@ class SequenceEvaluator:
                     e.add_reference_frame(inputs[i], lab, obj_nums=new_obj_nums, frame_step=t)
                     e.decode_current_logits((H, W))
                     e.update_memory(lab)
+            elif self.use_prev_prob:
+                for i, (nh, nw, flip) in enumerate(augs):                   # (:409-425)
+                    # the engine's own softmax, in the orientation it decoded in, nearest-resized plane by plane
+                    _, _, prob = aot_hip.fuse_probs(logits[i], [False], want_aug_labels=False, want_prob=True)
+                    self._engine(i).update_memory(torch.cat([aot_hip.label_resize(prob[0, c], nh, nw)
+                                                             for c in range(prob.shape[1])], 1))
             else:
                 for i, (nh, nw, flip) in enumerate(augs):                   # (:394-408)
                     self._engine(i).update_memory(aot_hip.label_resize(augl[i], nh, nw, flip))

@@ -86,6 +86,8 @@ class AOT(nn.Module):
                 'id_table': idw.permute(1, 2, 3, 0).contiguous(),            # [L, K, K, C]
                 'id_sumtab': idw.double().sum((2, 3)).t().float().contiguous(),  # [L, C]: all-taps sum per label
                 'id_bias': self.patch_wise_id_bank.bias.detach().float().contiguous(),
+                # the same bank as implicit-GEMM weights (channels padded to 12): identities of probability maps
+                'id_dense': fold_conv_bn(self.patch_wise_id_bank, pad_cin=(idw.shape[1] + 3) // 4 * 4),
             }
             for layer in self.LSTT.layers:
                 layer.pack()
@@ -145,9 +147,20 @@ class AOT(nn.Module):
         """Fused one_hot_mask + patch_wise_id_bank (aot.py:76-79, utils/image.py:69-74): label map [1,1,H,W]
         (float ids) -> id embedding [lanes*h*w, C]; the 18 MB one-hot tensor is never built.  group0 is not None: the map
         holds the labels of ALL objects and lane g is object group group0+g (the mask separation of AOTInferEngine,
-        aot_engine.py:515-534, happens inside the gather).  fuse = [(add_i, out_i)]: out_i = id_emb + add_i, same launch."""
+        aot_engine.py:515-534, happens inside the gather).  fuse = [(add_i, out_i)]: out_i = id_emb + add_i, same launch.
+        A map with max_obj_num+1 channels is a probability map (MODEL_USE_PREV_PROB) and takes the dense convolution."""
         p = self.pack()
         stream = stream if stream is not None else aot_hip.stream_ptr()
+        if mask.dim() == 4 and mask.shape[1] != 1:
+            if lanes != 1 or group0 is not None:
+                # (the reference splits the probability map of several groups along the BATCH axis, aot_engine.py:536-545,
+                #  which leaves every group but the first with an empty map: there is no behaviour to match)
+                raise NotImplementedError('probability-map identities are defined for one object group (<= %d objects)'
+                                          % self.max_obj_num)
+            out = self.id_emb_from_prob(mask, size_2d, stream)
+            for add_i, out_i in (fuse or []):
+                aot_hip.add(add_i, out, out_i, stream=stream)
+            return out
         H, W = mask.shape[-2:]
         h, w = size_2d
         conv = self.patch_wise_id_bank
@@ -158,14 +171,41 @@ class AOT(nn.Module):
                        group_size=0 if group0 is None else self.max_obj_num, group0=group0 or 0, fuse=fuse, stream=stream)
         return out
 
-    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream):
+    def id_emb_from_prob(self, prob, size_2d, stream=None):
+        """patch_wise_id_bank as the dense convolution it is in the reference (aot.py:76-79), for maps that are not one-hot:
+        prob [1, max_obj_num+1, H, W] -> id embedding [h*w, C].  The planar map is repacked token-major with the channels
+        padded to a multiple of four and goes through the implicit-GEMM kernel (K = KH*KW*12 taps per output token)."""
+        p = self.pack()
+        stream = stream if stream is not None else aot_hip.stream_ptr()
+        conv = self.patch_wise_id_bank
+        L = self.max_obj_num + 1
+        if prob.dim() != 4 or prob.shape[0] != 1 or prob.shape[1] != L:
+            raise aot_hip.AotHipError('identity map must be [1, %d, H, W], got %s' % (L, tuple(prob.shape)))
+        Lp = (L + 3) // 4 * 4
+        H, W = prob.shape[-2:]
+        h, w = size_2d
+        K, s, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        if (H + 2 * pd - K) // s + 1 != h or (W + 2 * pd - K) // s + 1 != w:
+            raise aot_hip.AotHipError('identity map %dx%d does not give the %dx%d token grid' % (H, W, h, w))
+        x = self.ws.get('id_prob_nhwc', (H * W, Lp), prob.device)
+        aot_hip.nchw_to_nhwc(prob.float().contiguous(), x, L, H, W, Lp, stream=stream)
+        out = torch.empty(h * w, conv.out_channels, dtype=torch.float32, device=prob.device)
+        aot_hip.conv2d(x, *p['id_dense'], out, H, W, Lp, h, w, conv.out_channels, K, K, s, pd, 1, stream=stream)
+        return out
+
+    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream, id_emb=None):
         """After the frame's mask is known (aot_engine.py:307-338): per LSTT layer V <- linear_V(V + id_emb(mask)).  One
-        gather launch forms V + id_emb for every layer, one GEMM per layer writes the fused V to dst[i]."""
+        gather launch forms V + id_emb for every layer, one GEMM per layer writes the fused V to dst[i].  id_emb given
+        ([lanes*N, C], e.g. assign_identity's): it is used as it is and `mask` is ignored."""
         L = len(mems)
         dev = mems[0][1].device
         sums = [self.ws.get('idsum_%d' % i, tuple(mems[i][1].shape), dev) for i in range(L)]
-        self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0,
-                              fuse=[(mems[i][1], sums[i]) for i in range(L)], want_out=False)
+        if id_emb is not None:
+            for i in range(L):
+                aot_hip.add(mems[i][1], id_emb, sums[i], stream=stream)
+        else:
+            self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0,
+                                  fuse=[(mems[i][1], sums[i]) for i in range(L)], want_out=False)
         return self.LSTT.update_values(mems, sums, self.ws, stream, dst=dst)
 
     def mem_widths(self):
@@ -178,14 +218,17 @@ class AOT(nn.Module):
         return self.pos_generator(x)
 
     def get_id_emb(self, x):
-        """x: one-hot [1, max_obj+1, H, W] (reference signature).  Converted to a label map (all-zero columns ->
-        label -1, contributing nothing) and sent through the fused gather kernel."""
-        lab = x.argmax(1, keepdim=True).float()
-        lab = torch.where(x.sum(1, keepdim=True) > 0, lab, torch.full_like(lab, -1.0))
+        """x: one-hot or probability map [1, max_obj+1, H, W] (reference signature).  A one-hot map is converted to a label
+        map (all-zero columns -> label -1, contributing nothing) and sent through the fused gather kernel; anything else takes
+        the dense convolution.  (Reference surface, not on the per-frame path: the one-hot test reads back one flag.)"""
         H, W = x.shape[-2:]
         conv = self.patch_wise_id_bank
         h = (H + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
         w = (W + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+        if not bool(((x == 0) | (x == 1)).all()) or bool((x.sum(1) > 1).any()):
+            return as_map(self.id_emb_from_mask(x, (h, w)), h, w)
+        lab = x.argmax(1, keepdim=True).float()
+        lab = torch.where(x.sum(1, keepdim=True) > 0, lab, torch.full_like(lab, -1.0))
         return as_map(self.id_emb_from_mask(lab, (h, w)), h, w)
 
     def encode_image(self, img):

@@ -38,10 +38,11 @@ class DeAOT(AOT):
         aot_hip.layernorm(raw, self.id_norm.weight, self.id_norm.bias, out, stream=stream)
         return out
 
-    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream):
+    def update_memory_values(self, mems, mask, size_2d, lanes, group0, dst, stream, id_emb=None):
         """deaot_engine.py:20-56: only ID_V is refreshed with the new identity embedding (in place in the frame's
-        [V | ID_V] buffers, which already are dst); K and V stay as produced."""
-        id_emb = self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0)
+        [V | ID_V] buffers, which already are dst); K and V stay as produced.  id_emb given: used instead of the mask's."""
+        if id_emb is None:
+            id_emb = self.id_emb_from_mask(mask, size_2d, stream, lanes=lanes, group0=group0)
         return self.LSTT.update_values(mems, id_emb, self.ws, stream, dst=dst)
 
     def mem_widths(self):

@@ -43,3 +43,26 @@ def jf_per_object(pred, ref, num_obj, bound_th=0.008):
     if not js:
         return 1.0, 1.0
     return sum(js) / len(js), sum(fs) / len(fs)
+
+
+def pytorch_iou(pred, target, obj_num, epsilon=1e-6):
+    """The trainer's running IoU (reference utils/metric.py:4-36), on the tensors' device.  pred / target [bs, H, W] label
+    maps, obj_num [bs]: per sample the mean over objects 1..n of (|p & t| + eps) / (|p | t| + eps); samples without objects
+    are skipped, a batch without any object scores 1.
+    The trainer itself passes [bs, 1, H, W] maps (trainer.py:507-509); the reference's reduction over dims (1, 2) then runs
+    over (objects, rows) and the ratio is averaged over image COLUMNS.  That is what the logged number is, so it is kept:
+    the reduction below is over dims (1, 2) of the same broadcast shape for either rank."""
+    per_sample = []
+    for b in range(pred.shape[0]):
+        n = int(obj_num[b])
+        if n == 0:
+            continue
+        ids = torch.arange(1, n + 1, device=pred.device).view(-1, 1, 1)
+        p = pred[b].unsqueeze(0) == ids                   # [n, H, W], or [1, n, H, W] for 4-D input
+        t = target[b].unsqueeze(0) == ids
+        inter = (p & t).sum((1, 2)).float()
+        union = (p | t).sum((1, 2)).float()
+        per_sample.append(((inter + epsilon) / (union + epsilon)).mean())
+    if per_sample:
+        return torch.stack(per_sample).mean()
+    return torch.ones(1, device=pred.device)

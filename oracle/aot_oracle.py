@@ -596,7 +596,9 @@ class OracleEngine:
         self.trace = {}
 
     def _id_emb(self, mask):                                       # assign_identity :168-179
-        oh = one_hot_mask(mask, self.AOT.max_obj_num)
+        # a map with max_obj+1 channels is a probability map fed back as it is (:309-313, MODEL_USE_PREV_PROB)
+        prob = mask.dim() == 4 and mask.shape[1] == self.AOT.max_obj_num + 1
+        oh = mask.to(torch.get_default_dtype()) if prob else one_hot_mask(mask, self.AOT.max_obj_num)
         return self.AOT.get_id_emb(oh).view(1, -1, self.enc_hw).permute(2, 0, 1)
 
     def add_reference_frame(self, img, mask, obj_nums, frame_step=-1, img_embs=None):   # :188-251
@@ -739,6 +741,101 @@ class OracleInferEngine:
         masks, _ = self.separate_mask(mask, self.obj_nums)
         for e, m in zip(self.aot_engines, masks):
             e.update_memory(m, skip_long_term_update)
+
+
+# --------------------------------------------------------------------------
+# training-step forward (networks/engines/aot_engine.py:33-108) and its losses
+# --------------------------------------------------------------------------
+def ce_topk_loss(logits, label, step, top_k_percent_pixels=0.15, hard_example_mining_step=50000.):
+    """networks/layers/loss.py:137-188 for one sample: logits [1,C,H,W], label [1,H,W] (255 = ignore) -> [1].  Mean of the
+    top-k per-pixel cross entropies, k annealed from all pixels to top_k_percent_pixels over the mining steps."""
+    px = F.cross_entropy(logits.flatten(2), label.flatten(1).long(), ignore_index=255, reduction='none')
+    if top_k_percent_pixels is None:
+        return (px.sum() / (label != 255).sum()).view(1)
+    n = float(px.shape[1])
+    mining = hard_example_mining_step + 1e-5
+    ratio = min(1.0, step / float(mining))
+    k = int((ratio * top_k_percent_pixels + (1.0 - ratio)) * n)
+    return torch.topk(px, k=k, dim=1)[0].mean().view(1)
+
+
+def soft_jaccard_loss(logits, label, eps=1e-6):
+    """loss.py:26-52,119-135 (tversky, alpha = beta = 1) for one sample: 1 - soft IoU averaged over the classes that
+    own at least one valid pixel."""
+    C = logits.shape[1]
+    prob = torch.softmax(logits, 1).permute(0, 2, 3, 1).reshape(-1, C)
+    lab = label.reshape(-1)
+    valid = lab != 255
+    prob, lab = prob[valid], lab[valid]
+    losses = []
+    for c in range(C):
+        fg = (lab == c).to(prob.dtype)
+        if fg.sum() == 0:
+            continue
+        p0 = prob[:, c]
+        num = (p0 * fg).sum()
+        den = num + (p0 * (1 - fg)).sum() + ((1 - p0) * fg).sum()
+        losses.append(1 - num / (den + eps))
+    return (sum(losses) / len(losses)).view(1)
+
+
+def train_forward(model, all_frames, all_masks, obj_nums, step, cfg, use_prev_pred=False, enable_prev_frame=False,
+                  use_prev_prob=False, perms=None):
+    """aot_engine.py:33-108 sample by sample (every op of that path is per-sample; the reference runs them batched).
+    all_frames [T*bs,3,H,W] / all_masks [T*bs,1,H,W] time-major; cfg: the five TRAIN_* values of _init_losses (:110-125);
+    perms[b][o] = channel identity o of sample b is shuffled to (:168-172, reversed on the logits :364-367).
+    Returns (loss, frame_loss [T, bs], masks [T, bs, H, W])."""
+    bs = len(obj_nums)
+    T = all_frames.shape[0] // bs
+    L = model.max_obj_num + 1
+    mining = cfg['TRAIN_HARD_MINING_RATIO'] * cfg['TRAIN_TOTAL_STEPS']
+    aux_step = cfg['TRAIN_TOTAL_STEPS'] * cfg['TRAIN_AUX_LOSS_RATIO'] + 1e-5
+    aux_weight = cfg['TRAIN_AUX_LOSS_WEIGHT'] * max(aux_step - step, 0.) / aux_step
+    n_aux = 2 if enable_prev_frame else 1
+    frame_loss = torch.zeros(T, bs)
+    masks = torch.zeros(T, bs, *all_masks.shape[-2:], dtype=torch.long)
+    for b in range(bs):
+        eng = OracleEngine(model, long_term_mem_gap=9999)
+        objs = int(obj_nums[b])
+        perm = None if perms is None else perms[b]
+        inv = None if perm is None else torch.argsort(perm)
+
+        def ident(m):                                   # what assign_identity sees: the shuffled one-hot / prob map
+            oh = m if m.shape[1] == L else one_hot_mask(m, model.max_obj_num)
+            return oh if perm is None else oh[:, inv]   # new channel t <- old channel o with perm[o] = t
+
+        def score(t):
+            gt = all_masks[t * bs + b:t * bs + b + 1]
+            lg = eng.decode_current_logits()
+            if perm is not None:
+                lg = lg[:, perm]
+                lg[:, objs + 1:] = -1e10
+                eng.pred_id_logits = lg
+            lg = F.interpolate(lg, size=gt.shape[-2:], mode='bilinear', align_corners=model.spec['align_corners'])
+            sl = lg[:, :objs + 1]
+            frame_loss[t, b] = (0.5 * ce_topk_loss(sl, gt[:, 0], step, cfg['TRAIN_TOP_K_PERCENT_PIXELS'], mining)
+                                + 0.5 * soft_jaccard_loss(sl, gt[:, 0]))[0]
+            masks[t, b] = lg.argmax(1)[0]
+            return torch.softmax(lg, 1) if use_prev_prob else lg.argmax(1, keepdim=True).float()
+
+        img = lambda t: all_frames[t * bs + b:t * bs + b + 1]
+        gtm = lambda t: all_masks[t * bs + b:t * bs + b + 1]
+        eng.add_reference_frame(img(0), ident(gtm(0)), [L - 1 if perm is not None else objs], frame_step=0)
+        score(0)
+        t = 1
+        if enable_prev_frame:                           # set_prev_frame :253-289
+            eng.frame_step = 1
+            eng.add_reference_frame(img(1), ident(gtm(1)), eng.obj_nums)
+            score(1)
+            t = 2
+        while t < T:
+            eng.match_propogate_one_frame(img(t))
+            pred = score(t)
+            if t < T - 1:
+                eng.update_memory(ident(pred if use_prev_pred else gtm(t)))
+            t += 1
+    loss = aux_weight * frame_loss[:n_aux].reshape(-1).mean() + frame_loss[n_aux:].reshape(-1).mean()
+    return loss, frame_loss, masks
 
 
 def run_clip(engine, frames, first_mask, obj_nums, output_size, teacher_masks=None, keep=('logits4',)):

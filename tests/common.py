@@ -165,3 +165,46 @@ def loss_case_inputs(name):
         lab[:, 20:22, 10:30] = 255.
         labels.append(lab)
     return logits, labels
+
+
+# ---- training-step forward (aot_engine.py:33-108): reference goldens in tests/golden/train_forward.npz ----------------
+TRAIN_CFG = dict(TRAIN_TOTAL_STEPS=100000, TRAIN_TOP_K_PERCENT_PIXELS=0.15, TRAIN_HARD_MINING_RATIO=0.5,
+                 TRAIN_AUX_LOSS_WEIGHT=1.0, TRAIN_AUX_LOSS_RATIO=1.0)      # the reference's defaults (configs/default.py:37-68)
+TRAIN_FWD_CASES = {
+    # ground-truth feedback (the default of the first training half), mid-way through the hard-example annealing
+    'tf_aott': dict(model='aott', size=(129, 161), frames=4, objs=(3, 1), step=30000),
+    # sequential-training half: the prediction is fed back; second frame memorises its own mask (TRAIN_ENABLE_PREV_FRAME)
+    'tf_aott_prev': dict(model='aott', size=(129, 161), frames=5, objs=(2, 4), step=70000, use_prev_pred=True,
+                         enable_prev_frame=True),
+    # identities shuffled per sample (trainer.py:457), auxiliary loss faded out, top-k at its final share
+    'tf_aott_shuffle': dict(model='aott', size=(113, 145), frames=4, objs=(3, 2), step=120000, shuffle=True),
+    # DeAOT; probabilities fed back (MODEL_USE_PREV_PROB) through the dense identity convolution, shuffled as well
+    'tf_deaott_prob': dict(model='deaott', size=(129, 161), frames=4, objs=(2, 3), step=0, use_prev_pred=True,
+                           use_prev_prob=True, shuffle=True),
+}
+
+
+def train_batch(name):
+    """The batch of a TRAIN_FWD_CASES entry, rebuilt from seeds: sample b is synthetic clip 30+b with objs[b] objects; the
+    label of frame t is the first-frame label moved with the clip's motion (synth_clip rolls by (2t, 3t)); one sample
+    carries an ignore band.  Returns (all_frames [T*bs,3,H,W], all_masks [T*bs,1,H,W], obj_nums, id permutations | None)
+    in the trainer's time-major order (trainer.py:452-455)."""
+    from utils.synth import synth_clip
+    c = TRAIN_FWD_CASES[name]
+    T, bs = c['frames'], len(c['objs'])
+    frames, masks = [], []
+    for b, n in enumerate(c['objs']):
+        f, m, _, _ = synth_clip(30 + b, T, c['size'], c['size'], n)
+        frames.append(f)
+        ms = [torch.roll(m, shifts=(2 * t, 3 * t), dims=(2, 3)) for t in range(T)]
+        if b == 1:
+            ms[2] = ms[2].clone()
+            ms[2][:, :, 5:9, :] = 255.
+        masks.append(ms)
+    all_frames = torch.cat([frames[b][t] for t in range(T) for b in range(bs)], 0)
+    all_masks = torch.cat([masks[b][t] for t in range(T) for b in range(bs)], 0)
+    perms = None
+    if c.get('shuffle'):
+        g = torch.Generator().manual_seed(77)
+        perms = [torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(10, generator=g)]) for _ in range(bs)]
+    return all_frames, all_masks, list(c['objs']), perms

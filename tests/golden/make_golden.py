@@ -186,12 +186,72 @@ def make_training():
             decays.append(min(0.999, (1 + ema.num_updates) / (10 + ema.num_updates)))
             if t <= 3:
                 shadows.append(ema.shadow_params[0].clone().numpy().tolist())
+        # the trainer's running IoU (utils/metric.py:4-36) on both input ranks it is called with
+        from utils.metric import pytorch_iou
+        gi = torch.Generator().manual_seed(1)
+        ipred = torch.randint(0, 5, (3, 1, 20, 30), generator=gi)
+        itgt = torch.randint(0, 5, (3, 1, 20, 30), generator=gi)
+        ious = []
+        for objs in ([4, 2, 0], [0, 0, 0], [1, 4, 3]):
+            ious.append([objs, float(pytorch_iou(ipred, itgt, objs)), float(pytorch_iou(ipred[:, 0], itgt[:, 0], objs))])
         with open(os.path.join(HERE, 'training.json'), 'w') as f:
-            json.dump({'schedule': sched, 'param_groups': groups, 'ema_decays': decays, 'ema_shadows': shadows}, f)
+            json.dump({'schedule': sched, 'param_groups': groups, 'ema_decays': decays, 'ema_shadows': shadows,
+                       'pytorch_iou': ious}, f)
     finally:
         refdriver._leave()
     np.savez_compressed(os.path.join(HERE, 'training_losses.npz'), **out)
     print('training', {k: v.shape for k, v in out.items() if k.endswith('.loss')}, 'groups', len(groups[0]), flush=True)
+
+
+def make_train_forward():
+    """Training-step forward (aot_engine.py:33-108) of the REAL reference training engine, eval-mode network (drop-path /
+    dropout off), on the seeded batches of tests/common.py: total loss, per-frame per-sample losses, per-frame masks and the
+    reference's own top-2 gap statistics of the frames' logits (near-tie pixels)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, train_batch
+    out = {}
+    for name, c in TRAIN_FWD_CASES.items():
+        net, _, cfg = refdriver.build_reference(c['model'])
+        net.load_state_dict(synth_state_dict(net.state_dict()))
+        for k, v in TRAIN_CFG.items():
+            setattr(cfg, k, v)
+        all_frames, all_masks, obj_nums, perms = train_batch(name)
+        bs = len(obj_nums)
+        refdriver._enter()
+        try:
+            from networks.engines import build_engine
+            engine = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=net, gpu_id=-1,
+                                  long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP).eval()
+            engine.restart_engine(bs, perms is not None)
+            if perms is not None:
+                m = torch.zeros(bs, 11, 11)
+                for b, pm in enumerate(perms):
+                    m[b, torch.arange(11), pm] = 1.          # identity o moves to channel perm[o] ('bohw,bot->bthw')
+                engine.id_shuffle_matrix = m
+            gaps = []
+            orig = engine.predict_current_mask
+
+            def spy(output_size=None, return_prob=False):       # records the near-ties of every scored frame
+                lg = F.interpolate(engine.pred_id_logits, size=engine.input_size_2d, mode='bilinear',
+                                   align_corners=engine.align_corners)
+                top2 = torch.topk(lg, 2, dim=1)[0]
+                gaps.append((top2[:, 0] - top2[:, 1]) < 2e-4)
+                return orig(output_size, return_prob)
+            engine.predict_current_mask = spy
+            with torch.no_grad():
+                loss, all_pred, all_loss, _ = engine(all_frames, all_masks, bs, obj_nums,
+                                                     step=c['step'], use_prev_pred=c.get('use_prev_pred', False),
+                                                     enable_prev_frame=c.get('enable_prev_frame', False),
+                                                     use_prev_prob=c.get('use_prev_prob', False))
+        finally:
+            refdriver._leave()
+        out[name + '.loss'] = loss.detach().numpy()
+        out[name + '.frame_loss'] = torch.stack(all_loss).detach().numpy()                     # [T, bs]
+        out[name + '.masks'] = torch.stack(all_pred).to(torch.uint8).numpy()          # [T, bs, H, W]
+        out[name + '.ties'] = np.packbits(torch.stack(gaps).numpy())
+        print(name, 'loss', float(loss), 'frame losses', torch.stack(all_loss).detach().numpy().round(4).tolist(),
+              'near-ties', int(torch.stack(gaps).sum()), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'train_forward.npz'), **out)
 
 
 def make_transforms():
@@ -337,6 +397,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'train_forward' in sys.argv[1:]:
+        make_train_forward()
+        if sys.argv[1:] == ['train_forward']:
             return
     if not sys.argv[1:] or 'gp_knobs' in sys.argv[1:]:
         make_gp_knobs()

@@ -121,7 +121,47 @@ def test_engine_factories_and_errors():
     with pytest.raises(NotImplementedError):
         build_vos_model('nope', cfg)
     with pytest.raises(NotImplementedError):
-        build_engine('aotengine', phase='train', aot_model=None)
+        build_engine('aotengine', phase='deploy', aot_model=None)
+    with pytest.raises(NotImplementedError):
+        build_engine('nope', phase='eval', aot_model=None)
+
+
+def test_training_engine_host_side():
+    """phase='train' gives the single-group engine whose forward() is the training step's forward (aot_engine.py:33-108):
+    argument checks, the identity shuffle drawn by restart_engine (utils/math.py:3-24: background fixed), and -- like every
+    product path -- a loud failure instead of a CPU fallback."""
+    import aot_hip
+    from networks.engines import build_engine
+    from networks.engines.aot_engine import AOTEngine, DeAOTEngine
+    from networks.models import build_vos_model
+    cfg = model_cfg('aott')
+    for k, v in dict(TRAIN_TOTAL_STEPS=1000, TRAIN_TOP_K_PERCENT_PIXELS=0.15, TRAIN_HARD_MINING_RATIO=0.5,
+                     TRAIN_AUX_LOSS_WEIGHT=1.0, TRAIN_AUX_LOSS_RATIO=1.0).items():
+        setattr(cfg, k, v)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    eng = build_engine('aotengine', phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=9999)
+    assert type(eng) is AOTEngine and type(build_engine('deaotengine', phase='train', aot_model=model)) is DeAOTEngine
+    eng.restart_engine(3, True)
+    assert eng.batch_size == 3 and len(eng.id_shuffle) == 3
+    for p in eng.id_shuffle:
+        assert int(p[0]) == 0 and sorted(p.tolist()) == list(range(11))
+    m = torch.tensor([0., 3., 10., 255.]).view(1, 1, 2, 2)
+    eng._sample = 1
+    sh = eng._shuffled(m)
+    assert sh.flatten().tolist() == [0., float(eng.id_shuffle[1][3]), float(eng.id_shuffle[1][10]), 255.]
+    prob = torch.rand(1, 11, 2, 2)
+    assert torch.equal(eng._shuffled(prob)[:, eng.id_shuffle[1]], prob)
+    eng.restart_engine(2, False)
+    assert eng.id_shuffle is None and eng._shuffled(m) is m
+    frames, masks = torch.zeros(8, 3, 33, 33), torch.zeros(8, 1, 33, 33)
+    with pytest.raises(ValueError):
+        eng(frames, masks, 3, [1, 1, 1])                   # batch size differs from restart_engine's
+    with pytest.raises(ValueError):
+        eng(frames[:4], masks[:4], 2, [1, 1])              # two frames per sample: no current frame
+    with pytest.raises(aot_hip.AotHipError):
+        eng(frames, masks, 2, [1, 1])                      # CPU model: no fallback
+    assert eng.loss_weights == [0.5, 0.5] and abs(eng.aux_step - 1000.00001) < 1e-9
+    assert eng.losses[0].hard_example_mining_step == pytest.approx(500.00001)
 
 
 def test_jf_metric():

@@ -215,3 +215,26 @@ def test_oracle_gated_propagation_knobs_match_reference(case):
         out = gated_propagation(sd, 'gp', Q, K, V, U, size_2d, 1, False, 128, **GP_KNOB_CASES[case])
     ref = g[case]
     assert np.abs(out.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob'])
+def test_oracle_training_forward_matches_reference(case):
+    """aot_engine.py:33-108 of the real reference (train_forward.npz): ground-truth / prediction / probability feedback,
+    second self-memorising frame, shuffled identities; losses per frame and sample, masks outside the reference's near-ties."""
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, train_batch
+    from oracle.aot_oracle import train_forward
+    c = TRAIN_FWD_CASES[case]
+    g = np.load(GOLD + '/train_forward.npz')
+    _, _, sd = synth_model_state(c['model'])
+    frames, masks, objs, perms = train_batch(case)
+    with torch.no_grad():
+        loss, frame_loss, pred = train_forward(OracleModel(c['model'], sd), frames, masks, objs, c['step'], TRAIN_CFG,
+                                               use_prev_pred=c.get('use_prev_pred', False),
+                                               enable_prev_frame=c.get('enable_prev_frame', False),
+                                               use_prev_prob=c.get('use_prev_prob', False), perms=perms)
+    ref = g[case + '.masks']
+    ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    bad = pred.numpy() != ref
+    assert int((bad & ~ties).sum()) == 0, 'masks differ outside near-ties: %d' % int((bad & ~ties).sum())
+    np.testing.assert_allclose(frame_loss.numpy(), g[case + '.frame_loss'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)

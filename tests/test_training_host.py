@@ -3,6 +3,7 @@ gradient all-reduce -- against goldens of the REAL reference (tests/golden/train
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -111,3 +112,83 @@ def test_bucketed_allreduce_gloo_world2():
                 assert got is None
             else:
                 assert torch.allclose(got, w, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob'])
+def test_training_forward_orchestration_vs_reference(case, monkeypatch):
+    """AOTEngine.forward's own logic -- frame order, which map is fed back, identity shuffle and its reversal, per-sample
+    slicing, loss combination -- checked on CPU against the REAL reference's training engine (train_forward.npz) with the
+    per-frame device stages stood in for by the oracle.  (The same forward on the real kernels: test_training_gpu.py.)"""
+    import types
+
+    import aot_hip
+    from common import GOLD, TRAIN_CFG, TRAIN_FWD_CASES, model_cfg, synth_model_state, train_batch
+    from networks.engines.aot_engine import AOTEngine
+    from oracle.aot_oracle import OracleEngine, OracleModel, ce_topk_loss, soft_jaccard_loss
+    c = TRAIN_FWD_CASES[case]
+    g = np.load(os.path.join(GOLD, 'train_forward.npz'))
+    _, _, sd = synth_model_state(c['model'])
+    om = OracleModel(c['model'], sd)
+    cfg = model_cfg(c['model'])
+
+    class Staged(AOTEngine):
+        def _restart_clip(self):
+            super()._restart_clip()
+            self._o = OracleEngine(om, long_term_mem_gap=9999)
+
+        def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
+            if obj_nums is not None:
+                self.obj_nums = obj_nums
+            self._o.frame_step = self.frame_step
+            self._o.add_reference_frame(img, mask, self.obj_nums)
+
+        def match_propogate_one_frame(self, img=None, img_embs=None):
+            self.frame_step += 1
+            self._o.match_propogate_one_frame(img)
+
+        def update_short_term_memory(self, curr_mask, curr_id_emb=None, skip_long_term_update=False):
+            self._o.update_memory(curr_mask)
+
+        def decode_current_logits(self, output_size=None):
+            lg = self._o.decode_current_logits(output_size)
+            self.pred_id_logits = self._o.pred_id_logits
+            return lg
+
+    def fuse_probs(logits, flips, new_label=None, want_aug_labels=True, want_prob=False, stream=None):
+        return logits.argmax(1, keepdim=True).float(), None, torch.softmax(logits, 1) if want_prob else None
+    monkeypatch.setattr(aot_hip, 'fuse_probs', fuse_probs)
+    stub = types.SimpleNamespace(cfg=cfg, max_obj_num=10, parameters=lambda: iter([torch.zeros(1)]))
+    eng = Staged(stub, gpu_id=0, long_term_mem_gap=9999)
+    mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
+    eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
+                  lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
+    eng.loss_weights = [0.5, 0.5]
+    eng.aux_weight = TRAIN_CFG['TRAIN_AUX_LOSS_WEIGHT']
+    eng.aux_step = TRAIN_CFG['TRAIN_TOTAL_STEPS'] * TRAIN_CFG['TRAIN_AUX_LOSS_RATIO'] + 1e-5
+    frames, masks, objs, perms = train_batch(case)
+    eng.restart_engine(len(objs), perms is not None)
+    if perms is not None:
+        eng.id_shuffle = perms
+    with torch.no_grad():
+        loss, pred, frame_loss, _ = eng(frames, masks, len(objs), objs, step=c['step'],
+                                        use_prev_pred=c.get('use_prev_pred', False),
+                                        enable_prev_frame=c.get('enable_prev_frame', False),
+                                        use_prev_prob=c.get('use_prev_prob', False))
+    ref = g[case + '.masks']
+    got = torch.stack(pred).numpy()
+    ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    assert int(((got != ref) & ~ties).sum()) == 0
+    np.testing.assert_allclose(torch.stack(frame_loss).numpy(), g[case + '.frame_loss'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
+
+
+def test_pytorch_iou_matches_reference():
+    """utils.metric.pytorch_iou on the 4-D maps the trainer passes (trainer.py:507-509: the reduction then runs over
+    objects x rows, per image column) and on the documented 3-D maps; empty samples skipped, an object-free batch scores 1."""
+    from utils.metric import pytorch_iou
+    gi = torch.Generator().manual_seed(1)
+    pred = torch.randint(0, 5, (3, 1, 20, 30), generator=gi)
+    tgt = torch.randint(0, 5, (3, 1, 20, 30), generator=gi)
+    for objs, r4, r3 in _gold()['pytorch_iou']:
+        assert float(pytorch_iou(pred, tgt, objs)) == pytest.approx(r4, abs=1e-7)
+        assert float(pytorch_iou(pred[:, 0], tgt[:, 0], objs)) == pytest.approx(r3, abs=1e-7)
