@@ -23,13 +23,19 @@ Parity pin: the reference ships no tests or golden vectors for this path
 itself* run in the build container: ``tests/golden/make_golden.py`` imports
 /root/reference, drives the demo loop (tools/demo.py:187-235) and stores the
 results under ``tests/golden/``; ``tests/test_oracle_golden.py`` replays them
-through this module (nine clips over all model families, the reference's
-MultiheadAttention with its top_k / max_mem_len_ratio knobs, its MultiRestrictSize
-/ MultiToTensor transform classes, all 13 model presets).
+through this module (clips over all model families up to the full-size BASELINE
+configs and 44 objects, the reference's MultiheadAttention / GatedPropagation with
+their top_k / max_mem_len_ratio knobs, its MultiRestrictSize / MultiToTensor
+transform classes, all 13 model presets, its training engine's forward
+(``train_forward``: four batches) and its ``Evaluator.evaluating`` loop run
+unmodified on an in-memory sequence (``sequence_eval``: single-scale and
+multi-scale + flip, with a new object injected mid-clip)).
 
 One function is PARITY UNPINNED: ``cv2_cubic_resize`` restates OpenCV's INTER_CUBIC
 (the reference's un-vendored, unpinned dependency ``opencv-python``, absent here)
-from its published algorithm and is only cross-checked against torch's bicubic.
+from its published algorithm and is only cross-checked against torch's bicubic
+(the evaluator-loop golden was made with this restatement standing in for
+``cv2.resize``, so it pins the loop around the filter, not the filter).
 """
 import math
 

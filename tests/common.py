@@ -208,3 +208,28 @@ def train_batch(name):
         g = torch.Generator().manual_seed(77)
         perms = [torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(10, generator=g)]) for _ in range(bs)]
     return all_frames, all_masks, list(c['objs']), perms
+
+
+# ---- evaluator loop (evaluator.py:209-505): reference goldens in tests/golden/evaluator_loop.npz ----------------------
+EVAL_LOOP_CASES = {'single': dict(flip=False, ms=(1,)), 'tta': dict(flip=True, ms=(1.3, 1.0))}
+EVAL_LOOP_OBJ_IDX = [0, 5, 9, 12]          # dataset object ids of the dense ids 0..3
+
+
+def evaluator_scenario():
+    """Four 96x150 frames of smoothed noise sliding by (1, 2) px per frame, two objects labelled in frame 0 and a third
+    injected at frame 2 (dense ids 1..3; the dataset's own ids are EVAL_LOOP_OBJ_IDX).  Returns (frames: list of float32
+    [H,W,3] in 0..255, labels {frame: [H,W] dense ids}, obj_nums {frame: objects known BEFORE that frame's label})."""
+    rs = np.random.RandomState(3)
+    H, W = 96, 150
+    base = rs.rand(H + 8, W + 8, 3).astype(np.float32)
+    k = np.ones(5, np.float32) / 5
+    for ax in (0, 1):       # smooth the noise so the cubic resize is well conditioned
+        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), ax, base)
+    base = (base - base.min()) / (base.max() - base.min()) * 255
+    frames = [np.ascontiguousarray(base[t:t + H, 2 * t:2 * t + W]).astype(np.float32) for t in range(4)]
+    lab0 = np.zeros((H, W), np.float32)
+    lab0[20:60, 30:80] = 1
+    lab0[50:90, 90:140] = 2
+    lab2 = np.zeros((H, W), np.float32)
+    lab2[5:25, 100:140] = 3
+    return frames, {0: lab0, 2: lab2}, {0: 2, 2: 3}

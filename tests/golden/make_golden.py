@@ -254,6 +254,161 @@ def make_train_forward():
     np.savez_compressed(os.path.join(HERE, 'train_forward.npz'), **out)
 
 
+def make_evaluator_loop():
+    """Pins the evaluator loop on the REAL reference: `Evaluator.evaluating` (networks/managers/evaluator.py:209-505) is run
+    unmodified on the 4-frame scenario of tests/common.py -- its own VOSTest dataset class (object bookkeeping, label
+    squeeze; frames served from memory, labels read from palette PNGs), its own MultiRestrictSize / MultiToTensor, its
+    DataLoader collation, its TTA fusion / new-object merge / feedback code and its save_mask call.  What is NOT the
+    reference: cv2 (absent) -- `cv2.resize` is the oracle's restated INTER_CUBIC, so the cubic filter itself stays unpinned --
+    and the CUDA-only calls (`.cuda()`, `torch.cuda.Event`, `empty_cache`, `synchronize`, `max_memory_allocated`), which are
+    stubbed to CPU no-ops.  Stored: every mask handed to save_mask (+ path tail and object ids), the fused class
+    probabilities of the last frame, and per frame the pixels whose fused top-2 probabilities are within 1e-3."""
+    import tempfile
+    import types
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, ROOT)
+    from common import EVAL_LOOP_CASES, EVAL_LOOP_OBJ_IDX, evaluator_scenario
+    from oracle.aot_oracle import cv2_cubic_resize
+    frames, labels, _ = evaluator_scenario()
+    H, W = frames[0].shape[:2]
+    lut = np.array(EVAL_LOOP_OBJ_IDX, np.uint8)
+    out = {}
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return _Any(name)
+
+        def __call__(self, *a, **k):
+            return None
+    cv2 = _Any('cv2')
+    cv2.INTER_CUBIC, cv2.INTER_NEAREST, cv2.INTER_LINEAR = 2, 0, 1
+    cv2.setNumThreads = lambda n: None
+    cv2.resize = lambda img, dsize=None, interpolation=None, **k: cv2_cubic_resize(img, int(dsize[1]), int(dsize[0]))
+    stubs = {'cv2': cv2, 'torchvision': _Any('torchvision'), 'torchvision.transforms': _Any('torchvision.transforms'),
+             'torchvision.transforms.functional': _Any('torchvision.transforms.functional')}
+
+    class _Event:
+        def __init__(self, enable_timing=False):
+            pass
+
+        def record(self):
+            pass
+
+        def elapsed_time(self, other):
+            return 1.0
+    for name, c in EVAL_LOOP_CASES.items():
+        net, _, cfg = refdriver.build_reference('aott', gap=2)
+        net.load_state_dict(synth_state_dict(net.state_dict()))
+        refdriver._enter()
+        saved_mods = {k: sys.modules.get(k) for k in stubs}
+        sys.modules.update(stubs)
+        saved_cuda = {k: getattr(torch.cuda, k) for k in ('Event', 'empty_cache', 'synchronize', 'max_memory_allocated')}
+        saved_tcuda = torch.Tensor.cuda
+        try:
+            torch.cuda.Event = _Event
+            torch.cuda.empty_cache = lambda: None
+            torch.cuda.synchronize = lambda *a, **k: None
+            torch.cuda.max_memory_allocated = lambda device=None: 0
+            torch.Tensor.cuda = lambda self, *a, **k: self
+            import dataloaders.video_transforms as tr
+            import networks.managers.evaluator as ev_mod
+            from dataloaders.eval_datasets import VOSTest
+            with tempfile.TemporaryDirectory() as tmp:
+                os.makedirs(os.path.join(tmp, 'labels', 'seq0'))
+                for t, lab in labels.items():          # the dataset's own object ids, as a DAVIS-style palette PNG
+                    Image.fromarray(lut[lab.astype(np.uint8)]).convert('P').save(
+                        os.path.join(tmp, 'labels', 'seq0', '%05d.png' % t))
+
+                class MemSeq(VOSTest):
+                    def read_image(self, idx):
+                        return frames[idx].copy()
+                chain = [tr.MultiRestrictSize(None, 800 * 1.3, c['flip'], list(c['ms']), cfg.MODEL_ALIGN_CORNERS),
+                         tr.MultiToTensor()]
+
+                def transform(sample):
+                    for f in chain:
+                        sample = f(sample)
+                    return sample
+                ds = MemSeq(os.path.join(tmp, 'images'), os.path.join(tmp, 'labels'), 'seq0',
+                            ['%05d.jpg' % t for t in range(len(frames))], ['%05d.png' % t for t in sorted(labels)],
+                            transform=transform)
+                ecfg = types.SimpleNamespace(**cfg.__dict__)
+                for k, v in dict(TEST_WORKERS=0, TEST_DATASET_SPLIT='val', TEST_FLIP=c['flip'], TEST_FRAME_LOG=False,
+                                 TEST_LONG_TERM_MEM_GAP=2, TEST_SHORT_TERM_MEM_SKIP=1, MODEL_USE_PREV_PROB=False).items():
+                    setattr(ecfg, k, v)
+                ev = ev_mod.Evaluator.__new__(ev_mod.Evaluator)
+                ev.cfg, ev.model, ev.gpu, ev.gpu_num, ev.rank = ecfg, net, 0, 1, 0
+                ev.seq_queue = ev.info_queue = None
+                ev.dataset = [ds]
+                ev.result_root = os.path.join(tmp, 'results')
+                ev.source_folder, ev.zip_dir = ev.result_root, os.path.join(tmp, 'results.zip')
+                os.makedirs(os.path.join(ev.result_root, 'seq0'))
+                written, decoded = [], []
+                real_build, real_zip = ev_mod.build_engine, ev_mod.zip_folder
+
+                def spy_build(*a, **k):
+                    e = real_build(*a, **k)
+                    inner = e.decode_current_logits
+                    idx = len([1 for _ in decoded_engines])
+                    decoded_engines.append(e)
+
+                    def dec(output_size=None):
+                        lg = inner(output_size)
+                        decoded.append((idx, lg.clone()))
+                        return lg
+                    e.decode_current_logits = dec
+                    return e
+                decoded_engines = []
+                ev_mod.build_engine = spy_build
+                ev_mod.save_mask = lambda m, path, idx: written.append((os.path.relpath(path, ev.result_root), m.clone(), list(idx)))
+                ev_mod.zip_folder = lambda *a, **k: None
+                try:
+                    ev.evaluating()
+                finally:
+                    ev_mod.build_engine, ev_mod.zip_folder = real_build, real_zip
+        finally:
+            torch.Tensor.cuda = saved_tcuda
+            for k, v in saved_cuda.items():
+                setattr(torch.cuda, k, v)
+            for k, v in saved_mods.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+            refdriver._leave()
+        n_aug = len(c['ms']) * (2 if c['flip'] else 1)
+        assert len(decoded_engines) == n_aug and [w[0] for w in written] == ['seq0/%05d.png' % t for t in (1, 2, 3)], \
+            ([w[0] for w in written], len(decoded_engines))
+        assert all(w[2] == EVAL_LOOP_OBJ_IDX[:len(w[2])] for w in written)
+        out[name + '.masks'] = np.stack([w[1].numpy().astype(np.uint8) for w in written])          # dense ids, [3, H, W]
+        out[name + '.obj_idx_len'] = np.array([len(w[2]) for w in written])
+        # fused probabilities per propagated frame from the engines' own logits (flipped samples flipped back, :329-352);
+        # frame 2's second decode (after the new-object reference frame, :392-393) is not part of the fusion
+        flips = [False, True] * len(c['ms']) if c['flip'] else [False] * len(c['ms'])
+        per_frame = {}
+        fi = 0
+        for idx, lg in decoded:
+            per_frame.setdefault(fi, []).append((idx, lg))
+            if len(per_frame[fi]) == (2 * n_aug if fi == 1 else n_aug):
+                fi += 1
+        ties, last_prob = [], None
+        for fi in range(3):
+            first = per_frame[fi][:n_aug]
+            probs = [torch.softmax(lg.flip(3) if flips[i] else lg, 1) for i, lg in first]
+            prob = torch.mean(torch.cat(probs, 0), 0)
+            top2 = torch.topk(prob, 2, 0)[0]
+            ties.append(((top2[0] - top2[1]) < 1e-3).numpy())
+            last_prob = prob
+        out[name + '.ties'] = np.packbits(np.stack(ties))
+        out[name + '.prob_last'] = last_prob.numpy()
+        print(name, 'augmentations', n_aug, 'labels', [np.unique(m).tolist() for m in out[name + '.masks']],
+              'near-ties', [int(t.sum()) for t in ties], flush=True)
+    np.savez_compressed(os.path.join(HERE, 'evaluator_loop.npz'), **out)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -397,6 +552,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'evaluator_loop' in sys.argv[1:]:
+        make_evaluator_loop()
+        if sys.argv[1:] == ['evaluator_loop']:
             return
     if not sys.argv[1:] or 'train_forward' in sys.argv[1:]:
         make_train_forward()

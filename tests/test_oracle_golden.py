@@ -238,3 +238,29 @@ def test_oracle_training_forward_matches_reference(case):
     assert int((bad & ~ties).sum()) == 0, 'masks differ outside near-ties: %d' % int((bad & ~ties).sum())
     np.testing.assert_allclose(frame_loss.numpy(), g[case + '.frame_loss'], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
+
+
+@pytest.mark.parametrize('case', ['single', 'tta'])
+def test_oracle_sequence_eval_matches_reference_evaluator(case):
+    """The oracle's restatement of the evaluator loop against the REAL `Evaluator.evaluating` run on the same scenario with
+    its own dataset / transform / collation / fusion / feedback / save code (evaluator_loop.npz; cv2.resize there is the
+    oracle's restated cubic, so the filter itself stays unpinned): every saved mask outside the reference's near-ties,
+    fused probabilities of the last frame."""
+    from common import EVAL_LOOP_CASES, evaluator_scenario
+    from oracle.aot_oracle import sequence_eval
+    c = EVAL_LOOP_CASES[case]
+    g = np.load(GOLD + '/evaluator_loop.npz')
+    _, _, sd = synth_model_state('aott')
+    frames, labels, nums = evaluator_scenario()
+    res = sequence_eval(OracleModel('aott', sd), frames, labels, nums, flip=c['flip'], multiscale=c['ms'], long_term_mem_gap=2)
+    ref = g[case + '.masks']
+    assert len(res) == ref.shape[0] == 3
+    ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    for t, (lab, prob) in enumerate(res):
+        bad = lab.numpy().astype(np.uint8) != ref[t]
+        assert int((bad & ~ties[t]).sum()) == 0, 'frame %d: %d pixels differ outside near-ties' % (t + 1, int((bad & ~ties[t]).sum()))
+        assert int(bad.sum()) <= max(4, int(ties[t].sum()))
+    assert (ref[1][5:25, 100:140] == 3).all()                       # the object injected at frame 2 is in the saved mask
+    assert g[case + '.obj_idx_len'].tolist() == [3, 4, 4]           # the dataset hands over the new object id from frame 2 on
+    err = np.abs(res[-1][1].numpy() - g[case + '.prob_last']).max()
+    assert err < 2e-5, err

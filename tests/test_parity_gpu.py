@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from common import (LOGIT_TOL, ROOT, case_clip, check_masks, load_case, lstt_last_of, run_teacher_forced,
+from common import (LOGIT_TOL, ROOT, case_clip, check_masks, evaluator_scenario, load_case, lstt_last_of, run_teacher_forced,
                     synth_model_state)
 
 pytestmark = pytest.mark.gpu
@@ -893,17 +893,8 @@ def test_sequence_evaluator_vs_oracle(hip, flip, ms, tmp_path):
                                                                   TEST_MAX_SHORT_EDGE=None, TEST_MAX_LONG_EDGE=800 * 1.3,
                                                                   TEST_LONG_TERM_MEM_GAP=2))
     model = model.cuda().eval()
-    rs = np.random.RandomState(3)
-    H, W = 96, 150
-    base = rs.rand(H + 8, W + 8, 3).astype(np.float32)
-    k = np.ones(5, np.float32) / 5
-    for ax in (0, 1):       # smooth the noise so the cubic resize is well conditioned
-        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode='same'), ax, base)
-    base = (base - base.min()) / (base.max() - base.min()) * 255
-    frames = [np.ascontiguousarray(base[t:t + H, 2 * t:2 * t + W]).astype(np.float32) for t in range(4)]
-    lab0 = np.zeros((H, W), np.float32); lab0[20:60, 30:80] = 1; lab0[50:90, 90:140] = 2
-    lab2 = np.zeros((H, W), np.float32); lab2[5:25, 100:140] = 3
-    labels, nums = {0: lab0, 2: lab2}, {0: 2, 2: 3}
+    frames, labels, nums = evaluator_scenario()      # the scenario the oracle's loop is pinned on (evaluator_loop.npz)
+    H, W = frames[0].shape[:2]
     ref = sequence_eval(OracleModel('aott', sd), frames, labels, nums, flip=flip, multiscale=ms, long_term_mem_gap=2)
     ev = SequenceEvaluator(cfg, model)
     got = ev.run([torch.from_numpy(f).cuda() for f in frames], {t: torch.from_numpy(l).cuda() for t, l in labels.items()}, nums,
