@@ -98,7 +98,7 @@ def test_ema_update_matches_reference(hip):
 def test_training_forward_matches_reference(hip, case):
     """AOTEngine.forward / DeAOTEngine.forward (aot_engine.py:33-108) against the REAL reference's training engine on the same
     seeded batch (tests/golden/train_forward.npz): ground-truth, prediction and probability feedback, the second
-    self-memorising frame, shuffled identities.  Per-frame per-sample losses within 1e-3 relative (values 2..5), masks equal
+    self-memorising frame, shuffled identities.  Per-frame per-sample losses within 1e-4 relative (values 2..5; measured <= 2e-6), masks equal
     outside the reference's own near-tie pixels (a handful of knock-on flips allowed where predictions are fed back)."""
     from common import TRAIN_CFG, TRAIN_FWD_CASES, synth_model_state, train_batch
     from networks.engines import build_engine
@@ -127,8 +127,8 @@ def test_training_forward_matches_reference(hip, case):
     hard = int((bad & ~ties).sum())
     assert hard <= (8 if c.get('use_prev_pred') else 0), 'masks differ outside near-ties: %d' % hard
     fl = torch.stack(frame_loss).cpu().numpy()
-    np.testing.assert_allclose(fl, g[case + '.frame_loss'], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-3)
+    np.testing.assert_allclose(fl, g[case + ".frame_loss"], rtol=1e-4, atol=2e-5)       # measured on MI355X: <= 2e-6
+    np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
     print('train_forward %s: loss %.6f (ref %.6f), max frame-loss err %.2e, mask flips %d (%d outside ties)'
           % (case, float(loss), float(g[case + '.loss']), np.abs(fl - g[case + '.frame_loss']).max(), int(bad.sum()), hard))
 
