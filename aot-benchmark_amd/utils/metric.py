@@ -6,39 +6,50 @@ import torch.nn.functional as F
 
 
 def _boundary(mask):
-    """1-pixel inner boundary of a boolean [H,W] mask (pixels whose right/down/diag neighbour differs)."""
-    m = mask.float()
-    e = torch.zeros_like(m)
-    e[:, :-1] += (m[:, :-1] != m[:, 1:]).float()
-    e[:-1, :] += (m[:-1, :] != m[1:, :]).float()
-    e[:-1, :-1] += (m[:-1, :-1] != m[1:, 1:]).float()
-    return (e > 0) & mask
+    """1-pixel inner boundary of boolean [..., H, W] masks (pixels whose right / down / diagonal neighbour differs)."""
+    e = torch.zeros_like(mask)
+    e[..., :, :-1] |= mask[..., :, :-1] != mask[..., :, 1:]
+    e[..., :-1, :] |= mask[..., :-1, :] != mask[..., 1:, :]
+    e[..., :-1, :-1] |= mask[..., :-1, :-1] != mask[..., 1:, 1:]
+    return e & mask
 
 
 def _dilate(b, r):
+    """Dilation by a (2r+1) x (2r+1) square as two 1-D max filters; b: boolean [..., H, W]."""
     if r <= 0:
         return b
-    return F.max_pool2d(b.float()[None, None], 2 * r + 1, 1, r)[0, 0] > 0
+    x = b.to(torch.float32).reshape(-1, 1, *b.shape[-2:])
+    x = F.max_pool2d(x, (2 * r + 1, 1), 1, (r, 0))
+    x = F.max_pool2d(x, (1, 2 * r + 1), 1, (0, r))
+    return x.reshape(b.shape) > 0
 
 
 def jf_per_object(pred, ref, num_obj, bound_th=0.008):
     """pred, ref: integer label maps [H,W]; returns (J, F) averaged over objects 1..num_obj present in either map.
-    F follows the DAVIS definition: boundary precision/recall with a tolerance of bound_th * image diagonal."""
+    F follows the DAVIS definition: boundary precision/recall with a tolerance of bound_th * image diagonal.
+    All objects are scored in one pass over [num_obj, H, W] stacks."""
     H, W = ref.shape[-2:]
     r = max(1, int(round(bound_th * (H * H + W * W) ** 0.5)))
+    if num_obj < 1:
+        return 1.0, 1.0
+    ids = torch.arange(1, num_obj + 1, device=ref.device).view(-1, 1, 1)
+    p, g = pred.reshape(1, H, W) == ids, ref.reshape(1, H, W) == ids
+    present = (p | g).flatten(1).any(1)
+    inter, union = (p & g).flatten(1).sum(1), (p | g).flatten(1).sum(1)
+    bp, bg = _boundary(p), _boundary(g)
+    wide = _dilate(torch.cat([bg, bp], 0), r)
+    hit_p, hit_g = (bp & wide[:num_obj]).flatten(1).sum(1), (bg & wide[num_obj:]).flatten(1).sum(1)
+    n_p, n_g = bp.flatten(1).sum(1), bg.flatten(1).sum(1)
+    rows = torch.stack([present.long(), inter, union, hit_p, hit_g, n_p, n_g], 1).tolist()      # one read-back
     js, fs = [], []
-    for o in range(1, num_obj + 1):
-        p, g = pred == o, ref == o
-        if not (p.any() or g.any()):
+    for there, i, u, hp, hg, np_, ng in rows:
+        if not there:
             continue
-        inter, union = (p & g).sum().item(), (p | g).sum().item()
-        js.append(inter / union if union else 1.0)
-        bp, bg = _boundary(p), _boundary(g)
-        if not bp.any() and not bg.any():
+        js.append(i / u if u else 1.0)
+        if np_ == 0 and ng == 0:
             fs.append(1.0)
             continue
-        prec = (bp & _dilate(bg, r)).sum().item() / max(1, bp.sum().item())
-        rec = (bg & _dilate(bp, r)).sum().item() / max(1, bg.sum().item())
+        prec, rec = hp / max(1, np_), hg / max(1, ng)
         fs.append(0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec))
     if not js:
         return 1.0, 1.0

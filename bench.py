@@ -197,10 +197,18 @@ def jf_vs_reference(device, graph=False):
     engine.restart_engine()
     engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
     js, fs, diff = [], [], 0
+    refs = torch.from_numpy(gold.astype('int64')).to(device)
+    on_device = True         # the metric's reductions and dilations run where the masks are; host fallback if the device refuses
     for t in range(1, len(frames)):
-        label = one_frame(engine, frames[t])[0, 0].long().cpu()
-        ref = torch.from_numpy(gold[t - 1].astype('int64'))
-        j, f = jf_per_object(label, ref, NUM_OBJ)
+        label = one_frame(engine, frames[t])[0, 0].long()
+        ref = refs[t - 1]
+        if on_device:
+            try:
+                j, f = jf_per_object(label, ref, NUM_OBJ)
+            except Exception:
+                on_device = False
+        if not on_device:
+            j, f = jf_per_object(label.cpu(), ref.cpu(), NUM_OBJ)
         js.append(j)
         fs.append(f)
         diff += int((label != ref).sum())
@@ -449,11 +457,15 @@ def main(argv=None):
 
     base = jf = None
     if rank == 0 and not dry:
+        t_ph = time.perf_counter()
         if not args.no_jf:
             with torch.no_grad():
                 jf = jf_vs_reference(device, bool(args.graph))
+            print('[bench] J&F pass on the golden clip: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
+        t_ph = time.perf_counter()
         if not args.no_cpu_baseline:
             base = cpu_baseline(sd)          # rank 0 only, after the timed region; the other ranks wait at the barrier
+            print('[bench] cpu_baseline: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
 
