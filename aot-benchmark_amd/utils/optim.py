@@ -50,3 +50,42 @@ class AdamW:
                 st['step'] += 1
                 aot_hip.adamw_step(p, p.grad.contiguous(), st['exp_avg'], st['exp_avg_sq'], g['lr'], g['weight_decay'], b1, b2,
                                    g['eps'], st['step'], grad_scale)
+
+    # ---- checkpointing: the layout of torch.optim.AdamW's state dict, so that checkpoints written by the reference's
+    # trainer (utils/checkpoint.py:124-160) resume here and the other way round ------------------------------------------
+    _TORCH_GROUP_KEYS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                             decoupled_weight_decay=True)
+
+    def state_dict(self):
+        index, groups = {}, []
+        for g in self.param_groups:
+            out = {k: v for k, v in g.items() if k != 'params'}
+            for k, v in self._TORCH_GROUP_KEYS.items():
+                out.setdefault(k, v)
+            out['params'] = [index.setdefault(id(p), len(index)) for p in g['params']]
+            groups.append(out)
+        state = {}
+        for p, st in self.state.items():
+            state[index[id(p)]] = {'step': torch.tensor(float(st['step'])), 'exp_avg': st['exp_avg'],
+                                   'exp_avg_sq': st['exp_avg_sq']}
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        saved = sd['param_groups']
+        if len(saved) != len(self.param_groups) or any(len(a['params']) != len(b['params'])
+                                                       for a, b in zip(saved, self.param_groups)):
+            raise ValueError('loaded state dict has different parameter groups')
+        by_index = {}
+        for g_saved, g in zip(saved, self.param_groups):
+            for i, p in zip(g_saved['params'], g['params']):
+                by_index[i] = p
+            for k, v in g_saved.items():
+                if k != 'params' and k not in self._TORCH_GROUP_KEYS:
+                    g[k] = tuple(v) if k == 'betas' else v
+        self.state = {}
+        for i, st in sd['state'].items():
+            p = by_index[int(i)]
+            self.state[p] = {'step': int(float(st['step'])),
+                             'exp_avg': st['exp_avg'].to(device=p.device, dtype=p.dtype).clone(),
+                             'exp_avg_sq': st['exp_avg_sq'].to(device=p.device, dtype=p.dtype).clone()}
+

@@ -194,9 +194,36 @@ def make_training():
         ious = []
         for objs in ([4, 2, 0], [0, 0, 0], [1, 4, 3]):
             ious.append([objs, float(pytorch_iou(ipred, itgt, objs)), float(pytorch_iou(ipred[:, 0], itgt[:, 0], objs))])
+        # a training checkpoint written by the reference's own save_network (utils/checkpoint.py:124-160): a 3-parameter
+        # toy network, torch.optim.AdamW over named one-parameter groups (what get_trainable_params builds), three steps
+        import shutil
+        import tempfile
+        from utils.checkpoint import save_network
+        from utils.meters import AverageMeter
+        torch.manual_seed(5)
+        toy = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2, bias=False))
+        named = [{'params': [p_], 'lr': 2e-4, 'weight_decay': 0.07 if p_.dim() > 1 else 0., 'name': n_}
+                 for n_, p_ in toy.named_parameters()]
+        topt = torch.optim.AdamW(named, lr=2e-4, weight_decay=0.07)
+        for _ in range(3):
+            for p_ in toy.parameters():
+                p_.grad = torch.randn_like(p_)
+            topt.step()
+        with tempfile.TemporaryDirectory() as tmp:
+            for st in (1, 2, 3):
+                save_network(toy, topt, st, tmp, max_keep=2)
+            kept = sorted(os.listdir(tmp))
+            shutil.copy(os.path.join(tmp, 'save_step_3.pth'), os.path.join(HERE, 'ref_train_ckpt.pth'))
+        meter = AverageMeter(momentum=0.9)
+        mrows = []
+        for i, v in enumerate([1.0, 3.0, 2.0, 8.0, 5.0, 4.0]):
+            if i == 4:
+                meter.reset()
+            meter.update(v, n=1 + i % 2)
+            mrows.append([meter.val, meter.avg, meter.moving_avg, meter.count, meter.long_count])
         with open(os.path.join(HERE, 'training.json'), 'w') as f:
             json.dump({'schedule': sched, 'param_groups': groups, 'ema_decays': decays, 'ema_shadows': shadows,
-                       'pytorch_iou': ious}, f)
+                       'pytorch_iou': ious, 'ckpt_kept': kept, 'meter': mrows}, f)
     finally:
         refdriver._leave()
     np.savez_compressed(os.path.join(HERE, 'training_losses.npz'), **out)

@@ -192,3 +192,88 @@ def test_pytorch_iou_matches_reference():
     for objs, r4, r3 in _gold()['pytorch_iou']:
         assert float(pytorch_iou(pred, tgt, objs)) == pytest.approx(r4, abs=1e-7)
         assert float(pytorch_iou(pred[:, 0], tgt[:, 0], objs)) == pytest.approx(r3, abs=1e-7)
+
+
+def _toy():
+    torch.manual_seed(5)
+    return torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2, bias=False))
+
+
+def _named_groups(net):
+    return [{'params': [p], 'lr': 2e-4, 'weight_decay': 0.07 if p.dim() > 1 else 0., 'name': n} for n, p in net.named_parameters()]
+
+
+def test_training_checkpoint_interop_with_reference(tmp_path):
+    """utils.checkpoint / utils.optim.AdamW state dicts against a checkpoint written by the REAL reference's save_network
+    with torch.optim.AdamW (tests/golden/ref_train_ckpt.pth): it resumes here (weights, moments, step counts, group
+    settings), what is saved here resumes into torch.optim.AdamW, files are pruned to max_keep like the reference's, and the
+    by-name resume (v2) survives reordered / new / vanished parameter groups."""
+    from utils.checkpoint import load_network_and_optimizer, load_network_and_optimizer_v2, save_network
+    from utils.optim import AdamW
+    ref = torch.load(os.path.join(GOLD, 'ref_train_ckpt.pth'), map_location='cpu', weights_only=True)
+    net = _toy()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.zero_()
+    opt = AdamW(_named_groups(net), lr=1e-3, weight_decay=0.5)
+    net, opt, removed = load_network_and_optimizer(net, opt, os.path.join(GOLD, 'ref_train_ckpt.pth'))
+    assert removed == []
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, ref['state_dict'][k])
+    for i, g in enumerate(opt.param_groups):
+        rg, rs = ref['optimizer']['param_groups'][i], ref['optimizer']['state'][i]
+        assert g['name'] == rg['name'] and g['lr'] == rg['lr'] and g['weight_decay'] == rg['weight_decay']
+        assert tuple(g['betas']) == tuple(rg['betas']) and g['eps'] == rg['eps']
+        st = opt.state[g['params'][0]]
+        assert st['step'] == 3 and torch.equal(st['exp_avg'], rs['exp_avg']) and torch.equal(st['exp_avg_sq'], rs['exp_avg_sq'])
+    # written here -> resumes into torch.optim.AdamW (the reference's optimiser), pruned like the reference's files
+    for step in (1, 2, 3):
+        save_network(net, opt, step, str(tmp_path / 'ckpt'), max_keep=2)
+    assert sorted(os.listdir(tmp_path / 'ckpt')) == _gold()['ckpt_kept']
+    mine = torch.load(str(tmp_path / 'ckpt' / 'save_step_3.pth'), map_location='cpu', weights_only=True)
+    net2 = _toy()
+    topt = torch.optim.AdamW(_named_groups(net2), lr=1e-3, weight_decay=0.5)
+    topt.load_state_dict(mine['optimizer'])
+    for i, g in enumerate(topt.param_groups):
+        rs = ref['optimizer']['state'][i]
+        st = topt.state[g['params'][0]]
+        assert float(st['step']) == 3.0 and torch.equal(st['exp_avg'], rs['exp_avg']) and g['lr'] == 2e-4
+        assert g['name'] == ref['optimizer']['param_groups'][i]['name']
+    # by name: groups reversed, one group the checkpoint does not know, one it knows dropped
+    net3 = _toy()
+    extra = torch.nn.Parameter(torch.ones(2))
+    groups = _named_groups(net3)[::-1][:-1] + [{'params': [extra], 'lr': 5e-4, 'weight_decay': 0., 'name': 'extra'}]
+    opt3 = AdamW(groups, lr=1e-3)
+    load_network_and_optimizer_v2(net3, opt3, os.path.join(GOLD, 'ref_train_ckpt.pth'))
+    names = [g['name'] for g in ref['optimizer']['param_groups']]
+    for g in opt3.param_groups:
+        p = g['params'][0]
+        if g['name'] == 'extra':
+            assert p not in opt3.state and g['lr'] == 5e-4
+        else:
+            rs = ref['optimizer']['state'][names.index(g['name'])]
+            assert torch.equal(opt3.state[p]['exp_avg'], rs['exp_avg']) and opt3.state[p]['step'] == 3
+    with pytest.raises(ValueError):
+        AdamW(_named_groups(_toy())[:2], lr=1e-3).load_state_dict(ref['optimizer'])
+
+
+def test_average_meter_and_zip_match_reference(tmp_path):
+    """utils.meters.AverageMeter against the reference class on a sequence with weights and a reset (training.json), and
+    utils.eval.zip_folder's archive layout (names start at the zipped folder's own name, utils/eval.py:5-13)."""
+    import zipfile
+    from utils.eval import zip_folder
+    from utils.meters import AverageMeter
+    m = AverageMeter(momentum=0.9)
+    for i, (v, row) in enumerate(zip([1.0, 3.0, 2.0, 8.0, 5.0, 4.0], _gold()['meter'])):
+        if i == 4:
+            m.reset()
+        m.update(v, n=1 + i % 2)
+        assert [m.val, m.avg, m.moving_avg, m.count, m.long_count] == pytest.approx(row, rel=1e-12)
+    root = tmp_path / 'eval' / 'Annotations'
+    (root / 'seq_a').mkdir(parents=True)
+    (root / 'seq_b').mkdir()
+    for f in ('seq_a/00000.png', 'seq_a/00001.png', 'seq_b/00000.png'):
+        (root / f).write_bytes(b'x')
+    zip_folder(str(root), str(tmp_path / 'out.zip'))
+    with zipfile.ZipFile(str(tmp_path / 'out.zip')) as z:
+        assert sorted(z.namelist()) == ['Annotations/seq_a/00000.png', 'Annotations/seq_a/00001.png', 'Annotations/seq_b/00000.png']
