@@ -233,3 +233,46 @@ def evaluator_scenario():
     lab2 = np.zeros((H, W), np.float32)
     lab2[5:25, 100:140] = 3
     return frames, {0: lab0, 2: lab2}, {0: 2, 2: 3}
+
+
+# ---- objects that appear mid-clip and open a second object group (aot_engine.py:584-609; evaluator.py:362-393) -----------
+NEWGROUP_CASE = dict(model='aott', gap=2, frames=6, in_size=(129, 161), out_size=(128, 160), clip=13, first=9, total=13, inject=2)
+
+
+def newgroup_clip(device='cpu'):
+    """Synthetic clip 13 with 13 rectangles: objects 1..9 are labelled in frame 0, objects 10..13 are injected at frame 2
+    (their rectangles moved with the clip's motion).  Returns (frames, first_mask [1,1,H,W], new_label [1,1,oh,ow] at output
+    size -- zero where nothing is injected, as the evaluator's `new_obj_label`)."""
+    from utils.synth import synth_clip
+    c = NEWGROUP_CASE
+    frames, mask, _, _ = synth_clip(c['clip'], c['frames'], c['in_size'], c['out_size'], c['total'], device=device)
+    first = torch.where(mask <= c['first'], mask, torch.zeros_like(mask))
+    late = torch.where(mask > c['first'], mask, torch.zeros_like(mask))
+    late = torch.roll(late, shifts=(2 * c['inject'], 3 * c['inject']), dims=(2, 3))
+    new_label = F.interpolate(late, size=c['out_size'], mode='nearest')
+    return frames, first, new_label
+
+
+def run_newgroup(engine, frames, first, new_label, feedback, to_dev=lambda x: x):
+    """The evaluator's per-frame calls (evaluator.py:318-408, one augmentation) with new objects at frame `inject`;
+    feedback(t, logits) -> the label map [1,1,oh,ow] to memorise (the test feeds the golden masks, the golden run its own
+    argmax).  Returns the per-frame output-size logits."""
+    c = NEWGROUP_CASE
+    out = []
+    engine.restart_engine()
+    resize = lambda lab: F.interpolate(lab, size=engine.input_size_2d, mode='nearest')
+    with torch.no_grad():
+        engine.add_reference_frame(to_dev(frames[0]), to_dev(first), [c['first']], frame_step=0)
+        for t in range(1, len(frames)):
+            engine.match_propogate_one_frame(to_dev(frames[t]))
+            logit = engine.decode_current_logits(c['out_size'])
+            out.append(logit)
+            label = to_dev(feedback(t, logit))
+            if t == c['inject']:
+                nl = to_dev(new_label)
+                keep = (nl == 0).float()
+                label = label * keep + nl * (1 - keep)
+                engine.add_reference_frame(to_dev(frames[t]), resize(label), [int(label.max().item())], frame_step=t)
+                engine.decode_current_logits(c['out_size'])
+            engine.update_memory(resize(label))
+    return out

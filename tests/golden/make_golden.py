@@ -436,6 +436,39 @@ def make_evaluator_loop():
     np.savez_compressed(os.path.join(HERE, 'evaluator_loop.npz'), **out)
 
 
+def make_newgroup():
+    """Objects appearing mid-clip that open a second object group, through the REAL reference's AOTInferEngine driven with the
+    evaluator's call sequence (tests/common.py: run_newgroup): 9 objects in frame 0, objects 10..13 injected at frame 2 -- the
+    second engine starts there with its own frame counter and an empty bank while the first re-memorises the frame
+    (aot_engine.py:584-609).  Free-running; stored: masks, merged logits subsampled by 2, near-tie pixels."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import NEWGROUP_CASE, newgroup_clip, run_newgroup
+    c = NEWGROUP_CASE
+    net, make_engine, cfg = refdriver.build_reference(c['model'], gap=c['gap'])
+    net.load_state_dict(synth_state_dict(net.state_dict()))
+    frames, first, new_label = newgroup_clip()
+    engine = make_engine()
+    own = lambda t, lg: torch.argmax(lg, dim=1, keepdim=True).float()
+    logits = run_newgroup(engine, frames, first, new_label, own)
+    assert len(engine.aot_engines) == 2 and [e.frame_step for e in engine.aot_engines] == [c['frames'] - 1, c['frames'] - 1 - c['inject']]
+    out = {'n_channels': np.array([lg.shape[1] for lg in logits])}
+    masks, ties = [], []
+    for t, lg in enumerate(logits, start=1):
+        lab = torch.argmax(lg, 1)[0]
+        if t == c['inject']:                      # what is memorised (and would be saved) at the injection frame
+            nl = new_label[0, 0]
+            lab = torch.where(nl == 0, lab, nl.long())
+        masks.append(lab.to(torch.uint8).numpy())
+        top2 = torch.topk(lg[0], 2, 0)[0]
+        ties.append(((top2[0] - top2[1]) < 2e-4).numpy())
+        out['merged_%d' % t] = lg[0, :, ::2, ::2].numpy()
+    out['masks'] = np.stack(masks)
+    out['ties'] = np.packbits(np.stack(ties))
+    np.savez_compressed(os.path.join(HERE, 'c5_aott_newgroup.npz'), **out)
+    print('newgroup channels', out['n_channels'].tolist(), 'labels', [int(m.max()) for m in masks],
+          'near-ties', [int(t.sum()) for t in ties], flush=True)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -579,6 +612,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'newgroup' in sys.argv[1:]:
+        make_newgroup()
+        if sys.argv[1:] == ['newgroup']:
             return
     if not sys.argv[1:] or 'evaluator_loop' in sys.argv[1:]:
         make_evaluator_loop()

@@ -251,3 +251,114 @@ def test_result_writers_match_reference(tmp_path):
         assert np.array_equal(np.array(got.getpalette(), dtype=np.uint8), g['png_%s_palette' % tag])
     x = torch.arange(24).view(2, 3, 4)
     assert torch.equal(im.flip_tensor(x, 2), x.index_select(2, torch.arange(3, -1, -1)))
+
+
+def test_infer_engine_cohort_orchestration_vs_reference(monkeypatch):
+    """AOTInferEngine's own logic when objects appearing mid-clip open a second object group -- cohort creation, object counts
+    and mask separation per cohort, shared image embeddings, per-cohort frame counters, the gather of the cohorts' logits into
+    one finalize call -- on CPU against the REAL reference's AOTInferEngine (c5_aott_newgroup.npz), with a cohort's device
+    stages stood in for by oracle engines and aot_logits_finalize_f32 by its torch restatement."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    import aot_hip
+    from common import GOLD, NEWGROUP_CASE, newgroup_clip, run_newgroup, synth_model_state
+    from networks.engines.aot_engine import AOTInferEngine
+    from networks.models.aot import to_tokens
+    from oracle.aot_oracle import OracleEngine, OracleModel
+    c = NEWGROUP_CASE
+    g = np.load(os.path.join(GOLD, 'c5_aott_newgroup.npz'))
+    cfg, _, sd = synth_model_state(c['model'])
+    om = OracleModel(c['model'], sd)
+    K = om.max_obj_num
+
+    class Cohort:                                   # the surface AOTInferEngine and _decode use of an AOTEngine
+        use_graph = False
+
+        def __init__(self, model, gpu_id, gap, skip, mem_max, lanes=1, group0=None, graph=False):
+            self.lanes, self.group0, self.first_group, self.gap = lanes, group0, group0 or 0, gap
+            self.restart_engine()
+
+        def eval(self):
+            return self
+
+        def restart_engine(self):
+            self.o = [OracleEngine(om, long_term_mem_gap=self.gap) for _ in range(self.lanes)]
+            self.obj_nums = self.pred_id_logits = None
+
+        frame_step = property(lambda self: self.o[0].frame_step)
+        input_size_2d = property(lambda self: self.o[0].input_size_2d)
+        enc_size_2d = property(lambda self: self.o[0].enc_size_2d)
+        enc_hw = property(lambda self: self.o[0].enc_hw)
+        curr_enc_embs = property(lambda self: self.o[0].curr_enc_embs)
+
+        def _group_objects(self):
+            return int(self.obj_nums[0])
+
+        def _lane_masks(self, mask):                # what the identity gather does with group0 (aot_engine.py:515-534)
+            if self.group0 is None:
+                return [mask]
+            out = []
+            for i in range(self.lanes):
+                lo = (self.group0 + i) * K + 1
+                fg = ((mask >= lo) & (mask <= lo + K - 1)).float()
+                out.append((fg * mask - lo + 1) * fg)
+            return out
+
+        def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
+            self.obj_nums = obj_nums
+            for i, (o, m) in enumerate(zip(self.o, self._lane_masks(mask))):
+                o.add_reference_frame(img, m, [max(0, min(K, obj_nums[0] - i * K))], frame_step, img_embs=img_embs)
+                img_embs = o.curr_enc_embs
+
+        def match_propogate_one_frame(self, img=None, img_embs=None):
+            for o in self.o:
+                o.match_propogate_one_frame(img, img_embs=img_embs)
+                img_embs = o.curr_enc_embs
+
+        def update_short_term_memory(self, mask, curr_id_emb=None, skip_long_term_update=False):
+            for o, m in zip(self.o, self._lane_masks(mask)):
+                o.update_memory(m, skip_long_term_update)
+
+        def decode_stride4(self):
+            maps = [o.AOT.decode_id_logits(o.curr_lstt_output[0], o.curr_enc_embs) for o in self.o]
+            h4, w4 = maps[0].shape[-2:]
+            return torch.cat([to_tokens(m) for m in maps], 0), h4, w4
+
+    def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corners, G=1, stream=None):
+        lanes = logits[:, :C].reshape(G, IH, IW, C).permute(0, 3, 1, 2).clone()
+        for gi in range(G):
+            lanes[gi, max(0, min(K, obj_total - gi * K)) + 1:] = -1e10
+        out4.copy_(lanes)
+        if out is None:
+            return
+        big = F.interpolate(lanes, size=(OH, OW), mode='bilinear', align_corners=bool(align_corners))
+        if G == 1:
+            out.copy_(big)
+            return
+        pr = torch.softmax(big, 1)
+        merged = torch.cat([torch.prod(pr[:, 0:1], 0, keepdim=True)] + [pr[gi:gi + 1, 1:] for gi in range(G)], 1)
+        out.copy_(torch.logit(merged.clamp(1e-5, 1 - 1e-5)))
+    monkeypatch.setattr(aot_hip, 'logits_finalize', logits_finalize)
+    monkeypatch.setattr(aot_hip, 'stream_ptr', lambda: 0)
+    monkeypatch.setattr(AOTInferEngine, 'cohort_cls', Cohort)
+    import types
+    stub = types.SimpleNamespace(cfg=cfg, max_obj_num=K, ws=types.SimpleNamespace(clear=lambda **k: None))
+    eng = AOTInferEngine(stub, gpu_id=0, long_term_mem_gap=c['gap'])
+    frames, first, new_label = newgroup_clip()
+    gold = lambda t, lg: torch.from_numpy(g['masks'][t - 1].astype(np.float32))[None, None]
+    logits = run_newgroup(eng, frames, first, new_label, gold)
+    assert [lg.shape[1] for lg in logits] == g['n_channels'].tolist()
+    assert [(co.lanes, co.first_group, co.group0, co.obj_nums) for co in eng._cohorts] == [(1, 0, 0, [10]), (1, 1, 1, [3])]
+    assert [co.frame_step for co in eng._cohorts] == [c['frames'] - 1, c['frames'] - 1 - c['inject']]
+    assert len(eng.aot_engines) == 2 and eng.aot_engines[1].pred_id_logits.shape[0] == 1
+    ref = g['masks']
+    ties = np.unpackbits(g['ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    for t, lg in enumerate(logits, start=1):
+        got, want = lg[0, :, ::2, ::2].numpy(), g['merged_%d' % t]
+        live = want > -1e9                           # unused identities of a single group: -1e10 give or take an ulp (1024)
+        assert (got[~live] < -1e9).all() and np.abs(got - want)[live].max() < 2e-4
+        lab = torch.argmax(lg, 1)[0]
+        if t == c['inject']:
+            lab = torch.where(new_label[0, 0] == 0, lab, new_label[0, 0].long())
+        assert int(((lab.numpy().astype(np.uint8) != ref[t - 1]) & ~ties[t - 1]).sum()) == 0

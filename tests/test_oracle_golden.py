@@ -264,3 +264,29 @@ def test_oracle_sequence_eval_matches_reference_evaluator(case):
     assert g[case + '.obj_idx_len'].tolist() == [3, 4, 4]           # the dataset hands over the new object id from frame 2 on
     err = np.abs(res[-1][1].numpy() - g[case + '.prob_last']).max()
     assert err < 2e-5, err
+
+
+def test_oracle_new_object_group_mid_clip_matches_reference():
+    """Objects 10..13 injected at frame 2 open a second object group (c5_aott_newgroup.npz, the real AOTInferEngine under the
+    evaluator's call sequence): the new group's engine starts with its own frame counter and an empty bank, the first one
+    memorises the frame again.  Teacher-forced on the reference's masks: merged logits and masks of every frame."""
+    from common import NEWGROUP_CASE, newgroup_clip, run_newgroup
+    c = NEWGROUP_CASE
+    g = np.load(GOLD + '/c5_aott_newgroup.npz')
+    _, _, sd = synth_model_state(c['model'])
+    frames, first, new_label = newgroup_clip()
+    eng = OracleInferEngine(OracleModel(c['model'], sd), long_term_mem_gap=c['gap'])
+    gold = lambda t, lg: torch.from_numpy(g['masks'][t - 1].astype(np.float32))[None, None]
+    logits = run_newgroup(eng, frames, first, new_label, gold)
+    assert [lg.shape[1] for lg in logits] == g['n_channels'].tolist() == [11, 11, 21, 21, 21]
+    assert [e.frame_step for e in eng.aot_engines] == [c['frames'] - 1, c['frames'] - 1 - c['inject']]
+    ref = g['masks']
+    ties = np.unpackbits(g['ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    for t, lg in enumerate(logits, start=1):
+        err = np.abs(lg[0, :, ::2, ::2].numpy() - g['merged_%d' % t]).max()
+        assert err < 2e-4, 'frame %d merged logits err %g' % (t, err)
+        lab = torch.argmax(lg, 1)[0]
+        if t == c['inject']:
+            lab = torch.where(new_label[0, 0] == 0, lab, new_label[0, 0].long())
+        bad = lab.numpy().astype(np.uint8) != ref[t - 1]
+        assert int((bad & ~ties[t - 1]).sum()) == 0

@@ -214,3 +214,44 @@ def test_prob_feedback_engine_vs_oracle(hip):
             agree = got[t - 1].cpu() == lg.argmax(1)[0].float()
             assert agree[sure].all(), 'frame %d: %d sure pixels differ' % (t, int((~agree[sure]).sum()))
             eng.update_memory(F.interpolate(prob, size=eng.input_size_2d, mode='nearest'))
+
+
+@pytest.mark.xfail(strict=False, reason='written after the GPU budget of round 2 was spent: the two-cohort decode path has not '
+                   'run on hardware yet (its only run stopped at a comparison bug of this test, fixed since); the same '
+                   'scenario is green for the oracle on CPU (test_oracle_new_object_group_mid_clip_matches_reference)')
+def test_new_object_group_mid_clip_vs_reference_golden(hip):
+    """(A parity test of the inference engine; it sits at the end of the GPU suite because it is the newest.)  Objects
+    10..13 injected at frame 2 open a second object group: AOTInferEngine starts a second COHORT there (own frame counter,
+    empty bank) while the first one memorises the frame again and switches to mask separation -- against the REAL reference's
+    AOTInferEngine under the evaluator's call sequence (tests/golden/c5_aott_newgroup.npz), teacher-forced on its masks:
+    merged logits within the 1e-3 bar, masks equal outside the reference's near-ties."""
+    from common import LOGIT_TOL, NEWGROUP_CASE, newgroup_clip, run_newgroup, synth_model_state
+    from networks.engines import build_engine
+    c = NEWGROUP_CASE
+    g = np.load(os.path.join(GOLD, 'c5_aott_newgroup.npz'))
+    cfg, model, _ = synth_model_state(c['model'])
+    model = model.cuda().eval()
+    eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=c['gap'])
+    frames, first, new_label = newgroup_clip()
+    gold = lambda t, lg: torch.from_numpy(g['masks'][t - 1].astype(np.float32))[None, None]
+    logits = run_newgroup(eng, frames, first, new_label, gold, to_dev=lambda x: x.cuda())
+    assert [lg.shape[1] for lg in logits] == g['n_channels'].tolist()
+    assert len(eng._cohorts) == 2 and len(eng.aot_engines) == 2
+    assert [co.frame_step for co in eng._cohorts] == [c['frames'] - 1, c['frames'] - 1 - c['inject']]
+    ref = g['masks']
+    ties = np.unpackbits(g['ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    worst = 0.0
+    for t, lg in enumerate(logits, start=1):
+        lg = lg.cpu()
+        got, want = lg[0, :, ::2, ::2].numpy(), g['merged_%d' % t]
+        live = want > -1e9                       # unused identities of a single group sit at -1e10 (+- an ulp of 1024)
+        assert (got[~live] < -1e9).all()
+        err = np.abs(got - want)[live].max()
+        worst = max(worst, float(err))
+        assert err < LOGIT_TOL, 'frame %d merged logits err %g' % (t, err)
+        lab = torch.argmax(lg, 1)[0]
+        if t == c['inject']:
+            lab = torch.where(new_label[0, 0] == 0, lab, new_label[0, 0].long())
+        bad = lab.numpy().astype(np.uint8) != ref[t - 1]
+        assert int((bad & ~ties[t - 1]).sum()) == 0, 'frame %d: %d pixels differ outside near-ties' % (t, int((bad & ~ties[t - 1]).sum()))
+    print('newgroup: max merged-logit err %.2e' % worst)
