@@ -276,3 +276,30 @@ def run_newgroup(engine, frames, first, new_label, feedback, to_dev=lambda x: x)
                 engine.decode_current_logits(c['out_size'])
             engine.update_memory(resize(label))
     return out
+
+
+# ---- memory schedule options of the engine (aot_engine.py:307-338: short_term_mem_skip, skip_long_term_update) -----------
+MEMSCHED_CASES = {
+    'aott': dict(model='aott', frames=8, in_size=(129, 161), out_size=(128, 160), num_obj=3, clip=14, gap=2, skip=2),
+    'deaott': dict(model='deaott', frames=8, in_size=(129, 161), out_size=(128, 160), num_obj=2, clip=15, gap=2, skip=3),
+}
+
+
+def memsched_skip_long(t):
+    """Frames whose long-term update is suppressed by the caller (skip_long_term_update=True)."""
+    return t % 3 == 0
+
+
+def run_memsched(engine, frames, mask, objs, out_size, feedback, to_dev=lambda x: x):
+    """Demo loop with skip_long_term_update on every third frame; feedback(t, logits) -> label map [1,1,oh,ow]."""
+    out = []
+    engine.restart_engine()
+    with torch.no_grad():
+        engine.add_reference_frame(to_dev(frames[0]), to_dev(mask), objs, frame_step=0)
+        for t in range(1, len(frames)):
+            engine.match_propogate_one_frame(to_dev(frames[t]))
+            logit = engine.decode_current_logits(out_size)
+            out.append(logit)
+            fb = F.interpolate(to_dev(feedback(t, logit)), size=engine.input_size_2d, mode='nearest')
+            engine.update_memory(fb, skip_long_term_update=memsched_skip_long(t))
+    return out

@@ -469,6 +469,41 @@ def make_newgroup():
           'near-ties', [int(t.sum()) for t in ties], flush=True)
 
 
+def make_memsched():
+    """The engine's memory-schedule options on the REAL reference: short_term_mem_skip 2 / 3 (the short-term memory is the
+    oldest of the last `skip` frames, aot_engine.py:328-331) and skip_long_term_update on every third frame (:333-338), long-term
+    gap 2, AOTT and DeAOTT.  Free-running; masks, output-size logits subsampled by 2, near-ties, and the bank length after the
+    last frame."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import MEMSCHED_CASES, run_memsched
+    out = {}
+    for name, c in MEMSCHED_CASES.items():
+        net, _, cfg = refdriver.build_reference(c['model'])
+        net.load_state_dict(synth_state_dict(net.state_dict()))
+        refdriver._enter()
+        try:
+            from networks.engines import build_engine
+            engine = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=net, gpu_id=-1, long_term_mem_gap=c['gap'],
+                                  short_term_mem_skip=c['skip'])
+            engine.eval()
+            frames, mask, objs, out_size = synth_clip(c['clip'], c['frames'], c['in_size'], c['out_size'], c['num_obj'])
+            logits = run_memsched(engine, frames, mask, objs, out_size, lambda t, lg: torch.argmax(lg, 1, keepdim=True).float())
+            bank = engine.aot_engines[0].long_term_memories[0][0].shape[0] // engine.enc_hw
+        finally:
+            refdriver._leave()
+        masks, ties = [], []
+        for t, lg in enumerate(logits, start=1):
+            masks.append(torch.argmax(lg, 1)[0].to(torch.uint8).numpy())
+            top2 = torch.topk(lg[0], 2, 0)[0]
+            ties.append(((top2[0] - top2[1]) < 2e-4).numpy())
+            out['%s.logits_%d' % (name, t)] = lg[0, :c['num_obj'] + 1, ::2, ::2].numpy()
+        out[name + '.masks'] = np.stack(masks)
+        out[name + '.ties'] = np.packbits(np.stack(ties))
+        out[name + '.bank_frames'] = np.array(bank)
+        print('memsched', name, 'bank frames', bank, 'near-ties', [int(t.sum()) for t in ties], flush=True)
+    np.savez_compressed(os.path.join(HERE, 'memsched.npz'), **out)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -612,6 +647,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'memsched' in sys.argv[1:]:
+        make_memsched()
+        if sys.argv[1:] == ['memsched']:
             return
     if not sys.argv[1:] or 'newgroup' in sys.argv[1:]:
         make_newgroup()

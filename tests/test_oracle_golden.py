@@ -290,3 +290,36 @@ def test_oracle_new_object_group_mid_clip_matches_reference():
             lab = torch.where(new_label[0, 0] == 0, lab, new_label[0, 0].long())
         bad = lab.numpy().astype(np.uint8) != ref[t - 1]
         assert int((bad & ~ties[t - 1]).sum()) == 0
+
+
+@pytest.mark.parametrize('case', ['aott', 'deaott'])
+def test_oracle_memory_schedule_options_match_reference(case):
+    """short_term_mem_skip (2 / 3) and skip_long_term_update on every third frame through the real reference's engines
+    (memsched.npz): the oracle, teacher-forced on the reference's masks, gives the same logits and bank length."""
+    from common import MEMSCHED_CASES, run_memsched
+    from oracle.aot_oracle import _set_skip
+    from utils.synth import synth_clip
+    c = MEMSCHED_CASES[case]
+    g = np.load(GOLD + '/memsched.npz')
+    _, _, sd = synth_model_state(c['model'])
+    eng = OracleInferEngine(OracleModel(c['model'], sd), long_term_mem_gap=c['gap'])
+    frames, mask, objs, out_size = synth_clip(c['clip'], c['frames'], c['in_size'], c['out_size'], c['num_obj'])
+    gold = lambda t, lg: torch.from_numpy(g[case + '.masks'][t - 1].astype(np.float32))[None, None]
+
+    class Skip:                                     # the engines exist only after the reference frame: set the option then
+        def __getattr__(self, name):
+            return getattr(eng, name)
+
+        def add_reference_frame(self, *a, **k):
+            eng.add_reference_frame(*a, **k)
+            _set_skip(eng, c['skip'])
+    logits = run_memsched(Skip(), frames, mask, objs, out_size, gold)
+    ref = g[case + '.masks']
+    ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    for t, lg in enumerate(logits, start=1):
+        err = np.abs(lg[0, :c['num_obj'] + 1, ::2, ::2].numpy() - g['%s.logits_%d' % (case, t)]).max()
+        assert err < 1e-4, 'frame %d logits err %g' % (t, err)
+        bad = torch.argmax(lg, 1)[0].numpy().astype(np.uint8) != ref[t - 1]
+        assert int((bad & ~ties[t - 1]).sum()) == 0
+    e0 = eng.aot_engines[0]
+    assert e0.long_term_memories[0][0].shape[0] // e0.enc_hw == int(g[case + '.bank_frames']) == 3
