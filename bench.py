@@ -205,8 +205,9 @@ def jf_vs_reference(device, graph=False):
         if on_device:
             try:
                 j, f = jf_per_object(label, ref, NUM_OBJ)
-            except Exception:
+            except Exception as exc:
                 on_device = False
+                print('[bench] J&F metric falls back to the host: %s' % exc, file=sys.stderr, flush=True)
         if not on_device:
             j, f = jf_per_object(label.cpu(), ref.cpu(), NUM_OBJ)
         js.append(j)
