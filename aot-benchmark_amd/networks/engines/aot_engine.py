@@ -170,6 +170,17 @@ class AOTEngine(nn.Module):
         mask, _, prob = aot_hip.fuse_probs(logits, [False], want_aug_labels=False, want_prob=want_prob)
         return loss, mask.view(1, *size).long(), prob
 
+    def generate_loss_mask(self, gt_mask, step, return_prob=False):
+        """aot_engine.py:421-430 for the clip this engine holds (batch 1): decode, score against gt_mask [1,1,H,W] or
+        [1,H,W], predict.  Returns (loss [1], mask [1,H,W]) and, return_prob, the class probabilities [1,L,H,W]."""
+        if self.losses is None:
+            self._init_losses()
+        if self.enable_id_shuffle and self._sample is None:
+            self._sample = 0
+        loss, mask, prob = self._loss_and_mask(gt_mask.reshape(1, *gt_mask.shape[-2:]).float(), self._group_objects(), step,
+                                               want_prob=return_prob)
+        return (loss, mask, prob) if return_prob else (loss, mask)
+
     def _shuffled(self, m):
         """Moves the identities of a label map [1,1,H,W] or a probability map [1,L,H,W] of the current sample to their
         shuffled channels (assign_identity's einsum, aot_engine.py:168-172); unchanged when the shuffle is off."""
@@ -411,10 +422,11 @@ class AOTEngine(nn.Module):
         """Objects of this cohort: obj_nums is the cohort's own count (the clip's total minus the groups before it)."""
         return int(self.obj_nums[0]) if isinstance(self.obj_nums, (list, tuple)) else int(self.obj_nums)
 
-    def assign_identity(self, mask):
-        """mask [1,1,H,W] label ids, or [1,max_obj_num+1,H,W] one-hot / probabilities (MODEL_USE_PREV_PROB) -> id embedding
-        [lanes*N, C] (aot_engine.py:168-179 + utils/image.py:69-74)."""
-        return self.AOT.id_emb_from_mask(mask, self.enc_size_2d, lanes=self.lanes, group0=self.group0)
+    def assign_identity(self, one_hot_mask):
+        """aot_engine.py:168-179 (+ utils/image.py:69-74): the reference's argument, a one-hot or probability map
+        [1, max_obj_num+1, H, W], goes through the dense identity convolution; a label map [1,1,H,W] (what this engine's own
+        stages pass) through the fused gather.  Returns the id embedding token-major, [lanes*N, C]."""
+        return self.AOT.id_emb_from_mask(one_hot_mask, self.enc_size_2d, lanes=self.lanes, group0=self.group0)
 
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
         if self.obj_nums is None and obj_nums is None:
@@ -621,6 +633,10 @@ class DeAOTEngine(AOTEngine):
     per token, only ID_V refreshed at update time) live in the model (DeAOT.update_memory_values / mem_widths) and in
     GatedPropagationModule.run; the state machine is the same."""
 
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, layer_loss_scaling_ratio=2., **kw):
+        super().__init__(aot_model, gpu_id, long_term_mem_gap, short_term_mem_skip, **kw)
+        self.layer_loss_scaling_ratio = layer_loss_scaling_ratio      # kept (and, as in the reference, read by nothing)
+
 
 class _GroupView:
     """What callers read from `engine.aot_engines[g]` (reference: one AOTEngine per object group): a window on lane `lane`
@@ -682,8 +698,8 @@ class AOTInferEngine(nn.Module):
                 self._spare.pop(i)
                 c.restart_engine()
                 return c
-        c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip, self.long_term_mem_max,
-                            lanes=lanes, group0=group0, graph=self.use_graph)
+        c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
+                            long_term_mem_max=self.long_term_mem_max, lanes=lanes, group0=group0, graph=self.use_graph)
         c.eval()
         return c
 

@@ -504,6 +504,53 @@ def make_memsched():
     np.savez_compressed(os.path.join(HERE, 'memsched.npz'), **out)
 
 
+def make_api_surface():
+    """Public call surface of the reference classes a caller of the hot path touches (names and parameter lists via inspect):
+    the engines, the models, the factories, losses, EMA, learning-rate helpers, checkpoint functions, image utilities."""
+    import importlib
+    import inspect
+    targets = {
+        'networks.engines.aot_engine': ['AOTEngine', 'AOTInferEngine'],
+        'networks.engines.deaot_engine': ['DeAOTEngine', 'DeAOTInferEngine'],
+        'networks.engines': ['build_engine'],
+        'networks.models': ['build_vos_model'],
+        'networks.models.aot': ['AOT'],
+        'networks.models.deaot': ['DeAOT'],
+        'networks.layers.loss': ['CrossEntropyLoss', 'SoftJaccordLoss'],
+        'utils.ema': ['ExponentialMovingAverage', 'get_param_buffer_for_ema'],
+        'utils.learning': ['adjust_learning_rate', 'get_trainable_params'],
+        'utils.checkpoint': ['load_network', 'load_network_and_optimizer', 'load_network_and_optimizer_v2', 'save_network'],
+        'utils.image': ['label2colormap', 'masked_image', 'save_image', 'save_mask', 'flip_tensor'],
+        'utils.metric': ['pytorch_iou'],
+        'utils.meters': ['AverageMeter'],
+        'utils.eval': ['zip_folder'],
+    }
+
+    def params(fn):
+        return [[p.name, p.default is not inspect.Parameter.empty, p.kind.name] for p in inspect.signature(fn).parameters.values()]
+    out = {}
+    build_reference_stubs = refdriver.build_reference('aott')       # imports the reference once with its attention patch
+    refdriver._enter()
+    try:
+        for mod, names in targets.items():
+            m = importlib.import_module(mod)
+            for n in names:
+                obj = getattr(m, n)
+                if inspect.isclass(obj):
+                    meths = {}
+                    for k, v in vars(obj).items():
+                        if callable(v) and (not k.startswith('_') or k == '__init__'):
+                            meths[k] = params(v)
+                    out['%s.%s' % (mod, n)] = {'kind': 'class', 'bases': [b.__name__ for b in obj.__mro__[1:-1]], 'methods': meths}
+                else:
+                    out['%s.%s' % (mod, n)] = {'kind': 'function', 'params': params(obj)}
+    finally:
+        refdriver._leave()
+    with open(os.path.join(HERE, 'api_surface.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('api surface:', {k: (len(v['methods']) if v['kind'] == 'class' else 'fn') for k, v in out.items()}, flush=True)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -647,6 +694,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'api_surface' in sys.argv[1:]:
+        make_api_surface()
+        if sys.argv[1:] == ['api_surface']:
             return
     if not sys.argv[1:] or 'memsched' in sys.argv[1:]:
         make_memsched()

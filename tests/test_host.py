@@ -275,7 +275,7 @@ def test_infer_engine_cohort_orchestration_vs_reference(monkeypatch):
     class Cohort:                                   # the surface AOTInferEngine and _decode use of an AOTEngine
         use_graph = False
 
-        def __init__(self, model, gpu_id, gap, skip, mem_max, lanes=1, group0=None, graph=False):
+        def __init__(self, model, gpu_id, gap, skip, long_term_mem_max=None, lanes=1, group0=None, graph=False):
             self.lanes, self.group0, self.first_group, self.gap = lanes, group0, group0 or 0, gap
             self.restart_engine()
 
@@ -362,3 +362,58 @@ def test_infer_engine_cohort_orchestration_vs_reference(monkeypatch):
         if t == c['inject']:
             lab = torch.where(new_label[0, 0] == 0, lab, new_label[0, 0].long())
         assert int(((lab.numpy().astype(np.uint8) != ref[t - 1]) & ~ties[t - 1]).sum()) == 0
+
+
+def test_call_surface_matches_reference():
+    """Drop-in check by introspection: every public method / function of the reference classes a caller of the hot path (or
+    of the training-side slice) touches exists here under the same module path and name, taking the reference's parameters in
+    the reference's order (this repo may add optional parameters after them).  Golden: tests/golden/api_surface.json, made
+    with inspect on the real reference.  Methods listed in NOT_BUILT are the documented gaps."""
+    import importlib
+    import inspect
+    import json
+    from common import GOLD
+    NOT_BUILT = {
+        # offline (batched) encoder plumbing of the training forward: frames are encoded per sample here (DESIGN.md section 7)
+        'networks.engines.aot_engine.AOTEngine': {'offline_encoder', 'encode_one_img_mask', 'split_frames', 'keep_gt_mask',
+                                                  'calculate_current_loss'},
+        # the groups' logits are aggregated inside aot_logits_finalize_f32 (one kernel with the masking and the resize)
+        'networks.engines.aot_engine.AOTInferEngine': {'min_logit_aggregation', 'soft_logit_aggregation'},
+    }
+    with open(os.path.join(GOLD, 'api_surface.json')) as f:
+        ref = json.load(f)
+    missing, mismatched = [], []
+
+    def compare(name, fn, want):
+        got = list(inspect.signature(fn).parameters.values())
+        want = [w for w in want if w[2] not in ('VAR_POSITIONAL', 'VAR_KEYWORD')]
+        names = [p.name for p in got]
+        if names[:len(want)] != [w[0] for w in want]:
+            mismatched.append((name, names, [w[0] for w in want]))
+            return
+        for p, w in zip(got, want):          # a parameter the reference makes optional must stay optional
+            if w[1] and p.default is inspect.Parameter.empty:
+                mismatched.append((name, p.name, 'must be optional'))
+        for p in got[len(want):]:            # whatever is added must be optional
+            if p.default is inspect.Parameter.empty and p.kind.name not in ('VAR_POSITIONAL', 'VAR_KEYWORD'):
+                mismatched.append((name, p.name, 'added parameter without default'))
+    for full, spec in ref.items():
+        mod, name = full.rsplit('.', 1)
+        try:
+            obj = getattr(importlib.import_module(mod), name)
+        except (ImportError, AttributeError):
+            missing.append(full)
+            continue
+        if spec['kind'] == 'function':
+            compare(full, obj, spec['params'])
+            continue
+        for meth, want in spec['methods'].items():
+            if meth in NOT_BUILT.get(full, ()):
+                continue
+            fn = getattr(obj, meth, None)
+            if fn is None:
+                missing.append(full + '.' + meth)
+            else:
+                compare(full + '.' + meth, fn, want)
+    assert not missing, missing
+    assert not mismatched, mismatched
