@@ -9,7 +9,7 @@ the reference's callers import from them.
 _COMMON = dict(
     # architecture
     MODEL_VOS='aot', MODEL_ENGINE='aotengine', MODEL_NAME='AOTDefault',
-    MODEL_ENCODER='mobilenetv2', MODEL_ENCODER_PRETRAIN='', MODEL_ENCODER_DIM=[24, 32, 96, 1280],   # 4x, 8x, 16x, 16x
+    MODEL_ENCODER='mobilenetv2', MODEL_ENCODER_PRETRAIN='./pretrain_models/mobilenet_v2-b0353104.pth', MODEL_ENCODER_DIM=[24, 32, 96, 1280],   # 4x, 8x, 16x, 16x
     MODEL_ENCODER_EMBEDDING_DIM=256, MODEL_LSTT_NUM=1, MODEL_SELF_HEADS=8, MODEL_ATT_HEADS=8,
     MODEL_DECODER_INTERMEDIATE_LSTT=True, MODEL_MAX_OBJ_NUM=10, MODEL_ALIGN_CORNERS=True,
     MODEL_FREEZE_BN=True, MODEL_FREEZE_BACKBONE=False, MODEL_EPSILON=1e-5, MODEL_USE_PREV_PROB=False,
@@ -22,10 +22,12 @@ _COMMON = dict(
 _DEAOT = dict(MODEL_VOS='deaot', MODEL_ENGINE='deaotengine', MODEL_NAME='DeAOTDefault', MODEL_DECODER_INTERMEDIATE_LSTT=False,
               MODEL_SELF_HEADS=1, MODEL_ATT_HEADS=1, TRAIN_AUG_TYPE='v2')
 _LARGE = dict(MODEL_LSTT_NUM=3, TRAIN_LONG_TERM_MEM_GAP=2, TEST_LONG_TERM_MEM_GAP=5)      # the "L" memory schedule
-_R50 = dict(MODEL_ENCODER='resnet50', MODEL_ENCODER_DIM=[256, 512, 1024, 1024])
+_R50 = dict(MODEL_ENCODER='resnet50', MODEL_ENCODER_DIM=[256, 512, 1024, 1024],
+            MODEL_ENCODER_PRETRAIN='./pretrain_models/resnet50-0676ba61.pth')
 _R101 = dict(MODEL_ENCODER='resnet101', MODEL_ENCODER_DIM=[256, 512, 1024, 1024],
              MODEL_ENCODER_PRETRAIN='./pretrain_models/resnet101-63fe2227.pth')
-_SWINB = dict(MODEL_ENCODER='swin_base', MODEL_ENCODER_DIM=[128, 256, 512, 512], MODEL_ALIGN_CORNERS=False)
+_SWINB = dict(MODEL_ENCODER='swin_base', MODEL_ENCODER_DIM=[128, 256, 512, 512], MODEL_ALIGN_CORNERS=False,
+              MODEL_ENCODER_PRETRAIN='./pretrain_models/swin_base_patch4_window7_224_22k.pth')
 
 # name -> (display name, DeAOT?, override dicts applied in order)
 ZOO = {

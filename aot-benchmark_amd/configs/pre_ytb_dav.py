@@ -1,0 +1,3 @@
+from .default import stage
+
+EngineConfig = stage('pre_ytb_dav')

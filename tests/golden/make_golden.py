@@ -551,6 +551,29 @@ def make_api_surface():
     print('api surface:', {k: (len(v['methods']) if v['kind'] == 'class' else 'fn') for k, v in out.items()}, flush=True)
 
 
+def make_engine_configs():
+    """Every attribute of the reference's stage configs (configs/{pre,pre_dav,pre_ytb,pre_ytb_dav,ytb}.py over configs/default.py)
+    for three models, with the directory creation of init_dir suppressed (os.makedirs stubbed)."""
+    import importlib
+    out = {}
+    refdriver._enter()
+    real = os.makedirs
+    os.makedirs = lambda *a, **k: None
+    try:
+        for stage in ('default', 'pre', 'pre_dav', 'pre_ytb', 'pre_ytb_dav', 'ytb'):
+            for model in ('aott', 'r50_aotl', 'swinb_deaotl'):
+                mod = importlib.import_module('configs.' + stage)
+                cls = mod.DefaultEngineConfig if stage == 'default' else mod.EngineConfig
+                cfg = cls('exp', model)
+                out['%s/%s' % (stage, model)] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()}
+    finally:
+        os.makedirs = real
+        refdriver._leave()
+    with open(os.path.join(HERE, 'engine_configs.json'), 'w') as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print('engine configs:', len(out), 'attributes each:', sorted({len(v) for v in out.values()}), flush=True)
+
+
 def make_transforms():
     """Golden for the evaluator's transforms (dataloaders/video_transforms.py:594-715) from the REAL reference classes.
     cv2 / torchvision are not installed: they are stubbed (the size rule and MultiToTensor never call into them; the stub's
@@ -694,6 +717,10 @@ def main():
     if not sys.argv[1:] or 'training' in sys.argv[1:]:
         make_training()
         if sys.argv[1:] == ['training']:
+            return
+    if not sys.argv[1:] or 'engine_configs' in sys.argv[1:]:
+        make_engine_configs()
+        if sys.argv[1:] == ['engine_configs']:
             return
     if not sys.argv[1:] or 'api_surface' in sys.argv[1:]:
         make_api_surface()

@@ -34,8 +34,7 @@ def test_model_presets_equal_reference_configs():
         mine = model_cfg(name).__dict__
         for k, v in attrs.items():
             assert k in mine, (name, k)
-            if k != 'MODEL_ENCODER_PRETRAIN':       # a checkpoint path, not used on the inference path
-                assert mine[k] == v, (name, k, mine[k], v)
+            assert mine[k] == v, (name, k, mine[k], v)
 
 
 def test_load_network_conventions(tmp_path):
@@ -417,3 +416,27 @@ def test_call_surface_matches_reference():
                 compare(full + '.' + meth, fn, want)
     assert not missing, missing
     assert not mismatched, mismatched
+
+
+def test_engine_stage_configs_match_reference():
+    """configs.<stage>.EngineConfig(exp, model) for the five stages (and DefaultEngineConfig) x three models: every attribute the
+    reference's config carries, same value (tests/golden/engine_configs.json), and no directory is created by constructing one."""
+    import importlib
+    import json
+    from common import GOLD
+    with open(os.path.join(GOLD, 'engine_configs.json')) as f:
+        gold = json.load(f)
+    before = set(os.listdir('.'))
+    for key, want in gold.items():
+        stage, model = key.split('/')
+        mod = importlib.import_module('configs.' + stage)
+        cfg = (mod.DefaultEngineConfig if stage == 'default' else mod.EngineConfig)('exp', model)
+        got = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()}
+        for k, v in want.items():
+            assert k in got, (key, k)
+            assert got[k] == v, (key, k, got[k], v)
+        extra = set(got) - set(want)
+        assert all(k.startswith(('MODEL_LT_',)) for k in extra), (key, extra)        # this repo's optional long-video keys
+    assert set(os.listdir('.')) == before
+    from configs.models.default_deaot import DefaultModelConfig
+    assert DefaultModelConfig().MODEL_ENGINE == 'deaotengine'
