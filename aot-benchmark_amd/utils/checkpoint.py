@@ -4,6 +4,13 @@
 import torch
 
 
+def get_device(gpu=None):
+    """The device checkpoints are mapped to (utils/checkpoint.py:7-10)."""
+    if torch.cuda.is_available():
+        return torch.device('cuda', gpu) if gpu is not None else torch.device('cuda')
+    return torch.device('cpu')
+
+
 def load_network(net, pretrained_dir, gpu=None, trusted=False):
     """Only tensors are needed (a state_dict, optionally wrapped in {'state_dict': ...} / {'model': ...}), so the file is
     read with weights_only=True: a downloaded checkpoint cannot run pickled code.  trusted=True restores torch's full

@@ -49,3 +49,21 @@ def get_trainable_params(model, base_lr, weight_decay, use_frozen_bn=False, excl
     if verbose:
         print('Total Param: {:.2f}M'.format(total / 1e6))
     return groups
+
+
+def freeze_params(module):
+    """Stops the gradients of every parameter of `module` (reference utils/learning.py:93-95)."""
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+def calculate_params(state_dict):
+    """Prints and returns the number of distinct parameters of a state dict, in millions (utils/learning.py:98-106: shared
+    tensors count once)."""
+    seen, total = set(), 0
+    for v in state_dict.values():
+        if id(v) not in seen:
+            seen.add(id(v))
+            total += v.numel()
+    print('Total Param: {:.2f}M'.format(total / 1e6))
+    return total / 1e6

@@ -221,9 +221,18 @@ def make_training():
                 meter.reset()
             meter.update(v, n=1 + i % 2)
             mrows.append([meter.val, meter.avg, meter.moving_avg, meter.count, meter.long_count])
+        # utils/math.py under fixed CPU seeds: the permutation matrices (as column indices per row) and a truncated normal
+        from utils.math import generate_permute_matrix, truncated_normal_
+        cpu = torch.device('cpu')
+        perms = {}
+        for keep in (True, False):
+            torch.manual_seed(3)
+            perms[str(keep)] = generate_permute_matrix(11, 4, keep, device=cpu).argmax(-1).tolist()
+        torch.manual_seed(5)
+        tnorm = truncated_normal_(torch.zeros(3, 7), 0.1, 0.5).tolist()
         with open(os.path.join(HERE, 'training.json'), 'w') as f:
             json.dump({'schedule': sched, 'param_groups': groups, 'ema_decays': decays, 'ema_shadows': shadows,
-                       'pytorch_iou': ious, 'ckpt_kept': kept, 'meter': mrows}, f)
+                       'pytorch_iou': ious, 'ckpt_kept': kept, 'meter': mrows, 'permute_cols': perms, 'trunc_normal': tnorm}, f)
     finally:
         refdriver._leave()
     np.savez_compressed(os.path.join(HERE, 'training_losses.npz'), **out)
@@ -518,8 +527,10 @@ def make_api_surface():
         'networks.models.deaot': ['DeAOT'],
         'networks.layers.loss': ['CrossEntropyLoss', 'SoftJaccordLoss'],
         'utils.ema': ['ExponentialMovingAverage', 'get_param_buffer_for_ema'],
-        'utils.learning': ['adjust_learning_rate', 'get_trainable_params'],
-        'utils.checkpoint': ['load_network', 'load_network_and_optimizer', 'load_network_and_optimizer_v2', 'save_network'],
+        'utils.learning': ['adjust_learning_rate', 'get_trainable_params', 'freeze_params', 'calculate_params'],
+        'utils.checkpoint': ['get_device', 'load_network', 'load_network_and_optimizer', 'load_network_and_optimizer_v2',
+                             'save_network'],
+        'utils.math': ['generate_permute_matrix', 'truncated_normal_'],
         'utils.image': ['label2colormap', 'masked_image', 'save_image', 'save_mask', 'flip_tensor'],
         'utils.metric': ['pytorch_iou'],
         'utils.meters': ['AverageMeter'],

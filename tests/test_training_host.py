@@ -277,3 +277,19 @@ def test_average_meter_and_zip_match_reference(tmp_path):
     zip_folder(str(root), str(tmp_path / 'out.zip'))
     with zipfile.ZipFile(str(tmp_path / 'out.zip')) as z:
         assert sorted(z.namelist()) == ['Annotations/seq_a/00000.png', 'Annotations/seq_a/00001.png', 'Annotations/seq_b/00000.png']
+
+
+def test_random_helpers_match_reference_streams():
+    """utils.math under fixed CPU seeds draws what the reference's functions draw (training.json): generate_permute_matrix
+    (background kept / not kept) and truncated_normal_; the engine's index form of the shuffle converts to the same matrices."""
+    from utils.math import generate_permute_matrix, permutation_to_matrix, truncated_normal_
+    gold = _gold()
+    for keep in (True, False):
+        torch.manual_seed(3)
+        m = generate_permute_matrix(11, 4, keep, device=torch.device('cpu'))
+        assert m.shape == (4, 11, 11) and torch.equal(m.sum(1), torch.ones(4, 11)) and torch.equal(m.sum(2), torch.ones(4, 11))
+        assert m.argmax(-1).tolist() == gold['permute_cols'][str(keep)]
+        assert all(torch.equal(permutation_to_matrix(m[i].argmax(-1)), m[i]) for i in range(4))
+    torch.manual_seed(5)
+    t = truncated_normal_(torch.zeros(3, 7), 0.1, 0.5)
+    assert torch.allclose(t, torch.tensor(gold['trunc_normal']), atol=0, rtol=0) and (t - 0.1).abs().max() < 1.0
