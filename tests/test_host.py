@@ -440,3 +440,62 @@ def test_engine_stage_configs_match_reference():
     assert set(os.listdir('.')) == before
     from configs.models.default_deaot import DefaultModelConfig
     assert DefaultModelConfig().MODEL_ENGINE == 'deaotengine'
+
+
+@pytest.mark.parametrize('case', ['single', 'tta'])
+def test_sequence_evaluator_orchestration_vs_reference_evaluator(case, monkeypatch, tmp_path):
+    """SequenceEvaluator's own logic -- augmentation order and sizes, flipped samples and labels, probability fusion across the
+    engines, the new-object merge and re-reference at frame 2, per-augmentation label feedback, the saved PNGs with the dataset's
+    object ids -- on CPU against the REAL reference's `Evaluator.evaluating` (evaluator_loop.npz), with the device stages
+    (`aot_hip.preprocess / fuse_probs / label_resize`, the engines) stood in for by the oracle and torch."""
+    import numpy as np
+    import torch.nn.functional as F
+    from PIL import Image
+
+    import aot_hip
+    import networks.managers.evaluator as ev_mod
+    from common import EVAL_LOOP_CASES, EVAL_LOOP_OBJ_IDX, GOLD, evaluator_scenario, synth_model_state
+    from oracle.aot_oracle import OracleInferEngine, OracleModel, cv2_cubic_resize, to_tensor_normalise
+    c = EVAL_LOOP_CASES[case]
+    g = np.load(os.path.join(GOLD, 'evaluator_loop.npz'))
+    cfg, _, sd = synth_model_state('aott', cfg_overrides=dict(TEST_FLIP=c['flip'], TEST_MULTISCALE=list(c['ms']),
+                                                              TEST_MAX_SHORT_EDGE=None, TEST_MAX_LONG_EDGE=800 * 1.3,
+                                                              TEST_LONG_TERM_MEM_GAP=2))
+    om = OracleModel('aott', sd)
+
+    def preprocess(img, out_h, out_w, flip=False, out=None, stream=None):
+        r = cv2_cubic_resize(img.numpy(), out_h, out_w)
+        return to_tensor_normalise(r[:, ::-1].copy() if flip else r).unsqueeze(0)
+
+    def fuse_probs(logits, flips, new_label=None, want_aug_labels=True, want_prob=False, stream=None):
+        probs = [torch.softmax(l[None].flip(3) if f else l[None], 1) for l, f in zip(logits, flips)]
+        labs = [p.argmax(1, keepdim=True).float() for p in probs]
+        prob = torch.mean(torch.cat(probs, 0), 0, keepdim=True)
+        fused = prob.argmax(1, keepdim=True).float()
+        if new_label is not None:
+            keep = (new_label == 0).float()
+            fused = fused * keep + new_label * (1 - keep)
+            labs = [l * keep + new_label * (1 - keep) for l in labs]
+        return fused, (torch.cat(labs, 0) if want_aug_labels else None), (prob if want_prob else None)
+
+    def label_resize(label, out_h, out_w, flip=False, stream=None):
+        lab = label.reshape(1, 1, *label.shape[-2:])
+        return F.interpolate(lab.flip(3) if flip else lab, size=(out_h, out_w), mode='nearest')
+    monkeypatch.setattr(aot_hip, 'preprocess', preprocess)
+    monkeypatch.setattr(aot_hip, 'fuse_probs', fuse_probs)
+    monkeypatch.setattr(aot_hip, 'label_resize', label_resize)
+    monkeypatch.setattr(ev_mod, 'build_engine', lambda name, phase, aot_model, gpu_id, long_term_mem_gap, short_term_mem_skip:
+                        type('E', (OracleInferEngine,), {'eval': lambda self: self})(aot_model, long_term_mem_gap))
+    frames, labels, nums = evaluator_scenario()
+    ev = ev_mod.SequenceEvaluator(cfg, om)
+    got = ev.run([torch.from_numpy(f) for f in frames], {t: torch.from_numpy(l) for t, l in labels.items()}, nums,
+                 save_dir=str(tmp_path), names=['%05d' % t for t in range(4)], obj_idx=EVAL_LOOP_OBJ_IDX)
+    ref = g[case + '.masks']
+    ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
+    lut = np.array(EVAL_LOOP_OBJ_IDX, np.uint8)
+    assert len(got) == 3 and len(ev.engines) == len(c['ms']) * (2 if c['flip'] else 1)
+    for t, lab in enumerate(got):
+        bad = lab.numpy().astype(np.uint8) != ref[t]
+        assert int((bad & ~ties[t]).sum()) == 0, 'frame %d: %d pixels differ outside near-ties' % (t + 1, int((bad & ~ties[t]).sum()))
+        png = np.array(Image.open(str(tmp_path / ('%05d.png' % (t + 1)))))
+        assert np.array_equal(png, lut[lab.numpy().astype(np.uint8)])          # what the reference hands to save_mask + obj_idx
