@@ -73,6 +73,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 #ifndef AOT_ATT_VPM
 #define AOT_ATT_VPM 4
 #endif
+#ifndef AOT_ATT_PKSUM      // row sums through v_pk_add_f32 (the plain `ps += p2` compiles to two scalar adds per pair); not yet timed
+#define AOT_ATT_PKSUM 0
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // max of three in ONE instruction (same NaN rule as fmaxf: a NaN operand is ignored)
 // packed fp32: two values per lane and instruction (hipcc scalarises most <2 x float> arithmetic next to MFMA operands)
@@ -227,7 +230,11 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
       pf[r] = __builtin_amdgcn_exp2f(t2[0]);
       pf[r + 1] = __builtin_amdgcn_exp2f(t2[1]);
       const f32x2 p2 = {pf[r], pf[r + 1]};
+#if AOT_ATT_PKSUM
+      ps = pk_add(ps, p2);
+#else
       ps += p2;
+#endif
     }
     l += ps[0] + ps[1];
 #else
