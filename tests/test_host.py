@@ -499,3 +499,23 @@ def test_sequence_evaluator_orchestration_vs_reference_evaluator(case, monkeypat
         assert int((bad & ~ties[t]).sum()) == 0, 'frame %d: %d pixels differ outside near-ties' % (t + 1, int((bad & ~ties[t]).sum()))
         png = np.array(Image.open(str(tmp_path / ('%05d.png' % (t + 1)))))
         assert np.array_equal(png, lut[lab.numpy().astype(np.uint8)])          # what the reference hands to save_mask + obj_idx
+
+
+@pytest.mark.parametrize('name', ['aott', 'deaott'])
+def test_infer_engine_builds_cohorts_with_every_option(name):
+    """The caller-facing engines hand every option (memory gap, short-term skip, bounded bank, graph replay) on to the cohorts
+    they create, for both engine families (DeAOTEngine keeps the reference's layer_loss_scaling_ratio in the reference's
+    position, so the cohort options travel by keyword)."""
+    from networks.engines import build_engine
+    from networks.engines.aot_engine import AOTEngine, DeAOTEngine
+    from networks.models import build_vos_model
+    cfg = model_cfg(name)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    for graph in (False, True):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=5, short_term_mem_skip=2,
+                           long_term_mem_max=4, graph=graph)
+        c = eng._new_cohort(3, 1)
+        assert type(c) is (DeAOTEngine if name == 'deaott' else AOTEngine)
+        assert (c.lanes, c.group0, c.first_group, c.long_term_mem_gap, c.short_term_mem_skip, c.long_term_mem_max, c.use_graph) \
+            == (3, 1, 1, 5, 2, 4, graph)
+    assert DeAOTEngine(model, 0, 7, 1, 3.).layer_loss_scaling_ratio == 3. if name == 'deaott' else True
