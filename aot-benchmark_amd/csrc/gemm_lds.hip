@@ -369,6 +369,23 @@ __device__ __forceinline__ float buf_load(const i32x4& desc, int voff) {
 __device__ __forceinline__ void buf_store(const i32x4& desc, int voff, float v) {
   asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(desc) : "memory");
 }
+// the same with a wave-uniform byte offset in an SGPR next to the lane's offset (address = base + soff + voff; an out-of-range
+// voff still masks the access whatever soff is)
+__device__ __forceinline__ float buf_load_s(const i32x4& desc, int voff, int soff) {
+  float v;
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(desc), "s"(soff));
+  return v;
+}
+__device__ __forceinline__ void buf_store_s(const i32x4& desc, int voff, int soff, float v) {
+  asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" : : "v"(v), "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+// AOT_LEAN_EPI = 1: the tile end of gemm_lean_kernel with (a) ONE wave-uniform branch on the activation per tile instead of the
+// if-chain of apply_act() per output element (16-32 elements per lane: five scalar compare-and-branch pairs each, seen in the
+// ISA), (b) the row part of every store / residual address as a scalar offset -- one integer multiply per tile instead of one per
+// element.  Same values stored; not yet timed on the GPU (tools/dev/gemm_check), hence off.
+#ifndef AOT_LEAN_EPI
+#define AOT_LEAN_EPI 0
+#endif
 template <int IMM>
 __device__ __forceinline__ void fetch_one(f32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
@@ -571,6 +588,20 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
     const bool col_ok = n < p.Cout;
     const int m0 = it.bm * BM;
     if (n_bias) bv = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
+#if AOT_LEAN_EPI
+    if (n_res && p.res_rows == 0) {          // a residual row per output row: lane offset once, row offsets as scalars
+      const int mlane = m0 + wm + 4 * half;
+      const int vbase = col_ok ? (mlane * p.ldr + n) * 4 : (int)OOB;
+      const int rows_left = p.M - mlane, ldr4 = p.ldr * 4;
+#pragma unroll
+      for (int x = 0; x < BMB; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = 32 * x + (r & 3) + 8 * (r >> 2);
+          rv[x][r] = buf_load_s(desc_res, c < rows_left ? vbase : (int)OOB, c * ldr4);
+        }
+    } else
+#endif
     if (n_res) {
       const int rr0 = p.res_rows ? m0 % p.res_rows : m0;
 #pragma unroll
@@ -619,6 +650,34 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[x][r]));
     }
     const int m0 = it.bm * BM;
+#if AOT_LEAN_EPI
+    {
+      const int mlane = m0 + wm + 4 * half;          // output row of accumulator register 0 (block 0) in this lane
+      const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+      auto store_all = [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int x = 0; x < BMB; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = 32 * x + (r & 3) + 8 * (r >> 2);
+            float v = acc[x][r];
+            if (n_bias) v += bv;
+            if (n_res) v += rv[x][r];
+            buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(v, act));
+            acc[x][r] = 0.f;
+          }
+      };
+      switch (p.act) {
+        case AOT_ACT_RELU: store_all(std::integral_constant<int, AOT_ACT_RELU>{}); break;
+        case AOT_ACT_RELU6: store_all(std::integral_constant<int, AOT_ACT_RELU6>{}); break;
+        case AOT_ACT_GELU: store_all(std::integral_constant<int, AOT_ACT_GELU>{}); break;
+        case AOT_ACT_SILU: store_all(std::integral_constant<int, AOT_ACT_SILU>{}); break;
+        default: store_all(std::integral_constant<int, AOT_ACT_NONE>{}); break;
+      }
+    }
+#else
 #pragma unroll
     for (int x = 0; x < BMB; ++x)
 #pragma unroll
@@ -630,6 +689,7 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
         buf_store(desc_out, (col_ok && m < p.M) ? (m * p.ldc + n) * 4 : (int)OOB, apply_act(v, p.act));
         acc[x][r] = 0.f;
       }
+#endif
     stores_pending = 16 * BMB;
   };
   constexpr int NM = 16 * BMB;              // MFMAs of one step
