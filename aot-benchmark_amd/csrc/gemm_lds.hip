@@ -655,6 +655,19 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
       const int mlane = m0 + wm + 4 * half;          // output row of accumulator register 0 (block 0) in this lane
       const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
       const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+      // bias and residual in passes of their own (a wave-uniform branch each; same order of additions as the fused form)
+      if (n_bias) {
+#pragma unroll
+        for (int x = 0; x < BMB; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[x][r] += bv;
+      }
+      if (n_res) {
+#pragma unroll
+        for (int x = 0; x < BMB; ++x)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[x][r] += rv[x][r];
+      }
       auto store_all = [&](auto ACT) __attribute__((always_inline)) -> void {
         constexpr int act = decltype(ACT)::value;
 #pragma unroll
@@ -662,10 +675,7 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int c = 32 * x + (r & 3) + 8 * (r >> 2);
-            float v = acc[x][r];
-            if (n_bias) v += bv;
-            if (n_res) v += rv[x][r];
-            buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(v, act));
+            buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(acc[x][r], act));
             acc[x][r] = 0.f;
           }
       };
