@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels of libaot_hip.so.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,5 +28,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == AOT_ACT_SILU) return v * (1.f / (1.f + expf(-v)));   // x * sigmoid(x), attention.py:585-586
   return v;
 }
+
+// One wave-uniform branch on the activation around a whole store loop instead of apply_act's if-chain per element:
+//   with_act(p.act, [&](auto ACT) { ... apply_act(v, decltype(ACT)::value) ... });
+template <class F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
+  switch (act) {
+    case AOT_ACT_RELU: f(std::integral_constant<int, AOT_ACT_RELU>{}); break;
+    case AOT_ACT_RELU6: f(std::integral_constant<int, AOT_ACT_RELU6>{}); break;
+    case AOT_ACT_GELU: f(std::integral_constant<int, AOT_ACT_GELU>{}); break;
+    case AOT_ACT_SILU: f(std::integral_constant<int, AOT_ACT_SILU>{}); break;
+    default: f(std::integral_constant<int, AOT_ACT_NONE>{}); break;
+  }
+}
+// AOT_CONV_EPI = 1: the register-staged and the wave-independent GEMM kernels (gemm_conv.hip) end their tiles through
+// with_act(); same values stored, not yet timed on the GPU, hence off.
+#ifndef AOT_CONV_EPI
+#define AOT_CONV_EPI 0
+#endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -166,23 +166,35 @@ conv_gemm_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: bias (folded BN) + residual + activation; 32 lanes write 128 contiguous bytes ----
+#if AOT_CONV_EPI
+  with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+    constexpr int act = decltype(ACT)::value;
+#else
+  {
+    const int act = p.act;
+#endif
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + j * 32 + l31;
-      if (n >= p.Cout) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + mfma32_row(r, kh);
-        if (m < p.M) {
-          float v = acc[i][j][r] + bv;
-          if (p.res) v += p.res[(long)(p.res_rows ? m % p.res_rows : m) * p.ldr + n];
-          p.out[(long)m * p.ldc + n] = apply_act(v, p.act);
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + mfma32_row(r, kh);
+          if (m < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (p.res) v += p.res[(long)(p.res_rows ? m % p.res_rows : m) * p.ldr + n];
+            p.out[(long)m * p.ldc + n] = apply_act(v, act);
+          }
         }
       }
-    }
+#if AOT_CONV_EPI
+  });
+#else
+  }
+#endif
 }
 
 
@@ -291,6 +303,13 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
   }
   if (n < p.Cout) {
     const float bv = p.bias ? p.bias[n] : 0.f;
+#if AOT_CONV_EPI
+    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+      constexpr int act = decltype(ACT)::value;
+#else
+    {
+      const int act = p.act;
+#endif
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = (KS > 1 ? wave * RPW : 0) + i;
@@ -298,9 +317,14 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
       if (mo < p.M) {
         float v = fin[i] + bv;
         if (p.res) v += p.res[(long)(p.res_rows ? mo % p.res_rows : mo) * p.ldr + n];
-        p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
+        p.out[(long)mo * p.ldc + n] = apply_act(v, act);
       }
     }
+#if AOT_CONV_EPI
+    });
+#else
+    }
+#endif
   }
 }
 
@@ -439,6 +463,13 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
   }
   if (n < p.Cout) {
     const float bv = p.bias ? p.bias[n] : 0.f;
+#if AOT_CONV_EPI
+    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+      constexpr int act = decltype(ACT)::value;
+#else
+    {
+      const int act = p.act;
+#endif
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = (KS > 1 ? wave * RPW : 0) + i;      // 0..15 -> fragment 0, 16..31 -> fragment 1
@@ -446,9 +477,14 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
       if (mo < p.M) {
         float v = fin[i] + bv;
         if (p.res) v += p.res[(long)(p.res_rows ? mo % p.res_rows : mo) * p.ldr + n];
-        p.out[(long)mo * p.ldc + n] = apply_act(v, p.act);
+        p.out[(long)mo * p.ldc + n] = apply_act(v, act);
       }
     }
+#if AOT_CONV_EPI
+    });
+#else
+    }
+#endif
   }
 }
 
