@@ -603,7 +603,10 @@ def _decode(owner, cohorts, output_size):
             for c in cohorts:
                 lg, h4, w4 = c.decode_stride4()
                 parts.append(lg.clone())                    # the decoder's output scratch is shared by the cohorts
-            buf = torch.empty(sum(p.shape[0] for p in parts), parts[0].stride(0), dtype=torch.float32, device=parts[0].device)
+            # (rows padded to a multiple of four floats, like the decoder's own output: the finalize kernel then takes its
+            #  16-byte loads, the path every multi-lane test runs)
+            buf = torch.zeros(sum(p.shape[0] for p in parts), (parts[0].shape[1] + 3) // 4 * 4, dtype=torch.float32,
+                              device=parts[0].device)
             r = 0
             for lg in parts:
                 buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
