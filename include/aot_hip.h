@@ -72,7 +72,8 @@ int aot_maxpool3x3s2_nhwc_f32(const float* in, float* out, int H, int W, int C, 
 /* [C,H,W] planar image -> [H*W, Cpad] interleaved, channels >= C zero filled (input layout
  * change in front of the stem conv; the reference keeps NCHW throughout). */
 int aot_nchw_to_nhwc_f32(const float* in, float* out, int C, int H, int W, int Cpad, void* stream);
-/* [H*W, C] (row stride ld) -> [C,H,W] planar. */
+/* [H*W, C] (row stride ld) -> [C,H,W] planar: the layout callers of the reference's surface expect back (feature maps of
+ * AOT.encode_image, aot.py:81-84; logits of decode_id_logits, aot.py:86-92). */
 int aot_nhwc_to_nchw_f32(const float* in, float* out, int C, int H, int W, int ld, void* stream);
 
 /* LayerNorm over the last dim (eps inside sqrt, biased variance, as torch):
@@ -117,7 +118,8 @@ int aot_gn_act_dwconv5_f32(const float* x, const double* stats, const float* gam
 int aot_attn_f32(const float* q, const float* k, const float* v, float* out, float* part, int B, long kv_brows,
                  int Nq, int T, const int* T_dev, int H, int d, int ldq, int ldk, int ldv, int ldo,
                  float scale_div, int nsplit, void* stream);
-/* Merge of the nsplit partials written by aot_attn_f32 / aot_gated_attn_f32 (nsplit > 1) into out [Nq, ldo]:
+/* Merge of the nsplit partials written by aot_attn_f32 / aot_gated_attn_f32 (nsplit > 1) into out [Nq, ldo] (second half of
+ * the softmax(QK^T)V of attention.py:92-117 / 672-707 when the bank is cut over workgroups):
  * C output channels in H groups that carry one (m, l) each; optional gate [Nq, ldg] multiplies the result. */
 int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq, int H, int C, int ldg,
                        int ldo, int nsplit, void* stream);
@@ -249,7 +251,7 @@ int aot_label_resize_f32(const float* src, float* dst, int H, int W, int OH, int
  * number). */
 int aot_ce_loss_f32(const float* logits, const float* labels, float* loss_px, float* loss, unsigned* thr, float* cnt, int B,
                     int C, long P, long top_k, void* stream);
-/* grad [B,C,P] = gscale[b] * (softmax - onehot) on the pixels that entered loss[b] (thr given: per-pixel loss >= the k-th
+/* What autograd derives from loss.py:137-188: grad [B,C,P] = gscale[b] * (softmax - onehot) on the pixels that entered loss[b] (thr given: per-pixel loss >= the k-th
  * largest; thr = NULL: every valid pixel), 0 elsewhere.  gscale[b] = upstream gradient / k (or / cnt[b]). */
 int aot_ce_loss_bwd_f32(const float* logits, const float* labels, const float* loss_px, const unsigned* thr,
                         const float* gscale, float* grad, int B, int C, long P, void* stream);
@@ -259,6 +261,7 @@ int aot_ce_loss_bwd_f32(const float* logits, const float* labels, const float* l
  * B*nchunk*16*3 doubles, sums [B,16,3] (I, sum p, sum g per class) is kept for the backward pass. */
 int aot_soft_jaccard_f32(const float* logits, const float* labels, double* part, double* sums, float* loss, int B, int C, long P,
                          int nchunk, float eps, void* stream);
+/* What autograd derives from loss.py:26-52,119-137: grad [B,C,P] of sum_b gout[b] * loss[b] w.r.t. the logits (through the softmax). */
 int aot_soft_jaccard_bwd_f32(const float* logits, const float* labels, const double* sums, const float* gout, float* grad, int B,
                              int C, long P, float eps, void* stream);
 
@@ -268,7 +271,8 @@ int aot_adamw_step_f32(float* p, const float* g, float* m, float* v, long n, flo
                        float beta2, float eps, int step, float gscale, void* stream);
 /* utils/ema.py:63-66: shadow -= one_minus_decay * (shadow - param). */
 int aot_ema_update_f32(float* shadow, const float* param, long n, float one_minus_decay, void* stream);
-/* out[0] += sum(x^2) in fp64 (one workgroup, fixed order): the gradient-norm reduction of clip_grad_norm_. */
+/* out[0] += sum(x^2) in fp64 (one workgroup, fixed order): the gradient-norm reduction of clip_grad_norm_
+ * (trainer.py:501-503). */
 int aot_sumsq_accum_f64(const float* x, long n, double* out, void* stream);
 
 #ifdef __cplusplus
