@@ -73,6 +73,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 #ifndef AOT_ATT_VPM
 #define AOT_ATT_VPM 4
 #endif
+#ifndef AOT_COOP_AGPR      // DeAOT kernel: the (rare) accumulator rescale reads / writes the accumulation registers explicitly, so that
+#define AOT_COOP_AGPR 0    // the 128 accumulators stay in AGPRs across the branch (the shipped build copies them to VGPRs and back
+#endif                     // on EVERY key tile: ~270 v_accvgpr moves per step in the ISA); not yet timed
 #ifndef AOT_ATT_PKSUM      // row sums through v_pk_add_f32 (the plain `ps += p2` compiles to two scalar adds per pair); not yet timed
 #define AOT_ATT_PKSUM 0
 #endif
@@ -656,9 +659,19 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
       for (int d = 0; d < NDV; ++d)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
+#if AOT_COOP_AGPR
+          float a0, a1;
+          asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a0), "=v"(a1) : "a"(o[d][r]), "a"(o[d][r + 1]));
+          const f32x2 t = pk_mul(f32x2{a0, a1}, al2);
+          float w0, w1;
+          asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(w0), "=a"(w1) : "v"(t[0]), "v"(t[1]));
+          o[d][r] = w0;
+          o[d][r + 1] = w1;
+#else
           const f32x2 t = pk_mul(f32x2{o[d][r], o[d][r + 1]}, al2);
           o[d][r] = t[0];
           o[d][r + 1] = t[1];
+#endif
         }
     }
 #pragma unroll
