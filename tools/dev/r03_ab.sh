@@ -11,6 +11,8 @@ for v in "$@"; do
   echo "$v: pytest rc=$? $(tail -1 $O/ab_$v.test.log)"
   timeout 300 python bench.py --no-cpu-baseline --no-jf > $O/ab_$v.bench.json 2> $O/ab_$v.bench.err
   python -c "import json,sys; d=json.load(open('$O/ab_$v.bench.json')); print('$v', d['value'], d['config']['single_stream']['fps'], d['roofline']['achieved'])"
+  case $v in base|*coop*|all*) timeout 200 python bench.py --model r50_deaotl --no-cpu-baseline > $O/ab_$v.deaot.json 2>/dev/null
+    python -c "import json; d=json.load(open('$O/ab_$v.deaot.json')); print('$v r50_deaotl', d['value'], d['config']['single_stream']['fps'])";; esac
   timeout 300 python tools/dev/mb_gemm.py -1,197 > $O/ab_$v.gemm.txt 2>&1; tail -2 $O/ab_$v.gemm.txt       # (uses the library in place)
 done
 cp /tmp/libaot_hip_base.so $L/libaot_hip.so
