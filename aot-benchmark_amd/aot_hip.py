@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libaot_hip.so')
+LIB_PATH = os.environ.get('AOT_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libaot_hip.so')   # (AOT_HIP_LIB: A/B runs of variant builds, tools/dev)
 _lib = None
 
 _P = ctypes.c_void_p
@@ -58,21 +58,31 @@ ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 
 # Which kernel table aot_conv2d_nhwc_f32 uses when a caller leaves the choice open (cfg = -1): 'latency' = fastest launch on
 # its own (one clip at a time), 'throughput' = cheapest in SIMD time when several clips share the GPU (include/aot_hip.h).
+# The choice belongs to an ENGINE (build_engine(..., gemm_table=)): every stage of an engine runs inside
+# `with use_gemm_table(engine.gemm_table)`, so two engines of one process can use different tables and nothing outlives
+# the stage call.  Outside any scope the table is 'latency'.
 GEMM_TABLES = {'latency': -1, 'throughput': -2}
-_gemm_table = -1
+_table_scopes = []
 
 
-def set_gemm_table(name):
-    """Selects the dispatch table for all later conv2d / linear calls of this process; returns the previous name.  Engines
-    in graph mode key their captured graphs on it, so switching never replays a graph captured under the other table."""
-    global _gemm_table
-    prev = gemm_table()
-    _gemm_table = GEMM_TABLES[name]
-    return prev
+class use_gemm_table:
+    """Scope in which conv2d / linear calls that leave the kernel choice open use the named dispatch table."""
+
+    def __init__(self, name):
+        self.cfg = GEMM_TABLES[name]
+
+    def __enter__(self):
+        _table_scopes.append(self.cfg)
+        return self
+
+    def __exit__(self, *exc):
+        _table_scopes.pop()
+        return False
 
 
 def gemm_table():
-    return 'throughput' if _gemm_table == -2 else 'latency'
+    """Name of the table in force here (graph keys carry it: a graph captured under one table never replays under the other)."""
+    return 'throughput' if _table_scopes and _table_scopes[-1] == -2 else 'latency'
 
 
 class AotHipError(RuntimeError):
@@ -148,7 +158,8 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
     _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), None, 0, B, H, W, Cin, OH,
                                     OW, Cout, KH, KW, stride, pad, dil, x.stride(0), w.stride(0),
                                     wt.stride(0) if wt is not None else 0, out.stride(0),
-                                    res.stride(0) if res is not None else 0, res_rows, act, _gemm_table if cfg == -1 else cfg,
+                                    res.stride(0) if res is not None else 0, res_rows, act,
+                                    (_table_scopes[-1] if _table_scopes else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 
@@ -466,17 +477,33 @@ def soft_jaccard_bwd(logits, labels, sums, gout, eps=1e-6, stream=None):
     return grad
 
 
+def _flat_f32(*tensors):
+    """The optimiser / EMA / norm kernels walk raw memory: fp32 and contiguous, or they would corrupt the tensor silently."""
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise AotHipError('expected a contiguous float32 tensor, got %s, contiguous=%s' % (t.dtype, t.is_contiguous()))
+
+
 def adamw_step(p, g, m, v, lr, weight_decay, beta1, beta2, eps, step, gscale=1.0, stream=None):
+    _flat_f32(p, g, m, v)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise AotHipError('adamw_step: parameter, gradient and moments differ in size')
     _chk(load().aot_adamw_step_f32(_dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, weight_decay, beta1, beta2, eps, int(step),
                                    gscale, stream if stream is not None else stream_ptr()), 'aot_adamw_step_f32')
 
 
 def ema_update(shadow, param, one_minus_decay, stream=None):
+    _flat_f32(shadow, param)
+    if shadow.numel() != param.numel():
+        raise AotHipError('ema_update: shadow and parameter differ in size')
     _chk(load().aot_ema_update_f32(_dev(shadow), _dev(param), shadow.numel(), one_minus_decay,
                                    stream if stream is not None else stream_ptr()), 'aot_ema_update_f32')
 
 
 def sumsq_accum(x, out, stream=None):
     """out (one fp64 element on the device) += sum(x^2)."""
+    _flat_f32(x)
+    if out.dtype != torch.float64:
+        raise AotHipError('sumsq_accum: the accumulator must be float64')
     _chk(load().aot_sumsq_accum_f64(_dev(x), x.numel(), _dev(out), stream if stream is not None else stream_ptr()),
          'aot_sumsq_accum_f64')

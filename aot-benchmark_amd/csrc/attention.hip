@@ -76,6 +76,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 #ifndef AOT_COOP_AGPR      // DeAOT kernel: the (rare) accumulator rescale reads / writes the accumulation registers explicitly, so that
 #define AOT_COOP_AGPR 0    // the 128 accumulators stay in AGPRs across the branch (the shipped build copies them to VGPRs and back
 #endif                     // on EVERY key tile: ~270 v_accvgpr moves per step in the ISA); not yet timed
+#ifndef AOT_ATT_SPLIT_MAJOR   // d = 32 kernel: workgroups of one key range (grid-level split) are dispatched together (see the launch)
+#define AOT_ATT_SPLIT_MAJOR 0
+#endif
 #ifndef AOT_ATT_PKSUM      // row sums through v_pk_add_f32 (the plain `ps += p2` compiles to two scalar adds per pair); not yet timed
 #define AOT_ATT_PKSUM 0
 #endif
@@ -118,9 +121,13 @@ __device__ __forceinline__ float exp2_w(float s, float mL) {
 __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnParams p) {
   // 4 waves per workgroup (one per SIMD of the CU), 4 workgroups per CU -> 4 waves per SIMD
   __shared__ float red[4][18][64];      // per wave: o[16], m, l  (18 KB)
-  const int h = blockIdx.x, split = blockIdx.y;
+#if AOT_ATT_SPLIT_MAJOR
+  const int h = blockIdx.x, split = blockIdx.z, bz = blockIdx.y;
+#else
+  const int h = blockIdx.x, split = blockIdx.y, bz = blockIdx.z;
+#endif
   const int ntq = (p.Nq + 31) >> 5;
-  const int b = blockIdx.z / ntq, qt = blockIdx.z - b * ntq;
+  const int b = bz / ntq, qt = bz - b * ntq;
   const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -749,7 +756,15 @@ extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, floa
   AttnParams p;
   const int rc = fill_params(p, q, k, v, out, part, B, kv_brows, Nq, T, T_dev, H, ldq, ldk, ldv, ldo, scale_div, nsplit);
   if (rc) return rc;
+  // Workgroup b of a grid runs on XCD b % 8 (observed dispatch rule), so with H = 8 heads in blockIdx.x every XCD serves one
+  // head: its L2 sees that head's K / V slices only.  The grid has 53 x nsplit workgroups per head on 128 resident slots
+  // per XCD; the ones that start in the second dispatch round re-stream their key range.  Split-major order makes that
+  // second round the tail of ONE key range instead of a slice of all of them (fabric traffic of the re-read / nsplit).
+#if AOT_ATT_SPLIT_MAJOR
+  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, B * cdiv(Nq, 32), nsplit), dim3(256), 0, (hipStream_t)stream, p);
+#else
   hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+#endif
   AOT_LAUNCH_CHECK();
 }
 

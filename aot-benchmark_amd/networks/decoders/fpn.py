@@ -53,6 +53,8 @@ class FPNSegmentationHead(nn.Module):
         p = self.pack()
         dev = x_in.device
         hd = self.hidden
+        if x_in.shape[1] != self.in_dim:      # conv_in's weight has in_dim rows: a wider input would read past it
+            raise aot_hip.AotHipError('decoder expects %d input channels, got %d' % (self.in_dim, x_in.shape[1]))
         (s16, h16, w16), (s8, h8, w8), (s4, h4, w4) = f16, f8, f4
         n16, n8, n4 = h16 * w16, h8 * w8, h4 * w4
         ad16 = ws.get('dec_ad16', (n16, hd), dev)

@@ -41,26 +41,29 @@ class Bottleneck(nn.Module):
             self._p = p
         return self._p
 
-    def run(self, x, H, W, ws, stream, out=None, tag=''):
-        """x [H*W, Cin] -> [OH*OW, 4*planes]; reference Bottleneck.forward, resnet.py:34-54."""
+    def run(self, x, H, W, ws, stream, out=None, tag='', B=1):
+        """x [B*H*W, Cin] (B images stacked along the rows) -> [B*OH*OW, 4*planes]; reference Bottleneck.forward,
+        resnet.py:34-54."""
         p = self.pack()
         dev = x.device
         cin = x.shape[1]
         planes = self.conv1.out_channels
         s, d = self.stride, self.dilation
         OH, OW = _osz(H, 3, s, d, d), _osz(W, 3, s, d, d)
-        t1 = ws.get('bt1' + tag, (H * W, planes), dev)
-        aot_hip.conv2d(x, *p['c1'], t1, H, W, cin, H, W, planes, act=aot_hip.ACT_RELU, stream=stream)
-        t2 = ws.get('bt2' + tag, (OH * OW, planes), dev)
-        aot_hip.conv2d(t1, *p['c2'], t2, H, W, planes, OH, OW, planes, 3, 3, s, d, d, act=aot_hip.ACT_RELU, stream=stream)
+        t1 = ws.get('bt1' + tag, (B * H * W, planes), dev)
+        aot_hip.conv2d(x, *p['c1'], t1, H, W, cin, H, W, planes, act=aot_hip.ACT_RELU, B=B, stream=stream)
+        t2 = ws.get('bt2' + tag, (B * OH * OW, planes), dev)
+        aot_hip.conv2d(t1, *p['c2'], t2, H, W, planes, OH, OW, planes, 3, 3, s, d, d, act=aot_hip.ACT_RELU, B=B,
+                       stream=stream)
         if self.downsample is not None:
-            res = ws.get('bds' + tag, (OH * OW, planes * 4), dev)
-            aot_hip.conv2d(x, *p['ds'], res, H, W, cin, OH, OW, planes * 4, 1, 1, s, 0, 1, stream=stream)
+            res = ws.get('bds' + tag, (B * OH * OW, planes * 4), dev)
+            aot_hip.conv2d(x, *p['ds'], res, H, W, cin, OH, OW, planes * 4, 1, 1, s, 0, 1, B=B, stream=stream)
         else:
             res = x
         if out is None:
-            out = ws.get('bout' + tag, (OH * OW, planes * 4), dev)
-        aot_hip.conv2d(t2, *p['c3'], out, OH, OW, planes, OH, OW, planes * 4, res=res, act=aot_hip.ACT_RELU, stream=stream)
+            out = ws.get('bout' + tag, (B * OH * OW, planes * 4), dev)
+        aot_hip.conv2d(t2, *p['c3'], out, OH, OW, planes, OH, OW, planes * 4, res=res, act=aot_hip.ACT_RELU, B=B,
+                       stream=stream)
         return out, OH, OW
 
 
@@ -100,21 +103,27 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes, dilation=dilation, BatchNorm=BatchNorm))
         return nn.Sequential(*layers)
 
+    batched = True       # run() takes B images at once (AOTEngine.encode_ahead: the frames ahead of a clip as one batch)
+
     def run(self, img, ws, stream):
-        """img [1,3,H,W] planar -> [(feat [h*w, C], h, w)] for strides 4, 8, 16 (reference forward, :140-157;
-        the reference returns the stride-16 map twice)."""
-        _, _, H, W = img.shape
+        """img [B,3,H,W] planar -> [(feat [B*h*w, C], h, w)] for strides 4, 8, 16, the B images stacked along the rows
+        (reference forward, :140-157; the reference returns the stride-16 map twice).  The reference's offline_encoder
+        (aot_engine.py:147-166) likewise encodes all frames it has in one batch."""
+        B, _, H, W = img.shape
         dev = img.device
         if self._stem is None:
             self._stem = fold_conv_bn(self.conv1, self.bn1, pad_cin=4)
-        x4 = ws.get('img_nhwc4', (H * W, 4), dev)
-        aot_hip.nchw_to_nhwc(img, x4, 3, H, W, 4, stream=stream)
+        x4 = ws.get('img_nhwc4', (B * H * W, 4), dev)
         H1, W1 = _osz(H, 7, 2, 3), _osz(W, 7, 2, 3)
-        s1 = ws.get('stem', (H1 * W1, 64), dev)
-        aot_hip.conv2d(x4, *self._stem, s1, H, W, 4, H1, W1, 64, 7, 7, 2, 3, 1, act=aot_hip.ACT_RELU, stream=stream)
+        for b in range(B):
+            aot_hip.nchw_to_nhwc(img[b:b + 1], x4[b * H * W:(b + 1) * H * W], 3, H, W, 4, stream=stream)
+        s1 = ws.get('stem', (B * H1 * W1, 64), dev)
+        aot_hip.conv2d(x4, *self._stem, s1, H, W, 4, H1, W1, 64, 7, 7, 2, 3, 1, act=aot_hip.ACT_RELU, B=B, stream=stream)
         H2, W2 = _osz(H1, 3, 2, 1), _osz(W1, 3, 2, 1)
-        x = ws.get('pool', (H2 * W2, 64), dev)
-        aot_hip.maxpool3x3s2(s1, x, H1, W1, 64, H2, W2, stream=stream)
+        x = ws.get('pool', (B * H2 * W2, 64), dev)
+        for b in range(B):
+            aot_hip.maxpool3x3s2(s1[b * H1 * W1:(b + 1) * H1 * W1], x[b * H2 * W2:(b + 1) * H2 * W2], H1, W1, 64, H2, W2,
+                                 stream=stream)
         feats = []
         h, w = H2, W2
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3)):
@@ -125,9 +134,9 @@ class ResNet(nn.Module):
                 if last:   # stage outputs are decoder shortcuts: keep them in their own buffers
                     planes4 = blk.conv3.out_channels
                     ho, wo = _osz(h, 3, blk.stride, blk.dilation, blk.dilation), _osz(w, 3, blk.stride, blk.dilation, blk.dilation)
-                    out = ws.get('stage%d' % li, (ho * wo, planes4), dev)
+                    out = ws.get('stage%d' % li, (B * ho * wo, planes4), dev)
                 # ping-pong block outputs so a block never overwrites its own input / residual
-                x, h, w = blk.run(x, h, w, ws, stream, out=out, tag='_%d_%d' % (li, bi & 1))
+                x, h, w = blk.run(x, h, w, ws, stream, out=out, tag='_%d_%d' % (li, bi & 1), B=B)
             feats.append((x, h, w))
         return feats
 

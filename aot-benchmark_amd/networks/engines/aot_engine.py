@@ -18,6 +18,8 @@ MI355X-first design -- same results as the reference, different machinery:
 
 ``AOTInferEngine`` is the caller-facing surface (tools/demo.py:187-235, networks/managers/evaluator.py:265-446).
 """
+import functools
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -26,6 +28,21 @@ import aot_hip
 from networks.engines.graphs import FrameGraphs, ptr_key
 from networks.layers.workspace import Workspace
 from networks.models.aot import as_map, to_tokens
+
+
+def _in_table(fn):
+    """Runs an engine stage inside the engine's own GEMM dispatch table (aot_hip.use_gemm_table): the table is an engine
+    attribute (build_engine(..., gemm_table=)), not process state."""
+    @functools.wraps(fn)
+    def stage(self, *args, **kwargs):
+        with aot_hip.use_gemm_table(self.gemm_table):
+            return fn(self, *args, **kwargs)
+    return stage
+
+
+def _img_key(img):
+    """Identity of a caller-owned frame: address, shape and version counter (a buffer re-filled in place is a new frame)."""
+    return (img.data_ptr(), tuple(img.shape), img._version)
 
 
 def _die(msg):
@@ -40,8 +57,13 @@ class AOTEngine(nn.Module):
     0..max_obj_num as they are."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None, lanes=1,
-                 group0=None, graph=False):
+                 group0=None, graph=False, gemm_table='latency'):
         super().__init__()
+        # which conv / linear dispatch table this engine's stages run under (include/aot_hip.h, cfg -1 / -2): 'latency' for
+        # one clip at a time, 'throughput' when several engines keep the GPU busy on their own streams
+        if gemm_table not in aot_hip.GEMM_TABLES:
+            raise ValueError('gemm_table must be one of %s' % sorted(aot_hip.GEMM_TABLES))
+        self.gemm_table = gemm_table
         # graph=True: the launch sequence of every stage (match / decode / memory update) is captured once per engine
         # state as a hipGraph and replayed (engines/graphs.py).  What decode_current_logits returns is then a buffer that
         # belongs to the graph: valid until the next decode of this engine (the reference returns a fresh tensor).
@@ -49,8 +71,7 @@ class AOTEngine(nn.Module):
         self._graphs = None
         self._static = {}            # staged copies of caller-owned inputs (image, label map): stable addresses for replay
         self._arena = Workspace()    # tensors that live from one stage of a frame to the next (curr_V, decoder input)
-        self._enc = None             # look-ahead encoder: two side streams (+ events, graph caches) used alternately
-        self._prefetched = None      # (image tensor, its token-major features, side-stream index) of prefetch_encode()
+        self._ahead = {}             # _img_key(image tensor) -> its token-major features: frames encoded by encode_ahead()
         # long_term_mem_max (repo extension; the reference bank grows without bound): at most that many
         # memorised frames -- the first one (the reference frame) is kept, the others form a ring of the most recent
         if long_term_mem_max is not None and long_term_mem_max < 2:
@@ -85,6 +106,7 @@ class AOTEngine(nn.Module):
         self.aux_weight = cfg.TRAIN_AUX_LOSS_WEIGHT
         self.aux_step = cfg.TRAIN_TOTAL_STEPS * cfg.TRAIN_AUX_LOSS_RATIO + 1e-5
 
+    @_in_table
     def forward(self, all_frames, all_masks, batch_size, obj_nums, step=0, tf_board=False, use_prev_pred=False,
                 enable_prev_frame=False, use_prev_prob=False):
         """The reference's training-step forward: all_frames [T*bs, 3, H, W] / all_masks [T*bs, 1, H, W], time-major
@@ -99,6 +121,12 @@ class AOTEngine(nn.Module):
         (DESIGN.md section 7), only the losses themselves differentiate (layers/loss.py)."""
         if self.lanes != 1 or self.group0 is not None:
             raise NotImplementedError('the training forward runs <= %d objects per sample on one lane' % self.max_obj_num)
+        if torch.is_grad_enabled() and not getattr(self, '_warned_no_graph', False):
+            # a caller porting the reference trainer would otherwise only find out at loss.backward()
+            import warnings
+            warnings.warn('AOTEngine.forward returns loss VALUES: the hand-written kernels carry no autograd graph; gradients of '
+                          'the model come from networks.engines.backward (see DESIGN.md, training path), not from loss.backward()')
+            self._warned_no_graph = True
         if self.losses is None:
             self._init_losses()
         bs = int(batch_size)
@@ -170,6 +198,7 @@ class AOTEngine(nn.Module):
         mask, _, prob = aot_hip.fuse_probs(logits, [False], want_aug_labels=False, want_prob=want_prob)
         return loss, mask.view(1, *size).long(), prob
 
+    @_in_table
     def generate_loss_mask(self, gt_mask, step, return_prob=False):
         """aot_engine.py:421-430 for the clip this engine holds (batch 1): decode, score against gt_mask [1,1,H,W] or
         [1,H,W], predict.  Returns (loss [1], mask [1,H,W]) and, return_prob, the class probabilities [1,L,H,W]."""
@@ -195,6 +224,7 @@ class AOTEngine(nn.Module):
         known = ids <= self.max_obj_num                           # (the ignore label stays what it is)
         return torch.where(known, perm[ids.clamp(max=self.max_obj_num)], ids).float()
 
+    @_in_table
     def set_prev_frame(self, img=None, mask=None, frame_step=1):
         """aot_engine.py:253-289: a second frame that memorises its own mask (appended to the bank, becomes the short-term
         memory) -- the reference-frame stage again at another frame counter."""
@@ -239,7 +269,7 @@ class AOTEngine(nn.Module):
         self._dst = None             # buffers this frame's K / V live in
         self.curr_id_embs = None
         self.pred_id_logits = None
-        self._prefetched = None
+        self._ahead = {}
 
     def update_size(self, input_size, enc_size):
         self.input_size_2d = tuple(int(x) for x in input_size)
@@ -271,9 +301,9 @@ class AOTEngine(nn.Module):
         reference keeps as curr_lstt_output[0][-1] (aot_engine.py:340-354)."""
         N = self.enc_hw
         rows = self._dec_in[lane * N:(lane + 1) * N]
-        if not self.AOT.decoder.decode_intermediate_input:
+        if type(self.AOT.LSTT).__name__ == 'DualBranchGPM':      # DeAOT: the decoder input IS the normed [tgt | tgt_id]
             return rows
-        return rows[:, -self.AOT.encoder_projector.out_channels:]
+        return rows[:, -self.AOT.encoder_projector.out_channels:]   # AOT: last column block of [feature | layer outputs]
 
     @property
     def long_term_memories(self):
@@ -372,42 +402,36 @@ class AOTEngine(nn.Module):
         return buf
 
     # ---- look-ahead encoding -------------------------------------------------------------------
-    def prefetch_encode(self, img):
-        """Optional: starts the encoder of the NEXT frame on a side stream now, so that it runs beside this frame's attention
-        and decoder -- the encoder (a third of a frame's work) does not depend on the memory state, and one clip alone cannot
-        fill the chip.  The match_propogate_one_frame call that receives the SAME tensor picks the result up; any other call
-        ignores it.  Two side streams alternate, each with its own scratch (scratch is keyed by stream), so a frame's shortcut
-        features stay intact while the frame after next is being encoded.  Results are bit-identical to encoding in line.
-        MEASURED SLOWER on MI355X (bench.py --prefetch 1: one clip at a time 307 vs 378 fps): the two cross-stream event waits
-        per frame cost more than the overlap returns, so nothing calls it by default."""
-        dev = img.device
-        if self._enc is None:
-            self._enc = {'streams': [torch.cuda.Stream(dev), torch.cuda.Stream(dev)],
-                         'events': [torch.cuda.Event(), torch.cuda.Event()], 'graphs': [None, None], 'sel': 0}
-        e = self._enc
-        i = e['sel']
-        e['sel'] ^= 1
-        side = e['streams'][i]
-        side.wait_stream(torch.cuda.current_stream(dev))     # everything issued so far (incl. the last readers of this set)
-        img.record_stream(side)
-        with torch.cuda.stream(side):
-            if self.use_graph:
-                if e['graphs'][i] is None:
-                    e['graphs'][i] = FrameGraphs(dev)
-                src = self._stage('img_ahead%d' % i, img)
-                feats = e['graphs'][i].run(ptr_key('encode', src, aot_hip.gemm_table()), lambda: self.AOT.encode_tokens(src))
-            else:
-                feats = self.AOT.encode_tokens(img)
-            e['events'][i].record(side)
-        self._prefetched = (img, feats, i)
+    @_in_table
+    def encode_ahead(self, imgs):
+        """Optional: encodes the NEXT frames of the clip (a list of [1,3,H,W] tensors, in the order they will be matched) as
+        ONE batch, on the current stream -- the encoder does not depend on the memory state (the reference's offline_encoder,
+        aot_engine.py:147-166, likewise encodes every frame it has at once), and a batch of three 480p frames fills the 256
+        CUs where one frame cannot (tile counts of the stride-8 / 16 stages triple).  The match_propogate_one_frame calls that
+        receive THE SAME tensors pick their features up; any other image is encoded in line as before.  The batch lives in
+        per-stream scratch: a new call replaces whatever an earlier call left unused.  Same arithmetic per output element up
+        to the split-K summation order of the GEMM dispatch (parity against the reference: the whole-clip golden tests run
+        with look-ahead on and off).  No-op for encoders that take one image per call."""
+        self._ahead = {}
+        if not imgs or not getattr(self.AOT.encoder, 'batched', False):
+            return
+        k = len(imgs)
+        key = ('imgs_ahead', k, tuple(imgs[0].shape))
+        src = self._static.get(key)          # the batch is gathered into one [k,3,H,W] buffer (stable address: replayable)
+        if src is None:
+            src = self._static[key] = torch.empty((k,) + tuple(imgs[0].shape[1:]), dtype=torch.float32, device=imgs[0].device)
+        for b, img in enumerate(imgs):
+            src[b:b + 1].copy_(img)
+        if self.use_graph:
+            feats = self._gx().run(ptr_key('encode_ahead', src, aot_hip.gemm_table()), lambda: self.AOT.encode_tokens(src))
+        else:
+            feats = self.AOT.encode_tokens(src)
+        for b, img in enumerate(imgs):
+            self._ahead[_img_key(img)] = [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats]
 
-    def _take_prefetched(self, img):
-        """Features of prefetch_encode(img) if that is the tensor being matched now (the current stream then waits for them)."""
-        pf, self._prefetched = self._prefetched, None
-        if pf is None or img is None or pf[0] is not img:
-            return None
-        torch.cuda.current_stream(img.device).wait_event(self._enc['events'][pf[2]])
-        return pf[1]
+    def _take_ahead(self, img):
+        """Features of a frame encoded by encode_ahead(), if `img` is the same memory, unmodified since."""
+        return self._ahead.pop(_img_key(img), None) if img is not None and self._ahead else None
 
     # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):
@@ -428,6 +452,7 @@ class AOTEngine(nn.Module):
         stages pass) through the fused gather.  Returns the id embedding token-major, [lanes*N, C]."""
         return self.AOT.id_emb_from_mask(one_hot_mask, self.enc_size_2d, lanes=self.lanes, group0=self.group0)
 
+    @_in_table
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
         if self.obj_nums is None and obj_nums is None:
             _die('No objects for reference frame!')
@@ -464,6 +489,7 @@ class AOTEngine(nn.Module):
         rows = self._brows_bank() if direct else self.enc_hw
         self._short = [[(k, v, rows) for k, v in dst]]
 
+    @_in_table
     def match_propogate_one_frame(self, img=None, img_embs=None):
         self.frame_step += 1
         T = self.bank_len
@@ -481,7 +507,7 @@ class AOTEngine(nn.Module):
         short = self._short[0]
         self._dst = dst
 
-        ahead = self._take_prefetched(img) if img_embs is None else None
+        ahead = self._take_ahead(img) if img_embs is None else None
 
         def launch(img_, embs_):
             feats = ahead if ahead is not None else self._encode(img_, embs_)
@@ -500,8 +526,15 @@ class AOTEngine(nn.Module):
     def decode_stride4(self):
         """Runs the decoder for the cohort's lanes: stride-4 logits [lanes*h4*w4, max_obj+1] (a scratch view), h4, w4."""
         f4, f8, f16, _ = self._feats
-        return self.AOT.decoder.run(self._dec_in, f16, f8, f4, self.AOT.ws, aot_hip.stream_ptr(), B=self.lanes)
+        dec = self.AOT.decoder
+        x_in = self._dec_in
+        if not dec.decode_intermediate_input and x_in.shape[1] != dec.in_dim:
+            # AOT with MODEL_DECODER_INTERMEDIATE_LSTT = False: the decoder takes the last LSTT output only (aot.py:86-92),
+            # the last column block of the concatenated buffer
+            x_in = x_in[:, -dec.in_dim:]
+        return dec.run(x_in, f16, f8, f4, self.AOT.ws, aot_hip.stream_ptr(), B=self.lanes)
 
+    @_in_table
     def decode_current_logits(self, output_size=None):
         """Single-cohort form of the reference call (aot_engine.py:356-380)."""
         return _decode(self, [self], output_size)
@@ -513,6 +546,7 @@ class AOTEngine(nn.Module):
         self._store([(to_tokens(m[0]).contiguous(), to_tokens(m[1]).contiguous()) for m in new_long_term_memories], slot)
         self._commit(slot)
 
+    @_in_table
     def update_short_term_memory(self, curr_mask, curr_id_emb=None, skip_long_term_update=False):
         """curr_mask: label map [1,1,H,W], or a probability map [1,max_obj_num+1,H,W] (one lane).  curr_id_emb, when given,
         replaces the mask's identity embedding: [N, C] token-major as assign_identity returns it, or the reference's [N,1,C]."""
@@ -666,8 +700,11 @@ class AOTInferEngine(nn.Module):
     cohort_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
-                 long_term_mem_max=None, graph=False):
+                 long_term_mem_max=None, graph=False, gemm_table='latency'):
         super().__init__()
+        if gemm_table not in aot_hip.GEMM_TABLES:
+            raise ValueError('gemm_table must be one of %s' % sorted(aot_hip.GEMM_TABLES))
+        self.gemm_table = gemm_table     # conv / linear dispatch table of every cohort of this engine (see AOTEngine)
         self.use_graph = bool(graph)    # replay captured hipGraphs per engine state (see AOTEngine.__init__, engines/graphs.py)
         self.cfg = aot_model.cfg
         self.AOT = aot_model
@@ -702,7 +739,8 @@ class AOTInferEngine(nn.Module):
                 c.restart_engine()
                 return c
         c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
-                            long_term_mem_max=self.long_term_mem_max, lanes=lanes, group0=group0, graph=self.use_graph)
+                            long_term_mem_max=self.long_term_mem_max, lanes=lanes, group0=group0, graph=self.use_graph,
+                            gemm_table=self.gemm_table)
         c.eval()
         return c
 
@@ -730,6 +768,7 @@ class AOTInferEngine(nn.Module):
             self.AOT.ws.clear(stream=aot_hip.stream_ptr())
         self._last_geom = geom
 
+    @_in_table
     def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
         if isinstance(obj_nums, (list, tuple)):
             obj_nums = obj_nums[0]
@@ -748,11 +787,12 @@ class AOTInferEngine(nn.Module):
         first = self._cohorts[0]
         self.input_size_2d, self.enc_size_2d, self.enc_hw = first.input_size_2d, first.enc_size_2d, first.enc_hw
 
-    def prefetch_encode(self, img):
-        """Optional look-ahead (see AOTEngine.prefetch_encode): call with the NEXT frame before matching the current one."""
+    def encode_ahead(self, imgs):
+        """Optional look-ahead (see AOTEngine.encode_ahead): the next frames of the clip, encoded as one batch."""
         if self._cohorts:
-            self._cohorts[0].prefetch_encode(img)
+            self._cohorts[0].encode_ahead(imgs)
 
+    @_in_table
     def match_propogate_one_frame(self, img=None):
         img_embs = None
         for c in self._cohorts:
@@ -760,9 +800,11 @@ class AOTInferEngine(nn.Module):
             if img_embs is None:
                 img_embs = c.curr_enc_embs
 
+    @_in_table
     def decode_current_logits(self, output_size=None):
         return _decode(self, self._cohorts, output_size)
 
+    @_in_table
     def update_memory(self, curr_mask, skip_long_term_update=False):
         for c in self._cohorts:
             c.update_short_term_memory(curr_mask, skip_long_term_update=skip_long_term_update)

@@ -16,6 +16,7 @@ from networks.layers.normalization import fold_dwconv_bn, linear_t
 
 _SIMDS = 1024                 # 256 CUs x 4 SIMDs; one 32-query x 1-head (or 1-chunk) tile = one wave
 _OCC_EFF = (0.8, 0.9, 0.97, 0.99, 1.0)   # measured MFMA-pipe fill at 1..5 resident waves per SIMD
+_TOPK_QROWS = 512             # query rows per launch of the top-k (sparse) forms: bounds their score scratch
 
 
 def attn_splits(nq, units, t, occ=4, c0=3.0, wg_waves=1):
@@ -74,11 +75,18 @@ class MultiheadAttention(nn.Module):
             if ratio > self.max_mem_len_ratio:      # Q *= log(ratio)/log(max ratio), folded into the divisor
                 scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
         if 0 < self.top_k < t:
-            scores = ws.get('attn_scores', (self.num_head * nq * ((t + 3) // 4 * 4),), q.device)
+            # score scratch: sized by the bank CAPACITY (kv_brows: it only changes when the bank re-allocates, i.e. doubles)
+            # and by a block of query rows, not by the bank length of the moment -- a buffer per distinct length would grow
+            # quadratically with the number of memorised frames (scratch buffers are persistent and keyed by shape)
+            rows = max(t, int(kv_brows))
+            qb = min(nq, _TOPK_QROWS)
+            scores = ws.get('attn_scores', (self.num_head * qb * ((rows + 3) // 4 * 4),), q.device)
             for b in range(B):       # the sparse form is a long-video knob; lanes one at a time
                 kb, vb = k[b * kv_brows:], v[b * kv_brows:]
-                aot_hip.attention_topk(q[b * nq:(b + 1) * nq], kb, vb, out[b * nq:(b + 1) * nq], t, self.num_head,
-                                       scale_div, self.top_k, scores, stream=stream)
+                for r0 in range(b * nq, (b + 1) * nq, qb):
+                    r1 = min(r0 + qb, (b + 1) * nq)
+                    aot_hip.attention_topk(q[r0:r1], kb, vb, out[r0:r1], t, self.num_head, scale_div, self.top_k, scores,
+                                           stream=stream)
             return out
         ns = attn_splits(nq * B, self.num_head, t, wg_waves=4)
         part = None
@@ -191,11 +199,15 @@ class GatedPropagation(nn.Module):
         """top_k > 0 (attention.py:689-693): scores materialised once, radix select of the k-th largest per query row, ordered
         gather of the selected [V | ID_V] rows, gate fused (csrc/attn_topk.hip); lanes one at a time."""
         nq = q.shape[0] // B
-        scores = ws.get('gattn_scores', (nq * ((t + 3) // 4 * 4),), q.device)
+        cap = max(t, int(kv_brows))            # bank capacity, see MultiheadAttention.core
+        qb = min(nq, _TOPK_QROWS)
+        scores = ws.get('gattn_scores', (qb * ((cap + 3) // 4 * 4),), q.device)
         for b in range(B):
-            rows = slice(b * nq, (b + 1) * nq)
-            aot_hip.gated_attention_topk(q[rows], k[b * kv_brows:], v[b * kv_brows:], gate[rows] if gate is not None else None,
-                                         out[rows], t, scale_div, self.top_k, scores, stream=stream)
+            for r0 in range(b * nq, (b + 1) * nq, qb):
+                rows = slice(r0, min(r0 + qb, (b + 1) * nq))
+                aot_hip.gated_attention_topk(q[rows], k[b * kv_brows:], v[b * kv_brows:],
+                                             gate[rows] if gate is not None else None, out[rows], t, scale_div, self.top_k,
+                                             scores, stream=stream)
         return out
 
     def tail(self, raw, out, size_2d, ws, stream, res=None, B=1):

@@ -124,10 +124,14 @@ class AOT(nn.Module):
 
     # ---- token-major internals -----------------------------------------------------------------
     def encode_tokens(self, img, stream=None, out_cat=None):
-        """img [1,3,H,W] -> [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major.
-        If out_cat is given the projected feature is written into its first C columns."""
+        """img [B,3,H,W] -> [(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] token-major, the B images stacked along the rows
+        (B > 1 only for encoders with `batched = True`).  If out_cat is given (B = 1) the projected feature is written
+        into its first C columns."""
         p = self.pack()
         stream = stream if stream is not None else aot_hip.stream_ptr()
+        B = img.shape[0]
+        if B > 1 and not getattr(self.encoder, 'batched', False):
+            raise aot_hip.AotHipError('%s encodes one image per call' % type(self.encoder).__name__)
         feats = self.encoder.run(img.float().contiguous(), self.ws, stream)
         if len(feats) == 4:          # mobilenetv2: 4 stages; stage 3 (96 ch) is the 16x shortcut, stage 4 (1280 ch) feeds the projector
             f4, f8, f16, top = feats
@@ -137,10 +141,10 @@ class AOT(nn.Module):
         x, h, w = top
         emb = self.encoder_projector.out_channels
         if out_cat is None:
-            out = self.ws.get('enc_proj16', (h * w, emb), img.device)     # per-stream scratch, like the encoder maps
+            out = self.ws.get('enc_proj16', (B * h * w, emb), img.device)     # per-stream scratch, like the encoder maps
         else:
             out = out_cat[:, :emb]
-        aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, stream=stream)
+        aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, B=B, stream=stream)
         return [f4, f8, f16, (out, h, w)]
 
     def id_emb_from_mask(self, mask, size_2d, stream=None, lanes=1, group0=None, fuse=None, want_out=True):

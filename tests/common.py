@@ -53,6 +53,14 @@ def case_clip(c, device='cpu', g=None):
     return frames, mask, objs, out_size
 
 
+def integration_snippet():
+    """The python code block of INTEGRATION.md section 2 (binding the C ABI directly), verbatim."""
+    import re
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = doc.split('## 2. Binding the C ABI directly')[1].split('\n## ')[0]
+    return re.search(r'```python\n(.*?)```', sec, re.S).group(1)
+
+
 def lstt_last_of(engine):
     """Last LSTT/GPM layer output after its decoder norm, [N, C] (AOT) / [N, 2C] (DeAOT) -- what the reference keeps
     in curr_lstt_output[0][-1] (aot_engine.py:340-354); first object group."""
@@ -79,10 +87,12 @@ def check_masks(pred, g, t, what):
     return int(bad.sum())
 
 
-def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lambda x: x, extra=None, sub=None):
+def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lambda x: x, extra=None, sub=None,
+                       label_fn=None):
     """demo loop (tools/demo.py:187-235) with the GOLDEN mask fed back into memory at every frame, so frame t is
     compared on identical history.  Returns {t: (logits4 [no,h,w], mask uint8 [H,W])}.  `extra` (dict) receives, for the
-    kept frames, 'lstt_last_<t>' and -- with `sub` -- the merged output-size logits subsampled by `sub`."""
+    kept frames, 'lstt_last_<t>' and -- with `sub` -- the merged output-size logits subsampled by `sub`.  label_fn(logit)
+    -> [1,1,H,W] label map replaces torch's softmax -> argmax (the GPU tests pass aot_hip.fuse_probs, what bench.py runs)."""
     out = {}
     engine.restart_engine()
     with torch.no_grad():
@@ -90,7 +100,7 @@ def run_teacher_forced(engine, frames, mask, objs, out_size, g, keep, to_dev=lam
         for t in range(1, len(frames)):
             engine.match_propogate_one_frame(to_dev(frames[t]))
             logit = engine.decode_current_logits(out_size)
-            lab = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True)
+            lab = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True) if label_fn is None else label_fn(logit)
             l4 = engine.pred_id_logits if hasattr(engine, 'pred_id_logits') else engine.aot_engines[0].pred_id_logits
             out[t] = (l4[0].detach().float().cpu().numpy() if t in keep else None, lab[0, 0].to(torch.uint8).cpu().numpy())
             if extra is not None and t in keep:

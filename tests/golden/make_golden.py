@@ -69,6 +69,13 @@ CASES = {
                               keep_logits=(1, 6), sub=4, demo_mask='1001_3iEIq5HBY1s/00002058.png'),
     'c4_deaott_44obj': dict(model='deaott', frames=4, in_size=(193, 337), out_size=(192, 336), num_obj=43, clip=12,
                             keep_logits=(1, 3), gap=2, sub=4, demo_mask='1007_YCTBBdbKSSg/00000693.png'),
+    # ---- round 3 -------------------------------------------------------------------------------------------
+    # DeAOT over whole 70-frame clips (bank M 1 -> 14, the bank sizes bench.py --model ... times): R50-DeAOTL at the
+    # config-2 geometry and BASELINE config 3 (SwinB-DeAOTL, 480x848); every mask, logits + GPM output at t = 1 / 35 / 69
+    'c3b_r50_deaotl_70': dict(model='r50_deaotl', frames=70, in_size=(481, 849), out_size=(480, 854), num_obj=10, clip=2,
+                              keep_logits=(1, 35, 69)),
+    'c3_swinb_deaotl_480_70': dict(model='swinb_deaotl', frames=70, in_size=(480, 848), out_size=(480, 854), num_obj=10,
+                                   clip=10, keep_logits=(1, 35, 69)),
     # ragged case: odd sizes, 3 objects, AOTT
     'c1b_aott_ragged': dict(model='aott', frames=4, in_size=(193, 305), out_size=(190, 300), num_obj=3, clip=3,
                             keep_logits=(1, 3)),

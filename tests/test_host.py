@@ -66,6 +66,80 @@ def test_cabi_exports_every_declared_symbol():
     assert b'gfx950' in lib.aot_hip_version()
 
 
+def _header_prototypes():
+    """{name: [class of every parameter]} parsed from include/aot_hip.h; classes: 'ptr', 'int', 'long', 'float'."""
+    hdr = open(os.path.join(ROOT, 'include', 'aot_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', ' ', hdr, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r'\b(int|const char\*)\s+(aot_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', hdr):
+        params = [a.strip() for a in args.split(',')] if args.strip() not in ('', 'void') else []
+        kinds = []
+        for a in params:
+            if '*' in a:
+                kinds.append('ptr')
+            else:
+                ty = a.split()[:-1]                      # drop the parameter name
+                ty = [t for t in ty if t != 'const']
+                assert ty in (['int'], ['long'], ['float']), 'unparsed parameter %r of %s' % (a, name)
+                kinds.append(ty[0])
+        protos[name] = kinds
+    return protos
+
+
+def test_header_arity_matches_ctypes():
+    """Every prototype of include/aot_hip.h against the hand-maintained ctypes table of aot_hip.py: same number of
+    parameters, and pointer / int / long / float in the same positions -- a binding that drifts from the header shifts every
+    argument after the drift (INTEGRATION.md section 2 once documented 17 of aot_attn_f32's 19 arguments)."""
+    import aot_hip
+    protos = _header_prototypes()
+    assert set(protos) == set(aot_hip._SIGS) | {'aot_hip_version'}
+    cls = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_long: 'long', ctypes.c_float: 'float'}
+    for name, sig in aot_hip._SIGS.items():
+        got = [cls[t] for t in sig]
+        assert got == protos[name], '%s: header %s\n  ctypes %s' % (name, protos[name], got)
+    assert protos['aot_hip_version'] == []
+    assert len(protos['aot_attn_f32']) == 19
+
+
+def test_integration_doc_binds_the_declared_signature():
+    """The ctypes example of INTEGRATION.md section 2 declares exactly the header's argument classes for aot_attn_f32 (the
+    GPU suite also RUNS the block: test_integration_snippet_runs_verbatim)."""
+    from common import integration_snippet
+    code = integration_snippet()
+    ns = {}
+
+    class _Fn:
+        pass
+
+    class _Lib:
+        aot_attn_f32 = _Fn()
+    fake = type('C', (), {'CDLL': staticmethod(lambda path: _Lib), 'c_void_p': ctypes.c_void_p, 'c_int': ctypes.c_int,
+                          'c_long': ctypes.c_long, 'c_float': ctypes.c_float})
+    head = code.split('rc = lib.aot_attn_f32(')[0].replace('import ctypes, torch', 'import torch')
+    exec(head, {'ctypes': fake}, ns)
+    cls = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_long: 'long', ctypes.c_float: 'float'}
+    assert [cls[t] for t in _Lib.aot_attn_f32.argtypes] == _header_prototypes()['aot_attn_f32']
+    call = code.split('rc = lib.aot_attn_f32(')[1].split(')\nassert')[0]
+    assert len(_split_args(call)) == 19
+
+
+def _split_args(text):
+    out, depth, cur = [], 0, ''
+    for ch in text:
+        if ch in '([':
+            depth += 1
+        elif ch in ')]':
+            depth -= 1
+        if ch == ',' and depth == 0:
+            out.append(cur.strip())
+            cur = ''
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly without a ROCm device tensor -- never compute on the CPU."""
     import aot_hip
@@ -274,7 +348,7 @@ def test_infer_engine_cohort_orchestration_vs_reference(monkeypatch):
     class Cohort:                                   # the surface AOTInferEngine and _decode use of an AOTEngine
         use_graph = False
 
-        def __init__(self, model, gpu_id, gap, skip, long_term_mem_max=None, lanes=1, group0=None, graph=False):
+        def __init__(self, model, gpu_id, gap, skip, long_term_mem_max=None, lanes=1, group0=None, graph=False, gemm_table='latency'):
             self.lanes, self.group0, self.first_group, self.gap = lanes, group0, group0 or 0, gap
             self.restart_engine()
 

@@ -216,9 +216,6 @@ def test_prob_feedback_engine_vs_oracle(hip):
             eng.update_memory(F.interpolate(prob, size=eng.input_size_2d, mode='nearest'))
 
 
-@pytest.mark.xfail(strict=False, reason='written after the GPU budget of round 2 was spent: the two-cohort decode path has not '
-                   'run on hardware yet (its only run stopped at a comparison bug of this test, fixed since); the same '
-                   'scenario is green for the oracle on CPU (test_oracle_new_object_group_mid_clip_matches_reference)')
 def test_new_object_group_mid_clip_vs_reference_golden(hip):
     """(A parity test of the inference engine; it sits at the end of the GPU suite because it is the newest.)  Objects
     10..13 injected at frame 2 open a second object group: AOTInferEngine starts a second COHORT there (own frame counter,
