@@ -44,6 +44,7 @@ _SIGS = {
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
+    'aot_copy_rows_f32': [_P, _P, _I, _L, _I, _L, _L, _I, _I, _P, _I, _P],
     # training-side stages (csrc/train_ops.hip)
     'aot_ce_loss_f32': [_P] * 6 + [_I, _I, _L, _L, _P],
     'aot_ce_loss_bwd_f32': [_P] * 6 + [_I, _I, _L, _P],
@@ -386,6 +387,15 @@ def add(a, b, out, stream=None):
     _chk(load().aot_add_f32(_dev(a), _dev(b), _dev(out), a.numel(), stream if stream is not None else stream_ptr()),
          'aot_add_f32')
     return out
+
+
+def copy_rows(src, dst, rows, B=1, src_brows=None, dst_brows=0, slot=0, slot_dev=None, stream=None):
+    """dst[b*dst_brows + slot*rows + r] = src[b*src_brows + r] for r < rows (token-major 2-D tensors, src.shape[1] columns);
+    src_brows = 0 broadcasts one block to every lane; slot_dev: device int32 overriding `slot` (graph replay)."""
+    _chk(load().aot_copy_rows_f32(_dev(src), _dev(dst), B, rows, src.shape[1], rows if src_brows is None else src_brows,
+                                  dst_brows, src.stride(0), dst.stride(0), _opt(slot_dev), slot,
+                                  stream if stream is not None else stream_ptr()), 'aot_copy_rows_f32')
+    return dst
 
 
 _MEAN3 = (ctypes.c_double * 3)(0.485, 0.456, 0.406)

@@ -58,29 +58,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 // costs ~20 VALU instructions per score; 16 scores per lane and tile made that as expensive as the tile's 32 MFMAs.)
 // Masked scores (-inf) and the initial mL = -inf give 2^-inf = 0 exactly; no clamps needed.
 #define AOT_LOG2E 1.44269502162933349609375f
-// A/B switches of the softmax step (tools/dev/mb_attn.py on MI355X, M = 14 / 8: plain 364 / 220 us; max3 359 / 219; max3 +
-// packed 350 / 216; any variant unrolled by two to drop the score-tile copy 369-390 / 223-231 -- the larger loop body costs
-// more than the nine v_mov it saves).  All variants give bit-identical results.
-#ifndef AOT_ATT_UNROLL2
-#define AOT_ATT_UNROLL2 0
-#endif
-#ifndef AOT_ATT_MAX3
-#define AOT_ATT_MAX3 1
-#endif
-#ifndef AOT_ATT_PK
-#define AOT_ATT_PK 1
-#endif
+// Measured variants of the softmax step (tools/dev/mb_attn.py on MI355X, M = 14 / 8): plain fmaxf / scalar fp32 364 / 220 us;
+// v_max3 359 / 219; v_max3 + packed fp32 350 / 216 (what is built); unrolled by two to drop the score-tile copy 369-390 /
+// 223-231 (the larger loop body costs more than the nine v_mov it saves); row sums through v_pk_add_f32 instead of the scalar
+// adds hipcc emits 362.6 vs 354.2 at M = 14 and -1.2 % on the whole frame (round 3): rejected and removed.
 #ifndef AOT_ATT_VPM
 #define AOT_ATT_VPM 4
 #endif
-#ifndef AOT_COOP_AGPR      // DeAOT kernel: the (rare) accumulator rescale reads / writes the accumulation registers explicitly, so that
-#define AOT_COOP_AGPR 0    // the 128 accumulators stay in AGPRs across the branch (the shipped build copies them to VGPRs and back
-#endif                     // on EVERY key tile: ~270 v_accvgpr moves per step in the ISA); not yet timed
 #ifndef AOT_ATT_SPLIT_MAJOR   // d = 32 kernel: workgroups of one key range (grid-level split) are dispatched together (see the launch)
-#define AOT_ATT_SPLIT_MAJOR 0
-#endif
-#ifndef AOT_ATT_PKSUM      // row sums through v_pk_add_f32 (the plain `ps += p2` compiles to two scalar adds per pair); not yet timed
-#define AOT_ATT_PKSUM 0
+#define AOT_ATT_SPLIT_MAJOR 0  // same launch time either way (353 vs 354 us at M = 14); which one ships is decided by the fabric traffic
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // max of three in ONE instruction (same NaN rule as fmaxf: a NaN operand is ignored)
@@ -208,20 +194,13 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
       for (int r = 0; r < 16; ++r)
         if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
     }
-#if AOT_ATT_MAX3
     float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
                     max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
-#else
-    float x = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) x = fmaxf(x, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-#endif
     const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // 1 when the max did not move; 0 on the first tile
     m = mnew;
     l *= alpha;
     float pf[16];
-#if AOT_ATT_PK
     {
       const f32x2 al2 = {alpha, alpha};
 #pragma unroll
@@ -240,26 +219,9 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
       pf[r] = __builtin_amdgcn_exp2f(t2[0]);
       pf[r + 1] = __builtin_amdgcn_exp2f(t2[1]);
       const f32x2 p2 = {pf[r], pf[r + 1]};
-#if AOT_ATT_PKSUM
-      ps = pk_add(ps, p2);
-#else
       ps += p2;
-#endif
     }
     l += ps[0] + ps[1];
-#else
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      pf[r] = exp2_w(sc[r], m);
-      pf[r + 1] = exp2_w(sc[r + 1], m);
-      ps0 += pf[r];
-      ps1 += pf[r + 1];
-    }
-    l += ps0 + ps1;
-#endif
     load_k(ka, kt + 64);     // K registers were consumed by qk() above
 #pragma unroll
     for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], pf[s], o, 0, 0, 0);
@@ -272,17 +234,10 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
     }
   };
   int kt = t0;
-#if AOT_ATT_UNROLL2
-  for (; kt + 64 < t1; kt += 64) {
-    step(kt, sa, sb, std::false_type{});
-    step(kt + 32, sb, sa, std::false_type{});
-  }
-#else
   for (; kt + 64 < t1; kt += 32) {
     step(kt, sa, sb, std::false_type{});
     sa = sb;
   }
-#endif
   if (kt + 32 < t1) {          // two tiles left
     step(kt, sa, sb, std::false_type{});
     step(kt + 32, sb, sa, std::true_type{});
@@ -661,12 +616,13 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
     }
     if (__any(moved)) {
+      // explicit AGPR reads / writes: written as plain C++ the (rarely taken) rescale made hipcc copy the 128 accumulators
+      // to VGPRs and back around the branch on EVERY key tile (~270 v_accvgpr moves per step); +2 % on R50-DeAOTL (round 3)
       const f32x2 al2 = {alpha, alpha};
 #pragma unroll
       for (int d = 0; d < NDV; ++d)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-#if AOT_COOP_AGPR
           float a0, a1;
           asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a0), "=v"(a1) : "a"(o[d][r]), "a"(o[d][r + 1]));
           const f32x2 t = pk_mul(f32x2{a0, a1}, al2);
@@ -674,11 +630,6 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
           asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(w0), "=a"(w1) : "v"(t[0]), "v"(t[1]));
           o[d][r] = w0;
           o[d][r + 1] = w1;
-#else
-          const f32x2 t = pk_mul(f32x2{o[d][r], o[d][r + 1]}, al2);
-          o[d][r] = t[0];
-          o[d][r + 1] = t[1];
-#endif
         }
     }
 #pragma unroll

@@ -41,10 +41,6 @@ __device__ __forceinline__ void with_act(int act, F&& f) {
     default: f(std::integral_constant<int, AOT_ACT_NONE>{}); break;
   }
 }
-// AOT_CONV_EPI = 1: the register-staged and the wave-independent GEMM kernels (gemm_conv.hip) end their tiles through
-// with_act(); same values stored, not yet timed on the GPU, hence off.
-#ifndef AOT_CONV_EPI
-#define AOT_CONV_EPI 0
-#endif
+// (the register-staged and the wave-independent GEMM kernels of gemm_conv.hip end their tiles through with_act() too)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -166,13 +166,8 @@ conv_gemm_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: bias (folded BN) + residual + activation; 32 lanes write 128 contiguous bytes ----
-#if AOT_CONV_EPI
   with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
     constexpr int act = decltype(ACT)::value;
-#else
-  {
-    const int act = p.act;
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -190,11 +185,7 @@ conv_gemm_kernel(const ConvParams p) {
           }
         }
       }
-#if AOT_CONV_EPI
   });
-#else
-  }
-#endif
 }
 
 
@@ -303,13 +294,8 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
   }
   if (n < p.Cout) {
     const float bv = p.bias ? p.bias[n] : 0.f;
-#if AOT_CONV_EPI
     with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
       constexpr int act = decltype(ACT)::value;
-#else
-    {
-      const int act = p.act;
-#endif
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = (KS > 1 ? wave * RPW : 0) + i;
@@ -320,11 +306,7 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct_kernel(const ConvParams p
         p.out[(long)mo * p.ldc + n] = apply_act(v, act);
       }
     }
-#if AOT_CONV_EPI
     });
-#else
-    }
-#endif
   }
 }
 
@@ -463,13 +445,8 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
   }
   if (n < p.Cout) {
     const float bv = p.bias ? p.bias[n] : 0.f;
-#if AOT_CONV_EPI
     with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
       constexpr int act = decltype(ACT)::value;
-#else
-    {
-      const int act = p.act;
-#endif
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = (KS > 1 ? wave * RPW : 0) + i;      // 0..15 -> fragment 0, 16..31 -> fragment 1
@@ -480,158 +457,8 @@ __global__ void __launch_bounds__(KS * 64) gemm_direct2_kernel(const ConvParams 
         p.out[(long)mo * p.ldc + n] = apply_act(v, act);
       }
     }
-#if AOT_CONV_EPI
-    });
-#else
-    }
-#endif
-  }
-}
-
-// Third form of the wave-independent kernel (cfg 3x; EXPERIMENTAL: compiled and selectable by number, in no dispatch table
-// until it has been checked and timed with tools/dev/gemm_check on the GPU).  What the ISA of gemm_direct_kernel shows per
-// 32-wide k slab next to its 16 MFMAs: sixteen strided 4-byte B loads with a 64-bit address add each, every load wrapped in
-// an exec-mask branch with a zero fill, and a copy of both register sets.  Here:
-//   * B comes from the k-contiguous weight twin wt [Cout, ldwt]: a lane's 16 k values are four 16-byte loads;
-//   * no predicated loads: rows >= M and columns >= Cout read row / column 0 (their results are never stored), filter taps
-//     outside the image read a 128-byte page of zeros through a pointer select;
-//   * the register sets of consecutive slabs alternate (loop unrolled by two), so nothing is copied.
-// Same tile, same order of accumulation over k as gemm_direct_kernel for a given KS.
-__device__ __attribute__((aligned(16))) float g_zero_row[32] = {};
-
-template <int KS, bool IS1X1>
-__global__ void __launch_bounds__(KS * 64) gemm_direct3_kernel(const ConvParams p) {
-  __shared__ float red[KS > 1 ? KS : 1][16][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the slab loop below branches on SGPRs
-  const int j = lane & 31, kh = lane >> 5;
-  const int nbn = (p.Cout + 31) >> 5, nbm = (p.M + 31) >> 5;
-  const int nwg = nbm * nbn, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * 32, n0 = bn * 32;
-
-  const int nslab = p.K >> 5;
-  const int per = (nslab + KS - 1) / KS;
-  const int s0 = wave * per, s1 = min(nslab, s0 + per);
-
-  const int mm = min(m0 + j, p.M - 1);                      // clamped row: always readable
-  const int hw_out = p.OH * p.OW;
-  const int bi = mm / hw_out, pix = mm - bi * hw_out;
-  const int oy = pix / p.OW, ox = pix - oy * p.OW;
-  const float* img = p.in + (long)bi * p.H * p.W * p.lda;
-  const float* a_ptr = nullptr;                             // 1x1: this lane's 16 floats of slab s0
-  int iy0 = 0, ix0 = 0, c = 0, ky = 0, kx = 0;
-  if (IS1X1) {
-    a_ptr = img + ((long)(oy * p.stride) * p.W + ox * p.stride) * p.lda + kh * 16 + (long)s0 * 32;
-  } else {
-    iy0 = oy * p.stride - p.pad;
-    ix0 = ox * p.stride - p.pad;
-    const int k = s0 * 32;
-    const int tap = k / p.Cin;
-    c = k - tap * p.Cin;
-    ky = tap / p.KW;
-    kx = tap - ky * p.KW;
-  }
-  const int n = n0 + j;
-  const float* b_ptr = p.wt + (long)min(n, p.Cout - 1) * p.ldwt + kh * 16 + (long)s0 * 32;
-
-  auto load = [&](float4 (&a)[4], float4 (&b)[4]) __attribute__((always_inline)) {       // the next slab of this wave
-    const float4* src;
-    if (IS1X1) {
-      src = reinterpret_cast<const float4*>(a_ptr);
-      a_ptr += 32;
-    } else {
-      const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
-      const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      src = reinterpret_cast<const float4*>(in ? img + ((long)iy * p.W + ix) * p.lda + c + kh * 16 : g_zero_row);
-      c += 32;
-      if (c >= p.Cin) { c = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
-    }
-    const float4* bsrc = reinterpret_cast<const float4*>(b_ptr);
-    b_ptr += 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a[i] = src[i]; b[i] = bsrc[i]; }
-  };
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  auto mfmas = [&](const float4 (&a)[4], const float4 (&b)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
-    }
-  };
-  float4 a0[4], b0[4], a1[4], b1[4];
-  int s = s0;
-  if (s < s1) load(a0, b0);
-  for (; s + 2 < s1; s += 2) {        // straight-line body (exact vmcnt waits): set 0 holds slab s on entry
-    load(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);      // the loads go out HERE, a slab ahead of their use (the scheduler otherwise sinks
-    mfmas(a0, b0);                          // them to their consumers and waits for each)
-    __builtin_amdgcn_sched_barrier(0);
-    load(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (s + 1 < s1) {                   // two slabs left
-    load(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(a0, b0);
-    mfmas(a1, b1);
-  } else if (s < s1) {                // one
-    mfmas(a0, b0);
-  }
-
-  constexpr int RPW = 16 / KS;
-  float fin[RPW];
-  if (KS > 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wave * RPW + i;
-      float v = red[0][r][lane];
-#pragma unroll
-      for (int w = 1; w < KS; ++w) v += red[w][r][lane];
-      fin[i] = v;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) fin[i] = acc[i];
-  }
-  if (n < p.Cout) {
-    const float bv = p.bias ? p.bias[n] : 0.f;
-    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
-      constexpr int act = decltype(ACT)::value;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int r = (KS > 1 ? wave * RPW : 0) + i;
-        const int mo = m0 + mfma32_row(r, kh);
-        if (mo < p.M) {
-          float v = fin[i] + bv;
-          if (p.res) v += p.res[(long)(p.res_rows ? mo % p.res_rows : mo) * p.ldr + n];
-          p.out[(long)mo * p.ldc + n] = apply_act(v, act);
-        }
-      }
     });
   }
-}
-
-template <int KS>
-static int launch_direct3(const ConvParams& p, bool is1x1, hipStream_t s) {
-  const int nb = cdiv(p.M, 32) * cdiv(p.Cout, 32);
-  if (is1x1)
-    hipLaunchKernelGGL((gemm_direct3_kernel<KS, true>), dim3(nb), dim3(KS * 64), 0, s, p);
-  else
-    hipLaunchKernelGGL((gemm_direct3_kernel<KS, false>), dim3(nb), dim3(KS * 64), 0, s, p);
-  AOT_LAUNCH_CHECK();
 }
 
 template <int KS>
@@ -719,14 +546,6 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
     case 3: return launch_cfg<128, 32, 32, 32, 16>(p, is1x1, s);
     case 4: return launch_cfg<64, 64, 32, 32, 32>(p, is1x1, s);
     case 5: return launch_cfg<128, 64, 64, 32, 32>(p, is1x1, s);
-    case 31: case 32: case 34: case 38:     // experimental third form (k-contiguous B): needs the weight twin
-      if ((Cin % 32) || (p.K % 32) || !p.wt || (p.ldwt % 4) || (p.lda % 4)) return AOT_ERR_UNSUPPORTED;
-      switch (cfg) {
-        case 31: return launch_direct3<1>(p, is1x1, s);
-        case 32: return launch_direct3<2>(p, is1x1, s);
-        case 34: return launch_direct3<4>(p, is1x1, s);
-        default: return launch_direct3<8>(p, is1x1, s);
-      }
     case 11: case 12: case 14: case 18: case 21: case 22: case 24: case 28:
       if ((Cin % 32) || (p.K % 32)) return AOT_ERR_UNSUPPORTED;
       switch (cfg) {

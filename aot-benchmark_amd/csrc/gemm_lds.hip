@@ -379,13 +379,6 @@ __device__ __forceinline__ float buf_load_s(const i32x4& desc, int voff, int sof
 __device__ __forceinline__ void buf_store_s(const i32x4& desc, int voff, int soff, float v) {
   asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" : : "v"(v), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
-// AOT_LEAN_EPI = 1: the tile end of gemm_lean_kernel with (a) ONE wave-uniform branch on the activation per tile instead of the
-// if-chain of apply_act() per output element (16-32 elements per lane: five scalar compare-and-branch pairs each, seen in the
-// ISA), (b) the row part of every store / residual address as a scalar offset -- one integer multiply per tile instead of one per
-// element.  Same values stored; not yet timed on the GPU (tools/dev/gemm_check), hence off.
-#ifndef AOT_LEAN_EPI
-#define AOT_LEAN_EPI 0
-#endif
 template <int IMM>
 __device__ __forceinline__ void fetch_one(f32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
@@ -418,6 +411,10 @@ __device__ __forceinline__ void frags_landed(f32x4 (&a)[BMB][4], f32x4 (&b)[4]) 
 //   * the loop is unrolled by four with the stage and the register set static: fragment reads are inline-asm ds_read_b128
 //     with immediate stage offsets (a plain LDS load would make hipcc drain the DMA queue), retired by one
 //     `s_waitcnt vmcnt(LPW) lgkmcnt(0)` in front of each step's barrier;
+//   * the tile end has ONE wave-uniform branch on the activation per tile (apply_act()'s if-chain per output element -- five
+//     scalar compare-and-branch pairs for each of 16-32 elements per lane -- was as long as the 32 MFMAs of a K = 64 tile), the
+//     row part of every store / residual address is a scalar offset (one integer multiply per tile), bias and residual are
+//     added in passes of their own: measured +2.5 % on the whole frame (round 3, profiles/r03a_variants.txt);
 //   * the 64x64 tile keeps TWO accumulators per wave (even / odd half of each k-step, summed in the epilogue): consecutive
 //     MFMAs are independent, so the step's few remaining instructions can sit between them (an instruction between two
 //     MFMAs on ONE accumulator costs ~43 cycles on gfx950, between independent ones ~6).
@@ -588,7 +585,6 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
     const bool col_ok = n < p.Cout;
     const int m0 = it.bm * BM;
     if (n_bias) bv = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
-#if AOT_LEAN_EPI
     if (n_res && p.res_rows == 0) {          // a residual row per output row: lane offset once, row offsets as scalars
       const int mlane = m0 + wm + 4 * half;
       const int vbase = col_ok ? (mlane * p.ldr + n) * 4 : (int)OOB;
@@ -601,7 +597,6 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
           rv[x][r] = buf_load_s(desc_res, c < rows_left ? vbase : (int)OOB, c * ldr4);
         }
     } else
-#endif
     if (n_res) {
       const int rr0 = p.res_rows ? m0 % p.res_rows : m0;
 #pragma unroll
@@ -650,7 +645,6 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[x][r]));
     }
     const int m0 = it.bm * BM;
-#if AOT_LEAN_EPI
     {
       const int mlane = m0 + wm + 4 * half;          // output row of accumulator register 0 (block 0) in this lane
       const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
@@ -687,19 +681,6 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
         default: store_all(std::integral_constant<int, AOT_ACT_NONE>{}); break;
       }
     }
-#else
-#pragma unroll
-    for (int x = 0; x < BMB; ++x)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + 32 * x + mfma32_row(r, half);
-        float v = acc[x][r];
-        if (n_bias) v += bv;
-        if (n_res) v += rv[x][r];
-        buf_store(desc_out, (col_ok && m < p.M) ? (m * p.ldc + n) * 4 : (int)OOB, apply_act(v, p.act));
-        acc[x][r] = 0.f;
-      }
-#endif
     stores_pending = 16 * BMB;
   };
   constexpr int NM = 16 * BMB;              // MFMAs of one step

@@ -711,4 +711,32 @@ extern "C" int aot_add_f32(const float* a, const float* b, float* out, long n, v
   AOT_LAUNCH_CHECK();
 }
 
-extern "C" const char* aot_hip_version(void) { return "aot_hip 0.2 gfx950"; }
+// Row-block copy between token-major buffers with a DEVICE-side destination slot (bank append inside a replayed graph):
+// one thread per float4.
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, long rows,
+                                                        int C4, long src_brows, long dst_brows, int lds, int ldd,
+                                                        const int* __restrict__ slot_dev, int slot) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = rows * C4;
+  if (idx >= per * B) return;
+  const int b = (int)(idx / per);
+  const long rem = idx - (long)b * per;
+  const long r = rem / C4;
+  const int c = (int)(rem - r * C4) * 4;
+  const long row0 = (long)(slot_dev ? *slot_dev : slot) * rows;
+  const float4 v = *reinterpret_cast<const float4*>(src + ((long)b * src_brows + r) * lds + c);
+  *reinterpret_cast<float4*>(dst + ((long)b * dst_brows + row0 + r) * ldd + c) = v;
+}
+
+extern "C" int aot_copy_rows_f32(const float* src, float* dst, int B, long rows, int C, long src_brows, long dst_brows, int lds,
+                                 int ldd, const int* slot_dev, int slot, void* stream) {
+  if (!src || !dst || B <= 0 || rows <= 0 || C <= 0 || (C & 3) || (lds & 3) || (ldd & 3) || slot < 0 || src_brows < 0 ||
+      dst_brows < 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+    return AOT_ERR_BADARG;
+  const long n = (long)B * rows * (C / 4);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B, rows, C / 4, src_brows,
+                     dst_brows, lds, ldd, slot_dev, slot);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" const char* aot_hip_version(void) { return "aot_hip 0.3 gfx950"; }

@@ -85,6 +85,17 @@ class AOTEngine(nn.Module):
         self.long_term_mem_gap = long_term_mem_gap
         self.short_term_mem_skip = max(1, int(short_term_mem_skip))
         self.lanes = int(lanes)
+        # Graph mode, "state-free" form: the captured launches must not depend on how many frames the bank holds, or a clip
+        # would need one graph per frame.  The bank length reaches the attention kernels through a device int (T_dev of
+        # aot_attn_f32 / aot_gated_attn_f32), a memorised frame is appended by a copy whose slot is a device int
+        # (aot_copy_rows_f32), and the launch geometry is planned for the bank's capacity -- a graph is keyed on (stage,
+        # frame geometry, bank buffer, which scratch set holds the previous frame), a handful per clip however long it is.
+        # The long-video knobs that change the ARITHMETIC with the bank length (top_k, max_mem_len_ratio) keep the
+        # one-graph-per-state form.
+        lt = [l.long_term_attn for l in aot_model.LSTT.layers]
+        self._state_free = self.use_graph and not any(a.top_k > 0 or a.max_mem_len_ratio > 0 for a in lt)
+        self._dev_ints = None        # [T, slot] int32 on the device (state-free graph mode)
+        self._dev_vals = [None, None]
         self.group0 = group0         # first object group of the clip's label map held by lane 0 (None: labels as they are)
         self.first_group = group0 or 0
         self._bank = None            # per layer (K [lanes, cap*N, Ck], V [lanes, cap*N, Cv]); survives restart_engine
@@ -270,6 +281,7 @@ class AOTEngine(nn.Module):
         self.curr_id_embs = None
         self.pred_id_logits = None
         self._ahead = {}
+        self._dev_vals = [None, None]
 
     def update_size(self, input_size, enc_size):
         self.input_size_2d = tuple(int(x) for x in input_size)
@@ -316,7 +328,7 @@ class AOTEngine(nn.Module):
     # ---- bank plumbing -------------------------------------------------------------------------
     def _direct(self):
         """K / V GEMMs may write straight into bank slots: one lane, unbounded bank, previous-frame short-term memory."""
-        return self.lanes == 1 and self.long_term_mem_max is None and self.short_term_mem_skip == 1
+        return self.lanes == 1 and self.long_term_mem_max is None and self.short_term_mem_skip == 1 and not self._state_free
 
     def _ensure_bank(self, frames_needed):
         N, B = self.enc_hw, self.lanes
@@ -324,13 +336,15 @@ class AOTEngine(nn.Module):
         dev = next(self.AOT.parameters()).device
         geom = (N, B, tuple(widths), dev)
         if self._bank is None or self._bank_geom != geom:
-            cap = 16      # memorised frames up front (a 70-frame clip at gap 5 needs 14); doubles beyond
+            # memorised frames up front (a 70-frame clip at gap 5 needs 14), x4 beyond: a re-allocation orphans the graphs
+            # captured on the old buffers, and the attention launches are planned for the capacity (layers/attention.py)
+            cap = 32
             self._bank = [(torch.empty(B, cap * N, ck, dtype=torch.float32, device=dev),
                            torch.empty(B, cap * N, cv, dtype=torch.float32, device=dev)) for ck, cv in widths]
             self._bank_geom = geom
         cap = self._bank[0][0].shape[1] // N
         if frames_needed > cap:
-            new_cap = max(2 * cap, frames_needed)
+            new_cap = max(4 * cap, frames_needed)
             used = self._slots * N
             grown = []
             for k, v in self._bank:
@@ -375,12 +389,26 @@ class AOTEngine(nn.Module):
         self._ring_pos += 1
         return s
 
-    def _store(self, kv, slot):
-        """Copies this frame's per-layer (K, V) [B*N, C] into bank slot `slot` of every lane (one strided copy each)."""
+    def _store(self, kv, slot, slot_dev=None):
+        """Copies this frame's per-layer (K, V) [B*N, C] into bank slot `slot` of every lane (one launch each; slot_dev: the
+        slot as a device int, for a replayed graph)."""
         N, B = self.enc_hw, self.lanes
+        stream = aot_hip.stream_ptr()
         for (bk, bv), (k, v) in zip(self._bank, kv):
-            bk[:, slot * N:(slot + 1) * N].copy_(k.view(B, N, -1))
-            bv[:, slot * N:(slot + 1) * N].copy_(v.view(B, N, -1))
+            aot_hip.copy_rows(k, bk.view(-1, bk.shape[2]), N, B=B, dst_brows=bk.shape[1], slot=slot, slot_dev=slot_dev,
+                              stream=stream)
+            aot_hip.copy_rows(v, bv.view(-1, bv.shape[2]), N, B=B, dst_brows=bv.shape[1], slot=slot, slot_dev=slot_dev,
+                              stream=stream)
+
+    def _dev_int(self, i, value):
+        """Device int i (0: bank length in tokens, 1: bank slot of the frame being memorised) set to `value` on the current
+        stream -- outside any capture, in front of the replay that reads it; written only when the value changes."""
+        if self._dev_ints is None:
+            self._dev_ints = torch.zeros(2, dtype=torch.int32, device=next(self.AOT.parameters()).device)
+        if self._dev_vals[i] != value:
+            self._dev_ints[i:i + 1].fill_(int(value))
+            self._dev_vals[i] = value
+        return self._dev_ints[i:i + 1]
 
     def _push_short(self, entry):
         self._short.append(entry)
@@ -503,7 +531,9 @@ class AOTEngine(nn.Module):
         else:
             dst = self._scratch_set()
         brows = self._brows_bank()
-        long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) for k, v in self._bank]
+        sf = self._state_free
+        tdev = (self._dev_int(0, T),) if sf else ()
+        long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) + tdev for k, v in self._bank]
         short = self._short[0]
         self._dst = dst
 
@@ -517,8 +547,12 @@ class AOTEngine(nn.Module):
 
         if self.use_graph:
             src = self._stage('img', img) if (img_embs is None and ahead is None) else None
-            key = ptr_key('match', src, img_embs, [f[0] for f in ahead] if ahead is not None else None, long_m, short, dst,
-                          self.pos_emb, self.lanes, self.enc_size_2d, aot_hip.gemm_table())
+            # state-free: the bank length is not part of the key (only whether the bank is still the reference frame alone:
+            # that launch is planned for its exact length)
+            bank_state = T <= self.enc_hw if sf else T
+            key = ptr_key('match', src, img_embs, [f[0] for f in ahead] if ahead is not None else None,
+                          [m[:2] for m in long_m], brows, bank_state, short, dst, self.pos_emb, self.lanes, self.enc_size_2d,
+                          aot_hip.gemm_table())
             self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
         else:
             self._feats, self._dec_in, self._curr = launch(img, img_embs)
@@ -562,17 +596,20 @@ class AOTEngine(nn.Module):
             store_slot = self._next_slot()
             self._ensure_bank(store_slot + 1)
 
+        slot_dev = self._dev_int(1, store_slot) if (self._state_free and store_slot is not None) else None
+
         def launch(mask_):
             self.AOT.update_memory_values(curr, mask_, self.enc_size_2d, self.lanes, self.group0, [d[1] for d in dst],
                                           aot_hip.stream_ptr(), id_emb=mask_ if curr_id_emb is not None else None)
             if store_slot is not None:
-                self._store(dst, store_slot)
+                self._store(dst, store_slot, slot_dev)
 
         if curr_id_emb is not None:
             curr_mask = curr_id_emb
         if self.use_graph:
             src = self._stage('mask' if curr_id_emb is None else 'id_emb', curr_mask)
-            key = ptr_key('update', src, curr, dst, store_slot, [b[0] for b in self._bank] if store_slot is not None else None,
+            key = ptr_key('update', src, curr, dst, (store_slot is not None) if self._state_free else store_slot,
+                          [b[0] for b in self._bank] if store_slot is not None else None,
                           self.lanes, self.group0, self.enc_size_2d, aot_hip.gemm_table())
             self._gx().run(key, lambda: launch(src))
         else:

@@ -42,6 +42,17 @@ def attn_splits(nq, units, t, occ=4, c0=3.0, wg_waves=1):
     return best
 
 
+def _planned_len(t, nq, kv_brows):
+    """Bank length a launch is PLANNED for: beyond the first memorised frame the launch geometry (the grid-level key split)
+    follows the bank's CAPACITY (kv_brows: rows between lanes = rows of the pre-allocated bank), not its length of the
+    moment -- the kernels cut the true length into that many ranges.  One captured launch then serves every bank length
+    (hipGraph replay with the length in a device int, T_dev), and the eager engine, planning the same way, stays
+    bit-identical to the replayed one."""
+    if t <= nq:
+        return t
+    return max(t, int(kv_brows))
+
+
 class MultiheadAttention(nn.Module):
     """Long-term attention over the memory bank and (with use_linear) self-attention
     (reference attention.py:29-126).  ``core`` is everything between the input linears and
@@ -88,7 +99,7 @@ class MultiheadAttention(nn.Module):
                     aot_hip.attention_topk(q[r0:r1], kb, vb, out[r0:r1], t, self.num_head, scale_div, self.top_k, scores,
                                            stream=stream)
             return out
-        ns = attn_splits(nq * B, self.num_head, t, wg_waves=4)
+        ns = attn_splits(nq * B, self.num_head, _planned_len(t, nq, kv_brows), wg_waves=4)
         part = None
         if ns > 1:      # one slab set sized for the largest grid split (4): no per-bank-size allocations
             part = ws.get('attn_part', (4 * B * nq * (self.d_model + 2 * self.num_head),), q.device)
@@ -187,7 +198,7 @@ class GatedPropagation(nn.Module):
                 scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
         if 0 < self.top_k < t:
             return self._core_topk(q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows)
-        ns = attn_splits(nq * B, out.shape[1] // 256, t, occ=1, c0=1.0)
+        ns = attn_splits(nq * B, out.shape[1] // 256, _planned_len(t, nq, kv_brows), occ=1, c0=1.0)
         part = None
         if ns > 1:
             part = ws.get('gattn_part', (16 * B * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)

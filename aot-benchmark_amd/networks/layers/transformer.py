@@ -78,7 +78,8 @@ class LongShortTermTransformerBlock(nn.Module):
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
     def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
-        """x [B*N, C(ld)] token-major (B lanes).  long_mem = (K, V, T, kv_brows): lane b's bank = rows b*kv_brows .. + T;
+        """x [B*N, C(ld)] token-major (B lanes).  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
+        (T_dev: device int holding T, for launches replayed from a graph while the bank grows);
         short_mem = (K, V, kv_brows).  dst = (k_out, v_out) [B*N, C] buffers for this frame's K (= linear_Q output) and, on
         a reference frame, the id-fused V (e.g. the lane's bank slot); allocated when None.  keep = the caller's arena
         (a Workspace) for the tensors that outlive this call; None: fresh tensors.
@@ -116,13 +117,14 @@ class LongShortTermTransformerBlock(nn.Module):
         fused_v = None
         if id_emb is not None:                                    # reference frame: memorise itself (:337-341)
             fused_v = self.fuse_kv_2d(x2, id_emb, ws, stream, out=dst[1] if dst is not None else None)
-            gk, gv, t, g_brows = qc, fused_v, N, N
+            gk, gv, t, g_brows, t_dev = qc, fused_v, N, N, ()
             lk, lv, l_brows = qc, fused_v, N
         else:
-            gk, gv, t, g_brows = long_mem
+            gk, gv, t, g_brows, *t_dev = long_mem
             lk, lv, l_brows = short_mem
         cat = ws.get('lst_cat', (M, 2 * C), dev)
-        self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream, B=B, kv_brows=g_brows)
+        self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream, t_dev=t_dev[0] if t_dev else None, B=B,
+                                 kv_brows=g_brows)
         self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream, B=B, kv_brows=l_brows)
         xb = ws.get('xb', (M, C), dev)
         aot_hip.linear(cat, p['lst_w'], p['lst_b'], xb, res=xa, stream=stream)
@@ -203,7 +205,7 @@ class LongShortTermTransformer(nn.Module):
             out_cat = keep.get('lstt_out_cat', (B * N, (L + 1) * C), x0.device)
         else:
             out_cat = torch.empty(B * N, (L + 1) * C, dtype=torch.float32, device=x0.device)
-        out_cat.view(B, N, (L + 1) * C)[:, :, :C].copy_(x0)      # the same image feature for every lane
+        aot_hip.copy_rows(x0, out_cat, N, B=B, src_brows=0, dst_brows=N, stream=stream)    # the same image feature for every lane
         x = out_cat[:, :C]
         mems = []
         for i, layer in enumerate(self.layers):
@@ -337,13 +339,14 @@ class GatedPropagationModule(nn.Module):
             aot_hip.linear(xi, p['idu_w'], p['idu_b'], U[:, E:], act=aot_hip.ACT_SILU, stream=stream)
         if id_emb is not None:                                              # reference frame (:613-620)
             self.fuse_id_into(vcat, xi, id_emb, ws, stream)
-            gk, gv, t, g_brows = qc, vcat, N, N
+            gk, gv, t, g_brows, t_dev = qc, vcat, N, N, ()
             lk, lv, l_brows = qc, vcat, N
         else:
-            gk, gv, t, g_brows = long_mem
+            gk, gv, t, g_brows, *t_dev = long_mem
             lk, lv, l_brows = short_mem
         raw = ws.get('gpm_raw', (M, 2 * E), dev)
-        self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream, B=B, kv_brows=g_brows)
+        self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream, t_dev=t_dev[0] if t_dev else None, B=B,
+                                 kv_brows=g_brows)
         Xm = ws.get('gpm_Xm', (M, 2 * D), dev)
         self.long_term_attn.tail(raw, Xm, size_2d, ws, stream, res=X, B=B)      # X + lt
         self.short_term_attn.core(qc, lk, lv, U, raw, size_2d, ws, stream, B=B, kv_brows=l_brows)
@@ -403,7 +406,7 @@ class DualBranchGPM(nn.Module):
         N, D = x0.shape
         dev = x0.device
         X = ws.get('gpm_X0', (B * N, 2 * D), dev)
-        X.view(B, N, 2 * D)[:, :, :D].copy_(x0)
+        aot_hip.copy_rows(x0, X, N, B=B, src_brows=0, dst_brows=N, stream=stream)
         X[:, D:].zero_()                                                    # tgt_id = 0 (transformer.py:602-603)
         mems = []
         for i, layer in enumerate(self.layers):

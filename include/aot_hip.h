@@ -220,6 +220,15 @@ int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int G,
 /* out = a + b over n floats (n % 4 == 0) -- V + id_emb in fuse_key_value_id (transformer.py:364-367). */
 int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream);
 
+/* Row-block copy between token-major buffers, B lanes: dst[(b*dst_brows + slot*rows + r), 0..C) = src[(b*src_brows + r), 0..C)
+ * for r < rows (row strides lds / ldd; src_brows = 0: the same source block for every lane).  `slot_dev` (optional) is a
+ * device int overriding `slot`, so that a captured graph can append to whichever bank slot is next.
+ * Replaces the torch.cat of update_long_term_memory (networks/engines/aot_engine.py:291-305: the frame's K / V are written
+ * into the next slot of the pre-allocated bank instead of re-copying the whole bank) and the per-lane copy of the shared
+ * image embedding in front of the LSTT (aot_engine.py:606-616). */
+int aot_copy_rows_f32(const float* src, float* dst, int B, long rows, int C, long src_brows, long dst_brows, int lds, int ldd,
+                      const int* slot_dev, int slot, void* stream);
+
 /* ---- evaluator-side steps: what the reference does on either side of the engine per frame ---- */
 
 /* Frame preparation: cubic resize of an interleaved H x W x 3 image (uint8 or float32 in [0,255], row stride ld_src

@@ -654,6 +654,13 @@ def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahe
     frames, mask, objs, out_size = case_clip(c, device='cuda', g=g)
     label_fn = _fuse_label(hip) if labels == 'fuse_probs' else \
         (lambda logit: torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float())
+    # SwinB-DeAOTL with the synthetic weights is CHAOTIC on this clip: a single near-tie flip (frame 11) is amplified by the
+    # mask feedback into thousands of pixels within a few frames -- for the CPU oracle exactly as for the HIP path
+    # (profiles/r03_swinb_free_running_oracle.txt), i.e. the reference itself is not reproducible free-running across fp32
+    # summation orders there.  That case runs TIE-SYNCHRONISED: the engine's own labels feed its memory everywhere except
+    # on the reference's near-tie pixels of the frame, which take the reference's label; any pixel differing OUTSIDE the
+    # near-ties is still an error, on every frame.
+    sync_ties = case == 'c3_swinb_deaotl_480_70'
     eng.restart_engine()
     diffs, hard = [], 0
     with torch.no_grad():
@@ -665,13 +672,18 @@ def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahe
             logit = eng.decode_current_logits(out_size)
             lab = label_fn(logit)
             bad = lab[0, 0].cpu().numpy().astype(np.uint8) != g['masks'][t - 1]
+            tie = unpack_gapmask(g, t, bad.shape)
             diffs.append(int(bad.sum()))
-            hard += int((bad & ~unpack_gapmask(g, t, bad.shape)).sum())
+            hard += int((bad & ~tie).sum())
+            if sync_ties and bad.any():
+                ref = torch.from_numpy(g['masks'][t - 1].astype(np.float32)).cuda()
+                lab = torch.where(torch.from_numpy(tie).cuda(), ref, lab[0, 0]).view(1, 1, *bad.shape)
             eng.update_memory(F.interpolate(lab, size=eng.input_size_2d, mode='nearest'))
     _record_parity(case, 'free_running/%s/%s/%s%s' % (table, 'graph' if graph else 'eager', labels,
                                                        '/ahead%d' % ahead if ahead > 1 else ''),
                    {'frames': len(diffs), 'pixels_differing_per_frame': diffs, 'pixels_differing': int(sum(diffs)),
-                    'outside_reference_near_ties': hard, 'pixels': int(g['masks'].size)})
+                    'outside_reference_near_ties': hard, 'pixels': int(g['masks'].size),
+                    'feedback': 'own labels; reference labels on its near-tie pixels' if sync_ties else 'own labels'})
     assert hard == 0, '%s free-running: %d differing pixels are not reference near-ties' % (case, hard)
     assert sum(diffs) <= len(diffs) and max(diffs) <= 4, '%s free-running: tie flips per frame %s' % (case, diffs)
     if case == 'c1_aott':
@@ -1154,6 +1166,46 @@ def test_graph_replay_bit_identical(hip, name, nobj, size):
     for e in engs:
         g = e._cohorts[0]._gx()
         assert g.captures <= 3 * 7 and g.replays == 2 * 3 * 7
+
+
+@pytest.mark.parametrize('name,frames,gap', [('aott', 400, 1), ('deaott', 120, 2)])
+def test_graph_replay_survives_long_clips(hip, name, frames, gap):
+    """graph=True on a LONG clip whose bank grows every `gap` frames (400 frames at gap 1: the bank is re-allocated twice on
+    the way, 32 -> 128 -> 512 frames): the captured launches take the bank length and the slot of a memorised frame from
+    device ints (T_dev of aot_attn_f32 / aot_gated_attn_f32, slot_dev of aot_copy_rows_f32), so the number of graphs does
+    NOT grow with the clip -- at most 32 captures -- and every frame's logits are BIT-identical to the eager engine's
+    (reference behaviour preserved: aot_engine.py:291-305,334-338, the bank grows without bound)."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state(name)
+    model = model.cuda().eval()
+    model.prepare()
+    size, osz = (97, 129), (96, 128)
+    fr, m, ob, _ = synth_clip(31, 8, size, osz, 3, device='cuda')
+    img = lambda t: fr[1 + (t * 5) % 7]           # the clip cycles through 7 distinct frames
+
+    def run(graph):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap, graph=graph)
+        eng.restart_engine()
+        eng.add_reference_frame(fr[0], m, ob, frame_step=0)
+        outs = []
+        for t in range(1, frames):
+            eng.match_propogate_one_frame(img(t))
+            lg = eng.decode_current_logits(osz)
+            eng.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=eng.input_size_2d, mode='nearest'))
+            outs.append(lg.clone())
+        torch.cuda.synchronize()
+        return outs, eng
+    with torch.no_grad():
+        want, e0 = run(False)
+        got, e1 = run(True)
+    c0 = e1._cohorts[0]
+    assert c0.bank_frames == e0._cohorts[0].bank_frames == 1 + (frames - 1) // gap
+    for t, (a, b) in enumerate(zip(want, got), start=1):
+        assert torch.equal(a, b), 'frame %d: graph replay differs from eager (max %g)' % (t, (a - b).abs().max().item())
+    g = c0._gx()
+    assert g.captures <= 32, '%d graphs captured for a %d-frame clip' % (g.captures, frames)
+    assert g.replays == 3 * (frames - 1)
 
 
 def test_scratch_released_when_clip_geometry_changes(hip):

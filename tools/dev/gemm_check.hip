@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
       {"dec c4 3x3 128", 121, 213, 128, 128, 3, 1, 1},  {"ragged 3x3 d2", 17, 19, 32, 96, 3, 1, 0}};
   // auto | 64x64 register-staged | LDS-direct 64x64 (2 / 3 DMA steps ahead) | lean 64x64 | lean 128x64 | lean 64x64 with
   // split-K 2 / 4 | lean 128x64 with split-K 2 / 4 | wave-independent kernels (in-block split-K 4 / 8, 64x32 waves x4)
-  const int cfgs[] = {-1, 4, 117, 133, 197, 213, 198, 200, 214, 216, 14, 18, 24, 32, 34, 38};
+  const int cfgs[] = {-1, 4, 117, 133, 197, 213, 198, 200, 214, 216, 14, 18, 24};
   const long scratch_floats = 48L << 20;
   float* scratch;
   CK(hipMalloc(&scratch, scratch_floats * 4));
