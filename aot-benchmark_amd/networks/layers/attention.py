@@ -99,12 +99,14 @@ class MultiheadAttention(nn.Module):
                     aot_hip.attention_topk(q[r0:r1], kb, vb, out[r0:r1], t, self.num_head, scale_div, self.top_k, scores,
                                            stream=stream)
             return out
-        ns = attn_splits(nq * B, self.num_head, _planned_len(t, nq, kv_brows), wg_waves=4)
+        t_plan = _planned_len(t, nq, kv_brows)
+        ns = attn_splits(nq * B, self.num_head, t_plan, wg_waves=4)
         part = None
         if ns > 1:      # one slab set sized for the largest grid split (4): no per-bank-size allocations
             part = ws.get('attn_part', (4 * B * nq * (self.d_model + 2 * self.num_head),), q.device)
-        aot_hip.attention(q, k, v, out, t, self.num_head, scale_div, part=part, nsplit=ns, T_dev=t_dev, B=B,
-                          kv_brows=kv_brows, stream=stream)
+        # (with a device-side length the host-side T only bounds the launch: the planned length)
+        aot_hip.attention(q, k, v, out, t if t_dev is None else t_plan, self.num_head, scale_div, part=part, nsplit=ns,
+                          T_dev=t_dev, B=B, kv_brows=kv_brows, stream=stream)
         return out
 
 
@@ -198,12 +200,13 @@ class GatedPropagation(nn.Module):
                 scale_div = self.T / (math.log(ratio) / math.log(self.max_mem_len_ratio))
         if 0 < self.top_k < t:
             return self._core_topk(q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows)
-        ns = attn_splits(nq * B, out.shape[1] // 256, _planned_len(t, nq, kv_brows), occ=1, c0=1.0)
+        t_plan = _planned_len(t, nq, kv_brows)
+        ns = attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
         part = None
         if ns > 1:
             part = ws.get('gattn_part', (16 * B * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)
-        aot_hip.gated_attention(q, k, v, gate, out, t, scale_div, part=part, nsplit=ns, T_dev=t_dev, B=B, kv_brows=kv_brows,
-                                stream=stream)
+        aot_hip.gated_attention(q, k, v, gate, out, t if t_dev is None else t_plan, scale_div, part=part, nsplit=ns,
+                                T_dev=t_dev, B=B, kv_brows=kv_brows, stream=stream)
         return out
 
     def _core_topk(self, q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows):

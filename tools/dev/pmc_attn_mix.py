@@ -1,23 +1,44 @@
-"""The attention launches of one 70-frame R50-AOTL clip (bench.py's mix: per propagated frame and layer one self-attention
-over the frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
-rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams)."""
+"""The attention launches of one 70-frame clip (bench.py's mix: per propagated frame and layer one self-attention over the
+frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
+rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams).
+    python tools/dev/pmc_attn_mix.py [aot|gated|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel), gated: R50-DeAOTL
+    (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel at M = 14 (SQ counter passes)
+AOT_HIP_LIB selects a variant build of the library."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
 aot_hip.load()
-from networks.layers.attention import attn_splits
-N, C, H = 1674, 256, 8
+from networks.layers.attention import attn_splits, _planned_len
+mode = sys.argv[1] if len(sys.argv) > 1 else 'aot'
+N, C, H, E, CAP = 1674, 256, 8, 1024, 32
 q = torch.randn(N, C, device='cuda'); out = torch.empty(N, C, device='cuda')
 k = torch.randn(14 * N, C, device='cuda'); v = torch.randn(14 * N, C, device='cuda')
 part = torch.empty(4 * N * (C + 2 * H), device='cuda')      # sized like MultiheadAttention.core's slab set
+gq = torch.randn(N, 128, device='cuda'); gk = torch.randn(14 * N, 128, device='cuda'); gv = torch.randn(14 * N, E, device='cuda')
+gu = torch.randn(N, E, device='cuda'); go = torch.empty(N, E, device='cuda'); gpart = torch.empty(16 * N * (E + 8), device='cuda')
+
+
+def d32(T, brows):
+    ns = attn_splits(N, H, _planned_len(T, N, brows), wg_waves=4)
+    aot_hip.attention(q, k, v, out, T, H, 32 ** 0.5, part=part if ns > 1 else None, nsplit=ns)
+
+
+def gated(T, brows):
+    ns = attn_splits(N, E // 256, _planned_len(T, N, brows), occ=1, c0=1.0)
+    aot_hip.gated_attention(gq, gk, gv, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
+
+
 n = 0
-for t in range(1, 70):
-    M = 1 + (t - 1) // 5
-    for layer in range(3):
-        for T in (N, M * N):
-            ns = attn_splits(N, H, T, wg_waves=4)
-            aot_hip.attention(q, k, v, out, T, H, 32 ** 0.5, part=part if ns > 1 else None, nsplit=ns)
-            n += 1
+if mode == 'm14':
+    for _ in range(3):
+        d32(14 * N, CAP * N); gated(14 * N, CAP * N); n += 2
+else:
+    fn = d32 if mode == 'aot' else gated
+    for t in range(1, 70):
+        M = 1 + (t - 1) // 5
+        for layer in range(3):
+            fn(N, N); fn(M * N, CAP * N)       # self-attention over the frame, long-term attention over the bank
+            n += 2
 torch.cuda.synchronize()
 print('launches', n)
