@@ -20,6 +20,8 @@ _L = ctypes.c_long
 
 _SIGS = {
     'aot_conv2d_nhwc_f32': [_P] * 7 + [_L] + [_I] * 20 + [_P],
+    'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
+    'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
@@ -63,17 +65,24 @@ ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 # `with use_gemm_table(engine.gemm_table)`, so two engines of one process can use different tables and nothing outlives
 # the stage call.  Outside any scope the table is 'latency'.
 GEMM_TABLES = {'latency': -1, 'throughput': -2}
+# Which matrix-core arithmetic those calls use: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32 products, the default), 'bf16x6' = the
+# fp32-equivalent six-term bf16 split (aot_conv2d_bf16x6_f32; include/aot_hip.h) wherever a layer qualifies.  An engine attribute
+# too (build_engine(..., mfma=)), carried by the same scope.
+MFMA_MODES = ('f32', 'bf16x6')
+X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
 _table_scopes = []
 
 
 class use_gemm_table:
-    """Scope in which conv2d / linear calls that leave the kernel choice open use the named dispatch table."""
+    """Scope in which conv2d / linear calls that leave the kernel choice open use the named dispatch table (and arithmetic)."""
 
-    def __init__(self, name):
-        self.cfg = GEMM_TABLES[name]
+    def __init__(self, name, mfma='f32'):
+        if mfma not in MFMA_MODES:
+            raise ValueError('mfma must be one of %s' % (MFMA_MODES,))
+        self.ent = (GEMM_TABLES[name], mfma == 'bf16x6')
 
     def __enter__(self):
-        _table_scopes.append(self.cfg)
+        _table_scopes.append(self.ent)
         return self
 
     def __exit__(self, *exc):
@@ -82,8 +91,12 @@ class use_gemm_table:
 
 
 def gemm_table():
-    """Name of the table in force here (graph keys carry it: a graph captured under one table never replays under the other)."""
-    return 'throughput' if _table_scopes and _table_scopes[-1] == -2 else 'latency'
+    """Name of the table (and arithmetic) in force here (graph keys carry it: a graph captured under one never replays under
+    another)."""
+    if not _table_scopes:
+        return 'latency'
+    cfg, x6 = _table_scopes[-1]
+    return ('throughput' if cfg == -2 else 'latency') + ('+bf16x6' if x6 else '')
 
 
 class AotHipError(RuntimeError):
@@ -148,19 +161,68 @@ def attach_wt(w, cin=None):
     aot_conv2d_nhwc_f32 pick the LDS-direct tile kernel (csrc/gemm_lds.hip) when the shape allows it."""
     if w.shape[0] % 32 == 0 and (cin is None or cin % 32 == 0):
         w._aot_wt = w.t().contiguous()
+    return _register_weight(w)
+
+
+_gemm_weights = None     # weak set of every packed GEMM weight (attach_wt): what pack_bf16x6_all() walks
+
+
+def _register_weight(w):
+    global _gemm_weights
+    if _gemm_weights is None:
+        import weakref
+        _gemm_weights = weakref.WeakSet()
+    _gemm_weights.add(w)
     return w
+
+
+def pack_bf16x6(w):
+    """Splits a packed GEMM weight w [K, ld] (K % 32 == 0) into the three bf16 planes of the bf16x6 kernels, once; kept on the
+    tensor (`_aot_w6`, int16 [3, K/32, 4, cout_pad, 8]).  Must not happen inside a graph capture: engines in bf16x6 mode call
+    pack_bf16x6_all() before their first captured stage."""
+    w6 = getattr(w, '_aot_w6', None)
+    if w6 is not None:
+        return w6
+    if torch.cuda.is_current_stream_capturing():
+        raise AotHipError('a GEMM weight reached the bf16x6 path unpacked inside a graph capture: call aot_hip.pack_bf16x6_all() '
+                          '(or model.prepare(mfma="bf16x6")) first')
+    K, ld = w.shape
+    if K % 32:
+        raise AotHipError('bf16x6 weights need K % 32 == 0')
+    cout_pad = (ld + 63) // 64 * 64
+    w6 = torch.empty(3, K // 32, 4, cout_pad, 8, dtype=torch.int16, device=w.device)
+    _chk(load().aot_pack_bf16x6_f32(_dev(w), _dev(w6), K, ld, w.stride(0), cout_pad, stream_ptr()), 'aot_pack_bf16x6_f32')
+    w._aot_w6 = w6
+    return w6
+
+
+def pack_bf16x6_all():
+    """Packs every registered GEMM weight that qualifies (on the device, K % 32 == 0) and has no bf16x6 twin yet."""
+    for w in list(_gemm_weights or ()):
+        if w.is_cuda and w.dim() == 2 and w.shape[0] % 32 == 0 and getattr(w, '_aot_w6', None) is None:
+            pack_bf16x6(w)
 
 
 def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
            B=1, res_rows=0, cfg=-1, stream=None):
     """B NHWC images [B*H*W, lda] -> [B*OH*OW, ldc]; res_rows > 0: the residual is one [res_rows, ldr] map shared by the
     images (row m % res_rows)."""
+    if cfg == -1 and _table_scopes and _table_scopes[-1][1] and Cin % 32 == 0 and Cout > 32 and \
+            -(-B * OH * OW // 64) * -(-Cout // 64) >= X6_MIN_TILES:
+        w6 = getattr(w, '_aot_w6', None)
+        if w6 is None:
+            w6 = pack_bf16x6(w)
+        _chk(load().aot_conv2d_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH,
+                                          OW, Cout, KH, KW, stride, pad, dil, x.stride(0), out.stride(0),
+                                          res.stride(0) if res is not None else 0, res_rows, act,
+                                          stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6_f32')
+        return out
     wt = getattr(w, '_aot_wt', None)
     _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), None, 0, B, H, W, Cin, OH,
                                     OW, Cout, KH, KW, stride, pad, dil, x.stride(0), w.stride(0),
                                     wt.stride(0) if wt is not None else 0, out.stride(0),
                                     res.stride(0) if res is not None else 0, res_rows, act,
-                                    (_table_scopes[-1] if _table_scopes else -1) if cfg == -1 else cfg,
+                                    (_table_scopes[-1][0] if _table_scopes else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 

@@ -65,9 +65,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v_descriptor(const float* v, l
 #ifndef AOT_ATT_VPM
 #define AOT_ATT_VPM 4
 #endif
-#ifndef AOT_ATT_SPLIT_MAJOR   // d = 32 kernel: workgroups of one key range (grid-level split) are dispatched together (see the launch)
-#define AOT_ATT_SPLIT_MAJOR 0  // same launch time either way (353 vs 354 us at M = 14); which one ships is decided by the fabric traffic
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // max of three in ONE instruction (same NaN rule as fmaxf: a NaN operand is ignored)
 // packed fp32: two values per lane and instruction (hipcc scalarises most <2 x float> arithmetic next to MFMA operands)
@@ -107,11 +104,7 @@ __device__ __forceinline__ float exp2_w(float s, float mL) {
 __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnParams p) {
   // 4 waves per workgroup (one per SIMD of the CU), 4 workgroups per CU -> 4 waves per SIMD
   __shared__ float red[4][18][64];      // per wave: o[16], m, l  (18 KB)
-#if AOT_ATT_SPLIT_MAJOR
   const int h = blockIdx.x, split = blockIdx.z, bz = blockIdx.y;
-#else
-  const int h = blockIdx.x, split = blockIdx.y, bz = blockIdx.z;
-#endif
   const int ntq = (p.Nq + 31) >> 5;
   const int b = bz / ntq, qt = bz - b * ntq;
   const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
@@ -499,11 +492,28 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
 // wave, so all four hold bit-identical scores) and each wave runs the softmax and its own 16*NDV value MFMAs.  144 instead
 // of 192 MFMAs per key tile and wave, q/k fragments of 16 registers instead of 64.  One barrier per key tile; the score
 // partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
+#ifndef AOT_GATED_XCD      // 1: XCD-aware walk of the (key range, query tile) pairs (see the kernel); decided by measurement
+#define AOT_GATED_XCD 0
+#endif
 template <int NDV>
 __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParams p) {
-  const int split = blockIdx.x;
   const int ntq = (p.Nq + 31) >> 5;
-  const int b = blockIdx.y / ntq, qt = blockIdx.y - b * ntq;
+#if AOT_GATED_XCD
+  // A workgroup streams its whole key range (one 128-wide K row + one 1024-wide V row per key: 4.6 KB); the 53 query tiles
+  // of a range re-read it.  Workgroup L runs on XCD L % 8: every XCD takes ONE contiguous run of the split-major (range,
+  // query tile) list, so it touches 2-3 key ranges instead of all of them and the tiles of a range find it in that XCD's L2.
+  int split, bz;
+  {
+    const int L = blockIdx.x + gridDim.x * blockIdx.y, Q = gridDim.y, G = gridDim.x * gridDim.y;
+    const int xcd = L & 7, li = L >> 3, q8 = G >> 3, r8 = G & 7;
+    const int P = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + li;
+    split = P / Q;
+    bz = P - split * Q;
+  }
+#else
+  const int split = blockIdx.x, bz = blockIdx.y;
+#endif
+  const int b = bz / ntq, qt = bz - b * ntq;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
   const int ch = wave;
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -709,13 +719,11 @@ extern "C" int aot_attn_f32(const float* q, const float* k, const float* v, floa
   if (rc) return rc;
   // Workgroup b of a grid runs on XCD b % 8 (observed dispatch rule), so with H = 8 heads in blockIdx.x every XCD serves one
   // head: its L2 sees that head's K / V slices only.  The grid has 53 x nsplit workgroups per head on 128 resident slots
-  // per XCD; the ones that start in the second dispatch round re-stream their key range.  Split-major order makes that
-  // second round the tail of ONE key range instead of a slice of all of them (fabric traffic of the re-read / nsplit).
-#if AOT_ATT_SPLIT_MAJOR
+  // per XCD; the ones that start in the second dispatch round re-stream their key range.  Split-major order (key range in
+  // blockIdx.z, query tile in .y) makes that second round the tail of ONE key range instead of a slice of all of them.
+  // Measured on the launch mix of a 70-frame clip (two PMC passes, profiles/r03_attn_traffic*.json): fabric traffic
+  // 37.4 -> 20.3 MB per launch = 2.10x -> 1.14x the algorithmic 17.8 MB, at the same launch time (353 vs 354 us at M = 14).
   hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, B * cdiv(Nq, 32), nsplit), dim3(256), 0, (hipStream_t)stream, p);
-#else
-  hipLaunchKernelGGL(attn_fwd_d32_pipe_kernel, dim3(H, nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
-#endif
   AOT_LAUNCH_CHECK();
 }
 

@@ -21,3 +21,7 @@ int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch
 bool gemm_lds_eligible(const ConvParams& p);
 // variant 6 / 7 = the lean 64x64 / 128x64 kernel (buffer-DMA addressing, interleaved issue; see gemm_lds.hip)
 bool gemm_lean_eligible(const ConvParams& p);
+// bf16 x 6 variant of the lean 64x64 kernel (gemm_lds.hip): w6 = the weight pre-split into three bf16 planes, layout
+// [3][K/32][4][cout_pad][8] (aot_pack_bf16x6_f32)
+bool gemm_x6_eligible(const ConvParams& p);
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);

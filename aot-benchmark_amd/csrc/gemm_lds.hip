@@ -787,6 +787,315 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 #endif
 }
 
+// ---- bf16 x 6 variant (second, parity-gated kernel family) --------------------------------------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950.  Every fp32 number is EXACTLY the sum of three bf16 numbers obtained by
+// truncation (8 + 8 + 8 significand bits: hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid), so
+//   a * w = sum of the nine products (a_i * w_j);   the six of order i + j <= 2 are kept (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+//   mid*mid): what is dropped is <= 3 * 2^-24 |a w| -- the size of one fp32 rounding of the product.  Each kept product of two
+//   bf16 values is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, the sums are fp32: an fp32-equivalent GEMM at
+//   6/16 of the fp32-MFMA cost (measured in registers: 268 vs 150 TFLOP/s-equivalent, profiles/r02_bf16_split_rate.txt;
+//   parity by emulation through the oracle: 1.8e-5 on the logits of BASELINE config 2, the fp32 path's own level).
+// Same 64x64 tile, item walk, LDS-DMA ring and tile end as gemm_lean_kernel<1>.  What differs:
+//   * the WEIGHT comes pre-split (aot_pack_bf16x6, once per model): three bf16 planes in a tile-friendly order,
+//     w6[plane][K/32][4][Cout_pad][8]: the 16-byte chunk cc = 2*s + h of a 32-wide k-block holds the eight k values lane-half h
+//     contracts in sub-step s (k = 16 s + 4 h + {0..3} and + 8), for Cout_pad (a multiple of 64) columns side by side -- one
+//     LDS-DMA piece is 64 columns x 16 bytes, contiguous in memory AND lane-linear in LDS, so the fragment reads
+//     (ds_read_b128, consecutive lanes = consecutive columns) are conflict-free without a swizzle;
+//   * the ACTIVATION tile arrives as fp32 exactly as in the lean kernel (im2col through the buffer descriptor) and is split in
+//     registers right before use: 4 VALU per element + 3 v_perm per pair;
+//   * three ring stages of 20.6 KB (two workgroups per CU); a k-step is 12 MFMAs of 32 cycles instead of 16 of 64.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct X6Weight {
+  const void* w6;     // [3][K/32][4][cout_pad][8] bf16
+  int cout_pad;       // multiple of 64
+};
+
+// two truncated bf16 (the upper halves of a and b) in one dword: [a.hi16 | b.hi16 << 16]
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// eight fp32 values (the lane's k-set of one sub-step) -> their three bf16 planes
+__device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, bf16x8 (&out)[3]) {
+  u32x4 w[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float r0 = e < 2 ? x0[2 * e] : x1[2 * e - 4], r1 = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      w[pl][e] = pack_hi16(r0, r1);
+      if (pl < 2) {
+        r0 -= __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        r1 -= __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, w[pl]);
+}
+
+// asynchronous fragment reads of one ring stage (IMM = its byte offset): four fp32 chunks of the lane's A row, and for each weight
+// plane the lane's two bf16 chunk columns (sub-steps 0 / 1 = pieces 4 pl + half and 4 pl + 2 + half; `half` is in baddr)
+template <int IMM, int PIECE>
+__device__ __forceinline__ void x6_fetch(f32x4 (&a)[4], bf16x8 (&b)[3][2], const unsigned (&aaddr)[4], unsigned baddr) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(aaddr[j]), "n"(IMM));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[0][0]) : "v"(baddr), "n"(IMM + 0 * PIECE));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[0][1]) : "v"(baddr), "n"(IMM + 2 * PIECE));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[1][0]) : "v"(baddr), "n"(IMM + 4 * PIECE));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[1][1]) : "v"(baddr), "n"(IMM + 6 * PIECE));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[2][0]) : "v"(baddr), "n"(IMM + 8 * PIECE));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[2][1]) : "v"(baddr), "n"(IMM + 10 * PIECE));
+}
+__device__ __forceinline__ void x6_landed(f32x4 (&a)[4], bf16x8 (&b)[3][2]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(b[pl][0]), "+v"(b[pl][1]));
+}
+
+template <bool IS1X1>
+__global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq) {
+  constexpr int NST = 3;
+  constexpr int BM = 64, BN = 64;
+  constexpr int AG = BM / 8, AGW = AG / 4;              // A: 8-row groups, two per wave
+  constexpr int BPW = 3;                                // B: one 16-byte chunk column (cc = wave) of each plane per wave
+  constexpr int LPW = AGW + BPW;
+  constexpr int OPA_BYTES = AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 12 * B_PIECE;
+  constexpr int STAGE_BYTES = OPA_BYTES + OPB_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nk = p.K / BK;
+  const int nitems = nbm * nbn;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
+  const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int mine = li < chunk_n ? (chunk_n - li + nwg_x - 1) / nwg_x : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  auto item_of = [&](int i) __attribute__((always_inline)) {
+    const int it = chunk0 + li + i * nwg_x;
+    Item r;
+    r.bn = it % nbn;
+    r.bm = it / nbn;
+    r.kt0 = 0;
+    return r;
+  };
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int lr = lane >> 3, lp = lane & 7;
+  const int cofs = (lp ^ lr) << 2;
+  const int hw_out = p.OH * p.OW;
+  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+  const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
+  const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
+  const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
+  const int n_res = p.res ? 16 : 0, n_bias = p.bias ? 1 : 0;
+
+  // ---- issue side --------------------------------------------------------------------------------------------------
+  int is_i = 0, is_kt = 0;
+  int a_off[AGW], a_iy0[AGW], a_ix0[AGW];
+  bool a_ok[AGW];
+  unsigned b_off = 0;
+  int s_k = 0, s_kb = 0;       // wave-uniform byte offsets along K: A rows of a 1x1 layer / the weight's k-blocks
+  int tap_c = 0, tap_ky = 0, tap_kx = 0, s_tap = 0;
+  auto setup_item = [&](int i) __attribute__((always_inline)) {
+    const bool live = i < mine;
+    const Item it = item_of(live ? i : 0);
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      const int m = it.bm * BM + 8 * (AGW * wave + g) + lr;
+      a_ok[g] = live && m < p.M;
+      const int mm = a_ok[g] ? m : 0;
+      const int b = mm / hw_out, pix = mm - b * hw_out;
+      const int oy = pix / p.OW, ox = pix - oy * p.OW;
+      a_iy0[g] = oy * p.stride - p.pad;
+      a_ix0[g] = ox * p.stride - p.pad;
+      a_off[g] = (((b * p.H + a_iy0[g]) * p.W + a_ix0[g]) * p.lda + cofs) * 4;
+      if (IS1X1 && !a_ok[g]) a_off[g] = (int)OOB;
+    }
+    b_off = live ? (unsigned)((wave * wq.cout_pad + it.bn * BN + lane) * 16) : OOB;    // chunk column cc = wave of k-block 0
+    s_k = 0;
+    s_kb = 0;
+    if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
+  };
+  auto issue = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    constexpr int slot = decltype(SLOT)::value;
+    if (is_kt == 0) setup_item(is_i);
+    if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4;
+    unsigned char* st = lds + slot * STAGE_BYTES;
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
+      if (IS1X1) {
+        dma16(rsrc_a, dst, a_off[g], s_k);
+      } else {
+        const int iy = a_iy0[g] + tap_ky * p.dil, ix = a_ix0[g] + tap_kx * p.dil;
+        const bool in = a_ok[g] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        dma16(rsrc_a, dst, in ? a_off[g] + s_tap : (int)OOB, 0);
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      dma16(rsrc_b, st + OPA_BYTES + (pl * 4 + wave) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
+    s_k += BK * 4;
+    s_kb += 4 * wq.cout_pad * 16;
+    if (!IS1X1) {
+      tap_c += BK;
+      if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
+    }
+    if (++is_kt == nk) { is_kt = 0; ++is_i; }
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
+  unsigned aaddr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aaddr[j] = lds_base + chunk_off(wm + l31, 2 * j + half);
+  const unsigned baddr = lds_base + OPA_BYTES + (half * 64 + wn + l31) * 16;      // chunk column cc = 2 s + half: + 2 s pieces
+  f32x4 ra[2][4];              // [register set][16-byte chunk j]: sub-step s contracts chunks 2 s and 2 s + 1
+  bf16x8 rb[2][3][2];          // [register set][plane][sub-step]
+  auto fetch = [&](auto SET, auto SLOT) __attribute__((always_inline)) -> void {
+    x6_fetch<decltype(SLOT)::value * STAGE_BYTES, B_PIECE>(ra[decltype(SET)::value], rb[decltype(SET)::value], aaddr, baddr);
+  };
+  auto landed = [&](auto SET) __attribute__((always_inline)) -> void { x6_landed(ra[decltype(SET)::value], rb[decltype(SET)::value]); };
+  f32x16 acc[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  int c_i = 0, c_kt = 0;
+  int stores_pending = 0;
+  float rv[16], bv = 0.f;
+  auto epi_loads = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int n = it.bn * BN + wn + l31;
+    const bool col_ok = n < p.Cout;
+    const int m0 = it.bm * BM;
+    if (n_bias) bv = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
+    if (n_res && p.res_rows == 0) {
+      const int mlane = m0 + wm + 4 * half;
+      const int vbase = col_ok ? (mlane * p.ldr + n) * 4 : (int)OOB;
+      const int rows_left = p.M - mlane, ldr4 = p.ldr * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        rv[r] = buf_load_s(desc_res, c < rows_left ? vbase : (int)OOB, c * ldr4);
+      }
+    } else if (n_res) {
+      const int rr0 = m0 % p.res_rows;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = wm + mfma32_row(r, half);
+        int rr = rr0 + dm;
+        if (p.res_rows >= BM) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+        else rr %= p.res_rows;
+        rv[r] = buf_load(desc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB);
+      }
+    }
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int n = it.bn * BN + wn + l31;
+    const bool col_ok = n < p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] += acc[1][r]; acc[1][r] = 0.f; }
+    // residual and bias were fetched under the tile's last k-step: older than the DMA pieces issued in that step
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));
+    if (n_bias) asm volatile("" : "+v"(bv));
+    if (n_res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[r]));
+    }
+    const int m0 = it.bm * BM;
+    const int mlane = m0 + wm + 4 * half;
+    const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+    const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+    if (n_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += bv;
+    }
+    if (n_res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += rv[r];
+    }
+    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+      constexpr int act = decltype(ACT)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(acc[0][r], act));
+        acc[0][r] = 0.f;
+      }
+    });
+    stores_pending = 16;
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  issue(I0{});
+  issue(I1{});
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));          // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  fetch(I0{}, I0{});
+  // step ss (ring stage U % 3, register set U % 2; the loop is unrolled by six): on entry the fragments of step ss are being
+  // read into set U % 2, the DMA of step ss+1 is in flight
+  auto step = [&](auto U) __attribute__((always_inline)) -> void {
+    constexpr int u = decltype(U)::value, set = u & 1, nslot = (u + 1) % 3, islot = (u + 2) % 3;
+    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished)
+    if (stores_pending) {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 0));
+      stores_pending = 0;
+    } else {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+    }
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 (= of step ss+2) is free
+    landed(std::integral_constant<int, set>{});
+    fetch(std::integral_constant<int, set ^ 1>{}, std::integral_constant<int, nslot>{});      // fragments of step ss+1
+    issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
+    if (c_kt == nk - 1) epi_loads();                         // last k-step of the tile: its residual and bias, now
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ap[3];
+      split3(ra[set][2 * s], ra[set][2 * s + 1], ap);
+      // smallest terms first; the two sub-steps feed two independent accumulators
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], rb[set][1][s], acc[s], 0, 0, 0);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[set][2][s], acc[s], 0, 0, 0);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], rb[set][0][s], acc[s], 0, 0, 0);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[set][1][s], acc[s], 0, 0, 0);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], rb[set][0][s], acc[s], 0, 0, 0);
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[set][0][s], acc[s], 0, 0, 0);
+    }
+    if (++c_kt == nk) {
+      epilogue();
+      c_kt = 0;
+      ++c_i;
+    }
+  };
+#pragma unroll 1
+  for (int ss = 0; ss < total; ss += 6) {
+    step(I0{});
+    if (ss + 1 < total) step(I1{});
+    if (ss + 2 < total) step(I2{});
+    if (ss + 3 < total) step(std::integral_constant<int, 3>{});
+    if (ss + 4 < total) step(std::integral_constant<int, 4>{});
+    if (ss + 5 < total) step(std::integral_constant<int, 5>{});
+  }
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
+}
+
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch) {
   const int nq = (p.Cout + 3) >> 2;
@@ -855,6 +1164,29 @@ bool gemm_lean_eligible(const ConvParams& p) {
   return gemm_lds_eligible(p) && (long)p.B * p.H * p.W * p.lda * 4 < 0x7fffffffL && (long)p.Cout * p.ldwt * 4 < 0x7fffffffL &&
          (long)p.M * p.ldc * 4 < 0x7fffffffL && (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL) &&
          ((uintptr_t)p.in & 15) == 0;
+}
+
+// the bf16 x 6 kernel takes what the lean kernel takes (32-bit operand offsets) with K a multiple of 32
+bool gemm_x6_eligible(const ConvParams& p) {
+  return (p.Cin % 32) == 0 && (p.K % 32) == 0 && (p.lda & 3) == 0 && ((uintptr_t)p.in & 15) == 0 &&
+         (long)p.B * p.H * p.W * p.lda * 4 < 0x7fffffffL && (long)p.M * p.ldc * 4 < 0x7fffffffL &&
+         (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL);
+}
+
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s) {
+  if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
+  const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nitems < 512 ? nitems : 512;             // two workgroups per CU
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  if (is1x1)
+    hipLaunchKernelGGL((gemm_x6_kernel<true>), dim3(grid), dim3(256), 0, s, p, wq);
+  else
+    hipLaunchKernelGGL((gemm_x6_kernel<false>), dim3(grid), dim3(256), 0, s, p, wq);
+  AOT_LAUNCH_CHECK();
 }
 
 int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s) {

@@ -35,7 +35,7 @@ def _in_table(fn):
     attribute (build_engine(..., gemm_table=)), not process state."""
     @functools.wraps(fn)
     def stage(self, *args, **kwargs):
-        with aot_hip.use_gemm_table(self.gemm_table):
+        with aot_hip.use_gemm_table(self.gemm_table, self.mfma):
             return fn(self, *args, **kwargs)
     return stage
 
@@ -57,8 +57,13 @@ class AOTEngine(nn.Module):
     0..max_obj_num as they are."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None, lanes=1,
-                 group0=None, graph=False, gemm_table='latency'):
+                 group0=None, graph=False, gemm_table='latency', mfma='f32'):
         super().__init__()
+        # matrix-core arithmetic of the conv / linear layers: 'f32' (exact fp32 products, default) or 'bf16x6' (the
+        # fp32-equivalent six-term bf16 split, aot_conv2d_bf16x6_f32: a second, parity-gated kernel family)
+        if mfma not in aot_hip.MFMA_MODES:
+            raise ValueError('mfma must be one of %s' % (aot_hip.MFMA_MODES,))
+        self.mfma = mfma
         # which conv / linear dispatch table this engine's stages run under (include/aot_hip.h, cfg -1 / -2): 'latency' for
         # one clip at a time, 'throughput' when several engines keep the GPU busy on their own streams
         if gemm_table not in aot_hip.GEMM_TABLES:
@@ -490,6 +495,9 @@ class AOTEngine(nn.Module):
             _die('No image for reference frame!')
         if mask is None:
             _die('No mask for reference frame!')
+        if self.mfma == 'bf16x6':
+            self.AOT.pack()
+            aot_hip.pack_bf16x6_all()        # (no-op once done; never inside a capture -- this stage is launched from the host)
         feats = self._encode(img, img_embs)
         x16, h, w = feats[3]
         if self.input_size_2d is None:
@@ -516,6 +524,8 @@ class AOTEngine(nn.Module):
         self.last_mem_step = self.frame_step
         rows = self._brows_bank() if direct else self.enc_hw
         self._short = [[(k, v, rows) for k, v in dst]]
+        if self.mfma == 'bf16x6':
+            aot_hip.pack_bf16x6_all()        # the weights this first frame packed lazily (encoder blocks)
 
     @_in_table
     def match_propogate_one_frame(self, img=None, img_embs=None):
@@ -523,12 +533,16 @@ class AOTEngine(nn.Module):
         T = self.bank_len
         # a frame that update_memory will memorise gets its K / V written straight into its bank slot
         self._curr_slot = None
-        if self._direct() and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+        dst = None
+        if self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            # the bank gets its room for this frame NOW, whichever way the frame will reach it (the attention launches are
+            # planned for the bank's capacity: every engine mode must see the same capacity at the same frame)
             slot = self._next_slot()
             self._ensure_bank(slot + 1)          # (may re-allocate the bank: the views below are taken afterwards)
-            self._curr_slot = slot
-            dst = self._slot_views(slot)
-        else:
+            if self._direct():
+                self._curr_slot = slot
+                dst = self._slot_views(slot)
+        if dst is None:
             dst = self._scratch_set()
         brows = self._brows_bank()
         sf = self._state_free
@@ -737,8 +751,11 @@ class AOTInferEngine(nn.Module):
     cohort_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
-                 long_term_mem_max=None, graph=False, gemm_table='latency'):
+                 long_term_mem_max=None, graph=False, gemm_table='latency', mfma='f32'):
         super().__init__()
+        if mfma not in aot_hip.MFMA_MODES:
+            raise ValueError('mfma must be one of %s' % (aot_hip.MFMA_MODES,))
+        self.mfma = mfma                 # matrix-core arithmetic of every cohort (see AOTEngine)
         if gemm_table not in aot_hip.GEMM_TABLES:
             raise ValueError('gemm_table must be one of %s' % sorted(aot_hip.GEMM_TABLES))
         self.gemm_table = gemm_table     # conv / linear dispatch table of every cohort of this engine (see AOTEngine)
@@ -777,7 +794,7 @@ class AOTInferEngine(nn.Module):
                 return c
         c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
                             long_term_mem_max=self.long_term_mem_max, lanes=lanes, group0=group0, graph=self.use_graph,
-                            gemm_table=self.gemm_table)
+                            gemm_table=self.gemm_table, mfma=self.mfma)
         c.eval()
         return c
 

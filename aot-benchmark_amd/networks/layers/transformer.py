@@ -275,6 +275,8 @@ class GatedPropagationModule(nn.Module):
             p['v_w'], p['v_b'] = wqv[:, da:], bqv[da:].contiguous()
             if getattr(wqv, '_aot_wt', None) is not None:             # ... and the matching row blocks of its k-contiguous twin
                 p['q_w']._aot_wt, p['v_w']._aot_wt = wqv._aot_wt[:da], wqv._aot_wt[da:]
+            aot_hip._register_weight(p['q_w'])
+            aot_hip._register_weight(p['v_w'])
             p['u_w'], p['u_b'] = linear_t(self.linear_U)
             widv, p['idv_b'] = linear_t(self.linear_ID_V)
             if self.layer_idx == 0:

@@ -44,6 +44,11 @@ IN_SIZE, OUT_SIZE, NUM_OBJ, CLIP_FRAMES = (481, 849), (480, 854), 10, 70
 FP32_MFMA_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def aot_hip_x6_min_tiles():
+    import aot_hip
+    return aot_hip.X6_MIN_TILES
+
+
 def shard_clips(num_clips, rank, world):
     """clip i -> rank i mod world (equal-length synthetic clips)."""
     return [i for i in range(num_clips) if i % world == rank]
@@ -58,7 +63,7 @@ def gather_stats(stats, world):
     return torch.stack(out).cpu()
 
 
-def build_model(device, graph=False, gemm_table='latency'):
+def build_model(device, graph=False, gemm_table='latency', mfma='f32'):
     from networks.engines import build_engine
     from networks.models import build_vos_model
     from utils.synth import synth_state_dict
@@ -68,7 +73,7 @@ def build_model(device, graph=False, gemm_table='latency'):
     model.load_state_dict(sd)
     model = model.to(device).eval()
     engine = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0,
-                          long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP, graph=graph, gemm_table=gemm_table)
+                          long_term_mem_gap=cfg.TEST_LONG_TERM_MEM_GAP, graph=graph, gemm_table=gemm_table, mfma=mfma)
     return cfg, model, engine, sd
 
 
@@ -227,7 +232,7 @@ JF_GOLDEN = {'r50_aotl': ('c2_r50_aotl_70', 0, False), 'r50_deaotl': ('c3b_r50_d
              'swinb_deaotl': ('c3_swinb_deaotl_480_70', 10, True)}
 
 
-def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1):
+def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f32'):
     """J&F of this engine's FREE-RUNNING masks against the real reference's masks on the committed golden clip of the
     benched model (BASELINE config 2: tests/golden/c2_r50_aotl_70.npz, R50-AOTL, 481x849, 10 objects, 69 propagated
     frames), run in EXACTLY the configuration the timed region used: same GEMM dispatch table, same launch mode (hipGraph
@@ -245,7 +250,7 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1):
         return None
     g = np.load(gp)
     gold = g['masks']
-    cfg, model, engine, _ = build_model(device, graph, gemm_table)
+    cfg, model, engine, _ = build_model(device, graph, gemm_table, mfma)
     frames, mask, objs, _ = synth_clip(clip_id, gold.shape[0] + 1, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
     run = StreamClip(engine, torch.cuda.current_stream(device), (frames, mask, objs))
     run.ahead = ahead
@@ -280,7 +285,8 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1):
     J, Fm = sum(js) / len(js), sum(fs) / len(fs)
     return {'J': round(J, 6), 'F': round(Fm, 6), 'J&F': round((J + Fm) / 2, 6), 'frames': len(js),
             'pixels_differing': diff, 'pixels_outside_near_ties': outside, 'of_pixels': int(gold.size),
-            'gemm_table': gemm_table, 'launch': 'hipGraph replay' if graph else 'host launches', 'labels': 'aot_hip.fuse_probs',
+            'gemm_table': gemm_table, 'mfma': mfma, 'launch': 'hipGraph replay' if graph else 'host launches',
+            'labels': 'aot_hip.fuse_probs',
             'encode_ahead_frames': ahead,
             'feedback': 'own labels; reference labels on its near-tie pixels (chaotic clip)' if sync_ties else 'own labels',
             'clip': 'tests/golden/%s.npz (free-running, masks of the real reference; near-tie = top-2 logit gap < 2e-4 in the '
@@ -376,6 +382,11 @@ def main(argv=None):
                     help='K > 1 (default 3): the encoder runs over the next K frames of a clip as one batch on the clip\'s own '
                          'stream (engine.encode_ahead; the encoder does not depend on the mask feedback), never past the end of '
                          'a timed window and never before its start; 1: every frame is encoded when it is matched')
+    ap.add_argument('--mfma', default='f32', choices=['f32', 'bf16x6'],
+                    help="matrix-core arithmetic of the conv / linear layers for the whole run: 'f32' (default, exact fp32 products) or "
+                         "'bf16x6' (the fp32-equivalent six-term bf16 split; reported as dtype 'f32 via bf16x6 split')")
+    ap.add_argument('--no-x6', action='store_true',
+                    help='skip the extra bf16x6 leg of a default (f32) run (config.bf16x6_split: throughput and J&F of the second kernel family)')
     ap.add_argument('--repeats', type=int, default=3,
                     help='the timed window plan of --steps frames is run this many times; `value` is the MEDIAN run, all runs are '
                          'listed in config.repeat_fps (a --steps 20 window is ~40 ms: one run is not the whole story)')
@@ -441,7 +452,7 @@ def main(argv=None):
     else:
         from networks.engines import build_engine
         from utils.synth import synth_clip
-        cfg, model, engine, sd = build_model(device, bool(args.graph), table)
+        cfg, model, engine, sd = build_model(device, bool(args.graph), table, args.mfma)
         gap = cfg.TEST_LONG_TERM_MEM_GAP
         if hasattr(model, 'prepare'):
             model.prepare()        # pack the weights once, before the clips fan out over streams
@@ -450,9 +461,9 @@ def main(argv=None):
             frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
             clips.append((frames, mask, objs))
 
-        def new_engine(tbl, graph=bool(args.graph)):
+        def new_engine(tbl, graph=bool(args.graph), mfma=args.mfma):
             return build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0, long_term_mem_gap=gap,
-                                graph=graph, gemm_table=tbl)
+                                graph=graph, gemm_table=tbl, mfma=mfma)
         engines = [engine] + [new_engine(table) for _ in range(S - 1)]
         streams = [torch.cuda.Stream(device) for _ in range(S)]
         lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
@@ -530,6 +541,24 @@ def main(argv=None):
                       'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead}
             del one
 
+        x6 = None
+        if args.mfma == 'f32' and not args.no_x6 and rank == 0 and not dry:
+            # the second kernel family on the same plan (same clips, streams, table, graphs): a separate number under its
+            # own dtype string, next to -- never instead of -- the fp32 value
+            xl = [StreamClip(new_engine(table, mfma='bf16x6'), streams[i], clips[i]) for i in range(S)]
+            for lane in xl:
+                lane.ahead = lanes[0].ahead
+                lane.restart()
+            for t in range(1, CLIP_FRAMES):          # untimed: packs the split weights, captures the graphs
+                for lane in xl:
+                    lane.step()
+            xruns = [run_plan(xl, passes, lambda pi, i: pi * S + i, collective=False) for _ in range(R)]
+            ex, fx, _ = median_run(xruns)
+            x6 = {'dtype': 'f32 via bf16x6 split', 'value': round(fx / ex, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in xruns],
+                  'n_gpus': 1, 'what': 'conv / linear layers with >= %d tiles of 64x64 on aot_conv2d_bf16x6_f32 (three truncated '
+                                       'bf16 planes per operand, six of the nine partial products, fp32 accumulation); attention '
+                                       'and everything else unchanged' % aot_hip_x6_min_tiles()}
+            del xl
         peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
         stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
                                           device=device), world)
@@ -546,7 +575,9 @@ def main(argv=None):
         t_ph = time.perf_counter()
         if not args.no_jf:
             with torch.no_grad():
-                jf = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead))
+                jf = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead), args.mfma)
+                if x6 is not None:
+                    x6['jf_vs_reference'] = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead), 'bf16x6')
             print('[bench] J&F pass on the golden clip: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
         t_ph = time.perf_counter()
         if not args.no_cpu_baseline:
@@ -561,7 +592,8 @@ def main(argv=None):
             'metric': 'frames/sec, 480p 10-object synthetic clips; J&F vs reference',
             'value': None if dry else round(total_frames / tmax, 2), 'unit': 'frames/s', 'n_gpus': joined,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.mfma == 'f32' else 'f32 via bf16x6 split',
             'data': 'dry-run (no device work)' if dry else 'synthetic',
             'config': {'workload': ('R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
                                     '70 frames/clip, long-term gap 5 (configs[1])') if default_model else
@@ -582,12 +614,15 @@ def main(argv=None):
                                        'bank size M is sampled like a whole clip (timed_M_mean; a whole clip is 7.41); '
                                        'restart + reference frame and the fast-forward between windows are untimed '
                                        'set-up, as in the reference FPS (evaluator.py:325-330,444-446)',
-                       'jf_vs_reference': jf},
+                       'jf_vs_reference': jf, 'bf16x6_split': x6},
             'roofline': roof, 'cpu_baseline': base,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and x6 is not None and x6.get('jf_vs_reference') and x6['jf_vs_reference']['pixels_outside_near_ties'] > 0:
+        print('[bench] bf16x6 leg: %d mask pixels outside the reference near-ties' % x6['jf_vs_reference']['pixels_outside_near_ties'],
+              file=sys.stderr, flush=True)
     if rank == 0 and jf is not None and jf['pixels_outside_near_ties'] > 0:
         # a timed configuration whose masks leave the reference's near-ties is not a valid measurement: fail loudly
         raise SystemExit('bench.py: %d mask pixels differ from the reference outside its argmax near-ties (%s)'

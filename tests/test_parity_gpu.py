@@ -116,6 +116,64 @@ def test_conv2d_lean_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, cfg):
         assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
 
 
+@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', [
+    (61, 107, 128, 128, 3, 1, 1, 1, 1, False, 1),     # 3x3
+    (61, 107, 128, 128, 3, 2, 1, 1, 1, True, 1),      # stride-2 3x3 + residual
+    (61, 107, 256, 512, 1, 2, 0, 1, 0, False, 1),     # 1x1 stride-2 downsample
+    (64, 66, 64, 256, 1, 1, 0, 1, 1, True, 1),        # K = 64: two k-steps per tile, residual + relu
+    (31, 54, 1024, 256, 1, 1, 0, 1, 0, True, 3),      # three lanes on a shared residual map (row m % res_rows)
+    (33, 35, 96, 96, 3, 1, 2, 2, 3, False, 1),        # dilation 2, Cout = 96 (ragged column tile), GELU
+    (17, 19, 32, 40, 3, 1, 1, 1, 0, False, 1),        # tiny map: fewer tiles than workgroups, ragged rows and columns
+    (9, 9, 64, 64, 1, 1, 0, 1, 0, True, 2),           # residual map smaller than a tile (general modulo path)
+    (121, 213, 256, 128, 1, 1, 0, 1, 4, False, 1),    # 4x map: 806 tiles on 512 workgroup slots (persistent item walk), SiLU
+])
+def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
+    """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
+    the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
+    never further from the fp64 result than 4x the fp32 kernel's own error + 1e-6 of the scale."""
+    g = torch.Generator().manual_seed(H * 131 + Cout + B)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    OH, OW = ref.shape[2:]
+    r = torch.randn(1, Cout, OH, OW, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    ref = {0: ref, 1: F.relu(ref), 3: F.gelu(ref), 4: F.silu(ref)}[act].float()
+    ldb = (Cout + 3) // 4 * 4
+    wk = torch.zeros(K * K * Cin, ldb)
+    wk[:, :Cout] = w.permute(2, 3, 1, 0).reshape(K * K * Cin, Cout)
+    wk = hip.attach_wt(_dev(wk), Cin)
+    w6 = hip.pack_bf16x6(wk)
+    assert w6.shape == (3, K * K * Cin // 32, 4, (ldb + 63) // 64 * 64, 8)
+    # the three planes add up to the weight EXACTLY (8 + 8 + 8 significand bits)
+    planes = (w6.view(torch.int16).to(torch.int32) << 16).view(torch.float32).double().sum(0)       # [K/32, 4, cout_pad, 8]
+    kk = torch.arange(K * K * Cin // 32).view(-1, 1, 1) * 32 + (torch.arange(4).view(1, -1, 1) >> 1) * 16 + \
+        (torch.arange(4).view(1, -1, 1) & 1) * 4 + (torch.arange(8) & 3) + 8 * (torch.arange(8) >> 2)
+    back = torch.zeros(K * K * Cin, planes.shape[2], dtype=torch.float64)
+    back[kk.reshape(-1)] = planes.permute(0, 1, 3, 2).reshape(-1, planes.shape[2]).cpu()
+    assert torch.equal(back[:, :ldb], wk.cpu().double()), 'the bf16 planes do not sum to the fp32 weight'
+    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
+    rt = _dev(r[0].permute(1, 2, 0).reshape(OH * OW, Cout)) if res else None
+    outs = {}
+    for mode in ('f32', 'bf16x6'):
+        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+        with hip.use_gemm_table('throughput', mode):
+            hip.conv2d(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B,
+                       res_rows=OH * OW if res else 0)
+        outs[mode] = out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
+        if ldb > Cout:
+            assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+    scale = max(1.0, ref.abs().max().item())
+    e32 = (outs['f32'].double() - ref.double()).abs().max().item()
+    e6 = _close(outs['bf16x6'], ref, 2e-5 * scale, 'bf16x6 conv')
+    tiles = -(-B * OH * OW // 64) * -(-Cout // 64)
+    if tiles >= hip.X6_MIN_TILES:          # (below that the dispatch keeps the fp32 kernels: nothing to compare)
+        assert not torch.equal(outs['f32'], outs['bf16x6']), 'the bf16x6 path did not run'
+    assert e6 <= 4 * e32 + 1e-6 * scale, 'bf16x6 error %g vs fp32-kernel error %g' % (e6, e32)
+
+
 def test_linear_strided_views(hip):
     """column slices of wider buffers as A, C and residual (how the LSTT avoids concat/split copies)."""
     g = torch.Generator().manual_seed(5)
@@ -551,7 +609,7 @@ def _hip_engine(model_name, **kw):
             cfg, model, sd = synth_model_state(model_name)
             _MODELS[model_name] = (cfg, model.cuda().eval(), sd)
         cfg, model, sd = _MODELS[model_name]
-    extra = {k: kw[k] for k in ('short_term_mem_skip', 'long_term_mem_max', 'graph', 'gemm_table') if k in kw}
+    extra = {k: kw[k] for k in ('short_term_mem_skip', 'long_term_mem_max', 'graph', 'gemm_table', 'mfma') if k in kw}
     eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0,
                        long_term_mem_gap=kw.get('gap') or cfg.TEST_LONG_TERM_MEM_GAP, **extra)
     return cfg, model, eng, sd
@@ -589,6 +647,52 @@ def _record_parity(case, mode, rec):
     data['%s/%s' % (case, mode)] = rec
     with open(p, 'w') as f:
         json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize('case,table,graph', [('c2_r50_aotl_70', 'throughput', True), ('c2_r50_aotl_70', 'latency', False),
+                                              ('c3b_r50_deaotl_70', 'throughput', True), ('c3_swinb_deaotl_480', 'latency', False)])
+def test_bf16x6_engine_vs_reference_golden(hip, case, table, graph):
+    """build_engine(..., mfma='bf16x6'): every conv / linear layer that qualifies on the six-term bf16 split -- held to EXACTLY
+    the bars of the fp32 engine on the whole-clip goldens of the real reference, teacher-forced: stride-4 logits and last
+    LSTT / GPM output within 2e-4, every mask equal outside the reference's near-ties; then free-running (R50 models) with
+    zero pixels outside near-ties.  Recorded next to the fp32 cells in parity_r03.json."""
+    from common import unpack_gapmask
+    c, g = load_case(case)
+    _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table, mfma='bf16x6')
+    frames, mask, objs, out_size = case_clip(c, g=g)
+    extra = {}
+    res = run_teacher_forced(eng, frames, mask, objs, out_size, g, set(c['keep_logits']), to_dev=lambda x: x.cuda(),
+                             extra=extra, label_fn=_fuse_label(hip))
+    no = c['num_obj'] + 1
+    flips, worst, worst_l = 0, 0.0, 0.0
+    for t, (l4, m) in res.items():
+        flips += check_masks(m, g, t, 'hip bf16x6')
+        if l4 is not None:
+            err = float(np.abs(l4[:no] - g['logits4_%d' % t]).max())
+            worst = max(worst, err)
+            assert err < 2e-4 < LOGIT_TOL, 'frame %d logits4 err %g' % (t, err)
+            ref = g['lstt_last_%d' % t]
+            el = float(np.abs(extra['lstt_last_%d' % t] - ref).max() / max(1.0, np.abs(ref).max()))
+            worst_l = max(worst_l, el)
+            assert el < 2e-4, 'frame %d last LSTT layer output err %g' % (t, el)
+    rec = {'frames': len(res), 'tie_flips': flips, 'max_logit4_err': worst, 'max_lstt_last_rel_err': worst_l,
+           'pixels': int(g['masks'].size)}
+    if 'r50' in c['model']:
+        frames = frames.cuda() if torch.is_tensor(frames) else [f.cuda() for f in frames]
+        eng.restart_engine()
+        diffs, hard = [], 0
+        with torch.no_grad():
+            eng.add_reference_frame(frames[0], mask.cuda(), objs, frame_step=0)
+            for t in range(1, len(frames)):
+                eng.match_propogate_one_frame(frames[t])
+                lab = _fuse_label(hip)(eng.decode_current_logits(out_size))
+                bad = lab[0, 0].cpu().numpy().astype(np.uint8) != g['masks'][t - 1]
+                diffs.append(int(bad.sum()))
+                hard += int((bad & ~unpack_gapmask(g, t, bad.shape)).sum())
+                eng.update_memory(F.interpolate(lab, size=eng.input_size_2d, mode='nearest'))
+        rec.update({'free_running_pixels_differing': int(sum(diffs)), 'free_running_outside_near_ties': hard})
+        assert hard == 0 and sum(diffs) <= len(diffs) and max(diffs) <= 4, 'bf16x6 free-running: %s' % diffs
+    _record_parity(case, 'bf16x6/%s/%s' % (table, 'graph' if graph else 'eager'), rec)
 
 
 def _fuse_label(hip):

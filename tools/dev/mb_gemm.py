@@ -1,5 +1,5 @@
 """Per-shape microbenchmark of the implicit-GEMM conv for every conv/linear of the R50-AOTL 480p frame.
-usage: python tools/dev/mb_gemm.py [cfgs e.g. -1,0,1,2]"""
+usage: python tools/dev/mb_gemm.py [cfgs e.g. -1,0,1,2,x6] [lib] [only] [batch]      (x6 = the bf16x6 family, auto dispatch)"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
@@ -7,7 +7,8 @@ import torch, aot_hip
 if len(sys.argv) > 2: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])
 ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 else None
 aot_hip.load()
-cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
+cfgs = [c if c == 'x6' else int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
+BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 # (name, H, W, Cin, Cout, K, stride, count per frame)
 S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
      ('l1.c1 64>64', 121, 213, 64, 64, 1, 1, 1), ('l1.c1 256>64', 121, 213, 256, 64, 1, 1, 2),
@@ -24,22 +25,28 @@ S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
      ('dec ad4 256>128', 121, 213, 256, 128, 1, 1, 1), ('dec c4 3x3 128', 121, 213, 128, 128, 3, 1, 1),
      ('dec out 128>11', 121, 213, 128, 11, 1, 1, 1)]
 tot = {c: 0.0 for c in cfgs}; totf = 0.0
-print('%-20s %7s %5s %5s %8s | ' % ('shape', 'M', 'K', 'N', 'GF') + ' | '.join('cfg%2d us    TF' % c for c in cfgs))
+print('%-20s %7s %5s %5s %8s | ' % ('shape', 'M', 'K', 'N', 'GF') + ' | '.join('cfg%3s us    TF' % c for c in cfgs))
 for (name, H, W, Cin, Cout, K, s, cnt) in S:
     if ONLY and not any(o in name for o in ONLY): continue
     p = K // 2
     OH, OW = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
-    M, KK = OH * OW, K * K * Cin
-    x = torch.randn(H * W, Cin, device='cuda'); ldb = (Cout + 3) // 4 * 4
+    M, KK = BATCH * OH * OW, K * K * Cin
+    x = torch.randn(BATCH * H * W, Cin, device='cuda'); ldb = (Cout + 3) // 4 * 4
     w = torch.randn(KK, ldb, device='cuda') / KK ** 0.5; b = torch.randn(Cout, device='cuda')
+    if KK % 32 == 0 and Cin % 32 == 0: w = aot_hip.attach_wt(w, Cin)
     out = torch.empty(M, ldb, device='cuda')
     gf = 2.0 * M * KK * Cout / 1e9
     row = []
     ref_out = None
     for c in cfgs:
-        if (c == 3 and Cout > 32) or (c >= 10 and Cin % 32): row.append('      -      -'); continue
-        def run():
-            aot_hip.conv2d_cfg(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, cfg=c)
+        if c == 'x6':
+            def run():        # (layers that do not qualify fall back to the fp32 dispatch inside conv2d, as in the engine)
+                with aot_hip.use_gemm_table('throughput', 'bf16x6'):
+                    aot_hip.conv2d(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
+        elif (c == 3 and Cout > 32) or (c >= 10 and Cin % 32): row.append('      -      -'); continue
+        else:
+          def run():
+            aot_hip.conv2d_cfg(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, cfg=c, wt=getattr(w, '_aot_wt', None), B=BATCH)
         for _ in range(3): run()
         if ref_out is None: ref_out = out[:, :Cout].clone()
         else:
@@ -55,4 +62,4 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
         row.append('%7.1f %6.1f' % (us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 if False else gf * 1e3 / us))
     totf += gf * cnt
     print('%-20s %7d %5d %5d %8.3f | ' % (name, M, KK, Cout, gf) + ' | '.join(row) + '   x%d' % cnt)
-print('per-frame total GF %.1f ; ' % totf + ' ; '.join('cfg%d: %.0f us (%.1f TF)' % (c, tot[c], totf * 1e3 / tot[c]) for c in cfgs))
+print('per-frame total GF %.1f ; ' % totf + ' ; '.join('cfg%s: %.0f us (%.1f TF)' % (c, tot[c], totf * 1e3 / tot[c]) for c in cfgs))
