@@ -1063,9 +1063,10 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     }
     __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 (= of step ss+2) is free
     landed(std::integral_constant<int, set>{});
+    if (c_kt == nk - 1) epi_loads();     // last k-step of the tile: its residual and bias, now -- BEFORE this step's DMA pieces, so
+                                         // that the epilogue's counted wait (all but the youngest LPW) covers them
     fetch(std::integral_constant<int, set ^ 1>{}, std::integral_constant<int, nslot>{});      // fragments of step ss+1
     issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
-    if (c_kt == nk - 1) epi_loads();                         // last k-step of the tile: its residual and bias, now
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 ap[3];

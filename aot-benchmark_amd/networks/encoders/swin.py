@@ -60,8 +60,9 @@ class SwinTransformerBlock(nn.Module):
             self._p = p
         return self._p
 
-    def run(self, x, out, H, W, ws, stream):
-        """x [H*W, C] -> out [H*W, C] (reference SwinTransformerBlock.forward, :262-318)."""
+    def run(self, x, out, H, W, ws, stream, B=1):
+        """x [B*H*W, C] -> out [B*H*W, C] (reference SwinTransformerBlock.forward, :262-318); B images stacked along the rows:
+        the GEMMs and LayerNorms see one tall matrix, the window attention runs per image."""
         p = self.pack()
         N, C = x.shape
         dev = x.device
@@ -70,8 +71,10 @@ class SwinTransformerBlock(nn.Module):
         qkv = ws.get('sw_qkv', (N, 3 * C), dev)
         aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
         a = ws.get('sw_a', (N, C), dev)
-        aot_hip.swin_window_attention(qkv, p['qkv_b'], p['table'], a, H, W, C, self.num_heads, self.shift_size,
-                                      self.attn.scale, stream=stream)
+        n1 = H * W
+        for b in range(B):
+            aot_hip.swin_window_attention(qkv[b * n1:(b + 1) * n1], p['qkv_b'], p['table'], a[b * n1:(b + 1) * n1], H, W, C,
+                                          self.num_heads, self.shift_size, self.attn.scale, stream=stream)
         xa = ws.get('sw_xa', (N, C), dev)
         aot_hip.linear(a, p['proj_w'], p['proj_b'], xa, res=x, stream=stream)
         aot_hip.layernorm(xa, *p['n2'], x1, stream=stream)
@@ -89,17 +92,18 @@ class PatchMerging(nn.Module):
         self.norm = nn.LayerNorm(4 * dim)
         self._p = None
 
-    def run(self, x, H, W, ws, stream):
+    def run(self, x, H, W, ws, stream, B=1):
         if self._p is None:
             self._p = (_ln(self.norm), linear_t(self.reduction)[0])
         (g, b), w = self._p
         C = self.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
         dev = x.device
-        gth = ws.get('sw_merge', (H2 * W2, 4 * C), dev)
-        aot_hip.patch_merge(x, gth, H, W, C, stream=stream)
+        gth = ws.get('sw_merge', (B * H2 * W2, 4 * C), dev)
+        for i in range(B):
+            aot_hip.patch_merge(x[i * H * W:(i + 1) * H * W], gth[i * H2 * W2:(i + 1) * H2 * W2], H, W, C, stream=stream)
         aot_hip.layernorm(gth, g, b, gth, stream=stream)
-        out = ws.get('sw_merged_%d' % C, (H2 * W2, 2 * C), dev)
+        out = ws.get('sw_merged_%d' % C, (B * H2 * W2, 2 * C), dev)
         aot_hip.linear(gth, w, None, out, stream=stream)
         return out, H2, W2
 
@@ -136,35 +140,38 @@ class SwinTransformer(nn.Module):
             self.add_module('norm%d' % i, nn.LayerNorm(self.num_features[i]))
         self._pe = None
 
+    batched = True       # run() takes B images at once (AOTEngine.encode_ahead)
+
     def run(self, img, ws, stream):
-        """img [1,3,H,W] -> [(feat, h, w)] x 3.  Sides that are not multiples of the 4x4 patch are zero-padded on the
-        right / bottom (PatchEmbed.forward, swin_transformer.py:501-509): the implicit-GEMM loader reads taps beyond the
-        image as zeros, so the padding is just the rounded-up output size."""
-        _, _, H, W = img.shape
+        """img [B,3,H,W] -> [(feat [B*h*w, C], h, w)] x 3, the B images stacked along the rows.  Sides that are not multiples
+        of the 4x4 patch are zero-padded on the right / bottom (PatchEmbed.forward, swin_transformer.py:501-509): the
+        implicit-GEMM loader reads taps beyond the image as zeros, so the padding is just the rounded-up output size."""
+        B, _, H, W = img.shape
         dev = img.device
         if self._pe is None:
             self._pe = (fold_conv_bn(self.patch_embed.proj, pad_cin=4), _ln(self.patch_embed.norm))
         (pw, pb), (g, b) = self._pe
-        x4 = ws.get('img_nhwc4', (H * W, 4), dev)
-        aot_hip.nchw_to_nhwc(img, x4, 3, H, W, 4, stream=stream)
+        x4 = ws.get('img_nhwc4', (B * H * W, 4), dev)
+        for i in range(B):
+            aot_hip.nchw_to_nhwc(img[i:i + 1], x4[i * H * W:(i + 1) * H * W], 3, H, W, 4, stream=stream)
         h, w = -(-H // 4), -(-W // 4)
         C = self.embed_dim
-        x = ws.get('sw_x_%d_0' % C, (h * w, C), dev)
-        aot_hip.conv2d(x4, pw, pb, x, H, W, 4, h, w, C, 4, 4, 4, 0, 1, stream=stream)
+        x = ws.get('sw_x_%d_0' % C, (B * h * w, C), dev)
+        aot_hip.conv2d(x4, pw, pb, x, H, W, 4, h, w, C, 4, 4, 4, 0, 1, B=B, stream=stream)
         aot_hip.layernorm(x, g, b, x, stream=stream)
         feats = []
         for li, layer in enumerate(self.layers):
             C = self.num_features[li]
             for bi, blk in enumerate(layer.blocks):
-                out = ws.get('sw_x_%d_%d' % (C, (bi + 1) & 1), (h * w, C), dev)
-                x = blk.run(x, out, h, w, ws, stream)
+                out = ws.get('sw_x_%d_%d' % (C, (bi + 1) & 1), (B * h * w, C), dev)
+                x = blk.run(x, out, h, w, ws, stream, B=B)
             if li in self.out_indices:
                 nm = getattr(self, 'norm%d' % li)
-                f = ws.get('sw_stage%d' % li, (h * w, C), dev)
+                f = ws.get('sw_stage%d' % li, (B * h * w, C), dev)
                 aot_hip.layernorm(x, nm.weight, nm.bias, f, stream=stream)
                 feats.append((f, h, w))
             if layer.downsample is not None:
-                x, h, w = layer.downsample.run(x, h, w, ws, stream)
+                x, h, w = layer.downsample.run(x, h, w, ws, stream, B=B)
         return feats
 
 

@@ -742,13 +742,13 @@ def test_end_to_end_full_size_vs_reference_golden(hip, case, table, graph, label
 @pytest.mark.parametrize('case,table,graph,labels,ahead',
                          [(c, 'latency', False, 'torch', 1) for c in ('c1_aott', 'c3_swinb_deaotl_480')] +
                          [(c,) + cell + (1,) for c in _FULL for cell in _CELLS] +
-                         [(c, tb, True, 'fuse_probs', 3) for c in _FULL[:2] for tb in ('latency', 'throughput')])
+                         [(c, tb, True, 'fuse_probs', 3) for c in _FULL for tb in ('latency', 'throughput')])
 def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahead):
     """BASELINE configs 1 / 2 / 3 and R50-DeAOTL FREE-RUNNING (the engine's own argmax feeds its memory, exactly the demo
     loop, tools/demo.py:187-235): the mask ids of every frame against the real reference's -- for the whole-clip goldens in
     EVERY configuration bench.py can time: GEMM table {latency, throughput} x {host launches, hipGraph replay} x label path
     {torch softmax/argmax, aot_hip.fuse_probs}, and with the encoder batched over 3 frames ahead (`ahead` = 3, bench.py's
-    default --encode-ahead; the ResNet models).  Any differing pixel must be one of the reference's own argmax near-ties
+    default --encode-ahead).  Any differing pixel must be one of the reference's own argmax near-ties
     (top-2 logit gap < 2e-4: an fp32 summation-order difference decides those, the reference itself flips such pixels
     between fp32 and fp64 -- SURVEY section 7) and there may be at most one per frame on average; the exact per-frame counts
     of every cell are recorded in parity_r03.json."""

@@ -4,8 +4,8 @@ import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
-if len(sys.argv) > 2: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])
-ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 else None
+if len(sys.argv) > 2 and sys.argv[2]: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])
+ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 and sys.argv[3] else None
 aot_hip.load()
 cfgs = [c if c == 'x6' else int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
 BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1
