@@ -21,7 +21,7 @@ _L = ctypes.c_long
 _SIGS = {
     'aot_conv2d_nhwc_f32': [_P] * 7 + [_L] + [_I] * 20 + [_P],
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
-    'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
+    'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
@@ -69,6 +69,7 @@ GEMM_TABLES = {'latency': -1, 'throughput': -2}
 # fp32-equivalent six-term bf16 split (aot_conv2d_bf16x6_f32; include/aot_hip.h) wherever a layer qualifies.  An engine attribute
 # too (build_engine(..., mfma=)), carried by the same scope.
 MFMA_MODES = ('f32', 'bf16x6')
+X6_TILE = 0                  # 0: tile of the bf16x6 kernels chosen by shape; 64 / 128 force one (tests, tuning)
 X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
 _table_scopes = []
 
@@ -214,7 +215,7 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
             w6 = pack_bf16x6(w)
         _chk(load().aot_conv2d_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH,
                                           OW, Cout, KH, KW, stride, pad, dil, x.stride(0), out.stride(0),
-                                          res.stride(0) if res is not None else 0, res_rows, act,
+                                          res.stride(0) if res is not None else 0, res_rows, act, X6_TILE,
                                           stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6_f32')
         return out
     wt = getattr(w, '_aot_wt', None)

@@ -492,27 +492,10 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
 // wave, so all four hold bit-identical scores) and each wave runs the softmax and its own 16*NDV value MFMAs.  144 instead
 // of 192 MFMAs per key tile and wave, q/k fragments of 16 registers instead of 64.  One barrier per key tile; the score
 // partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
-#ifndef AOT_GATED_XCD      // 1: XCD-aware walk of the (key range, query tile) pairs (see the kernel); decided by measurement
-#define AOT_GATED_XCD 0
-#endif
 template <int NDV>
 __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParams p) {
   const int ntq = (p.Nq + 31) >> 5;
-#if AOT_GATED_XCD
-  // A workgroup streams its whole key range (one 128-wide K row + one 1024-wide V row per key: 4.6 KB); the 53 query tiles
-  // of a range re-read it.  Workgroup L runs on XCD L % 8: every XCD takes ONE contiguous run of the split-major (range,
-  // query tile) list, so it touches 2-3 key ranges instead of all of them and the tiles of a range find it in that XCD's L2.
-  int split, bz;
-  {
-    const int L = blockIdx.x + gridDim.x * blockIdx.y, Q = gridDim.y, G = gridDim.x * gridDim.y;
-    const int xcd = L & 7, li = L >> 3, q8 = G >> 3, r8 = G & 7;
-    const int P = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + li;
-    split = P / Q;
-    bz = P - split * Q;
-  }
-#else
   const int split = blockIdx.x, bz = blockIdx.y;
-#endif
   const int b = bz / ntq, qt = bz - b * ntq;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
   const int ch = wave;

@@ -24,4 +24,5 @@ bool gemm_lean_eligible(const ConvParams& p);
 // bf16 x 6 variant of the lean 64x64 kernel (gemm_lds.hip): w6 = the weight pre-split into three bf16 planes, layout
 // [3][K/32][4][cout_pad][8] (aot_pack_bf16x6_f32)
 bool gemm_x6_eligible(const ConvParams& p);
-int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);
+// tile: 0 = chosen by shape, 64 / 128 = forced (the 128x128 eight-wave form / the 64x64 form)
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s);

@@ -605,8 +605,8 @@ extern "C" int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, in
 extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
                                      float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
-                                     void* stream) {
-  if (!in || !w6 || !out) return AOT_ERR_BADARG;
+                                     int tile, void* stream) {
+  if (!in || !w6 || !out || (tile != 0 && tile != 64 && tile != 128)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
@@ -617,5 +617,5 @@ extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_p
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  return launch_gemm_x6(p, w6, cout_pad, (hipStream_t)stream);
+  return launch_gemm_x6(p, w6, cout_pad, tile, (hipStream_t)stream);
 }

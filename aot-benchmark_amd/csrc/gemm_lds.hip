@@ -1097,6 +1097,296 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
 }
 
+// wide tile: A fragments double-buffered, weight fragments of the current step (planes x sub-steps x column blocks)
+// (three stages of 41 KB: the stage offset does not fit the 16-bit immediate, it is added to the address registers)
+__device__ __forceinline__ void x6w_fetch_a(f32x4 (&a)[4], const unsigned (&aaddr)[4], unsigned stage) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(a[j]) : "v"(aaddr[j] + stage));
+}
+template <int PIECE>
+__device__ __forceinline__ void x6w_fetch_b(bf16x8 (&b)[3][2][2], unsigned baddr) {
+#define AOT_X6W_B(PL, S, NB) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[PL][S][NB]) : "v"(baddr), "n"(((PL) * 4 + 2 * (S)) * 2 * PIECE + (NB) * 512));
+  AOT_X6W_B(0, 0, 0) AOT_X6W_B(0, 0, 1) AOT_X6W_B(0, 1, 0) AOT_X6W_B(0, 1, 1)
+  AOT_X6W_B(1, 0, 0) AOT_X6W_B(1, 0, 1) AOT_X6W_B(1, 1, 0) AOT_X6W_B(1, 1, 1)
+  AOT_X6W_B(2, 0, 0) AOT_X6W_B(2, 0, 1) AOT_X6W_B(2, 1, 0) AOT_X6W_B(2, 1, 1)
+#undef AOT_X6W_B
+}
+__device__ __forceinline__ void x6w_landed_a(f32x4 (&a)[4]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+__device__ __forceinline__ void x6w_landed_b(bf16x8 (&b)[3][2][2]) {
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(b[pl][0][0]), "+v"(b[pl][0][1]), "+v"(b[pl][1][0]), "+v"(b[pl][1][1]));
+}
+
+// 128x128 tile, eight waves (4 along M x 2 along N, each 32 rows x 64 columns): the activation split of a wave -- the VALU work
+// of this family -- now feeds TWO column blocks, 24 MFMAs per k-step against the same 88 split instructions as the 64x64 tile's 12
+// (there the split, not the matrix pipe, set the pace: 1.25x the fp32 lean kernel instead of the 2.67x of the MFMA count).  One
+// workgroup per CU (123.6 KB of ring), still two waves per SIMD.  The weight fragments are read at the start of their own step
+// (single register set: 48 registers instead of 96); the second wave of the SIMD covers their latency.
+template <bool IS1X1>
+__global__ void __launch_bounds__(512, 2) gemm_x6w_kernel(const ConvParams p, const X6Weight wq) {
+  constexpr int NST = 3;
+  constexpr int BM = 128, BN = 128;
+  constexpr int AG = BM / 8, AGW = AG / 8;              // A: 8-row groups, two per wave (eight waves)
+  constexpr int BPW = 3;                                // B: one 16-byte chunk column (cc = wave) of each plane per wave
+  constexpr int LPW = AGW + BPW;
+  constexpr int OPA_BYTES = AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 24 * B_PIECE;      // piece (pl, cc, column half)
+  constexpr int STAGE_BYTES = OPA_BYTES + OPB_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nk = p.K / BK;
+  const int nitems = nbm * nbn;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
+  const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int mine = li < chunk_n ? (chunk_n - li + nwg_x - 1) / nwg_x : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  auto item_of = [&](int i) __attribute__((always_inline)) {
+    const int it = chunk0 + li + i * nwg_x;
+    Item r;
+    r.bn = it % nbn;
+    r.bm = it / nbn;
+    r.kt0 = 0;
+    return r;
+  };
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;       // wave tile: 32 rows x 64 columns (two 32-column blocks)
+  const int lr = lane >> 3, lp = lane & 7;
+  const int cofs = (lp ^ lr) << 2;
+  const int hw_out = p.OH * p.OW;
+  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+  const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
+  const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
+  const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
+  const int n_res = p.res ? 32 : 0, n_bias = p.bias ? 1 : 0;
+
+  // ---- issue side --------------------------------------------------------------------------------------------------
+  int is_i = 0, is_kt = 0;
+  int a_off[AGW], a_iy0[AGW], a_ix0[AGW];
+  bool a_ok[AGW];
+  unsigned b_off = 0;
+  int s_k = 0, s_kb = 0;       // wave-uniform byte offsets along K: A rows of a 1x1 layer / the weight's k-blocks
+  int tap_c = 0, tap_ky = 0, tap_kx = 0, s_tap = 0;
+  auto setup_item = [&](int i) __attribute__((always_inline)) {
+    const bool live = i < mine;
+    const Item it = item_of(live ? i : 0);
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      const int m = it.bm * BM + 8 * (AGW * wave + g) + lr;
+      a_ok[g] = live && m < p.M;
+      const int mm = a_ok[g] ? m : 0;
+      const int b = mm / hw_out, pix = mm - b * hw_out;
+      const int oy = pix / p.OW, ox = pix - oy * p.OW;
+      a_iy0[g] = oy * p.stride - p.pad;
+      a_ix0[g] = ox * p.stride - p.pad;
+      a_off[g] = (((b * p.H + a_iy0[g]) * p.W + a_ix0[g]) * p.lda + cofs) * 4;
+      if (IS1X1 && !a_ok[g]) a_off[g] = (int)OOB;
+    }
+    // this wave's DMA column: chunk cc = wave & 3 of k-block 0, column half wave >> 2 of the tile (columns past the padded
+    // width -- a 128-wide tile on a weight padded to 64 -- are masked)
+    b_off = (live && it.bn * BN + (wave >> 2) * 64 < wq.cout_pad)
+                ? (unsigned)(((wave & 3) * wq.cout_pad + it.bn * BN + (wave >> 2) * 64 + lane) * 16) : OOB;
+    s_k = 0;
+    s_kb = 0;
+    if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
+  };
+  auto issue = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    constexpr int slot = decltype(SLOT)::value;
+    if (is_kt == 0) setup_item(is_i);
+    if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4;
+    unsigned char* st = lds + slot * STAGE_BYTES;
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
+      if (IS1X1) {
+        dma16(rsrc_a, dst, a_off[g], s_k);
+      } else {
+        const int iy = a_iy0[g] + tap_ky * p.dil, ix = a_ix0[g] + tap_kx * p.dil;
+        const bool in = a_ok[g] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        dma16(rsrc_a, dst, in ? a_off[g] + s_tap : (int)OOB, 0);
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      dma16(rsrc_b, st + OPA_BYTES + ((pl * 4 + (wave & 3)) * 2 + (wave >> 2)) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
+    s_k += BK * 4;
+    s_kb += 4 * wq.cout_pad * 16;
+    if (!IS1X1) {
+      tap_c += BK;
+      if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
+    }
+    if (++is_kt == nk) { is_kt = 0; ++is_i; }
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
+  unsigned aaddr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aaddr[j] = lds_base + chunk_off(wm + l31, 2 * j + half);
+  // piece (pl, cc = 2 s + half, column half wn / 64) at ((pl * 4 + cc) * 2 + wn / 64) * B_PIECE; column block nb: + nb * 32 columns
+  const unsigned baddr = lds_base + OPA_BYTES + (half * 2 + (wn >> 6)) * B_PIECE + l31 * 16;
+  f32x4 ra[2][4];              // [register set][16-byte chunk j]: sub-step s contracts chunks 2 s and 2 s + 1
+  bf16x8 rb[3][2][2];          // [plane][sub-step][column block]
+  auto fetch_a = [&](auto SET, auto SLOT) __attribute__((always_inline)) -> void {
+    x6w_fetch_a(ra[decltype(SET)::value], aaddr, (unsigned)(decltype(SLOT)::value * STAGE_BYTES));
+  };
+  auto fetch_b = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    x6w_fetch_b<B_PIECE>(rb, baddr + (unsigned)(decltype(SLOT)::value * STAGE_BYTES));
+  };
+  f32x16 acc[4];               // [2 * sub-step + column block]
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  int c_i = 0, c_kt = 0;
+  int stores_pending = 0;
+  float rv[2][16], bv[2] = {0.f, 0.f};
+  auto epi_loads = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int m0 = it.bm * BM;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (n_bias) bv[nb] = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
+      if (n_res && p.res_rows == 0) {
+        const int mlane = m0 + wm + 4 * half;
+        const int vbase = col_ok ? (mlane * p.ldr + n) * 4 : (int)OOB;
+        const int rows_left = p.M - mlane, ldr4 = p.ldr * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          rv[nb][r] = buf_load_s(desc_res, c < rows_left ? vbase : (int)OOB, c * ldr4);
+        }
+      } else if (n_res) {
+        const int rr0 = m0 % p.res_rows;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = wm + mfma32_row(r, half);
+          int rr = rr0 + dm;
+          if (p.res_rows >= BM) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+          else rr %= p.res_rows;
+          rv[nb][r] = buf_load(desc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB);
+        }
+      }
+    }
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[nb][r] += acc[2 + nb][r]; acc[2 + nb][r] = 0.f; }
+    // residual and bias were fetched under the tile's last k-step: older than the DMA pieces issued in that step
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));
+    const int m0 = it.bm * BM;
+    const int mlane = m0 + wm + 4 * half;
+    const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (n_bias) asm volatile("" : "+v"(bv[nb]));
+      if (n_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[nb][r]));
+      }
+      const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      if (n_bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += bv[nb];
+      }
+      if (n_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += rv[nb][r];
+      }
+      with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(acc[nb][r], act));
+          acc[nb][r] = 0.f;
+        }
+      });
+    }
+    stores_pending = 32;
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  issue(I0{});
+  issue(I1{});
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));          // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  fetch_a(I0{}, I0{});
+  // step ss (ring stage U % 3, A register set U % 2; the loop is unrolled by six): on entry the A fragments of step ss are being
+  // read into set U % 2, the DMA of step ss+1 is in flight
+  auto step = [&](auto U) __attribute__((always_inline)) -> void {
+    constexpr int u = decltype(U)::value, set = u & 1, slot = u % 3, nslot = (u + 1) % 3, islot = (u + 2) % 3;
+    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished)
+    if (stores_pending) {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(32, 0));
+      stores_pending = 0;
+    } else {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+    }
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 (= of step ss+2) is free
+    x6w_landed_a(ra[set]);
+    fetch_b(std::integral_constant<int, slot>{});             // this step's weight fragments (asynchronous)
+    if (c_kt == nk - 1) epi_loads();     // last k-step of the tile: its residual and bias, now -- BEFORE this step's DMA pieces, so
+                                         // that the epilogue's counted wait (all but the youngest LPW) covers them
+    issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));           // the weight fragments have landed (nothing else is on lgkmcnt)
+    x6w_landed_b(rb);
+    fetch_a(std::integral_constant<int, set ^ 1>{}, std::integral_constant<int, nslot>{});     // A fragments of step ss+1, under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ap[3];
+      split3(ra[set][2 * s], ra[set][2 * s + 1], ap);
+      // smallest terms first; sub-steps and column blocks feed four independent accumulators
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        f32x16& a = acc[2 * s + nb];
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], rb[1][s][nb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[2][s][nb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], rb[0][s][nb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[1][s][nb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], rb[0][s][nb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], rb[0][s][nb], a, 0, 0, 0);
+      }
+    }
+    if (++c_kt == nk) {
+      epilogue();
+      c_kt = 0;
+      ++c_i;
+    }
+  };
+#pragma unroll 1
+  for (int ss = 0; ss < total; ss += 6) {
+    step(I0{});
+    if (ss + 1 < total) step(I1{});
+    if (ss + 2 < total) step(I2{});
+    if (ss + 3 < total) step(std::integral_constant<int, 3>{});
+    if (ss + 4 < total) step(std::integral_constant<int, 4>{});
+    if (ss + 5 < total) step(std::integral_constant<int, 5>{});
+  }
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
+}
+
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch) {
   const int nq = (p.Cout + 3) >> 2;
@@ -1174,15 +1464,25 @@ bool gemm_x6_eligible(const ConvParams& p) {
          (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL);
 }
 
-int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s) {
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
-  const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
-  const int grid = nitems < 512 ? nitems : 512;             // two workgroups per CU
   X6Weight wq;
   wq.w6 = w6;
   wq.cout_pad = cout_pad;
+  const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
+  const bool wide = tile == 128 || (tile == 0 && p.Cout >= 128 && nwide >= 192);     // enough 128x128 tiles for the 256 CUs
+  if (wide) {
+    const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
+    if (is1x1)
+      hipLaunchKernelGGL((gemm_x6w_kernel<true>), dim3(grid), dim3(512), 0, s, p, wq);
+    else
+      hipLaunchKernelGGL((gemm_x6w_kernel<false>), dim3(grid), dim3(512), 0, s, p, wq);
+    AOT_LAUNCH_CHECK();
+  }
+  const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nitems < 512 ? nitems : 512;             // two workgroups per CU
   if (is1x1)
     hipLaunchKernelGGL((gemm_x6_kernel<true>), dim3(grid), dim3(256), 0, s, p, wq);
   else

@@ -127,7 +127,8 @@ def test_conv2d_lean_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, cfg):
     (9, 9, 64, 64, 1, 1, 0, 1, 0, True, 2),           # residual map smaller than a tile (general modulo path)
     (121, 213, 256, 128, 1, 1, 0, 1, 4, False, 1),    # 4x map: 806 tiles on 512 workgroup slots (persistent item walk), SiLU
 ])
-def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
+@pytest.mark.parametrize('tile', [64, 128])
+def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
     the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
     never further from the fp64 result than 4x the fp32 kernel's own error + 1e-6 of the scale."""
@@ -159,9 +160,13 @@ def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
     outs = {}
     for mode in ('f32', 'bf16x6'):
         out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-        with hip.use_gemm_table('throughput', mode):
-            hip.conv2d(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B,
-                       res_rows=OH * OW if res else 0)
+        hip.X6_TILE = tile                  # both tile forms of the family: 64x64 (four waves) and 128x128 (eight waves)
+        try:
+            with hip.use_gemm_table('throughput', mode):
+                hip.conv2d(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B,
+                           res_rows=OH * OW if res else 0)
+        finally:
+            hip.X6_TILE = 0
         outs[mode] = out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
         if ldb > Cout:
             assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'

@@ -7,7 +7,7 @@ import torch, aot_hip
 if len(sys.argv) > 2 and sys.argv[2]: aot_hip.LIB_PATH = os.path.abspath(sys.argv[2])
 ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 and sys.argv[3] else None
 aot_hip.load()
-cfgs = [c if c == 'x6' else int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
+cfgs = [c if c.startswith('x6') else int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '-1').split(',')]
 BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 # (name, H, W, Cin, Cout, K, stride, count per frame)
 S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
@@ -39,7 +39,8 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
     row = []
     ref_out = None
     for c in cfgs:
-        if c == 'x6':
+        if str(c).startswith('x6'):      # x6 = tile by shape, x6n = 64x64 forced, x6w = 128x128 forced
+            aot_hip.X6_TILE = {'x6': 0, 'x6n': 64, 'x6w': 128}[c]
             def run():        # (layers that do not qualify fall back to the fp32 dispatch inside conv2d, as in the engine)
                 with aot_hip.use_gemm_table('throughput', 'bf16x6'):
                     aot_hip.conv2d(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
