@@ -512,7 +512,7 @@ def ce_loss(logits, labels, top_k=0, stream=None):
     dev = logits.device
     loss_px = torch.empty(B, P, dtype=torch.float32, device=dev)
     loss = torch.empty(B, dtype=torch.float32, device=dev)
-    thr = torch.empty(B, dtype=torch.int32, device=dev) if top_k > 0 else None
+    thr = torch.empty(2 * B, dtype=torch.int32, device=dev) if top_k > 0 else None      # [order key | share of the ties] per sample
     cnt = torch.empty(B, dtype=torch.float32, device=dev) if top_k <= 0 else None
     _chk(load().aot_ce_loss_f32(_dev(logits), _dev(labels), _dev(loss_px), _dev(loss), _opt(thr), _opt(cnt), B, C, P, int(top_k),
                                 stream if stream is not None else stream_ptr()), 'aot_ce_loss_f32')

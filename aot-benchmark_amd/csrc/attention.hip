@@ -492,8 +492,12 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
 // wave, so all four hold bit-identical scores) and each wave runs the softmax and its own 16*NDV value MFMAs.  144 instead
 // of 192 MFMAs per key tile and wave, q/k fragments of 16 registers instead of 64.  One barrier per key tile; the score
 // partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
+#ifndef AOT_GATED_OCC2     // 1: two waves per SIMD (registers capped at 256, V fetched one chunk ahead instead of two); decided by measurement
+#define AOT_GATED_OCC2 0
+#endif
 template <int NDV>
-__global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, AOT_GATED_OCC2 ? 2 : 1) attn_fwd_wide_coop_kernel(const AttnParams p) {
+  constexpr int NVB = AOT_GATED_OCC2 ? 2 : 3;       // rotating V register sets
   const int ntq = (p.Nq + 31) >> 5;
   const int split = blockIdx.x, bz = blockIdx.y;
   const int b = bz / ntq, qt = bz - b * ntq;
@@ -553,7 +557,7 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
     for (int r = 0; r < 16; ++r) part[buf][wave][r][lane] = sc[r];
   };
 
-  float ka[16], vb[3][16];
+  float ka[16], vb[NVB][16];
   if (t0 < t1) {
     load_k(ka, t0);
     qk_part(ka, 0);
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
     constexpr bool TAIL = decltype(tail)::value;
     const int buf = it & 1;
     load_v(vb[0], kt, 0);
-    load_v(vb[1], kt, 1);
+    if (NVB > 2) load_v(vb[1], kt, 1);
     f32x16 sc;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {   // fixed wave order: every wave of the workgroup gets the same bits (two rows per v_pk_add)
@@ -627,9 +631,9 @@ __global__ void __launch_bounds__(256) attn_fwd_wide_coop_kernel(const AttnParam
     }
 #pragma unroll
     for (int d = 0; d < NDV; ++d) {
-      if (d + 2 < NDV) load_v(vb[(d + 2) % 3], kt, d + 2);
+      if (d + NVB - 1 < NDV) load_v(vb[(d + NVB - 1) % NVB], kt, d + NVB - 1);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[d % 3][s], pf[s], o[d], 0, 0, 0);
+      for (int s = 0; s < 16; ++s) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[d % NVB][s], pf[s], o[d], 0, 0, 0);
     }
     ++it;
     __syncthreads();     // next tile's partials visible; this tile's buffer free for the tile after next

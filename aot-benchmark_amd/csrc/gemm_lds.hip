@@ -1472,7 +1472,10 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
   wq.w6 = w6;
   wq.cout_pad = cout_pad;
   const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  const bool wide = tile == 128 || (tile == 0 && p.Cout >= 128 && nwide >= 192);     // enough 128x128 tiles for the 256 CUs
+  // 128x128 tiles win where they fill the chip: at least 150 of them, and either a single dispatch round or rounds that are
+  // >= 70 % full (measured per shape at batch 1 and 3: profiles/r03e_mb_gemm_bf16x6_batch{1,3}.txt)
+  const int rounds = (nwide + 255) / 256;
+  const bool wide = tile == 128 || (tile == 0 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
   if (wide) {
     const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
     if (is1x1)

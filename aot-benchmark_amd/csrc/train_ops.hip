@@ -44,8 +44,10 @@ __global__ void __launch_bounds__(256) ce_pixel_kernel(const float* __restrict__
 
 // Hard-example mining: mean of the k largest per-pixel losses of one sample (torch.topk + mean, loss.py:176-180).  One
 // 1024-thread block per sample: 4-pass 8-bit radix select of the k-th largest, then the sum of everything above it plus the
-// wanted share of the ties (equal values: which ones are taken does not change the sum).  Also returns the order key of the
-// k-th largest for the backward pass.
+// wanted share of the ties (equal values: which ones are taken does not change the sum).  For the backward pass it also returns
+// the order key of the k-th largest (thr_out[b]) and the share of the pixels tied with it that entered the mean
+// (thr_out[B + b], float bits: need / number of ties -- torch.topk takes `need` of them, which ones is unspecified; spreading
+// their weight over all of them is the symmetric sub-gradient, and equals torch's whenever there is no tie).
 __global__ void __launch_bounds__(1024) topk_mean_kernel(const float* __restrict__ vals, long P, long k, float* __restrict__ mean_out,
                                                          unsigned* __restrict__ thr_out) {
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -83,12 +85,17 @@ __global__ void __launch_bounds__(1024) topk_mean_kernel(const float* __restrict
   }
   double acc = 0.0;
   float vthr = 0.f;
+  unsigned nt = 0;
   for (long t = tid; t < P; t += 1024) {
     const float f = s[t];
     const unsigned u = ord_u32_t(f);
     if (u > prefix) acc += (double)f;
-    if (u == prefix) vthr = f;
+    if (u == prefix) { vthr = f; ++nt; }
   }
+  __shared__ unsigned sh_ties;
+  if (tid == 0) sh_ties = 0;
+  __syncthreads();
+  if (nt) atomicAdd(&sh_ties, nt);      // integer sum: order-independent
   red[tid] = acc;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
@@ -104,6 +111,7 @@ __global__ void __launch_bounds__(1024) topk_mean_kernel(const float* __restrict
   if (tid == 0) {
     mean_out[b] = (float)((red[0] + (double)need * (double)sh_v) / (double)k);
     thr_out[b] = prefix;
+    thr_out[gridDim.x + b] = __float_as_uint((float)((double)need / (double)(sh_ties ? sh_ties : 1u)));
   }
 }
 
@@ -139,7 +147,8 @@ __global__ void __launch_bounds__(256) ce_bwd_kernel(const float* __restrict__ l
   float* g = grad + (long)b * C * P + i;
   const float lab = labels[(long)b * P + i];
   const bool valid = lab != IGNORE && lab >= 0.f && lab < (float)C;
-  const bool take = valid && (thr == nullptr || ord_u32_t(loss[(long)b * P + i]) >= thr[b]);
+  const unsigned key = thr ? ord_u32_t(loss[(long)b * P + i]) : 0u;
+  const bool take = valid && (thr == nullptr || key >= thr[b]);
   if (!take) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
@@ -154,7 +163,8 @@ __global__ void __launch_bounds__(256) ce_bwd_kernel(const float* __restrict__ l
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
     if (c < C) { v[c] = expf(v[c] - mx); s += v[c]; }
-  const float gs = gscale[b];
+  // a pixel tied with the k-th largest loss carries the share of the ties the forward mean took
+  const float gs = gscale[b] * ((thr && key == thr[b]) ? __uint_as_float(thr[gridDim.y + b]) : 1.f);
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
     if (c < C) g[(long)c * P] = gs * (v[c] / s - ((float)c == lab ? 1.f : 0.f));

@@ -97,8 +97,8 @@ class AOTEngine(nn.Module):
         # frame geometry, bank buffer, which scratch set holds the previous frame), a handful per clip however long it is.
         # The long-video knobs that change the ARITHMETIC with the bank length (top_k, max_mem_len_ratio) keep the
         # one-graph-per-state form.
-        lt = [l.long_term_attn for l in aot_model.LSTT.layers]
-        self._state_free = self.use_graph and not any(a.top_k > 0 or a.max_mem_len_ratio > 0 for a in lt)
+        self._state_free = self.use_graph and not any(l.long_term_attn.top_k > 0 or l.long_term_attn.max_mem_len_ratio > 0
+                                                      for l in aot_model.LSTT.layers)
         self._dev_ints = None        # [T, slot] int32 on the device (state-free graph mode)
         self._dev_vals = [None, None]
         self.group0 = group0         # first object group of the clip's label map held by lane 0 (None: labels as they are)
@@ -140,8 +140,8 @@ class AOTEngine(nn.Module):
         if torch.is_grad_enabled() and not getattr(self, '_warned_no_graph', False):
             # a caller porting the reference trainer would otherwise only find out at loss.backward()
             import warnings
-            warnings.warn('AOTEngine.forward returns loss VALUES: the hand-written kernels carry no autograd graph; gradients of '
-                          'the model come from networks.engines.backward (see DESIGN.md, training path), not from loss.backward()')
+            warnings.warn('AOTEngine.forward returns loss VALUES: the hand-written kernels carry no autograd graph and the model\'s '
+                          'backward pass is not built (DESIGN.md section 7, row f4) -- loss.backward() has nothing to propagate into')
             self._warned_no_graph = True
         if self.losses is None:
             self._init_losses()

@@ -270,13 +270,14 @@ int aot_label_resize_f32(const float* src, float* dst, int H, int W, int OH, int
  * logits [B, C, P] planar (the reference's [B,C,H,W], P = H*W), labels [B, P] fp32 class ids, 255 = ignore; C <= 16. */
 
 /* CrossEntropyLoss of the reference (loss.py:137-188) for B samples: loss_px [B,P] = per-pixel cross entropy (0 on ignored
- * pixels); loss[b] = mean of the top_k largest per-pixel losses of sample b (hard-example mining, top_k > 0; thr[b] receives
- * the order key of the k-th largest for the backward pass) or, with top_k = 0, the mean over the valid pixels (cnt[b] = their
+ * pixels); loss[b] = mean of the top_k largest per-pixel losses of sample b (hard-example mining, top_k > 0; thr [2B] receives
+ * for the backward pass the order key of the k-th largest, thr[b], and the share of the pixels tied with it that entered the
+ * mean, thr[B + b] as float bits) or, with top_k = 0, the mean over the valid pixels (cnt[b] = their
  * number). */
 int aot_ce_loss_f32(const float* logits, const float* labels, float* loss_px, float* loss, unsigned* thr, float* cnt, int B,
                     int C, long P, long top_k, void* stream);
-/* What autograd derives from loss.py:137-188: grad [B,C,P] = gscale[b] * (softmax - onehot) on the pixels that entered loss[b] (thr given: per-pixel loss >= the k-th
- * largest; thr = NULL: every valid pixel), 0 elsewhere.  gscale[b] = upstream gradient / k (or / cnt[b]). */
+/* What autograd derives from loss.py:137-188: grad [B,C,P] = gscale[b] * (softmax - onehot) on the pixels that entered loss[b] (thr given: per-pixel loss > the k-th
+ * largest, and the pixels tied with it weighted by their share; thr = NULL: every valid pixel), 0 elsewhere.  gscale[b] = upstream gradient / k (or / cnt[b]). */
 int aot_ce_loss_bwd_f32(const float* logits, const float* labels, const float* loss_px, const unsigned* thr,
                         const float* gscale, float* grad, int B, int C, long P, void* stream);
 
