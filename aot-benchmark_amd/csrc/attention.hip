@@ -492,12 +492,14 @@ __global__ void __launch_bounds__(64) attn_fwd_wide_pipe_kernel(const AttnParams
 // wave, so all four hold bit-identical scores) and each wave runs the softmax and its own 16*NDV value MFMAs.  144 instead
 // of 192 MFMAs per key tile and wave, q/k fragments of 16 registers instead of 64.  One barrier per key tile; the score
 // partials of tile i+1 are produced (software-pipelined, as above) while tile i is being exponentiated.
-#ifndef AOT_GATED_OCC2     // 1: two waves per SIMD (registers capped at 256, V fetched one chunk ahead instead of two); decided by measurement
-#define AOT_GATED_OCC2 0
-#endif
+// Two waves per SIMD (round 3): the registers are capped at 256 (launch bound 2) and V is fetched ONE chunk ahead through two
+// rotating register sets instead of two ahead through three.  With one wave per SIMD every stall -- the per-tile barrier, a late V
+// row -- idled the matrix pipe (PMC: MFMA busy 52 %, waves parked 35 %); the second wave fills those holes although the capped
+// allocation makes hipcc park ~300 values per key tile in spare AGPRs: R50-DeAOTL 262.6 -> 306.4 fps with three clips per GPU,
+// 212 -> 219 one clip at a time (profiles/r03f_gated_occ2.txt).
 template <int NDV>
-__global__ void __launch_bounds__(256, AOT_GATED_OCC2 ? 2 : 1) attn_fwd_wide_coop_kernel(const AttnParams p) {
-  constexpr int NVB = AOT_GATED_OCC2 ? 2 : 3;       // rotating V register sets
+__global__ void __launch_bounds__(256, 2) attn_fwd_wide_coop_kernel(const AttnParams p) {
+  constexpr int NVB = 2;       // rotating V register sets
   const int ntq = (p.Nq + 31) >> 5;
   const int split = blockIdx.x, bz = blockIdx.y;
   const int b = bz / ntq, qt = bz - b * ntq;
