@@ -42,6 +42,17 @@ def attn_splits(nq, units, t, occ=4, c0=3.0, wg_waves=1):
     return best
 
 
+def gated_splits(nq, t):
+    """Grid-level key split of the gated (DeAOT) attention kernel: one 4-wave workgroup per (32 queries, key range), two
+    resident per CU (two waves per SIMD) = 512 slots.  Measured on MI355X (tools/dev/mb_gated.py, profiles/r03g_mb_gated.txt,
+    N = 1674, bank of 1..14 frames): the fastest split at EVERY bank size is the largest one whose grid still fits one
+    dispatch round (9 x 53 = 477 workgroups: 909 us = 99 TF at M = 14 against 1131 us for 14 splits) -- a second round
+    costs more than longer key ranges.  At least four key tiles per range, at most 16 ranges (the partial-slab scratch)."""
+    qt = (nq + 31) // 32
+    tiles = (t + 31) // 32
+    return max(1, min(512 // max(qt, 1), tiles // 4, 16))
+
+
 def _planned_len(t, nq, kv_brows):
     """Bank length a launch is PLANNED for: beyond the first memorised frame the launch geometry (the grid-level key split)
     follows the bank's CAPACITY (kv_brows: rows between lanes = rows of the pre-allocated bank), not its length of the
@@ -201,7 +212,7 @@ class GatedPropagation(nn.Module):
         if 0 < self.top_k < t:
             return self._core_topk(q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows)
         t_plan = _planned_len(t, nq, kv_brows)
-        ns = attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
+        ns = gated_splits(nq * B, t_plan) if out.shape[1] == 1024 else attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
         part = None
         if ns > 1:
             part = ws.get('gattn_part', (16 * B * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)

@@ -9,7 +9,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
 aot_hip.load()
-from networks.layers.attention import attn_splits, _planned_len
+from networks.layers.attention import attn_splits, gated_splits, _planned_len
 mode = sys.argv[1] if len(sys.argv) > 1 else 'aot'
 N, C, H, E, CAP = 1674, 256, 8, 1024, 32
 q = torch.randn(N, C, device='cuda'); out = torch.empty(N, C, device='cuda')
@@ -25,7 +25,7 @@ def d32(T, brows):
 
 
 def gated(T, brows):
-    ns = attn_splits(N, E // 256, _planned_len(T, N, brows), occ=1, c0=1.0)
+    ns = gated_splits(N, _planned_len(T, N, brows))
     aot_hip.gated_attention(gq, gk, gv, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
 
 
