@@ -117,13 +117,15 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     const double pq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     int is_last = 1;
     if (nsplit > 1) {
-      // publish the partial (write-through stores), then take a ticket; the workgroup that draws the last ticket reduces
+      // publish the partial, then take a ticket; the workgroup that draws the last ticket reduces.  Both sides use 8-byte
+      // agent-scope atomics (`sc1`: stores write through to L2, loads bypass the CU's L1), so no cache needs flushing or
+      // invalidating -- the stores only have to be acknowledged before the ticket goes out (MI355X_MICROARCH.md: "sc1 payload
+      // -> asm vmcnt(0) -> flag"; an agent-scope release + acquire fence pair here cost 3-8 us of the launch's 11.5)
       __hip_atomic_store(&part[sp * 2], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&part[sp * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned prev = __hip_atomic_fetch_add(&ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = prev == (unsigned)(nsplit - 1);
-      if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     if (is_last) {
       double ts = 0.0, tq = 0.0;
