@@ -6,6 +6,7 @@ is missing, or a tensor is not on a ROCm device, the call raises.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -71,7 +72,16 @@ GEMM_TABLES = {'latency': -1, 'throughput': -2}
 MFMA_MODES = ('f32', 'bf16x6')
 X6_TILE = 0                  # 0: tile of the bf16x6 kernels chosen by shape; 64 / 128 force one (tests, tuning)
 X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
-_table_scopes = []
+
+
+class _Scopes(threading.local):
+    """The scope stack is per host thread: engines driven from different threads do not see each other's tables."""
+
+    def __init__(self):
+        self.stack = []
+
+
+_scopes = _Scopes()
 
 
 class use_gemm_table:
@@ -83,20 +93,20 @@ class use_gemm_table:
         self.ent = (GEMM_TABLES[name], mfma == 'bf16x6')
 
     def __enter__(self):
-        _table_scopes.append(self.ent)
+        _scopes.stack.append(self.ent)
         return self
 
     def __exit__(self, *exc):
-        _table_scopes.pop()
+        _scopes.stack.pop()
         return False
 
 
 def gemm_table():
     """Name of the table (and arithmetic) in force here (graph keys carry it: a graph captured under one never replays under
     another)."""
-    if not _table_scopes:
+    if not _scopes.stack:
         return 'latency'
-    cfg, x6 = _table_scopes[-1]
+    cfg, x6 = _scopes.stack[-1]
     return ('throughput' if cfg == -2 else 'latency') + ('+bf16x6' if x6 else '')
 
 
@@ -208,7 +218,8 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
            B=1, res_rows=0, cfg=-1, stream=None):
     """B NHWC images [B*H*W, lda] -> [B*OH*OW, ldc]; res_rows > 0: the residual is one [res_rows, ldr] map shared by the
     images (row m % res_rows)."""
-    if cfg == -1 and _table_scopes and _table_scopes[-1][1] and Cin % 32 == 0 and Cout > 32 and \
+    stack = _scopes.stack
+    if cfg == -1 and stack and stack[-1][1] and Cin % 32 == 0 and Cout > 32 and \
             -(-B * OH * OW // 64) * -(-Cout // 64) >= X6_MIN_TILES:
         w6 = getattr(w, '_aot_w6', None)
         if w6 is None:
@@ -223,7 +234,7 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     OW, Cout, KH, KW, stride, pad, dil, x.stride(0), w.stride(0),
                                     wt.stride(0) if wt is not None else 0, out.stride(0),
                                     res.stride(0) if res is not None else 0, res_rows, act,
-                                    (_table_scopes[-1][0] if _table_scopes else -1) if cfg == -1 else cfg,
+                                    (stack[-1][0] if stack else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
 

@@ -79,10 +79,15 @@ __device__ __forceinline__ void lgp_stage(const float* base, int ld, int c0, int
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NWV>
-__global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams pin) {
-  __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
-  const LgpParams p = lgp_lane(pin, blockIdx.z);
+// One workgroup per (64-wide strip of an image row, window row dy): its four waves take the four 32-channel chunks of the
+// 128-wide q.k contraction and meet in LDS (summed in chunk order: deterministic).  (Round 2 gave a workgroup a whole image
+// row and let eight waves walk the 15 window rows: 31 workgroups for a 480p map, 12 % of the CUs, 56 us; the window rows are
+// independent outputs, so they are grid work: 465 workgroups.)
+__global__ void __launch_bounds__(256) lgp_scores_kernel(const LgpParams pin) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * LGP_SLAB];
+  __shared__ float part[3][LGP_WS][64];
+  const int bl = blockIdx.z / LGP_WS, dy = blockIdx.z - bl * LGP_WS;
+  const LgpParams p = lgp_lane(pin, bl);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x0 = blockIdx.x * 64, y = blockIdx.y;
@@ -90,57 +95,61 @@ __global__ void __launch_bounds__(NWV * 64) lgp_scores_kernel(const LgpParams pi
   const int x = active ? x0 + lane : p.w - 1;
   const int n = y * p.w + x;
   const int N = p.h * p.w;
+  const int ky = y + dy - LGP_R;
+  if (ky < 0 || ky >= p.h) {           // whole window row outside the image (uniform over the workgroup)
+    if (wave == 0 && active)
+#pragma unroll
+      for (int dx = 0; dx < LGP_WS; ++dx) p.prob[(long)(dy * LGP_WS + dx) * N + n] = -INFINITY;
+    return;
+  }
   float* slab = lds + wave * LGP_SLAB;
-  for (int dy = wave; dy < LGP_WS; dy += NWV) {
-    const int ky = y + dy - LGP_R;
-    if (ky < 0 || ky >= p.h) {           // whole window row outside the image
-      if (active)
+  const int c0 = wave * 32;
+  float s[LGP_WS];
 #pragma unroll
-        for (int dx = 0; dx < LGP_WS; ++dx) p.prob[(long)(dy * LGP_WS + dx) * N + n] = -INFINITY;
-      continue;
+  for (int dx = 0; dx < LGP_WS; ++dx) s[dx] = 0.f;
+  {
+    float qs[32], tk[32];
+    {
+      const float4* src = reinterpret_cast<const float4*>(p.q + (long)n * p.ldq + c0);
+      const float* wk = p.relk_t + ((long)dy * 128 + c0) * 16 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 t = src[i];
+        qs[4 * i] = t.x / p.scale_div; qs[4 * i + 1] = t.y / p.scale_div;
+        qs[4 * i + 2] = t.z / p.scale_div; qs[4 * i + 3] = t.w / p.scale_div;
+      }
+#pragma unroll
+      for (int c = 0; c < 32; ++c) tk[c] = __builtin_nontemporal_load(wk + c * 16);
     }
-    float s[LGP_WS];
+    lgp_stage(p.k, p.ldk, c0, ky, x0, p.w, lane, slab);
 #pragma unroll
-    for (int dx = 0; dx < LGP_WS; ++dx) s[dx] = p.relk_b[dy * 16 + dx];
-    for (int c0 = 0; c0 < 128; c0 += 32) {
-      float qs[32], tk[32];
-      {
-        const float4* src = reinterpret_cast<const float4*>(p.q + (long)n * p.ldq + c0);
-        const float* wk = p.relk_t + ((long)dy * 128 + c0) * 16 + (lane & 15);
+    for (int dx = 0; dx < LGP_WS; ++dx) {
+      float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 t = src[i];
-          qs[4 * i] = t.x / p.scale_div; qs[4 * i + 1] = t.y / p.scale_div;
-          qs[4 * i + 2] = t.z / p.scale_div; qs[4 * i + 3] = t.w / p.scale_div;
-        }
-#pragma unroll
-        for (int c = 0; c < 32; ++c) tk[c] = __builtin_nontemporal_load(wk + c * 16);
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 kk = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LGP_LD + c4 * 4]);
+        dot = fmaf(qs[4 * c4], kk.x, dot);
+        dot = fmaf(qs[4 * c4 + 1], kk.y, dot);
+        dot = fmaf(qs[4 * c4 + 2], kk.z, dot);
+        dot = fmaf(qs[4 * c4 + 3], kk.w, dot);
       }
-      lgp_stage(p.k, p.ldk, c0, ky, x0, p.w, lane, slab);
-#pragma unroll
-      for (int dx = 0; dx < LGP_WS; ++dx) {
-        float dot = 0.f;
-#pragma unroll
-        for (int c4 = 0; c4 < 8; ++c4) {
-          const float4 kk = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LGP_LD + c4 * 4]);
-          dot = fmaf(qs[4 * c4], kk.x, dot);
-          dot = fmaf(qs[4 * c4 + 1], kk.y, dot);
-          dot = fmaf(qs[4 * c4 + 2], kk.z, dot);
-          dot = fmaf(qs[4 * c4 + 3], kk.w, dot);
-        }
-        s[dx] += dot;
-      }
-#pragma unroll
-      for (int c = 0; c < 32; ++c) lgp_dpp_axpy15(s, tk[c], qs[c]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();     // slab reads done before the next chunk overwrites it
+      s[dx] = dot;
     }
-    if (active)
 #pragma unroll
-      for (int dx = 0; dx < LGP_WS; ++dx) {
-        const int kx = x + dx - LGP_R;
-        p.prob[(long)(dy * LGP_WS + dx) * N + n] = (kx >= 0 && kx < p.w) ? s[dx] : -INFINITY;
-      }
+    for (int c = 0; c < 32; ++c) lgp_dpp_axpy15(s, tk[c], qs[c]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int dx = 0; dx < LGP_WS; ++dx) part[wave - 1][dx][lane] = s[dx];
+  }
+  __syncthreads();
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int dx = 0; dx < LGP_WS; ++dx) {
+      const float t = (((p.relk_b[dy * 16 + dx] + s[dx]) + part[0][dx][lane]) + part[1][dx][lane]) + part[2][dx][lane];
+      const int kx = x + dx - LGP_R;
+      p.prob[(long)(dy * LGP_WS + dx) * N + n] = (kx >= 0 && kx < p.w) ? t : -INFINITY;
+    }
   }
 }
 
@@ -253,7 +262,7 @@ extern "C" int aot_local_gated_f32(const float* q, const float* k, const float* 
                                    float scale_div, void* stream) {
   if (!q || !k || !v || !relk_t || !relk_b || !prob || !out || h <= 0 || w <= 0 || B <= 0) return AOT_ERR_BADARG;
   if (B > 1 && kv_brows < (long)h * w) return AOT_ERR_BADARG;
-  if ((long)B * h > 65535) return AOT_ERR_UNSUPPORTED;
+  if ((long)B * h > 65535 || (long)B * LGP_WS > 65535) return AOT_ERR_UNSUPPORTED;
   if (dqk != 128 || max_dis != 7 || dv <= 0 || (dv & 31)) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (gate && (ldg & 3))) return AOT_ERR_BADARG;
   LgpParams p;
@@ -262,7 +271,7 @@ extern "C" int aot_local_gated_f32(const float* q, const float* k, const float* 
   p.kv_brows = kv_brows;
   hipStream_t s = (hipStream_t)stream;
   constexpr int NWV = 8;
-  hipLaunchKernelGGL((lgp_scores_kernel<NWV>), dim3(cdiv(w, 64), h, B), dim3(NWV * 64), 0, s, p);
+  hipLaunchKernelGGL(lgp_scores_kernel, dim3(cdiv(w, 64), h, B * LGP_WS), dim3(256), 0, s, p);
   hipLaunchKernelGGL(lgp_softmax_kernel, dim3(cdiv(h * w, 16), B), dim3(256), 0, s, prob, h * w);
   hipLaunchKernelGGL((lgp_aggregate_kernel<NWV>), dim3(cdiv(w, 64), B * h, dv / 32), dim3(NWV * 64), 0, s, p);
   AOT_LAUNCH_CHECK();
