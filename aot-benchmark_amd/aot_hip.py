@@ -56,6 +56,22 @@ _SIGS = {
     'aot_adamw_step_f32': [_P] * 4 + [_L] + [_F] * 5 + [_I, _F, _P],
     'aot_ema_update_f32': [_P, _P, _L, _F, _P],
     'aot_sumsq_accum_f64': [_P, _L, _P, _P],
+    # training path, differentiable primitives (csrc/train_bwd.hip)
+    'aot_matmul_strided_f32': [_P] * 4 + [_I] * 4 + [_L] * 7 + [_I, _F, _I, _P],
+    'aot_im2col_f32': [_P, _P] + [_I] * 11 + [_P],
+    'aot_col2im_f32': [_P, _P] + [_I] * 11 + [_P],
+    'aot_dwconv2d_bwd_data_f32': [_P] * 3 + [_I] * 11 + [_P],
+    'aot_dwconv2d_bwd_weight_f32': [_P] * 3 + [_I] * 11 + [_P],
+    'aot_act_f32': [_P, _P, _L, _I, _P],
+    'aot_act_bwd_f32': [_P, _P, _P, _L, _I, _P],
+    'aot_layernorm_bwd_f32': [_P] * 5 + [_I, _I, _F, _P],
+    'aot_groupnorm_bwd_f32': [_P] * 6 + [_I] * 4 + [_P],
+    'aot_norm_param_grads_f32': [_P] * 4 + [_L, _I, _P],
+    'aot_softmax_rows_f32': [_P, _P, _L, _I, _P],
+    'aot_softmax_rows_bwd_f32': [_P, _P, _P, _L, _I, _P],
+    'aot_bilinear_bwd_nhwc_f32': [_P, _P] + [_I] * 7 + [_P],
+    'aot_window_gather_f32': [_P, _P] + [_I] * 4 + [_F, _P],
+    'aot_window_scatter_f32': [_P, _P] + [_I] * 4 + [_F, _P],
 }
 
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4

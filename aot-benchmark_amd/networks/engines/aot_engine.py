@@ -131,18 +131,14 @@ class AOTEngine(nn.Module):
         (or, use_prev_pred, their own prediction / probabilities) back; every frame is decoded and scored.
 
         The samples of a batch are independent clips (every reference op on this path is per-sample), so they run here one
-        after the other through the single-lane per-frame path -- the same kernels as inference, with the per-frame encoder
-        instead of the reference's batched offline one.  This is the deterministic network: drop-path and dropout
-        (TRAIN_LSTT_*) are not applied, and the returned loss carries no autograd graph -- the model backward is not built
-        (DESIGN.md section 7), only the losses themselves differentiate (layers/loss.py)."""
+        after the other.  Two forms:
+          * autograd enabled (a training step): the differentiable forward of networks/models/train_forward.py -- every graph
+            node a C-ABI kernel with a hand-written backward (csrc/train_bwd.hip), drop-path / dropout as the modules'
+            `training` flag says; `loss.backward()` fills the parameters' .grad as the reference's does;
+          * under torch.no_grad() (validation, the parity tests of the forward): the fused inference kernels, single lane,
+            per-frame encoder; no graph, no regularisers."""
         if self.lanes != 1 or self.group0 is not None:
             raise NotImplementedError('the training forward runs <= %d objects per sample on one lane' % self.max_obj_num)
-        if torch.is_grad_enabled() and not getattr(self, '_warned_no_graph', False):
-            # a caller porting the reference trainer would otherwise only find out at loss.backward()
-            import warnings
-            warnings.warn('AOTEngine.forward returns loss VALUES: the hand-written kernels carry no autograd graph and the model\'s '
-                          'backward pass is not built (DESIGN.md section 7, row f4) -- loss.backward() has nothing to propagate into')
-            self._warned_no_graph = True
         if self.losses is None:
             self._init_losses()
         bs = int(batch_size)
@@ -152,6 +148,10 @@ class AOTEngine(nn.Module):
         if T < 3 or all_frames.shape[0] != T * bs or all_masks.shape[0] != T * bs:
             raise ValueError('need >= 3 frames per sample, time-major: got %d frames / %d masks for batch %d'
                              % (all_frames.shape[0], all_masks.shape[0], bs))
+        if torch.is_grad_enabled():
+            from networks.models.train_forward import training_forward
+            return training_forward(self, all_frames, all_masks, bs, obj_nums, step=step, use_prev_pred=use_prev_pred,
+                                    enable_prev_frame=enable_prev_frame, use_prev_prob=use_prev_prob)
         aux_weight = self.aux_weight * max(self.aux_step - step, 0.) / self.aux_step
         frames = all_frames.view(T, bs, *all_frames.shape[1:])
         masks = all_masks.view(T, bs, *all_masks.shape[1:]).float()

@@ -73,6 +73,7 @@ class MultiheadAttention(nn.Module):
                  qk_chunks=1, max_mem_len_ratio=-1, top_k=-1):
         super().__init__()
         self.d_model = d_model
+        self.dropout_p = dropout          # on the attention weights (attention.py:110); training-time only
         self.num_head = num_head
         self.hidden_dim = d_model // num_head
         self.d_att = self.hidden_dim if d_att is None else d_att
@@ -133,6 +134,7 @@ class MultiheadLocalAttention(nn.Module):
         if use_linear or dilation != 1:
             raise NotImplementedError('AOT uses use_linear=False, dilation=1 (reference transformer.py:284-288)')
         self.window_size = 2 * max_dis + 1
+        self.dropout_p = dropout
         self.max_dis = max_dis
         self.num_head = num_head
         self.hidden_dim = d_model // num_head
@@ -174,6 +176,7 @@ class GatedPropagation(nn.Module):
         self.max_mem_len_ratio = float(max_mem_len_ratio)     # eval-time Q rescale for long banks, attention.py:674-679
         self.top_k = int(top_k)                               # eval-time sparse softmax, attention.py:689-693
         self.expand_d_vu = int(d_vu * expand_ratio)
+        self.dropout_p = dropout
         self.d_vu, self.d_qk, self.num_head = d_vu, d_qk, num_head
         self.hidden_dim = self.expand_d_vu // num_head
         self.d_att = d_qk // num_head if d_att is None else d_att
@@ -255,6 +258,7 @@ class LocalGatedPropagation(nn.Module):
         if num_head != 1 or use_linear or dilation != 1 or use_dis:
             raise NotImplementedError('DeAOT uses one head, use_linear=False, dilation=1 (transformer.py:550-559)')
         self.expand_d_vu = int(d_vu * expand_ratio)
+        self.dropout_p = dropout
         self.window_size = 2 * max_dis + 1
         self.max_dis, self.num_head = max_dis, num_head
         self.hidden_dim = self.expand_d_vu // num_head

@@ -20,6 +20,7 @@ class DWConv2d(nn.Module):  # basic.py:38-57
     def __init__(self, indim, dropout=0.1):
         super().__init__()
         self.conv = nn.Conv2d(indim, indim, 5, dilation=1, padding=2, groups=indim, bias=False)
+        self.dropout_p = dropout          # nn.Dropout2d after the conv: training-time only (models/train_forward.py)
 
 
 class ConvGN(nn.Module):  # basic.py:75-85: conv (with bias) + GroupNorm(8)

@@ -1,0 +1,395 @@
+"""Differentiable primitives of the training path: torch.autograd.Function wrappers over the C ABI
+(csrc/train_bwd.hip and the forward kernels of the inference path).  The reference builds its autograd graph out of
+ATen ops (networks/engines/aot_engine.py:33-108 under loss.backward(), trainer.py:460-519); here every node of the
+graph is one of the few primitives below, each with a hand-written backward:
+
+    matmul      C = alpha * A . B (+ bias) on arbitrarily strided 3-D views (nn.Linear, 1x1 convs, QK^T, PV and -- on
+                transposed views -- every one of their gradients)
+    im2col      KxK convolutions = im2col + matmul (adjoint: col2im)
+    dwconv2d    depthwise KxK
+    act, layernorm, groupnorm, softmax_rows, bilinear, window_gather / window_scatter, to_nchw
+
+All tensors are fp32 on a ROCm device, activations token-major / NHWC ([B*H*W, C]).  torch itself is used for views,
+concatenation and elementwise adds / multiplies of the graph (plumbing); there is no CPU path."""
+import torch
+from torch.autograd import Function
+
+import aot_hip
+from aot_hip import _chk, _dev, _opt, load, stream_ptr
+
+ACT = {'none': aot_hip.ACT_NONE, 'relu': aot_hip.ACT_RELU, 'relu6': aot_hip.ACT_RELU6, 'gelu': aot_hip.ACT_GELU,
+       'silu': aot_hip.ACT_SILU}
+
+
+def _f32c(t):
+    """fp32, contiguous (the streaming kernels walk raw memory)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- matmul ------------------------------------------------------------------------------------------------------------
+def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
+    """a [bt, m, k], b [bt, k, n]: any strides (views welcome) -> contiguous [bt, m, n]."""
+    bt, m, k = a.shape
+    n = b.shape[2]
+    if b.shape[0] != bt or b.shape[1] != k:
+        raise aot_hip.AotHipError('matmul shapes %s x %s' % (tuple(a.shape), tuple(b.shape)))
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise aot_hip.AotHipError('matmul operands must be float32')
+    c = out if out is not None else torch.empty(bt, m, n, dtype=torch.float32, device=a.device)
+    sa, sb = a.stride(), b.stride()
+    _chk(load().aot_matmul_strided_f32(_dev(a), _dev(b), _opt(bias), _dev(c), bt, m, n, k, sa[0], sa[1], sa[2], sb[0], sb[1],
+                                       sb[2], m * n, n, float(alpha), 0, stream_ptr()), 'aot_matmul_strided_f32')
+    return c
+
+
+class _Matmul(Function):
+    @staticmethod
+    def forward(ctx, a, b, bias, alpha):
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        ctx.has_bias = bias is not None
+        return _matmul_raw(a, b, bias, alpha)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = _f32c(dc)
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            da = _matmul_raw(dc, b.transpose(1, 2), alpha=ctx.alpha)            # dC . B^T
+        if ctx.needs_input_grad[1]:
+            db = _matmul_raw(a.transpose(1, 2), dc, alpha=ctx.alpha)            # A^T . dC
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            rows = dc.shape[0] * dc.shape[1]
+            ones = torch.ones(1, dtype=torch.float32, device=dc.device).expand(1, 1, rows)   # stride-0 view: no buffer
+            dbias = _matmul_raw(ones, dc.view(1, rows, dc.shape[2])).view(-1)
+        return da, db, dbias, None
+
+
+def matmul(a, b, bias=None, alpha=1.0):
+    """alpha * a @ b (+ bias): a [bt, m, k], b [bt, k, n] (any strides), bias [n]."""
+    return _Matmul.apply(a, b, bias, alpha)
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear on token-major x [M, in]: weight [out, in] as the parameter holds it."""
+    return matmul(x.unsqueeze(0), weight.t().unsqueeze(0), bias)[0]
+
+
+# ---- KxK convolution = im2col + matmul ---------------------------------------------------------------------------------
+def _osz(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class _Im2col(Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        B, H, W, C, KH, KW, stride, pad, dil = geom
+        OH, OW = _osz(H, KH, stride, pad, dil), _osz(W, KW, stride, pad, dil)
+        x = _f32c(x)
+        cols = torch.empty(B * OH * OW, KH * KW * C, dtype=torch.float32, device=x.device)
+        _chk(load().aot_im2col_f32(_dev(x), _dev(cols), B, H, W, C, OH, OW, KH, KW, stride, pad, dil, stream_ptr()), 'aot_im2col_f32')
+        ctx.geom = geom
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        B, H, W, C, KH, KW, stride, pad, dil = ctx.geom
+        OH, OW = _osz(H, KH, stride, pad, dil), _osz(W, KW, stride, pad, dil)
+        dcols = _f32c(dcols)
+        dx = torch.empty(B * H * W, C, dtype=torch.float32, device=dcols.device)
+        _chk(load().aot_col2im_f32(_dev(dcols), _dev(dx), B, H, W, C, OH, OW, KH, KW, stride, pad, dil, stream_ptr()), 'aot_col2im_f32')
+        return dx, None
+
+
+def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, dil=1):
+    """nn.Conv2d (groups = 1) on B NHWC maps x [B*H*W, Cin] (Cin % 4 == 0 for KxK): weight [Cout, Cin, KH, KW] as the
+    parameter holds it.  Returns ([B*OH*OW, Cout], OH, OW)."""
+    cout, cin, kh, kw = weight.shape
+    OH, OW = _osz(H, kh, stride, pad, dil), _osz(W, kw, stride, pad, dil)
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0:
+        return linear(x, weight.view(cout, cin), bias), OH, OW
+    if x.shape[1] != cin:           # channel padding of the input (one-hot maps: 11 -> 12): pad the weight with zeros
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, x.shape[1] - cin))
+        cin = x.shape[1]
+    cols = _Im2col.apply(x, (B, H, W, cin, kh, kw, stride, pad, dil))
+    wmat = weight.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)          # k = (ky, kx, c), as im2col lays the taps out
+    return linear(cols, wmat, bias), OH, OW
+
+
+# ---- depthwise convolution ---------------------------------------------------------------------------------------------
+class _DwConv(Function):
+    @staticmethod
+    def forward(ctx, x, wk, geom):
+        B, H, W, C, K, stride, pad, dil = geom
+        OH, OW = _osz(H, K, stride, pad, dil), _osz(W, K, stride, pad, dil)
+        x, wk = _f32c(x), _f32c(wk)
+        y = torch.empty(B * OH * OW, C, dtype=torch.float32, device=x.device)
+        aot_hip.dwconv2d(x, wk, None, y, H, W, C, OH, OW, K, stride, pad, dil, B=B)
+        ctx.save_for_backward(x, wk)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wk = ctx.saved_tensors
+        B, H, W, C, K, stride, pad, dil = ctx.geom
+        OH, OW = _osz(H, K, stride, pad, dil), _osz(W, K, stride, pad, dil)
+        dy = _f32c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _chk(load().aot_dwconv2d_bwd_data_f32(_dev(dy), _dev(wk), _dev(dx), B, H, W, C, OH, OW, K, K, stride, pad, dil,
+                                                  stream_ptr()), 'aot_dwconv2d_bwd_data_f32')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wk)
+            _chk(load().aot_dwconv2d_bwd_weight_f32(_dev(dy), _dev(x), _dev(dw), B, H, W, C, OH, OW, K, K, stride, pad, dil,
+                                                    stream_ptr()), 'aot_dwconv2d_bwd_weight_f32')
+        return dx, dw, None
+
+
+def dwconv2d(x, weight, B, H, W, stride=1, pad=0, dil=1):
+    """Depthwise nn.Conv2d (groups = C, no bias) on B NHWC maps x [B*H*W, C] (C % 4 == 0): weight [C, 1, K, K]."""
+    C, _, K, _ = weight.shape
+    wk = weight.reshape(C, K * K).t()                  # [K*K, C], the kernels' tap-major layout
+    y = _DwConv.apply(x, wk, (B, H, W, C, K, stride, pad, dil))
+    return y, _osz(H, K, stride, pad, dil), _osz(W, K, stride, pad, dil)
+
+
+# ---- pointwise / normalisation -----------------------------------------------------------------------------------------
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _chk(load().aot_act_f32(_dev(x), _dev(y), x.numel(), kind, stream_ptr()), 'aot_act_f32')
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        _chk(load().aot_act_bwd_f32(_dev(x), _dev(dy), _dev(dx), x.numel(), ctx.kind, stream_ptr()), 'aot_act_bwd_f32')
+        return dx, None
+
+
+def act(x, kind):
+    return x if kind == 'none' else _Act.apply(x, ACT[kind])
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        y = torch.empty_like(x)
+        aot_hip.layernorm(x, gamma, beta, y, eps=eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, C = x.shape
+        dx, xhat = torch.empty_like(x), torch.empty_like(x)
+        _chk(load().aot_layernorm_bwd_f32(_dev(x), _dev(dy), _dev(gamma), _dev(dx), _dev(xhat), M, C, ctx.eps, stream_ptr()),
+             'aot_layernorm_bwd_f32')
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        _chk(load().aot_norm_param_grads_f32(_dev(dy), _dev(xhat), _dev(dg), _dev(db), M, C, stream_ptr()), 'aot_norm_param_grads_f32')
+        return dx, dg, db, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    """nn.LayerNorm over the last dim of x [M, C]."""
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, B, eps):
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        dev = x.device
+        nsplit = 8
+        bufs = (torch.empty(B * groups * nsplit * 2, dtype=torch.float64, device=dev),
+                torch.empty(B * groups * 2, dtype=torch.float64, device=dev),
+                torch.zeros(B * groups, dtype=torch.int32, device=dev))
+        y = torch.empty_like(x)
+        aot_hip.groupnorm(x, gamma, beta, y, groups, bufs, act=aot_hip.ACT_NONE, eps=eps, nsplit=nsplit, B=B)
+        ctx.save_for_backward(x, gamma, bufs[1])
+        ctx.groups, ctx.B = groups, B
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        dx, xhat = torch.empty_like(x), torch.empty_like(x)
+        _chk(load().aot_groupnorm_bwd_f32(_dev(x), _dev(dy), _dev(stats), _dev(gamma), _dev(dx), _dev(xhat), ctx.B, R // ctx.B, C,
+                                          ctx.groups, stream_ptr()), 'aot_groupnorm_bwd_f32')
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        _chk(load().aot_norm_param_grads_f32(_dev(dy), _dev(xhat), _dev(dg), _dev(db), R, C, stream_ptr()), 'aot_norm_param_grads_f32')
+        return dx, dg, db, None, None, None
+
+
+def groupnorm(x, gamma, beta, groups, B=1, eps=1e-5):
+    """nn.GroupNorm on B NHWC maps x [B*M, C] (statistics per map and group)."""
+    return _GroupNorm.apply(x, gamma, beta, groups, B, eps)
+
+
+class _SoftmaxRows(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        rows = x.numel() // x.shape[-1]
+        _chk(load().aot_softmax_rows_f32(_dev(x), _dev(y), rows, x.shape[-1], stream_ptr()), 'aot_softmax_rows_f32')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        _chk(load().aot_softmax_rows_bwd_f32(_dev(y), _dev(dy), _dev(dx), y.numel() // y.shape[-1], y.shape[-1], stream_ptr()),
+             'aot_softmax_rows_bwd_f32')
+        return dx
+
+
+def softmax_rows(x):
+    """softmax over the last dim (entries at -inf give exactly 0)."""
+    return _SoftmaxRows.apply(x)
+
+
+class _Bilinear(Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        B, IH, IW, OH, OW, align = geom
+        x = _f32c(x)
+        C = x.shape[1]
+        y = torch.empty(B * OH * OW, C, dtype=torch.float32, device=x.device)
+        aot_hip.bilinear(x, y, IH, IW, OH, OW, C, align, B=B)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, IH, IW, OH, OW, align = ctx.geom
+        dy = _f32c(dy)
+        C = dy.shape[1]
+        dx = torch.empty(B * IH * IW, C, dtype=torch.float32, device=dy.device)
+        _chk(load().aot_bilinear_bwd_nhwc_f32(_dev(dy), _dev(dx), B, IH, IW, OH, OW, C, int(align), stream_ptr()),
+             'aot_bilinear_bwd_nhwc_f32')
+        return dx, None
+
+
+def bilinear(x, B, IH, IW, OH, OW, align_corners):
+    """F.interpolate(mode='bilinear') on B NHWC maps x [B*IH*IW, C] (C % 4 == 0)."""
+    return _Bilinear.apply(x, (B, IH, IW, OH, OW, bool(align_corners)))
+
+
+class _WindowGather(Function):
+    @staticmethod
+    def forward(ctx, dense, geom):
+        h, w, R, fill = geom
+        dense = _f32c(dense)
+        G, N = dense.shape[0], h * w
+        win = torch.empty(G, N, (2 * R + 1) ** 2, dtype=torch.float32, device=dense.device)
+        _chk(load().aot_window_gather_f32(_dev(dense), _dev(win), G, h, w, R, float(fill), stream_ptr()), 'aot_window_gather_f32')
+        ctx.geom = geom
+        return win
+
+    @staticmethod
+    def backward(ctx, dwin):
+        h, w, R, _ = ctx.geom
+        dwin = _f32c(dwin)
+        G, N = dwin.shape[0], h * w
+        dd = torch.empty(G, N, N, dtype=torch.float32, device=dwin.device)
+        _chk(load().aot_window_scatter_f32(_dev(dwin), _dev(dd), G, h, w, R, 0.0, stream_ptr()), 'aot_window_scatter_f32')
+        return dd, None
+
+
+class _WindowScatter(Function):
+    @staticmethod
+    def forward(ctx, win, geom):
+        h, w, R, fill = geom
+        win = _f32c(win)
+        G, N = win.shape[0], h * w
+        dense = torch.empty(G, N, N, dtype=torch.float32, device=win.device)
+        _chk(load().aot_window_scatter_f32(_dev(win), _dev(dense), G, h, w, R, float(fill), stream_ptr()), 'aot_window_scatter_f32')
+        ctx.geom = geom
+        return dense
+
+    @staticmethod
+    def backward(ctx, dd):
+        h, w, R, _ = ctx.geom
+        dd = _f32c(dd)
+        G, N = dd.shape[0], h * w
+        dwin = torch.empty(G, N, (2 * R + 1) ** 2, dtype=torch.float32, device=dd.device)
+        _chk(load().aot_window_gather_f32(_dev(dd), _dev(dwin), G, h, w, R, 0.0, stream_ptr()), 'aot_window_gather_f32')
+        return dwin, None
+
+
+def window_gather(dense, h, w, max_dis, fill=0.0):
+    """dense [G, N, N] -> [G, N, (2R+1)^2]: the entries at each query's window keys (`fill` where the key is outside the map)."""
+    return _WindowGather.apply(dense, (h, w, max_dis, fill))
+
+
+def window_scatter(win, h, w, max_dis, fill=0.0):
+    """[G, N, (2R+1)^2] -> dense [G, N, N] (`fill` outside each query's window): local2global, attention.py:378-417."""
+    return _WindowScatter.apply(win, (h, w, max_dis, fill))
+
+
+class _ToNCHW(Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x = _f32c(x)
+        C = x.shape[1]
+        y = torch.empty(1, C, H, W, dtype=torch.float32, device=x.device)
+        aot_hip.nhwc_to_nchw(x, y, C, H, W)
+        ctx.geom = (C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C, H, W = ctx.geom
+        dy = _f32c(dy)
+        dx = torch.empty(H * W, C, dtype=torch.float32, device=dy.device)
+        aot_hip.nchw_to_nhwc(dy, dx, C, H, W, C)
+        return dx, None, None
+
+
+def to_nchw(x, H, W):
+    """token-major [H*W, C] -> [1, C, H, W] (the layout the losses and callers of the reference surface take)."""
+    return _ToNCHW.apply(x, H, W)
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x, cpad):
+        x = _f32c(x)
+        _, C, H, W = x.shape
+        y = torch.empty(H * W, cpad, dtype=torch.float32, device=x.device)
+        aot_hip.nchw_to_nhwc(x, y, C, H, W, cpad)
+        ctx.geom = (C, H, W, cpad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C, H, W, cpad = ctx.geom
+        dy = _f32c(dy)
+        full = torch.empty(1, cpad, H, W, dtype=torch.float32, device=dy.device)
+        aot_hip.nhwc_to_nchw(dy, full, cpad, H, W)
+        return full[:, :C].contiguous(), None
+
+
+def to_nhwc(x, cpad=None):
+    """[1, C, H, W] -> token-major [H*W, cpad] (channels >= C zero): the one-hot / probability map in front of the identity bank."""
+    return _ToNHWC.apply(x, cpad if cpad is not None else x.shape[1])

@@ -26,12 +26,21 @@ def _ln_params(ln):
     return ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous()
 
 
+def _droppath_rate(droppath, idx, num_layers, scaling):
+    """transformer.py:71-78: with droppath_scaling the rate grows linearly over the layers."""
+    if not scaling:
+        return droppath
+    return 0 if num_layers == 1 else droppath * idx / (num_layers - 1)
+
+
 class LongShortTermTransformerBlock(nn.Module):
     def __init__(self, d_model, self_nhead, att_nhead, dim_feedforward=1024, droppath=0.1, lt_dropout=0.,
                  st_dropout=0., droppath_lst=False, activation='gelu', local_dilation=1):
         super().__init__()
         self.d_model = d_model
         self.dim_ff = dim_feedforward
+        # training-time regularisers (transformer.py:288-289,302; applied by models/train_forward.py only)
+        self.droppath_p, self.droppath_lst, self.lst_dropout_p = droppath, droppath_lst, max(lt_dropout, st_dropout)
         # parameter names/shapes = reference transformer.py:273-300
         self.norm1 = nn.LayerNorm(d_model)
         self.linear_Q = nn.Linear(d_model, d_model)
@@ -188,9 +197,11 @@ class LongShortTermTransformer(nn.Module):
         self.num_layers = num_layers
         self.return_intermediate = return_intermediate
         self.mask_token = nn.Parameter(torch.randn([1, 1, d_model]))   # unused at inference (transformer.py:59,105)
+        self.emb_dropout_p = emb_dropout
         self.layers = nn.ModuleList([
-            LongShortTermTransformerBlock(d_model, self_nhead, att_nhead, dim_feedforward, droppath, lt_dropout,
-                                          st_dropout, droppath_lst, activation) for _ in range(num_layers)])
+            LongShortTermTransformerBlock(d_model, self_nhead, att_nhead, dim_feedforward,
+                                          _droppath_rate(droppath, i, num_layers, droppath_scaling), lt_dropout,
+                                          st_dropout, droppath_lst, activation) for i in range(num_layers)])
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
@@ -247,6 +258,7 @@ class GatedPropagationModule(nn.Module):
         self.expand_d_model, self.d_model, self.att_nhead = expand_d_model, d_model, att_nhead
         d_att = d_model // 2 if att_nhead == 1 else d_model // att_nhead
         self.d_att, self.layer_idx = d_att, layer_idx
+        self.droppath_p, self.droppath_lst, self.lst_dropout_p = droppath, droppath_lst, max(lt_dropout, st_dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.linear_QV = nn.Linear(d_model, d_att * att_nhead + expand_d_model)
         self.linear_U = nn.Linear(d_model, expand_d_model)
@@ -394,8 +406,10 @@ class DualBranchGPM(nn.Module):
         self.intermediate_norm, self.final_norm = intermediate_norm, final_norm
         self.num_layers, self.return_intermediate = num_layers, return_intermediate
         self.d_model = d_model
+        self.emb_dropout_p = emb_dropout
         self.layers = nn.ModuleList([
-            GatedPropagationModule(d_model, self_nhead, att_nhead, dim_feedforward, droppath, lt_dropout, st_dropout,
+            GatedPropagationModule(d_model, self_nhead, att_nhead, dim_feedforward,
+                                   _droppath_rate(droppath, i, num_layers, droppath_scaling), lt_dropout, st_dropout,
                                    droppath_lst, activation, layer_idx=i) for i in range(num_layers)])
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([GroupNorm1D(d_model * 2, 2) for _ in range(num_norms)]) if num_norms > 0 else None

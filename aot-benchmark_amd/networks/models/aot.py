@@ -70,6 +70,7 @@ class AOT(nn.Module):
             self.patch_wise_id_bank = nn.Conv2d(cfg.MODEL_MAX_OBJ_NUM + 1, emb, kernel_size=17, stride=16, padding=8)
         else:
             self.patch_wise_id_bank = nn.Conv2d(cfg.MODEL_MAX_OBJ_NUM + 1, emb, kernel_size=16, stride=16, padding=0)
+        self.id_dropout_p = float(getattr(cfg, 'TRAIN_LSTT_ID_DROPOUT', 0.))   # aot.py:65; training-time only
         self.pos_generator = PositionEmbeddingSine(emb // 2, normalize=True)
         self.ws = Workspace()
         self._packed = None

@@ -300,6 +300,55 @@ int aot_ema_update_f32(float* shadow, const float* param, long n, float one_minu
  * (trainer.py:501-503). */
 int aot_sumsq_accum_f64(const float* x, long n, double* out, void* stream);
 
+/* ---- training path, differentiable primitives (csrc/train_bwd.hip) ----
+ * What `loss.backward()` (networks/managers/trainer.py:460-519) derives for the training engine's forward
+ * (networks/engines/aot_engine.py:33-108) decomposes into these primitives and their adjoints; the host side wraps them as
+ * torch.autograd.Function (networks/layers/train_ops.py).  Correctness-first kernels, fixed summation order. */
+
+/* C[b][m][n] (ldc) = alpha * sum_k A[b][m][k] B[b][k][n] (+ bias[n]) (accumulate: C += ...) for operands with arbitrary ELEMENT
+ * strides (sab, sam, sak / sbb, sbk, sbn): nn.Linear and 1x1 convs (transformer.py:321-359, fpn.py:34-58), the QK^T / PV
+ * products of attention.py:92-117,672-707 per head, and -- on transposed views -- all of their gradients.  Exact fp32
+ * (v_mfma_f32_32x32x2_f32, k-ordered). */
+int aot_matmul_strided_f32(const float* a, const float* b, const float* bias, float* c, int batch, int M, int N, int K, long sab,
+                           long sam, long sak, long sbb, long sbk, long sbn, long scb, int ldc, float alpha, int accumulate,
+                           void* stream);
+/* cols [B*OH*OW, KH*KW*C] = im2col of B NHWC maps [B*H*W, C] (C % 4 == 0; k = (ky*KW + kx)*C + c, zeros outside the image), and its
+ * adjoint dx [B*H*W, C] = col2im(cols) as a gather.  KxK convolutions = im2col + matmul: fpn.py:41-56 (3x3), the identity bank
+ * (models/aot.py:50-63: 17x17 / stride 16 on the one-hot or probability map). */
+int aot_im2col_f32(const float* x, float* cols, int B, int H, int W, int C, int OH, int OW, int KH, int KW, int stride, int pad,
+                   int dil, void* stream);
+int aot_col2im_f32(const float* cols, float* dx, int B, int H, int W, int C, int OH, int OW, int KH, int KW, int stride, int pad,
+                   int dil, void* stream);
+/* Adjoint of aot_dwconv2d_nhwc_f32 (no bias, no activation): dx from dy and w [KH*KW, C]; dw [KH*KW, C] from dy and x.
+ * basic.py:19-25,41-47 (5x5), mobilenetv2.py:93-98 (3x3, stride 1 / 2, dilation). */
+int aot_dwconv2d_bwd_data_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int OH, int OW, int KH, int KW,
+                              int stride, int pad, int dil, void* stream);
+int aot_dwconv2d_bwd_weight_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int OH, int OW, int KH,
+                                int KW, int stride, int pad, int dil, void* stream);
+/* y = act(x) and dx = dy * act'(x) over n floats (AOT_ACT_*): F.relu / relu6 (mobilenetv2.py:44-45), F.gelu (basic.py:32), silu
+ * (attention.py:585-586). */
+int aot_act_f32(const float* x, float* y, long n, int act, void* stream);
+int aot_act_bwd_f32(const float* x, const float* dy, float* dx, long n, int act, void* stream);
+/* nn.LayerNorm backward over rows of contiguous [M, C]: dx, and xhat = (x - mean) * rstd for the parameter gradients. */
+int aot_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* xhat, int M, int C, float eps,
+                          void* stream);
+/* nn.GroupNorm backward over B lanes of contiguous [M, C] maps with the forward's statistics (aot_groupnorm_stats_f32): dx, xhat. */
+int aot_groupnorm_bwd_f32(const float* x, const float* dy, const double* stats, const float* gamma, float* dx, float* xhat, int B,
+                          int M, int C, int G, void* stream);
+/* dgamma[c] = sum_r dy[r][c] * xhat[r][c], dbeta[c] = sum_r dy[r][c] over R rows of [R, C] (both norms). */
+int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, void* stream);
+/* y = softmax(x) over rows of length T (entries at -inf give 0) and dx = y * (dy - sum(dy * y)): attention.py:107,359,703,846. */
+int aot_softmax_rows_f32(const float* x, float* y, long rows, int T, void* stream);
+int aot_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int T, void* stream);
+/* Adjoint of aot_bilinear_nhwc_f32 (contiguous maps): dx [B*IH*IW, C] from dy [B*OH*OW, C]. */
+int aot_bilinear_bwd_nhwc_f32(const float* dy, float* dx, int B, int IH, int IW, int OH, int OW, int C, int align_corners,
+                              void* stream);
+/* Window <-> dense layouts of the windowed attentions (local2global, attention.py:378-417,863-903) for G maps of N = h*w tokens:
+ * gather: win [G][N][(2R+1)^2] = dense [G][N][N] at the window's keys (`fill` outside the image); scatter: the reverse (`fill`
+ * outside the window).  Each is the other's adjoint (with fill = 0). */
+int aot_window_gather_f32(const float* dense, float* win, int G, int h, int w, int max_dis, float fill, void* stream);
+int aot_window_scatter_f32(const float* win, float* dense, int G, int h, int w, int max_dis, float fill, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,48 @@ TRAIN_FWD_CASES = {
 }
 
 
+# gradient goldens (tests/golden/train_grads.npz, make_golden.make_train_grads): the cases, the parameters stored in full, and
+# the fixed subsample of every other parameter's gradient
+TRAIN_GRAD_CASES = ('tf_aott', 'tf_deaott_prob')
+TRAIN_GRAD_FULL = ('patch_wise_id_bank.bias', 'decoder.conv_out.weight', 'decoder.conv_out.bias', 'LSTT.layers.0.norm1.weight',
+                   'encoder_projector.bias')
+
+
+def grad_sample_index(n):
+    """64 fixed positions of a flattened gradient of n entries (all of it when n <= 64)."""
+    if n <= 64:
+        return torch.arange(n)
+    return (torch.arange(64, dtype=torch.float64) * (n - 1) / 63.0).round().long()
+
+
+def check_grads_against_golden(case, grads, g, rel=5e-3):
+    """Holds {parameter name: gradient} to the reference's gradient fixture `g` (train_grads.npz) of `case`: every parameter
+    the reference gives a gradient has one, L2 norm within 0.2 %, the 64 sampled entries within rel x the rms entry (+ 0.2 % of
+    the largest), the few small tensors stored in full elementwise.  Returns the worst sampled error in units of the rms."""
+    names = [str(n) for n in g[case + '.names']]
+    worst = 0.0
+    for i, k in enumerate(names):
+        gr = grads.get(k)
+        assert gr is not None, 'no gradient reached %s' % k
+        flat = gr.detach().double().flatten().cpu()
+        ref_norm = float(g[case + '.norm'][i])
+        tol = 2e-3 * ref_norm + 1e-6
+        assert abs(float(flat.norm()) - ref_norm) <= tol, '%s: |grad| %g vs %g' % (k, float(flat.norm()), ref_norm)
+        idx = grad_sample_index(flat.numel())
+        got = flat[idx].numpy()
+        ref = g[case + '.sample'][i][:got.size]
+        scale = ref_norm / max(1.0, flat.numel()) ** 0.5            # rms entry of the reference gradient
+        err = float(np.abs(got - ref).max())
+        assert err <= rel * scale + 2e-3 * float(np.abs(ref).max()) + 1e-7, '%s: sampled entries differ by %g (rms %g)' % (k, err, scale)
+        worst = max(worst, err / (scale + 1e-12))
+        if k in TRAIN_GRAD_FULL:
+            full = g['%s.full.%s' % (case, k)]
+            np.testing.assert_allclose(gr.detach().cpu().numpy(), full, rtol=rel, atol=rel * scale + 1e-7)
+    extra = [k for k, v in grads.items() if v is not None and k not in names]
+    assert not extra, 'gradients on parameters the reference leaves without one: %s' % extra[:5]
+    return worst
+
+
 def train_batch(name):
     """The batch of a TRAIN_FWD_CASES entry, rebuilt from seeds: sample b is synthetic clip 30+b with objs[b] objects; the
     label of frame t is the first-frame label moved with the clip's motion (synth_clip rolls by (2t, 3t)); one sample

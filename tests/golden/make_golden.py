@@ -297,6 +297,64 @@ def make_train_forward():
     np.savez_compressed(os.path.join(HERE, 'train_forward.npz'), **out)
 
 
+def make_train_grads():
+    """Gradients of the training-step loss from the REAL reference under autograd (trainer.py:460-519 calls loss.backward() on
+    what aot_engine.py:33-108 returns): eval-mode network (drop-path / dropout off, FrozenBN), encoder frozen as
+    TRAIN_ENCODER_FREEZE_AT = 2 leaves it, on two of the train_forward batches.  Stored per trainable parameter: L2 norm, sum
+    and a fixed subsample of 64 entries; the full tensor for a few small ones.  These pin the BACKWARD of the oracle today
+    (tests/test_oracle_golden.py) and are the target of the HIP backward kernels of the training path."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, TRAIN_GRAD_CASES, TRAIN_GRAD_FULL, grad_sample_index, train_batch
+    out = {}
+    for name in TRAIN_GRAD_CASES:
+        c = TRAIN_FWD_CASES[name]
+        net, _, cfg = refdriver.build_reference(c['model'])
+        net.load_state_dict(synth_state_dict(net.state_dict()))
+        for k, v in TRAIN_CFG.items():
+            setattr(cfg, k, v)
+        all_frames, all_masks, obj_nums, perms = train_batch(name)
+        bs = len(obj_nums)
+        refdriver._enter()
+        try:
+            from networks.engines import build_engine
+            engine = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=net, gpu_id=-1,
+                                  long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP).eval()
+            engine.restart_engine(bs, perms is not None)
+            if perms is not None:
+                m = torch.zeros(bs, 11, 11)
+                for b, pm in enumerate(perms):
+                    m[b, torch.arange(11), pm] = 1.
+                engine.id_shuffle_matrix = m
+            net.zero_grad()
+            loss, _, _, _ = engine(all_frames, all_masks, bs, obj_nums, step=c['step'],
+                                   use_prev_pred=c.get('use_prev_pred', False),
+                                   enable_prev_frame=c.get('enable_prev_frame', False),
+                                   use_prev_prob=c.get('use_prev_prob', False))
+            loss.backward()
+        finally:
+            refdriver._leave()
+        names, norms, sums, samples = [], [], [], []
+        for k, prm in net.named_parameters():
+            if not prm.requires_grad or prm.grad is None:
+                continue
+            g = prm.grad.detach().double().flatten()
+            names.append(k)
+            norms.append(float(g.norm()))
+            sums.append(float(g.sum()))
+            smp = g[grad_sample_index(g.numel())].float().numpy()
+            samples.append(np.pad(smp, (0, 64 - smp.size)))           # (parameters with < 64 entries: zero-padded)
+            if k in TRAIN_GRAD_FULL:
+                out['%s.full.%s' % (name, k)] = prm.grad.detach().numpy()
+        out[name + '.loss'] = loss.detach().numpy()
+        out[name + '.names'] = np.array(names)
+        out[name + '.norm'] = np.array(norms)
+        out[name + '.sum'] = np.array(sums)
+        out[name + '.sample'] = np.stack(samples)
+        print(name, 'loss', float(loss), 'parameters with gradients:', len(names), 'largest norms:',
+              sorted(zip(norms, names), reverse=True)[:3], flush=True)
+    np.savez_compressed(os.path.join(HERE, 'train_grads.npz'), **out)
+
+
 def make_evaluator_loop():
     """Pins the evaluator loop on the REAL reference: `Evaluator.evaluating` (networks/managers/evaluator.py:209-505) is run
     unmodified on the 4-frame scenario of tests/common.py -- its own VOSTest dataset class (object bookkeeping, label
@@ -759,6 +817,10 @@ def main():
     if not sys.argv[1:] or 'train_forward' in sys.argv[1:]:
         make_train_forward()
         if sys.argv[1:] == ['train_forward']:
+            return
+    if not sys.argv[1:] or 'train_grads' in sys.argv[1:]:
+        make_train_grads()
+        if sys.argv[1:] == ['train_grads']:
             return
     if not sys.argv[1:] or 'gp_knobs' in sys.argv[1:]:
         make_gp_knobs()

@@ -243,6 +243,33 @@ def test_oracle_training_forward_matches_reference(case):
     np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
 
 
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+def test_oracle_training_gradients_match_reference(case):
+    """The BACKWARD of the training step: gradients of the loss of aot_engine.py:33-108 with respect to every trainable
+    parameter, from the real reference's `loss.backward()` (tests/golden/train_grads.npz: 105 / 108 parameters -- L2 norm, sum,
+    64 sampled entries each, a few small tensors in full), against autograd through the oracle's train_forward.  The
+    encoder's frozen part (TRAIN_ENCODER_FREEZE_AT = 2) carries no gradient in either.  This pins the oracle's backward;
+    the HIP training path is to be held to the same fixture."""
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, check_grads_against_golden, train_batch
+    from oracle.aot_oracle import train_forward
+    c = TRAIN_FWD_CASES[case]
+    g = np.load(GOLD + '/train_grads.npz')
+    names = [str(n) for n in g[case + '.names']]
+    _, _, sd = synth_model_state(c['model'])
+    model = OracleModel(c['model'], sd)
+    for k in names:
+        model.sd[k].requires_grad_(True)
+    frames, masks, objs, perms = train_batch(case)
+    loss, _, _ = train_forward(model, frames, masks, objs, c['step'], TRAIN_CFG, use_prev_pred=c.get('use_prev_pred', False),
+                               enable_prev_frame=c.get('enable_prev_frame', False),
+                               use_prev_prob=c.get('use_prev_prob', False), perms=perms)
+    np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
+    loss.backward()
+    check_grads_against_golden(case, {k: t.grad for k, t in model.sd.items() if t.requires_grad}, g)
+    # parameters the reference leaves without a gradient (frozen encoder stages) have none here either
+    assert all(not t.requires_grad for k, t in model.sd.items() if k not in names)
+
+
 @pytest.mark.parametrize('case', ['single', 'tta'])
 def test_oracle_sequence_eval_matches_reference_evaluator(case):
     """The oracle's restatement of the evaluator loop against the REAL `Evaluator.evaluating` run on the same scenario with

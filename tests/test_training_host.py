@@ -293,3 +293,41 @@ def test_random_helpers_match_reference_streams():
     torch.manual_seed(5)
     t = truncated_normal_(torch.zeros(3, 7), 0.1, 0.5)
     assert torch.allclose(t, torch.tensor(gold['trunc_normal']), atol=0, rtol=0) and (t - 0.1).abs().max() < 1.0
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+def test_training_graph_glue_vs_reference_gradients(case, monkeypatch):
+    """The differentiable training forward (networks/models/train_forward.py, reached through AOTEngine.forward with autograd
+    on) against the REAL reference's `loss.backward()` (tests/golden/train_grads.npz): loss and the gradient of every trainable
+    parameter.  On CPU the graph's primitives are plain-torch stand-ins (tests/train_stand_ins.py) and the losses the
+    oracle's, so this pins the GLUE -- weight layouts, which tensor feeds which op, memories carried through time, the
+    shuffle and its reversal, what is frozen.  The same graph on the HIP kernels: tests/test_training_gpu.py."""
+    import train_stand_ins
+    from common import GOLD, TRAIN_CFG, TRAIN_FWD_CASES, check_grads_against_golden, synth_model_state, train_batch
+    from networks.engines import build_engine
+    from oracle.aot_oracle import ce_topk_loss, soft_jaccard_loss
+    train_stand_ins.install(monkeypatch)
+    c = TRAIN_FWD_CASES[case]
+    g = np.load(os.path.join(GOLD, 'train_grads.npz'))
+    cfg, model, _ = synth_model_state(c['model'], cfg_overrides=TRAIN_CFG)
+    model.eval()                                                   # how the fixture was made: regularisers off
+    eng = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
+    mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
+    eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
+                  lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
+    eng.loss_weights = [0.5, 0.5]
+    eng.aux_weight = TRAIN_CFG['TRAIN_AUX_LOSS_WEIGHT']
+    eng.aux_step = TRAIN_CFG['TRAIN_TOTAL_STEPS'] * TRAIN_CFG['TRAIN_AUX_LOSS_RATIO'] + 1e-5
+    frames, masks, objs, perms = train_batch(case)
+    eng.restart_engine(len(objs), perms is not None)
+    if perms is not None:
+        eng.id_shuffle = perms
+    model.zero_grad()
+    loss, pred, frame_loss, _ = eng(frames, masks, len(objs), objs, step=c['step'], use_prev_pred=c.get('use_prev_pred', False),
+                                    enable_prev_frame=c.get('enable_prev_frame', False),
+                                    use_prev_prob=c.get('use_prev_prob', False))
+    np.testing.assert_allclose(float(loss.detach()), float(g[case + '.loss']), rtol=1e-4)
+    assert len(pred) == len(frame_loss) == c['frames'] and pred[0].shape == (len(objs), *c['size'])
+    loss.backward()
+    worst = check_grads_against_golden(case, {k: p.grad for k, p in model.named_parameters()}, g)
+    print('training graph %s: loss %.6f, worst sampled gradient error %.2e of the rms entry' % (case, float(loss.detach()), worst))
