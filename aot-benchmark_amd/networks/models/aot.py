@@ -74,9 +74,13 @@ class AOT(nn.Module):
         self.pos_generator = PositionEmbeddingSine(emb // 2, normalize=True)
         self.ws = Workspace()
         self._packed = None
+        self._params_touched = False      # set by a training step (models/train_forward.py): the packed copies are stale
 
     # ---- packing: kernel-layout copies of the parameters, built once ---------------------------
     def pack(self):
+        if self._params_touched:          # an optimiser has been at the parameters since they were packed
+            self.invalidate()
+            self._params_touched = False
         if self._packed is None:
             if not next(self.parameters()).is_cuda:
                 raise aot_hip.AotHipError('AOT must be moved to a ROCm device before inference (no CPU fallback)')

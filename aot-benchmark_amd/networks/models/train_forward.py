@@ -411,8 +411,7 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
                      use_prev_prob=False):
     """aot_engine.py:33-108 with an autograd graph: same arguments and return values as AOTEngine.forward."""
     model = engine.AOT
-    if engine.losses is None:
-        engine._init_losses()
+    model._params_touched = True           # a training step follows: the inference path re-packs its weight copies when next used
     bs = int(batch_size)
     T_ = all_frames.shape[0] // bs
     L = model.max_obj_num + 1

@@ -227,7 +227,8 @@ def check_grads_against_golden(case, grads, g, rel=5e-3):
         scale = ref_norm / max(1.0, flat.numel()) ** 0.5            # rms entry of the reference gradient
         err = float(np.abs(got - ref).max())
         assert err <= rel * scale + 2e-3 * float(np.abs(ref).max()) + 1e-7, '%s: sampled entries differ by %g (rms %g)' % (k, err, scale)
-        worst = max(worst, err / (scale + 1e-12))
+        if ref_norm > 1e-6:                                         # (a key bias has gradient 0 up to rounding: softmax ignores it)
+            worst = max(worst, err / scale)
         if k in TRAIN_GRAD_FULL:
             full = g['%s.full.%s' % (case, k)]
             np.testing.assert_allclose(gr.detach().cpu().numpy(), full, rtol=rel, atol=rel * scale + 1e-7)

@@ -344,7 +344,36 @@ def make_train_grads():
             smp = g[grad_sample_index(g.numel())].float().numpy()
             samples.append(np.pad(smp, (0, 64 - smp.size)))           # (parameters with < 64 entries: zero-padded)
             if k in TRAIN_GRAD_FULL:
-                out['%s.full.%s' % (name, k)] = prm.grad.detach().numpy()
+                out['%s.full.%s' % (name, k)] = prm.grad.detach().numpy().copy()
+        # ... and the parameters after ONE optimiser step as the trainer takes it (trainer.py:460-503, the AMP branch's order
+        # without the scaler: backward -> clip_grad_norm_(5.0) -> AdamW over the reference's own parameter groups), at the base
+        # learning rate: per parameter the norm and the same 64 sampled entries of (new - old)
+        refdriver._enter()
+        try:
+            from configs.default import DefaultEngineConfig
+            from utils.learning import get_trainable_params
+            tcfg = DefaultEngineConfig('golden', c['model'])          # the trainer's recipe (configs/default.py:36-70)
+            groups = get_trainable_params(model=net, base_lr=tcfg.TRAIN_LR, use_frozen_bn=tcfg.MODEL_FREEZE_BN,
+                                          weight_decay=tcfg.TRAIN_WEIGHT_DECAY, exclusive_wd_dict=tcfg.TRAIN_WEIGHT_DECAY_EXCLUSIVE,
+                                          no_wd_keys=tcfg.TRAIN_WEIGHT_DECAY_EXEMPTION)
+        finally:
+            refdriver._leave()
+        before = {k: prm.detach().clone() for k, prm in net.named_parameters()}
+        opt = torch.optim.AdamW(groups, lr=tcfg.TRAIN_LR, weight_decay=tcfg.TRAIN_WEIGHT_DECAY)
+        total = torch.nn.utils.clip_grad_norm_(net.parameters(), tcfg.TRAIN_CLIP_GRAD_NORM)
+        opt.step()
+        dnorm, dsample = [], []
+        after = dict(net.named_parameters())
+        for k in names:
+            d = (after[k].detach().double() - before[k].double()).flatten()
+            dnorm.append(float(d.norm()))
+            smp = d[grad_sample_index(d.numel())].numpy()
+            dsample.append(np.pad(smp, (0, 64 - smp.size)))
+        out[name + '.step.total_norm'] = np.array(float(total))
+        out[name + '.step.lr_wd_clip'] = np.array([tcfg.TRAIN_LR, tcfg.TRAIN_WEIGHT_DECAY, tcfg.TRAIN_CLIP_GRAD_NORM])
+        out[name + '.step.dnorm'] = np.array(dnorm)
+        out[name + '.step.dsample'] = np.stack(dsample)
+        out[name + '.step.wd'] = np.array([next(gr['weight_decay'] for gr in groups if gr['name'] == k) for k in names])
         out[name + '.loss'] = loss.detach().numpy()
         out[name + '.names'] = np.array(names)
         out[name + '.norm'] = np.array(norms)

@@ -1,0 +1,263 @@
+"""The model's backward pass on the device: each differentiable primitive of networks/layers/train_ops.py --
+forward value and every gradient -- against torch's own autograd of the same op in fp64 (tests/train_stand_ins.py), then the
+whole training step (AOTEngine.forward with autograd on -> loss.backward() -> clip -> AdamW) against the REAL reference's
+gradients and updated parameters (tests/golden/train_grads.npz).  Run on the MI355X box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import train_stand_ins as S
+from common import GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    import aot_hip
+    aot_hip.load()
+    from networks.layers import train_ops
+    return train_ops
+
+
+def _check(name, ours, ref, inputs, tol=2e-5):
+    """ours / ref: callables on the list of leaf tensors (fp32 device / fp64 device copies) returning one tensor.  Compares the
+    value and, under one random cotangent, the gradient of every leaf that requires one."""
+    a = [t.detach().clone().requires_grad_(t.requires_grad) for t in inputs]
+    b = [t.detach().double().clone().requires_grad_(t.requires_grad) for t in inputs]
+    ya, yb = ours(a), ref(b)
+    assert ya.shape == yb.shape, '%s: shape %s vs %s' % (name, tuple(ya.shape), tuple(yb.shape))
+    fin = torch.isfinite(yb)
+    assert torch.equal(torch.isfinite(ya), fin)
+    scale = float(yb[fin].abs().max()) + 1e-30
+    err = float((ya.double() - yb)[fin].abs().max()) / scale
+    assert err <= tol, '%s: forward differs by %.2e of the largest entry' % (name, err)
+    ct = torch.randn(yb.shape, dtype=torch.float64, device=yb.device, generator=torch.Generator(device=yb.device).manual_seed(7))
+    ct = torch.where(fin, ct, torch.zeros_like(ct))
+    ya.backward(ct.float())
+    yb.backward(ct)
+    worst = err
+    for i, (p, q) in enumerate(zip(a, b)):
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, '%s: no gradient for input %d' % (name, i)
+        s = float(q.grad.abs().max()) + 1e-30
+        e = float((p.grad.double() - q.grad).abs().max()) / s
+        assert e <= tol, '%s: gradient of input %d differs by %.2e of its largest entry' % (name, i, e)
+        worst = max(worst, e)
+    return worst
+
+
+def _r(*shape, grad=True, seed=0, scale=1.0):
+    g = torch.Generator(device='cuda').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device='cuda', generator=g) * scale).requires_grad_(grad)
+
+
+def test_matmul_on_strided_views(T):
+    """aot_matmul_strided_f32 forward and both operand gradients + the bias gradient: contiguous, transposed, head-split
+    (permuted) and broadcast (stride 0) operands, alpha != 1 -- the shapes nn.Linear, QK^T, PV and the relative-position
+    products take in models/train_forward.py."""
+    x, w, b = _r(437, 256), _r(96, 256, seed=1), _r(96, seed=2)
+    _check('linear', lambda t: T.linear(*t), lambda t: S.linear(*t), [x, w, b])
+    q, k = _r(437, 256, seed=3), _r(1311, 256, seed=4)
+    heads = lambda t: t.view(t.shape[0], 8, 32).permute(1, 0, 2)
+    _check('qk^t', lambda t: T.matmul(heads(t[0]), heads(t[1]).transpose(1, 2), alpha=0.25),
+           lambda t: S.matmul(heads(t[0]), heads(t[1]).transpose(1, 2), alpha=0.25), [q, k])
+    p, v = _r(8, 437, 225, seed=5), _r(8, 32, 225, seed=6)
+    _check('attn x rel_v', lambda t: T.matmul(t[0], t[1].transpose(1, 2)), lambda t: S.matmul(t[0], t[1].transpose(1, 2)), [p, v])
+    a1, b1 = _r(1, 33, 70, seed=7), _r(1, 70, 5, seed=8)
+    _check('small odd', lambda t: T.matmul(t[0], t[1]), lambda t: S.matmul(t[0], t[1]), [a1, b1])
+
+
+@pytest.mark.parametrize('geom', [
+    # (H, W, Cin of the map, Cin of the weight, Cout, K, stride, pad, dil)
+    (33, 41, 4, 3, 32, 3, 2, 1, 1),         # stem: image padded 3 -> 4 channels
+    (17, 21, 64, 64, 48, 3, 1, 1, 1),       # decoder 3x3
+    (129, 161, 12, 11, 256, 17, 16, 8, 1),  # identity bank, align-corners geometry
+    (128, 160, 12, 11, 256, 16, 16, 0, 1),  # identity bank, the other geometry
+    (9, 11, 96, 96, 40, 1, 1, 0, 1),        # 1x1
+])
+def test_conv2d_im2col(T, geom):
+    H, W, cmap, cw, cout, K, s, p, d = geom
+    x = _r(H * W, cmap)
+    if cmap != cw:
+        x = x.detach().clone()
+        x[:, cw:] = 0
+        x.requires_grad_(True)
+    w, b = _r(cout, cw, K, K, seed=1, scale=0.1), _r(cout, seed=2)
+    _check('conv2d', lambda t: T.conv2d(t[0], t[1], t[2], 1, H, W, s, p, d)[0], lambda t: S.conv2d(t[0], t[1], t[2], 1, H, W, s, p, d)[0],
+           [x, w, b])
+
+
+@pytest.mark.parametrize('geom', [(17, 21, 64, 3, 1, 1, 1), (33, 41, 96, 3, 2, 1, 1), (9, 11, 192, 3, 1, 2, 2), (30, 38, 1024, 5, 1, 2, 1)])
+def test_dwconv2d(T, geom):
+    H, W, C, K, s, p, d = geom
+    x, w = _r(H * W, C), _r(C, 1, K, K, seed=1)
+    _check('dwconv2d', lambda t: T.dwconv2d(t[0], t[1], 1, H, W, s, p, d)[0], lambda t: S.dwconv2d(t[0], t[1], 1, H, W, s, p, d)[0], [x, w])
+
+
+@pytest.mark.parametrize('kind', ['relu', 'relu6', 'gelu', 'silu'])
+def test_activations(T, kind):
+    x = _r(301, 77, scale=4.0)
+    _check(kind, lambda t: T.act(t[0], kind), lambda t: S.act(t[0], kind), [x])
+
+
+def test_layernorm_and_groupnorm(T):
+    x, g, b = _r(437, 256, scale=3.0), _r(256, seed=1), _r(256, seed=2)
+    _check('layernorm', lambda t: T.layernorm(*t), lambda t: S.layernorm(*t), [x, g, b])
+    for C, G, rows in ((1024, 32, 437), (256, 8, 1700), (512, 2, 437), (128, 8, 6000)):
+        x, g, b = _r(rows, C, scale=2.0, seed=G), _r(C, seed=1), _r(C, seed=2)
+        _check('groupnorm %d/%d' % (C, G), lambda t: T.groupnorm(t[0], t[1], t[2], G), lambda t: S.groupnorm(t[0], t[1], t[2], G), [x, g, b],
+               tol=5e-5)
+
+
+def test_softmax_rows_with_masked_entries(T):
+    x = _r(8, 437, 225, scale=3.0).detach()
+    x[:, :, ::7] = float('-inf')
+    x[:, 5, :] = x[:, 5, :].clamp(max=-1.0)
+    x.requires_grad_(True)
+    _check('softmax_rows', lambda t: T.softmax_rows(t[0]), lambda t: S.softmax_rows(t[0]), [x])
+    y = _r(1, 437, 1311, scale=5.0)
+    _check('softmax_rows long', lambda t: T.softmax_rows(t[0]), lambda t: S.softmax_rows(t[0]), [y])
+
+
+@pytest.mark.parametrize('geom', [(9, 11, 17, 21, 256, True), (17, 21, 33, 41, 128, True), (8, 10, 16, 20, 128, False),
+                                  (33, 41, 129, 161, 12, True), (32, 40, 128, 160, 12, False)])
+def test_bilinear(T, geom):
+    IH, IW, OH, OW, C, align = geom
+    x = _r(IH * IW, C)
+    _check('bilinear', lambda t: T.bilinear(t[0], 1, IH, IW, OH, OW, align), lambda t: S.bilinear(t[0], 1, IH, IW, OH, OW, align), [x])
+
+
+def test_window_gather_and_scatter(T):
+    h, w, R = 9, 11, 7
+    d = _r(8, h * w, h * w)
+    _check('window_gather', lambda t: T.window_gather(t[0], h, w, R, float('-inf')), lambda t: S.window_gather(t[0], h, w, R, float('-inf')), [d])
+    a = _r(8, h * w, 225, seed=1)
+    _check('window_scatter', lambda t: T.window_scatter(t[0], h, w, R, 0.0), lambda t: S.window_scatter(t[0], h, w, R, 0.0), [a])
+    h, w = 19, 23                                     # a map larger than the window in both directions
+    d = _r(1, h * w, h * w, seed=2)
+    _check('window_gather big', lambda t: T.window_gather(t[0], h, w, R, 0.0), lambda t: S.window_gather(t[0], h, w, R, 0.0), [d])
+
+
+def test_layout_changes(T):
+    x = _r(33 * 41, 12)
+    _check('to_nchw', lambda t: T.to_nchw(t[0], 33, 41), lambda t: S.to_nchw(t[0], 33, 41), [x])
+    m = _r(1, 11, 33, 41, seed=1)
+    _check('to_nhwc', lambda t: T.to_nhwc(t[0], 12), lambda t: S.to_nhwc(t[0], 12), [m])
+
+
+def _train_engine(case, train_mode=False):
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, synth_model_state, train_batch
+    from networks.engines import build_engine
+    c = TRAIN_FWD_CASES[case]
+    cfg, model, _ = synth_model_state(c['model'], cfg_overrides=TRAIN_CFG)
+    model = model.cuda()
+    model.train(train_mode)
+    engine = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
+    engine.train(train_mode)
+    frames, masks, objs, perms = train_batch(case)
+    engine.restart_engine(len(objs), perms is not None)
+    if perms is not None:
+        engine.id_shuffle = [p.cuda() for p in perms]
+    kw = dict(step=c['step'], use_prev_pred=c.get('use_prev_pred', False), enable_prev_frame=c.get('enable_prev_frame', False),
+              use_prev_prob=c.get('use_prev_prob', False))
+    return c, cfg, model, engine, frames.cuda(), masks.cuda(), objs, kw
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+def test_training_step_matches_reference(T, case):
+    """One training step on the device against the REAL reference (train_grads.npz): AOTEngine.forward with autograd on (every
+    graph node a HIP kernel), `loss.backward()`, the gradient clip, one AdamW step over the reference's parameter groups.
+      * loss within 1e-5 relative; the gradient of each of the 105 / 108 trainable parameters: L2 norm within 0.2 %, 64 sampled
+        entries within 0.5 % of the rms entry, five small tensors in full; no gradient where the reference has none;
+      * clip_grad_norm's total norm within 1e-4 relative;
+      * the UPDATED parameters: on every sampled entry whose clipped reference gradient is above 1e-5 (where AdamW's first step,
+        -lr * g / (|g| + 1e-8), is not at the mercy of the gradient's last bits) new - old within 1e-5 x the parameter's rms of
+        the reference's; on the others within the step's bound lr * (1 + wd * |p|)."""
+    from common import check_grads_against_golden, grad_sample_index
+    from utils.learning import get_trainable_params
+    from utils.optim import AdamW
+    c, cfg, model, engine, frames, masks, objs, kw = _train_engine(case)
+    g = np.load(os.path.join(GOLD, 'train_grads.npz'))
+    model.zero_grad()
+    loss, pred, frame_loss, _ = engine(frames, masks, len(objs), objs, **kw)
+    assert loss.requires_grad and len(pred) == len(frame_loss) == c['frames']
+    np.testing.assert_allclose(float(loss.detach()), float(g[case + '.loss']), rtol=1e-5)
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = check_grads_against_golden(case, {k: p.grad for k, p in model.named_parameters()}, g)
+    lr, wd, clip = (float(v) for v in g[case + '.step.lr_wd_clip'])
+    groups = get_trainable_params(model, lr, wd, use_frozen_bn=cfg.MODEL_FREEZE_BN, exclusive_wd_dict={},
+                                  no_wd_keys=['absolute_pos_embed', 'relative_position_bias_table', 'relative_emb_v', 'conv_out'])
+    names = [str(n) for n in g[case + '.names']]
+    assert [gr['name'] for gr in groups if gr['params'][0].grad is not None] == names
+    assert [gr['weight_decay'] for gr in groups if gr['name'] in set(names)] == pytest.approx(g[case + '.step.wd'].tolist())
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt = AdamW(groups, lr=lr, weight_decay=wd)
+    total, scale = opt.clip_grad_norm(clip)
+    assert total == pytest.approx(float(g[case + '.step.total_norm']), rel=1e-4)
+    opt.step(grad_scale=scale)
+    torch.cuda.synchronize()
+    after = dict(model.named_parameters())
+    worst_upd = 0.0
+    for i, k in enumerate(names):
+        p0 = before[k].double().flatten()
+        d = (after[k].detach().double().flatten() - p0).cpu()
+        idx = grad_sample_index(d.numel())
+        ref_d = torch.from_numpy(g[case + '.step.dsample'][i][:idx.numel()])
+        ref_g = torch.from_numpy(g[case + '.sample'][i][:idx.numel()]).double() * min(1.0, clip / (float(g[case + '.step.total_norm']) + 1e-6))
+        rms = float(p0.norm()) / max(1.0, p0.numel()) ** 0.5
+        firm = ref_g.abs() >= 1e-5
+        err = (d[idx] - ref_d).abs()
+        if firm.any():
+            e = float(err[firm].max())
+            assert e <= 1e-5 * max(rms, 1e-3), '%s: updated entries differ by %g (parameter rms %g)' % (k, e, rms)
+            worst_upd = max(worst_upd, e / max(rms, 1e-3))
+        bound = lr * (1.0 + float(g[case + '.step.wd'][i]) * p0[idx].abs().cpu()) * 1.001
+        assert bool((d[idx].abs() <= bound).all()), '%s: a step larger than lr (1 + wd |p|)' % k
+        assert abs(float(d.norm()) - float(g[case + '.step.dnorm'][i])) <= 0.02 * float(g[case + '.step.dnorm'][i]) + 1e-9
+    print('training step %s: loss %.6f; worst sampled gradient error %.2e of the rms entry; worst updated entry %.2e of the parameter rms'
+          % (case, float(loss.detach()), worst, worst_upd))
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+def test_training_steps_reduce_the_loss(T, case):
+    """Six steps of the trainer's loop in train mode (drop-path / Dropout2d drawing, trainer.py:460-519: forward -> backward ->
+    clip 5.0 -> AdamW -> EMA) on one batch: the loss of the deterministic network -- measured by the OTHER form of
+    AOTEngine.forward, the fused inference kernels under no_grad, which re-pack the updated weights -- goes down, and the EMA
+    shadow follows the parameters."""
+    from utils.ema import ExponentialMovingAverage, get_param_buffer_for_ema
+    from utils.learning import get_trainable_params
+    from utils.optim import AdamW
+    c, cfg, model, engine, frames, masks, objs, kw = _train_engine(case, train_mode=True)
+
+    def eval_loss():
+        model.eval()
+        with torch.no_grad():
+            l = float(engine(frames, masks, len(objs), objs, **kw)[0])
+        model.train()
+        return l
+    l0 = eval_loss()
+    opt = AdamW(get_trainable_params(model, 2e-4, 0.07, use_frozen_bn=cfg.MODEL_FREEZE_BN, no_wd_keys=['relative_emb_v', 'conv_out']),
+                lr=2e-4, weight_decay=0.07)
+    ema_params = get_param_buffer_for_ema(model, update_buffer=False)
+    ema = ExponentialMovingAverage(ema_params, decay=0.99)
+    seen = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = engine(frames, masks, len(objs), objs, **kw)[0]
+        loss.backward()
+        _, scale = opt.clip_grad_norm(5.0)
+        opt.step(grad_scale=scale)
+        ema.update(ema_params)
+        seen.append(float(loss.detach()))
+    l1 = eval_loss()
+    print('six training steps %s: eval loss %.4f -> %.4f (train-mode losses %s)' % (case, l0, l1, ' '.join('%.3f' % v for v in seen)))
+    assert l1 < l0 - 0.02, 'the loss did not go down: %.4f -> %.4f' % (l0, l1)
+    assert all(np.isfinite(seen))
+    moved = max(float((s - p.detach()).abs().max()) for s, p in zip(ema.shadow_params, ema_params))
+    assert 0 < moved < 6 * 2e-4 * 1.1

@@ -331,3 +331,71 @@ def test_training_graph_glue_vs_reference_gradients(case, monkeypatch):
     loss.backward()
     worst = check_grads_against_golden(case, {k: p.grad for k, p in model.named_parameters()}, g)
     print('training graph %s: loss %.6f, worst sampled gradient error %.2e of the rms entry' % (case, float(loss.detach()), worst))
+
+
+def _ddp_worker(rank, world, port, case, q):
+    """One rank of a data-parallel training step: its own sample of the batch through the differentiable forward (stand-in
+    primitives on CPU), backward, bucketed all-reduce average of the MODEL's gradients."""
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import train_stand_ins
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, synth_model_state, train_batch
+    from networks.engines import build_engine
+    from networks.layers import train_ops
+    from oracle.aot_oracle import ce_topk_loss, soft_jaccard_loss
+    from utils.dist_grad import BucketedAllReduce
+
+    class Patch:
+        def setattr(self, obj, name, value):
+            setattr(obj, name, value)
+    train_stand_ins.install(Patch())
+    c = TRAIN_FWD_CASES[case]
+    cfg, model, _ = synth_model_state(c['model'], cfg_overrides=TRAIN_CFG)
+    model.eval()
+    eng = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
+    mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
+    eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
+                  lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
+    eng.loss_weights = [0.5, 0.5]
+    eng.aux_weight = TRAIN_CFG['TRAIN_AUX_LOSS_WEIGHT']
+    eng.aux_step = TRAIN_CFG['TRAIN_TOTAL_STEPS'] * TRAIN_CFG['TRAIN_AUX_LOSS_RATIO'] + 1e-5
+    frames, masks, objs, perms = train_batch(case)
+    bs = len(objs)
+    assert bs == world
+    mine = slice(rank, None, bs)                                   # time-major batch: this rank's sample of every frame
+    eng.restart_engine(1, perms is not None)
+    if perms is not None:
+        eng.id_shuffle = [perms[rank]]
+    loss, _, _, _ = eng(frames[mine], masks[mine], 1, [objs[rank]], step=c['step'], use_prev_pred=c.get('use_prev_pred', False),
+                        enable_prev_frame=c.get('enable_prev_frame', False), use_prev_prob=c.get('use_prev_prob', False))
+    loss.backward()
+    BucketedAllReduce(list(model.parameters()), bucket_mb=1.0).average()
+    if rank == 0:
+        q.put({k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})   # (by value)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+def test_data_parallel_step_averages_model_gradients_gloo_world2(case):
+    """The DDP step of trainer.py:59-74 over gloo, world 2, with REAL model gradients: each rank runs one sample of the batch
+    through the differentiable forward and backward, the bucketed all-reduce averages the parameters' gradients -- and the
+    result is the reference's full-batch `loss.backward()` (train_grads.npz): the batch loss is the mean of per-sample
+    losses, so averaging per-rank gradients is exactly what the reference's DistributedDataParallel computes."""
+    import socket
+    from common import GOLD, check_grads_against_golden
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # (a parameter no rank has a gradient for -- LSTT.mask_token, unused -- comes out of the all-reduce as zeros)
+    check_grads_against_golden(case, {k: torch.from_numpy(v) for k, v in grads.items() if v.any()},
+                               np.load(os.path.join(GOLD, 'train_grads.npz')))
