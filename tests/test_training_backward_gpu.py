@@ -32,8 +32,8 @@ def _check(name, ours, ref, inputs, tol=2e-5):
     assert ya.shape == yb.shape, '%s: shape %s vs %s' % (name, tuple(ya.shape), tuple(yb.shape))
     fin = torch.isfinite(yb)
     assert torch.equal(torch.isfinite(ya), fin)
-    scale = float(yb[fin].abs().max()) + 1e-30
-    err = float((ya.double() - yb)[fin].abs().max()) / scale
+    scale = float(yb.detach()[fin].abs().max()) + 1e-30
+    err = float((ya.detach().double() - yb.detach())[fin].abs().max()) / scale
     assert err <= tol, '%s: forward differs by %.2e of the largest entry' % (name, err)
     ct = torch.randn(yb.shape, dtype=torch.float64, device=yb.device, generator=torch.Generator(device=yb.device).manual_seed(7))
     ct = torch.where(fin, ct, torch.zeros_like(ct))
@@ -219,7 +219,9 @@ def test_training_step_matches_reference(T, case):
             worst_upd = max(worst_upd, e / max(rms, 1e-3))
         bound = lr * (1.0 + float(g[case + '.step.wd'][i]) * p0[idx].abs().cpu()) * 1.001
         assert bool((d[idx].abs() <= bound).all()), '%s: a step larger than lr (1 + wd |p|)' % k
-        assert abs(float(d.norm()) - float(g[case + '.step.dnorm'][i])) <= 0.02 * float(g[case + '.step.dnorm'][i]) + 1e-9
+        if float(g[case + '.norm'][i]) / max(1.0, p0.numel()) ** 0.5 * min(1.0, clip / float(g[case + '.step.total_norm'])) >= 1e-6:
+            # (a gradient that is rounding noise -- a key bias -- moves its parameter by noise too: no norm to compare)
+            assert abs(float(d.norm()) - float(g[case + '.step.dnorm'][i])) <= 0.02 * float(g[case + '.step.dnorm'][i]) + 1e-9
     print('training step %s: loss %.6f; worst sampled gradient error %.2e of the rms entry; worst updated entry %.2e of the parameter rms'
           % (case, float(loss.detach()), worst, worst_upd))
 
@@ -246,7 +248,10 @@ def test_training_steps_reduce_the_loss(T, case):
                 lr=2e-4, weight_decay=0.07)
     ema_params = get_param_buffer_for_ema(model, update_buffer=False)
     ema = ExponentialMovingAverage(ema_params, decay=0.99)
+    import time
     seen = []
+    torch.cuda.synchronize()
+    t0 = time.time()
     for _ in range(6):
         opt.zero_grad()
         loss = engine(frames, masks, len(objs), objs, **kw)[0]
@@ -255,6 +260,9 @@ def test_training_steps_reduce_the_loss(T, case):
         opt.step(grad_scale=scale)
         ema.update(ema_params)
         seen.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    print('  %.1f ms per training step (batch %d x %d frames at %dx%d, forward + backward + clip + AdamW + EMA)'
+          % ((time.time() - t0) / 6 * 1e3, len(objs), c['frames'], *c['size']))
     l1 = eval_loss()
     print('six training steps %s: eval loss %.4f -> %.4f (train-mode losses %s)' % (case, l0, l1, ' '.join('%.3f' % v for v in seen)))
     assert l1 < l0 - 0.02, 'the loss did not go down: %.4f -> %.4f' % (l0, l1)
