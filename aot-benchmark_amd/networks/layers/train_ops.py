@@ -7,7 +7,7 @@ graph is one of the few primitives below, each with a hand-written backward:
                 transposed views -- every one of their gradients)
     im2col      KxK convolutions = im2col + matmul (adjoint: col2im)
     dwconv2d    depthwise KxK
-    act, layernorm, groupnorm, softmax_rows, bilinear, window_gather / window_scatter, to_nchw
+    act, layernorm, groupnorm, softmax_rows, bilinear, window_gather / window_scatter, to_nchw, maxpool3x3s2 (forward only)
 
 All tensors are fp32 on a ROCm device, activations token-major / NHWC ([B*H*W, C]).  torch itself is used for views,
 concatenation and elementwise adds / multiplies of the graph (plumbing); there is no CPU path."""
@@ -156,6 +156,19 @@ def dwconv2d(x, weight, B, H, W, stride=1, pad=0, dil=1):
     wk = weight.reshape(C, K * K).t()                  # [K*K, C], the kernels' tap-major layout
     y = _DwConv.apply(x, wk, (B, H, W, C, K, stride, pad, dil))
     return y, _osz(H, K, stride, pad, dil), _osz(W, K, stride, pad, dil)
+
+
+def maxpool3x3s2(x, H, W):
+    """nn.MaxPool2d(3, 2, 1) on one NHWC map x [H*W, C] -> ([OH*OW, C], OH, OW).  Forward only: it sits behind the ResNet stem,
+    which every reference recipe freezes (TRAIN_ENCODER_FREEZE_AT >= 1), so no gradient ever reaches it."""
+    if x.requires_grad:
+        raise NotImplementedError('the max pool has no backward kernel: a trainable ResNet stem (TRAIN_ENCODER_FREEZE_AT = 0) '
+                                  'is not built')
+    x = _f32c(x)
+    OH, OW = _osz(H, 3, 2, 1, 1), _osz(W, 3, 2, 1, 1)
+    y = torch.empty(OH * OW, x.shape[1], dtype=torch.float32, device=x.device)
+    aot_hip.maxpool3x3s2(x, y, H, W, x.shape[1], OH, OW)
+    return y, OH, OW
 
 
 # ---- pointwise / normalisation -----------------------------------------------------------------------------------------

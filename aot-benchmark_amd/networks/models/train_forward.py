@@ -12,8 +12,8 @@ modules' `nn.Parameter`s, so that `loss.backward()` fills `.grad` exactly as it 
     the engine's frame recurrence: reference frame, optional second self-memorising frame, propagated frames with
     ground-truth / prediction / probability feedback (back-propagation through time comes from autograd)
 
-Scope: the MobileNetV2 models (AOT-T/S/B/L, DeAOT-T/S/B/L: what BASELINE config 5's recipe pre-trains first); the
-ResNet / Swin trunks raise NotImplementedError here.  One sample at a time (the reference batches; every op on this
+Scope: the MobileNetV2 and ResNet-50 / 101 models (AOT-T/S/B/L, DeAOT-T/S/B/L, R50-/R101-AOTL, R50-/R101-DeAOTL: BASELINE
+config 5 trains R50-DeAOTL); the Swin trunk raises NotImplementedError here.  One sample at a time (the reference batches; every op on this
 path is per-sample).  Drop-path / Dropout2d follow the modules' `training` flag with torch's generator (they are
 identities in eval mode, which is how the gradient goldens were made)."""
 import torch
@@ -76,8 +76,6 @@ def _cbr(x, seq, H, W):
 
 def mobilenetv2_features(enc, img):
     """img [1, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w), (top, h, w)] token-major (mobilenetv2.py:219-224)."""
-    if type(enc).__name__ != 'MobileNetV2':
-        raise NotImplementedError('the differentiable training forward covers the MobileNetV2 models; got %s' % type(enc).__name__)
     _, _, H, W = img.shape
     x = T.to_nhwc(img.float(), 4)
     x, h, w = _cbr(x, enc.features[0], H, W)
@@ -99,6 +97,49 @@ def mobilenetv2_features(enc, img):
     x, h, w = _cbr(x, enc.features[18], h, w)
     feats.append((x, h, w))
     return feats
+
+
+def resnet_features(enc, img):
+    """ResNet-50 / 101 trunk (encoders/resnet.py:140-157): img [1, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w)] token-major.
+    conv + FrozenBN folded per call; the stem's max pool has no backward kernel -- with the stem frozen
+    (TRAIN_ENCODER_FREEZE_AT >= 1, every reference recipe) nothing asks for one."""
+    _, _, H, W = img.shape
+    x = T.to_nhwc(img.float(), 4)
+    w, b = _fold_bn(enc.conv1.weight, enc.bn1)
+    x, h, wd = T.conv2d(x, w, b, 1, H, W, 2, 3, 1)
+    x = T.act(x, 'relu')
+    x, h, wd = T.maxpool3x3s2(x, h, wd)
+    feats = []
+    for layer in (enc.layer1, enc.layer2, enc.layer3):
+        for blk in layer:
+            s, d = blk.stride, blk.dilation
+            w1, b1 = _fold_bn(blk.conv1.weight, blk.bn1)
+            y = T.act(T.conv2d(x, w1, b1, 1, h, wd)[0], 'relu')
+            w2, b2 = _fold_bn(blk.conv2.weight, blk.bn2)
+            y, oh, ow = T.conv2d(y, w2, b2, 1, h, wd, s, d, d)
+            y = T.act(y, 'relu')
+            w3, b3 = _fold_bn(blk.conv3.weight, blk.bn3)
+            y = T.conv2d(y, w3, b3, 1, oh, ow)[0]
+            if blk.downsample is not None:
+                wds, bds = _fold_bn(blk.downsample[0].weight, blk.downsample[1])
+                res = T.conv2d(x, wds, bds, 1, h, wd, s, 0, 1)[0]                # (stride 2: im2col of a 1x1 window = every 2nd pixel)
+            else:
+                res = x
+            x, h, wd = T.act(y + res, 'relu'), oh, ow
+        feats.append((x, h, wd))
+    return feats
+
+
+def encoder_features(enc, img):
+    """-> ([f4, f8, f16] shortcuts, (top, h, w) the map the projector reads), aot.py:81-84."""
+    kind = type(enc).__name__
+    if kind == 'MobileNetV2':
+        feats = mobilenetv2_features(enc, img)
+        return feats[:3], feats[3]
+    if kind == 'ResNet':
+        feats = resnet_features(enc, img)
+        return feats, feats[2]
+    raise NotImplementedError('the differentiable training forward covers the MobileNetV2 and ResNet trunks; got %s' % kind)
 
 
 def _heads(t, H):
@@ -300,11 +341,9 @@ class ClipGraph:
         self.dec_in = None
 
     def _encode(self, img):
-        feats = mobilenetv2_features(self.m.encoder, img)
-        top, h, w = feats[3]
+        self.feats, (top, h, w) = encoder_features(self.m.encoder, img)
         proj = self.m.encoder_projector
         x16 = T.conv2d(top, proj.weight, proj.bias, 1, h, w)[0]
-        self.feats = feats[:3]
         if self.size_2d is None:
             self.size_2d = (h, w)
             with torch.no_grad():

@@ -786,7 +786,7 @@ def soft_jaccard_loss(logits, label, eps=1e-6):
 
 
 def train_forward(model, all_frames, all_masks, obj_nums, step, cfg, use_prev_pred=False, enable_prev_frame=False,
-                  use_prev_prob=False, perms=None):
+                  use_prev_prob=False, perms=None, long_term_mem_gap=9999):
     """aot_engine.py:33-108 sample by sample (every op of that path is per-sample; the reference runs them batched).
     all_frames [T*bs,3,H,W] / all_masks [T*bs,1,H,W] time-major; cfg: the five TRAIN_* values of _init_losses (:110-125);
     perms[b][o] = channel identity o of sample b is shuffled to (:168-172, reversed on the logits :364-367).
@@ -801,7 +801,7 @@ def train_forward(model, all_frames, all_masks, obj_nums, step, cfg, use_prev_pr
     frame_loss = torch.zeros(T, bs)
     masks = torch.zeros(T, bs, *all_masks.shape[-2:], dtype=torch.long)
     for b in range(bs):
-        eng = OracleEngine(model, long_term_mem_gap=9999)
+        eng = OracleEngine(model, long_term_mem_gap=long_term_mem_gap)     # cfg.TRAIN_LONG_TERM_MEM_GAP (2 for the L models)
         objs = int(obj_nums[b])
         perm = None if perms is None else perms[b]
         inv = None if perm is None else torch.argsort(perm)

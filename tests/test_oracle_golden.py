@@ -220,11 +220,11 @@ def test_oracle_gated_propagation_knobs_match_reference(case):
     assert np.abs(out.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl'])
 def test_oracle_training_forward_matches_reference(case):
     """aot_engine.py:33-108 of the real reference (train_forward.npz): ground-truth / prediction / probability feedback,
     second self-memorising frame, shuffled identities; losses per frame and sample, masks outside the reference's near-ties."""
-    from common import TRAIN_CFG, TRAIN_FWD_CASES, train_batch
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, model_cfg, train_batch
     from oracle.aot_oracle import train_forward
     c = TRAIN_FWD_CASES[case]
     g = np.load(GOLD + '/train_forward.npz')
@@ -234,7 +234,8 @@ def test_oracle_training_forward_matches_reference(case):
         loss, frame_loss, pred = train_forward(OracleModel(c['model'], sd), frames, masks, objs, c['step'], TRAIN_CFG,
                                                use_prev_pred=c.get('use_prev_pred', False),
                                                enable_prev_frame=c.get('enable_prev_frame', False),
-                                               use_prev_prob=c.get('use_prev_prob', False), perms=perms)
+                                               use_prev_prob=c.get('use_prev_prob', False), perms=perms,
+                                               long_term_mem_gap=model_cfg(c['model']).TRAIN_LONG_TERM_MEM_GAP)
     ref = g[case + '.masks']
     ties = np.unpackbits(g[case + '.ties'])[:ref.size].reshape(ref.shape).astype(bool)
     bad = pred.numpy() != ref
@@ -243,14 +244,14 @@ def test_oracle_training_forward_matches_reference(case):
     np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
 def test_oracle_training_gradients_match_reference(case):
     """The BACKWARD of the training step: gradients of the loss of aot_engine.py:33-108 with respect to every trainable
     parameter, from the real reference's `loss.backward()` (tests/golden/train_grads.npz: 105 / 108 parameters -- L2 norm, sum,
     64 sampled entries each, a few small tensors in full), against autograd through the oracle's train_forward.  The
     encoder's frozen part (TRAIN_ENCODER_FREEZE_AT = 2) carries no gradient in either.  This pins the oracle's backward;
     the HIP training path is to be held to the same fixture."""
-    from common import TRAIN_CFG, TRAIN_FWD_CASES, check_grads_against_golden, train_batch
+    from common import TRAIN_CFG, TRAIN_FWD_CASES, check_grads_against_golden, model_cfg, train_batch
     from oracle.aot_oracle import train_forward
     c = TRAIN_FWD_CASES[case]
     g = np.load(GOLD + '/train_grads.npz')
@@ -262,7 +263,8 @@ def test_oracle_training_gradients_match_reference(case):
     frames, masks, objs, perms = train_batch(case)
     loss, _, _ = train_forward(model, frames, masks, objs, c['step'], TRAIN_CFG, use_prev_pred=c.get('use_prev_pred', False),
                                enable_prev_frame=c.get('enable_prev_frame', False),
-                               use_prev_prob=c.get('use_prev_prob', False), perms=perms)
+                               use_prev_prob=c.get('use_prev_prob', False), perms=perms,
+                               long_term_mem_gap=model_cfg(c['model']).TRAIN_LONG_TERM_MEM_GAP)
     np.testing.assert_allclose(float(loss.detach()), float(g[case + '.loss']), rtol=1e-4)
     loss.backward()
     check_grads_against_golden(case, {k: t.grad for k, t in model.sd.items() if t.requires_grad}, g)

@@ -114,7 +114,7 @@ def test_bucketed_allreduce_gloo_world2():
                 assert torch.allclose(got, w, rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl'])
 def test_training_forward_orchestration_vs_reference(case, monkeypatch):
     """AOTEngine.forward's own logic -- frame order, which map is fed back, identity shuffle and its reversal, per-sample
     slicing, loss combination -- checked on CPU against the REAL reference's training engine (train_forward.npz) with the
@@ -134,7 +134,7 @@ def test_training_forward_orchestration_vs_reference(case, monkeypatch):
     class Staged(AOTEngine):
         def _restart_clip(self):
             super()._restart_clip()
-            self._o = OracleEngine(om, long_term_mem_gap=9999)
+            self._o = OracleEngine(om, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
 
         def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
             if obj_nums is not None:
@@ -158,7 +158,7 @@ def test_training_forward_orchestration_vs_reference(case, monkeypatch):
         return logits.argmax(1, keepdim=True).float(), None, torch.softmax(logits, 1) if want_prob else None
     monkeypatch.setattr(aot_hip, 'fuse_probs', fuse_probs)
     stub = types.SimpleNamespace(cfg=cfg, max_obj_num=10, parameters=lambda: iter([torch.zeros(1)]))
-    eng = Staged(stub, gpu_id=0, long_term_mem_gap=9999)
+    eng = Staged(stub, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
     mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
     eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
                   lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
@@ -295,7 +295,7 @@ def test_random_helpers_match_reference_streams():
     assert torch.allclose(t, torch.tensor(gold['trunc_normal']), atol=0, rtol=0) and (t - 0.1).abs().max() < 1.0
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
 def test_training_graph_glue_vs_reference_gradients(case, monkeypatch):
     """The differentiable training forward (networks/models/train_forward.py, reached through AOTEngine.forward with autograd
     on) against the REAL reference's `loss.backward()` (tests/golden/train_grads.npz): loss and the gradient of every trainable

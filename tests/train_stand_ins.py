@@ -38,6 +38,11 @@ def dwconv2d(x, weight, B, H, W, stride=1, pad=0, dil=1):
     return _tokens(y), y.shape[2], y.shape[3]
 
 
+def maxpool3x3s2(x, H, W):
+    y = F.max_pool2d(_maps(x, 1, H, W), 3, 2, 1)
+    return _tokens(y), y.shape[2], y.shape[3]
+
+
 def act(x, kind):
     return {'none': lambda t: t, 'relu': F.relu, 'relu6': F.relu6, 'gelu': F.gelu, 'silu': F.silu}[kind](x)
 
@@ -102,5 +107,5 @@ def install(monkeypatch):
     """Replaces the primitives of networks.layers.train_ops by the stand-ins above for one test."""
     from networks.layers import train_ops
     for name in ('matmul', 'linear', 'conv2d', 'dwconv2d', 'act', 'layernorm', 'groupnorm', 'softmax_rows', 'bilinear',
-                 'window_gather', 'window_scatter', 'to_nchw', 'to_nhwc'):
+                 'window_gather', 'window_scatter', 'to_nchw', 'to_nhwc', 'maxpool3x3s2'):
         monkeypatch.setattr(train_ops, name, globals()[name])
