@@ -33,6 +33,8 @@ _SIGS = {
     'aot_gn_act_dwconv5_f32': [_P] * 6 + [_I] * 8 + [_P],
     'aot_attn_f32': [_P] * 5 + [_I, _L, _I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
+    'aot_attn_pack_x6_f32': [_P] * 3 + [_I, _L, _I, _L, _I, _I, _L, _P, _I, _P],
+    'aot_attn_x6_f32': [_P] * 4 + [_I, _L, _I, _I, _P] + [_I] * 4 + [_F, _I, _P],
     'aot_preprocess_f32': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     'aot_fuse_probs_f32': [_P] * 5 + [_I] * 5 + [_P],
     'aot_label_resize_f32': [_P, _P] + [_I] * 5 + [_P],
@@ -353,6 +355,37 @@ def attention(q, k, v, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, B=
     nq = q.shape[0] // B
     _chk(lib.aot_attn_f32(_dev(q), _dev(k), _dev(v), _dev(out), _opt(part), B, kv_brows, nq, T, _opt(T_dev), H, 32,
                           q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale_div, nsplit, s), 'aot_attn_f32')
+    if nsplit > 1:
+        _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
+             'aot_attn_merge_f32')
+    return out
+
+
+def x6_bank(B, rows, C, device):
+    """Packed (pre-split, tile-major) K / V bank of the bf16x6 attention kernel for B lanes of up to `rows` memorised rows:
+    (planes, cap_rows).  Zero-filled: rows past the bank length are multiplied by weights that are exactly 0."""
+    cap = (rows + 31) // 32 * 32
+    return torch.zeros(B * cap * C * 6, dtype=torch.int16, device=device), cap
+
+
+def attention_pack_x6(k, v, bank, rows, B=1, src_brows=None, slot=0, slot_dev=None, stream=None):
+    """Splits rows [b*src_brows, + rows) of k / v (token-major fp32, C columns) into the three bf16 planes of lane b's packed
+    bank at rows slot*rows .. (aot_attn_pack_x6_f32; slot_dev: device int32 overriding `slot`, for graph replay)."""
+    kv, cap = bank
+    _chk(load().aot_attn_pack_x6_f32(_dev(k), _dev(v), _dev(kv), B, rows, k.shape[1], rows if src_brows is None else src_brows,
+                                     k.stride(0), v.stride(0), cap, _opt(slot_dev), slot,
+                                     stream if stream is not None else stream_ptr()), 'aot_attn_pack_x6_f32')
+    return bank
+
+
+def attention_x6(q, bank, out, T, H, scale_div, part=None, nsplit=1, T_dev=None, B=1, stream=None):
+    """aot_hip.attention on a packed bank: the bf16x6 member (fp32-equivalent arithmetic on the bf16 matrix cores)."""
+    kv, cap = bank
+    s = stream if stream is not None else stream_ptr()
+    lib = load()
+    nq = q.shape[0] // B
+    _chk(lib.aot_attn_x6_f32(_dev(q), _dev(kv), _dev(out), _opt(part), B, cap, nq, T, _opt(T_dev), H, 32, q.stride(0),
+                             out.stride(0), scale_div, nsplit, s), 'aot_attn_x6_f32')
     if nsplit > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
              'aot_attn_merge_f32')

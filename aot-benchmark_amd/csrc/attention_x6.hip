@@ -1,0 +1,320 @@
+// Long-term / self attention of AOT on the bf16 matrix cores with fp32-equivalent arithmetic: the attention member of the
+// bf16x6 kernel family (gemm_lds.hip holds the conv / linear members and the argument: every fp32 number is EXACTLY the sum of
+// three bf16 numbers obtained by truncation; of the nine partial products the six of order <= 2 are kept, each exact in the
+// fp32 accumulator of v_mfma_f32_32x32x16_bf16; what is dropped is <= 3 * 2^-24 of a product).  Same algorithm, grid, key
+// split, partial-slab format and merge as attn_fwd_d32_pipe_kernel (attention.hip; reference attention.py:92-117); what
+// differs is where the operands come from:
+//
+//   * the BANK is kept pre-split and TILE-MAJOR (aot_attn_pack_x6_f32, once per memorised frame; every later frame reads it):
+//       kv[lane][row / 32][head][K: 3 planes x 2 sub-steps x 64 lanes x 8 | V: the same]  bf16, 12 KB per (32-row tile, head)
+//     i.e. every MFMA operand fetch of a wave -- 64 lanes x 16 bytes -- is ONE contiguous KB (8 cache lines), laid out in the
+//     lane order of the instruction.  K chunk (plane, c) holds for lane (row j, half hi) the dims 16 c + 8 hi .. + 8 of bank row
+//     32 tile + j; V is stored TRANSPOSED: chunk (plane, c) holds for lane (dim j, half hi) the eight bank rows the score tile's
+//     C/D layout keeps in that lane's registers 8 c .. 8 c + 7, so that P^T goes from the accumulator registers of the first
+//     product straight into the B operand of the second (no LDS, no shuffles -- as in the fp32 kernel).  (A row-major packed
+//     bank was measured first: each 16-byte fetch then touches 32 cache lines and the kernel is bound by the L1 tag rate --
+//     no faster than the fp32 kernel.)
+//   * Q is split once per wave (registers), P once per key tile (4 VALU per value + 3 v_perm per pair);
+//   * a key tile is 24 MFMAs of 32 cycles instead of 32 of 64 -- and, unlike fp32 MFMAs, these do not occupy the vector
+//     ALUs the softmax runs on.
+#include "common.h"
+#include <type_traits>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct AttnX6Params {
+  const float* q;
+  const unsigned short* kv;   // [B][cap_rows / 32][H][6144]
+  float* out;
+  float* part;          // [nsplit][B*Nq][H*32] O partials, then [nsplit][B*Nq][H][2] (m, l): attn_merge_kernel's format
+  const int* T_dev;
+  int Nq, T, H, ldq, ldo, nsplit, B;
+  long cap_rows;        // rows of one lane's packed bank (a multiple of 32)
+  float scale_div;
+};
+
+#define AOT_LOG2E 1.44269502162933349609375f
+
+// two truncated bf16 (the upper halves of a and b) in one dword: [a.hi16 | b.hi16 << 16]
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// eight fp32 values -> their three bf16 planes (hi, mid, lo), element order preserved
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&out)[3]) {
+  u32x4 w[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float r0 = x[2 * e], r1 = x[2 * e + 1];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      w[pl][e] = pack_hi16(r0, r1);
+      if (pl < 2) {
+        r0 -= __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        r1 -= __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, w[pl]);
+}
+
+// acc += the six kept partial products of (a0 + a1 + a2) x (b0 + b1 + b2), smallest first
+__device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// NO inline asm in this kernel: hipcc inserts the wait states gfx950 needs between an MFMA and a vector instruction that reads or
+// writes one of its registers only for instructions it knows; an asm statement touching a score / output accumulator
+// (v_max3_f32 on the scores, a v_mul on the accumulator) gave results that changed from run to run in some instruction orders
+// (tools/dev/dbg_attn_x6.py: sporadic workgroups with a wrong O for 16 of their 32 queries, row maxima and sums intact).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Variants measured on MI355X and dropped (tools/dev/mb_attn_x6.py, profiles/r03n_attn_x6_variants.txt; N = 1674, 8 heads,
+// bank of 4 / 14 frames: 80.8 / 243.2 us as built): sched_group_barrier interleaves of the MFMAs with the softmax / split VALU
+// (82.1-83.2 / 246.8-249.4), both halves of P split before the value MFMAs (81.0 / 248.7), rescaling the accumulator only when
+// some lane's maximum moved (a wave-uniform branch: 84.0-87.5 / 250-255).  hipcc's own order is the fastest.
+// One wave = 32 queries x 1 head; the four waves of a workgroup take the four quarters of the workgroup's key range and merge
+// through LDS; blockIdx = (head, lane * query tile, key split) exactly as attn_fwd_d32_pipe_kernel.
+__global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params p) {
+  __shared__ float red[4][18][64];
+  const int h = blockIdx.x, split = blockIdx.z, bz = blockIdx.y;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int b = bz / ntq, qt = bz - b * ntq;
+  const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int tpw = (tps + 3) >> 2;
+  const int s1 = min(T, (split + 1) * tps * 32);
+  const int t0 = min(s1, (split * tps + wave * tpw) * 32);
+  const int t1 = min(s1, t0 + tpw * 32);
+  const long qrow0 = (long)b * p.Nq;
+  const int C = p.H * 32;
+  const long cap_tiles = p.cap_rows >> 5;
+
+  // Q^T as the B operand of the score product: lane (query j, half hi) contracts dims 16 c + 8 hi .. + 8 in sub-step c
+  bf16x8 qp[2][3];
+  {
+    const int qrow = min(qt * 32 + j, p.Nq - 1);
+    const float* src = p.q + (qrow0 + qrow) * p.ldq + h * 32 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,      // the reference divides
+                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};     // (attention.py:82)
+      split3(x, qp[c]);
+    }
+  }
+  // K: lane = key row j of the tile; V: lane = value channel j; chunk (plane, c) of either = 64 lanes x 16 bytes
+  const unsigned short* kvbase = p.kv + ((long)b * cap_tiles * p.H + h) * 6144 + lane * 8;
+  const long tile_stride = (long)p.H * 6144;
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
+  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
+    const unsigned short* src = kvbase + min((long)(kt >> 5), cap_tiles - 1) * tile_stride;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto load_v = [&](bf16x8 (&vf)[2][3], int kt) {
+    const unsigned short* src = kvbase + min((long)(kt >> 5), cap_tiles - 1) * tile_stride + 3072;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto qk = [&](const bf16x8 (&kf)[2][3], f32x16& sc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    mfma6(kf[0], qp[0], sc);
+    mfma6(kf[1], qp[1], sc);
+  };
+
+  bf16x8 ka[2][3], va[2][3];
+  f32x16 sa, sb;
+  if (t0 < t1) {
+    load_k(ka, t0);
+    load_v(va, t0);
+    qk(ka, sa);
+    load_k(ka, t0 + 32);
+  }
+  auto step = [&](int kt, f32x16& sc, f32x16& scn, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
+    qk(ka, scn);      // scores of the NEXT tile (past the range end: clamped rows, result unused)
+    if (TAIL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                    max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    float pf[16], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -m));      // as exp2_w() of attention.hip
+      ps += pf[r];
+    }
+    l += ps;
+    load_k(ka, kt + 64);
+    // P^T as the B operand of the value product: the lane's registers 8 c .. 8 c + 7 are keys 16 c + 8 (i >> 2) + 4 hi + (i & 3),
+    // the order the packed V rows are stored in
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float x8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+      bf16x8 pp[3];
+      split3(x8, pp);
+      mfma6(va[c], pp, o);
+    }
+    load_v(va, kt + 32);
+  };
+  int kt = t0;
+  for (; kt + 64 < t1; kt += 32) {
+    step(kt, sa, sb, std::false_type{});
+    sa = sb;
+  }
+  if (kt + 32 < t1) {
+    step(kt, sa, sb, std::false_type{});
+    step(kt + 32, sb, sa, std::true_type{});
+  } else if (kt < t1) {
+    step(kt, sa, sb, std::true_type{});
+  }
+
+  // ---- merge of the four key quarters through LDS (fixed wave order: deterministic); identical to the fp32 kernel ----
+  {
+    const float lt = l + __shfl_xor(l, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = o[r];
+    red[wave][16][lane] = m;
+    red[wave][17][lane] = lt;
+  }
+  __syncthreads();
+  float mm = fmaxf(fmaxf(red[0][16][lane], red[1][16][lane]), fmaxf(red[2][16][lane], red[3][16][lane]));
+  float f[4], lsum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; ++w2) {
+    const float mw = red[w2][16][lane];
+    f[w2] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+    lsum += f[w2] * red[w2][17][lane];
+  }
+  float4 acc;
+  {
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * wave + i;
+      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+    }
+    acc = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  const long grow = qrow0 + qi;
+  const int c = h * 32 + 8 * wave + 4 * hi;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / lsum;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    *reinterpret_cast<float4*>(p.out + grow * p.ldo + c) = acc;
+  } else {
+    const long rows = (long)p.B * p.Nq;
+    *reinterpret_cast<float4*>(p.part + ((long)split * rows + grow) * C + c) = acc;
+    if (wave == 0 && hi == 0) {
+      float* ml = p.part + (long)p.nsplit * rows * C + (((long)split * rows + grow) * p.H + h) * 2;
+      ml[0] = mm;
+      ml[1] = lsum;
+    }
+  }
+}
+
+// position of bank row w (of its 32-row tile) in the value product: sub-step c = w >> 4, lane half hi = (w >> 2) & 1, element
+// i = ((w >> 3) & 1) * 4 + (w & 3) -- the order the score tile's C/D layout holds the keys in
+// k / v [B lanes][rows][C] fp32 -> planes of the packed bank at rows row0 .. row0 + rows of each lane.  One thread per
+// (row, 4 channels): K planes go out as 8-byte pieces, V planes (transposed) as 2-byte scatters.
+__global__ void __launch_bounds__(256) attn_pack_x6_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                           unsigned short* __restrict__ kv, int B, long rows, int C, long src_brows,
+                                                           int ldk, int ldv, long cap_rows, const int* __restrict__ slot_dev,
+                                                           int slot) {
+  const int C4 = C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = rows * C4;
+  if (idx >= per * B) return;
+  const int b = (int)(idx / per);
+  const long rem = idx - (long)b * per;
+  const long r = rem / C4;
+  const int c = (int)(rem - r * C4) * 4;
+  const long t = (long)(slot_dev ? *slot_dev : slot) * rows + r;
+  const int H = C >> 5, hh = c >> 5, d = c & 31, w = (int)(t & 31);
+  const float4 kk = *reinterpret_cast<const float4*>(k + ((long)b * src_brows + r) * ldk + c);
+  const float4 vv = *reinterpret_cast<const float4*>(v + ((long)b * src_brows + r) * ldv + c);
+  float kr[4] = {kk.x, kk.y, kk.z, kk.w}, vr[4] = {vv.x, vv.y, vv.z, vv.w};
+  unsigned short* blk = kv + (((long)b * (cap_rows >> 5) + (t >> 5)) * H + hh) * 6144;
+  // K: lane (row w, half (d >> 3) & 1), sub-step d >> 4, elements d & 7 .. + 3
+  unsigned short* kdst = blk + ((d >> 4) * 64 + ((d >> 3) & 1) * 32 + w) * 8 + (d & 7);
+  // V: lane (dim d + e, half (w >> 2) & 1), sub-step w >> 4, element ((w >> 3) & 1) * 4 + (w & 3)
+  unsigned short* vdst = blk + 3072 + ((w >> 4) * 64 + ((w >> 2) & 1) * 32 + d) * 8 + ((w >> 3) & 1) * 4 + (w & 3);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    unsigned short kb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned ku = __float_as_uint(kr[e]) & 0xffff0000u, vu = __float_as_uint(vr[e]) & 0xffff0000u;
+      kb[e] = (unsigned short)(ku >> 16);
+      vdst[pl * 1024 + e * 8] = (unsigned short)(vu >> 16);
+      kr[e] -= __uint_as_float(ku);
+      vr[e] -= __uint_as_float(vu);
+    }
+    *reinterpret_cast<uint2*>(kdst + pl * 1024) = make_uint2(kb[0] | ((unsigned)kb[1] << 16), kb[2] | ((unsigned)kb[3] << 16));
+  }
+}
+
+}  // namespace
+
+// ===== C ABI ==============================================================================================================
+extern "C" int aot_attn_pack_x6_f32(const float* k, const float* v, void* kv, int B, long rows, int C, long src_brows, int ldk,
+                                    int ldv, long cap_rows, const int* slot_dev, int slot, void* stream) {
+  if (!k || !v || !kv || B <= 0 || rows <= 0 || C <= 0 || (C & 31) || (ldk & 3) || (ldv & 3) || cap_rows <= 0 ||
+      (cap_rows & 31) || slot < 0 || src_brows < 0 || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)kv & 15))
+    return AOT_ERR_BADARG;
+  if (!slot_dev && ((long)slot + 1) * rows > cap_rows) return AOT_ERR_BADARG;
+  const long n = (long)B * rows * (C / 4);
+  hipLaunchKernelGGL(attn_pack_x6_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k, v, (unsigned short*)kv,
+                     B, rows, C, src_brows, ldk, ldv, cap_rows, slot_dev, slot);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_attn_x6_f32(const float* q, const void* kv, float* out, float* part, int B, long cap_rows, int Nq, int T,
+                               const int* T_dev, int H, int d, int ldq, int ldo, float scale_div, int nsplit, void* stream) {
+  if (d != 32) return AOT_ERR_UNSUPPORTED;
+  if (!q || !kv || !out || Nq <= 0 || T <= 0 || H <= 0 || B <= 0 || cap_rows < T || (cap_rows & 31)) return AOT_ERR_BADARG;
+  if ((long)B * cdiv(Nq, 32) > 65535) return AOT_ERR_UNSUPPORTED;
+  if ((ldq & 3) || (ldo & 3) || ((uintptr_t)q & 15) || ((uintptr_t)out & 15) || ((uintptr_t)kv & 15))
+    return AOT_ERR_BADARG;
+  if (nsplit < 1 || (nsplit > 1 && !part)) return AOT_ERR_BADARG;
+  AttnX6Params p;
+  p.q = q; p.kv = (const unsigned short*)kv; p.out = out; p.part = part; p.T_dev = T_dev;
+  p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldo = ldo; p.nsplit = nsplit; p.B = B; p.cap_rows = cap_rows;
+  p.scale_div = scale_div;
+  hipLaunchKernelGGL(attn_x6_d32_kernel, dim3(H, B * cdiv(Nq, 32), nsplit), dim3(256), 0, (hipStream_t)stream, p);
+  AOT_LAUNCH_CHECK();
+}

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'attention.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip', 'train_ops.hip', 'train_bwd.hip']
+SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'attention.hip', 'attention_x6.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip', 'train_ops.hip', 'train_bwd.hip']
 LIB = os.path.join(HERE, 'libaot_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-Wno-unused-result']

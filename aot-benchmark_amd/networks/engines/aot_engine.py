@@ -105,6 +105,11 @@ class AOTEngine(nn.Module):
         self.first_group = group0 or 0
         self._bank = None            # per layer (K [lanes, cap*N, Ck], V [lanes, cap*N, Cv]); survives restart_engine
         self._bank_geom = None
+        # mfma = 'bf16x6', AOT's 32-wide heads: the bank also exists pre-split into bf16 planes (aot_attn_pack_x6_f32), which is
+        # what the long-term attention of that kernel family reads (aot_attn_x6_f32); per layer (planes, rows per lane)
+        self._bank_x6 = None
+        self._x6_attn = (mfma == 'bf16x6' and type(aot_model.LSTT).__name__ != 'DualBranchGPM'
+                         and all(l.long_term_attn.hidden_dim == 32 and l.long_term_attn.top_k <= 0 for l in aot_model.LSTT.layers))
         self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot; survives too
         self.losses = None           # built by the first forward() (training only)
         self.restart_engine()
@@ -347,6 +352,7 @@ class AOTEngine(nn.Module):
             self._bank = [(torch.empty(B, cap * N, ck, dtype=torch.float32, device=dev),
                            torch.empty(B, cap * N, cv, dtype=torch.float32, device=dev)) for ck, cv in widths]
             self._bank_geom = geom
+            self._bank_x6 = [aot_hip.x6_bank(B, cap * N, ck, dev) for ck, _ in widths] if self._x6_attn else None
         cap = self._bank[0][0].shape[1] // N
         if frames_needed > cap:
             new_cap = max(4 * cap, frames_needed)
@@ -359,6 +365,12 @@ class AOTEngine(nn.Module):
                 v2[:, :used].copy_(v[:, :used])
                 grown.append((k2, v2))
             self._bank = grown
+            if self._x6_attn:            # the packed copy: re-split what the bank holds
+                self._bank_x6 = [aot_hip.x6_bank(B, new_cap * N, k.shape[2], dev) for k, _ in grown]
+                if used:
+                    for (k, v), xb in zip(grown, self._bank_x6):
+                        aot_hip.attention_pack_x6(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), xb, used, B=B,
+                                                  src_brows=k.shape[1])
 
     def _next_slot(self):
         """Bank slot the next memorised frame goes to (append; a bounded bank overwrites its oldest non-first frame)."""
@@ -404,6 +416,17 @@ class AOTEngine(nn.Module):
                               stream=stream)
             aot_hip.copy_rows(v, bv.view(-1, bv.shape[2]), N, B=B, dst_brows=bv.shape[1], slot=slot, slot_dev=slot_dev,
                               stream=stream)
+        self._pack_x6(kv, slot, slot_dev, N)
+
+    def _pack_x6(self, kv, slot, slot_dev, src_brows):
+        """The bf16x6 family's packed copy of bank slot `slot`: per layer (K, V) rows [b * src_brows, + N) of every lane, split
+        into planes.  kv may be the frame's own buffers or the bank slot's rows themselves (direct-write path)."""
+        if not self._x6_attn:
+            return
+        stream = aot_hip.stream_ptr()
+        for xb, (k, v) in zip(self._bank_x6, kv):
+            aot_hip.attention_pack_x6(k, v, xb, self.enc_hw, B=self.lanes, src_brows=src_brows, slot=slot, slot_dev=slot_dev,
+                                      stream=stream)
 
     def _dev_int(self, i, value):
         """Device int i (0: bank length in tokens, 1: bank slot of the frame being memorised) set to `value` on the current
@@ -518,6 +541,8 @@ class AOTEngine(nn.Module):
         self._curr = mems
         if not direct:
             self._store(dst, slot)
+        else:
+            self._pack_x6(dst, slot, None, self._brows_bank())
         self._commit(slot)
         self._curr_slot = None
         self._dst = dst
@@ -550,13 +575,14 @@ class AOTEngine(nn.Module):
         long_m = [(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), T, brows) + tdev for k, v in self._bank]
         short = self._short[0]
         self._dst = dst
+        x6 = {'x6': self._bank_x6} if self._x6_attn else {}
 
         ahead = self._take_ahead(img) if img_embs is None else None
 
         def launch(img_, embs_):
             feats = ahead if ahead is not None else self._encode(img_, embs_)
             dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, short, None, self.pos_emb, self.enc_size_2d, self.AOT.ws,
-                                             aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena)
+                                             aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena, **x6)
             return feats, dec_in, mems
 
         if self.use_graph:
@@ -566,7 +592,7 @@ class AOTEngine(nn.Module):
             bank_state = T <= self.enc_hw if sf else T
             key = ptr_key('match', src, img_embs, [f[0] for f in ahead] if ahead is not None else None,
                           [m[:2] for m in long_m], brows, bank_state, short, dst, self.pos_emb, self.lanes, self.enc_size_2d,
-                          aot_hip.gemm_table())
+                          aot_hip.gemm_table(), [b[0] for b in self._bank_x6] if self._x6_attn else None)
             self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
         else:
             self._feats, self._dec_in, self._curr = launch(img, img_embs)
@@ -617,6 +643,8 @@ class AOTEngine(nn.Module):
                                           aot_hip.stream_ptr(), id_emb=mask_ if curr_id_emb is not None else None)
             if store_slot is not None:
                 self._store(dst, store_slot, slot_dev)
+            elif in_bank and memorise and not skip_long_term_update:
+                self._pack_x6(dst, self._curr_slot, None, self._brows_bank())     # (written in place: the packed copy follows)
 
         if curr_id_emb is not None:
             curr_mask = curr_id_emb
@@ -624,7 +652,9 @@ class AOTEngine(nn.Module):
             src = self._stage('mask' if curr_id_emb is None else 'id_emb', curr_mask)
             key = ptr_key('update', src, curr, dst, (store_slot is not None) if self._state_free else store_slot,
                           [b[0] for b in self._bank] if store_slot is not None else None,
-                          self.lanes, self.group0, self.enc_size_2d, aot_hip.gemm_table())
+                          self.lanes, self.group0, self.enc_size_2d, aot_hip.gemm_table(),
+                          [b[0] for b in self._bank_x6] if (self._x6_attn and memorise) else None,
+                          self._curr_slot if (in_bank and memorise) else None)
             self._gx().run(key, lambda: launch(src))
         else:
             launch(curr_mask)

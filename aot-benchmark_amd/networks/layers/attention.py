@@ -89,8 +89,9 @@ class MultiheadAttention(nn.Module):
             self.linear_V = nn.Linear(d_model, d_model)
         self.projection = nn.Linear(d_model, d_model)
 
-    def core(self, q, k, v, out, t, ws, stream, t_dev=None, B=1, kv_brows=0):
-        """q [B*Nq, C], k/v token-major (lane b: rows b*kv_brows .. + t) -> out [B*Nq, C] (pre-projection)."""
+    def core(self, q, k, v, out, t, ws, stream, t_dev=None, B=1, kv_brows=0, x6=None):
+        """q [B*Nq, C], k/v token-major (lane b: rows b*kv_brows .. + t) -> out [B*Nq, C] (pre-projection).  x6 = (planes, rows per
+        lane): the same bank pre-split for the bf16x6 kernel (aot_attn_x6_f32), used instead of k / v."""
         nq = q.shape[0] // B
         scale_div = self.T
         if self.max_mem_len_ratio > 0:
@@ -117,6 +118,10 @@ class MultiheadAttention(nn.Module):
         if ns > 1:      # one slab set sized for the largest grid split (4): no per-bank-size allocations
             part = ws.get('attn_part', (4 * B * nq * (self.d_model + 2 * self.num_head),), q.device)
         # (with a device-side length the host-side T only bounds the launch: the planned length)
+        if x6 is not None and self.hidden_dim == 32:
+            aot_hip.attention_x6(q, x6, out, t if t_dev is None else t_plan, self.num_head, scale_div, part=part, nsplit=ns,
+                                 T_dev=t_dev, B=B, stream=stream)
+            return out
         aot_hip.attention(q, k, v, out, t if t_dev is None else t_plan, self.num_head, scale_div, part=part, nsplit=ns,
                           T_dev=t_dev, B=B, kv_brows=kv_brows, stream=stream)
         return out

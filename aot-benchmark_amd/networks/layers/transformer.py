@@ -86,8 +86,9 @@ class LongShortTermTransformerBlock(nn.Module):
         return p
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
-    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
-        """x [B*N, C(ld)] token-major (B lanes).  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
+    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
+        """x [B*N, C(ld)] token-major (B lanes).  x6 = the bank's pre-split copy (planes, rows per lane) for the bf16x6 attention
+        kernel, when the engine keeps one.  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
         (T_dev: device int holding T, for launches replayed from a graph while the bank grows);
         short_mem = (K, V, kv_brows).  dst = (k_out, v_out) [B*N, C] buffers for this frame's K (= linear_Q output) and, on
         a reference frame, the id-fused V (e.g. the lane's bank slot); allocated when None.  keep = the caller's arena
@@ -133,7 +134,7 @@ class LongShortTermTransformerBlock(nn.Module):
             lk, lv, l_brows = short_mem
         cat = ws.get('lst_cat', (M, 2 * C), dev)
         self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream, t_dev=t_dev[0] if t_dev else None, B=B,
-                                 kv_brows=g_brows)
+                                 kv_brows=g_brows, x6=x6 if id_emb is None else None)
         self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream, B=B, kv_brows=l_brows)
         xb = ws.get('xb', (M, C), dev)
         aot_hip.linear(cat, p['lst_w'], p['lst_b'], xb, res=xa, stream=stream)
@@ -205,7 +206,7 @@ class LongShortTermTransformer(nn.Module):
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
         """Runs the stack for B lanes on the projected encoder feature x0 [N, C] (shared by the lanes).  Returns
         (dec_in, mems): dec_in is the decoder's concatenated input [B*N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0,
         blocks 1.. = the layer outputs after their decoder norm (transformer.py:124-135), written in place so the concat is
@@ -223,7 +224,7 @@ class LongShortTermTransformer(nn.Module):
             x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
                                       short_mems[i] if short_mems is not None else None,
                                       id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
-                                      keep=keep)
+                                      keep=keep, x6=x6[i] if x6 is not None else None)
             mems.append((ck, cv, fv))
             is_last = i == L - 1
             norm = None

@@ -139,6 +139,23 @@ int aot_attn_f32(const float* q, const float* k, const float* v, float* out, flo
 int aot_attn_merge_f32(const float* part, const float* gate, float* out, int Nq, int H, int C, int ldg,
                        int ldo, int nsplit, void* stream);
 
+/* bf16x6 member of the attention family (fp32-equivalent arithmetic on the bf16 matrix cores, like
+ * aot_conv2d_bf16x6_f32: every fp32 operand is exactly the sum of three truncated bf16 numbers, six of the nine partial
+ * products are kept, each exact in its fp32 accumulator).  The memory bank is kept PRE-SPLIT and tile-major:
+ *   kv [B][cap_rows / 32][H][K: 3 planes x 2 sub-steps x 64 lanes x 8 | V: the same] bf16   (12 KB per 32-row tile and head;
+ *   every operand fetch of a wave is one contiguous KB; V transposed, rows in the order the score tile leaves P in)
+ * cap_rows (a multiple of 32) = rows of one lane's bank.  aot_attn_pack_x6_f32 splits rows [b*src_brows, +rows) of k / v
+ * (fp32, C = H*32 columns, row strides ldk / ldv) into lane b's planes at bank rows slot*rows .. (slot_dev: optional device
+ * int overriding slot, so that a replayed graph can append); the planes must start zeroed (rows past the bank length are
+ * multiplied by weights that are exactly 0).  aot_attn_x6_f32 is aot_attn_f32 on such a bank: same grid, key split,
+ * `part` format and merge (aot_attn_merge_f32 must follow when nsplit > 1).
+ * Replaces MultiheadAttention.forward's core, networks/layers/attention.py:82-117, and the bank append of
+ * networks/engines/aot_engine.py:329-338 for the packed copy. */
+int aot_attn_pack_x6_f32(const float* k, const float* v, void* kv, int B, long rows, int C, long src_brows, int ldk, int ldv,
+                         long cap_rows, const int* slot_dev, int slot, void* stream);
+int aot_attn_x6_f32(const float* q, const void* kv, float* out, float* part, int B, long cap_rows, int Nq, int T,
+                    const int* T_dev, int H, int d, int ldq, int ldo, float scale_div, int nsplit, void* stream);
+
 /* Top-k sparse form of aot_attn_f32 (MultiheadAttention with top_k > 0, networks/layers/attention.py:102-105, a
  * default-off long-video knob): per query row and head only the top_k largest scores enter the softmax and the
  * value sum.  `scores` is caller-owned scratch of H*Nq*((T+3)&~3) floats (the materialised score matrix).

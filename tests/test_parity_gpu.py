@@ -470,6 +470,133 @@ def test_attention_peaky_rescale_branch(hip):
     _close(out, _mha_ref(q, k, v, 8, 32 ** 0.5), 2e-5, 'peaky')
 
 
+def _x6_bank_of(hip, k, v, T, rows_per_slot=None, lanes=1, cap=None):
+    """Packed bank holding rows [0, T) of k / v ([lanes*rows, C] with `cap` rows between lanes), appended slot by slot."""
+    C = k.shape[1]
+    cap = cap or T
+    bank = hip.x6_bank(lanes, cap, C, 'cuda')
+    step = rows_per_slot or T
+    assert T % step == 0
+    for slot in range(T // step):
+        src_k = torch.cat([k[b * cap + slot * step:b * cap + (slot + 1) * step] for b in range(lanes)])
+        src_v = torch.cat([v[b * cap + slot * step:b * cap + (slot + 1) * step] for b in range(lanes)])
+        hip.attention_pack_x6(_dev(src_k), _dev(src_v), bank, step, B=lanes, src_brows=step, slot=slot)
+    return bank
+
+
+@pytest.mark.parametrize('Nq,T,nsplit', [(1674, 1674, 1), (1674, 1674, 5), (289, 289, 1), (100, 77, 1),
+                                         (1674, 3 * 1674 + 13, 3), (33, 2000, 16), (64, 31, 1), (40, 31, 4)])
+def test_attention_x6_vs_fp64(hip, Nq, T, nsplit):
+    """aot_attn_x6_f32 on a bank packed by aot_attn_pack_x6_f32 (the bf16x6 member of the attention family) against the
+    fp64 softmax(QK^T)V -- the SAME cases and the SAME 2e-5 bar as the fp32 kernel (test_attention_vs_fp64), and within 4x
+    the fp32 kernel's own error."""
+    g = torch.Generator().manual_seed(Nq + T)
+    H, C = 8, 256
+    q = torch.randn(Nq, C, generator=g) * 2
+    k = torch.randn(T, C, generator=g) * 2
+    v = torch.randn(T, C, generator=g)
+    bank = _x6_bank_of(hip, k, v, T, cap=T + 40)           # (rows past T stay zero: masked by the kernel, never NaN)
+    out = torch.full((Nq, C), float('nan'), device='cuda')
+    out32 = torch.empty(Nq, C, device='cuda')
+    part = torch.empty(nsplit * Nq * (C + 2 * H), device='cuda') if nsplit > 1 else None
+    hip.attention_x6(_dev(q), bank, out, T, H, 32 ** 0.5, part=part, nsplit=nsplit)
+    hip.attention(_dev(q), _dev(k), _dev(v), out32, T, H, 32 ** 0.5, part=part, nsplit=nsplit)
+    ref = _mha_ref(q, k, v, H, 32 ** 0.5)
+    _close(out, ref, 2e-5, 'attention x6')
+    e6, e32 = float((out.cpu() - ref).abs().max()), float((out32.cpu() - ref).abs().max())
+    assert e6 <= 4 * e32 + 1e-7, 'x6 error %g against the fp32 kernel\'s %g' % (e6, e32)
+    rerun = out.clone()
+    hip.attention_x6(_dev(q), bank, out, T, H, 32 ** 0.5, part=part, nsplit=nsplit)
+    assert torch.equal(rerun, out), 'not reproducible run to run'
+
+
+def test_attention_x6_bank_append_lanes_and_device_ints(hip):
+    """The packed bank as the engine uses it: two lanes, frames appended slot by slot with the slot in a device int (graph
+    replay), the bank length in a device int, a bank with more capacity than content; exactness of the three planes (their sum
+    IS the fp32 number) read back through the documented layout."""
+    g = torch.Generator().manual_seed(41)
+    H, C, N, slots, cap = 8, 256, 130, 3, 5 * 130
+    k = torch.randn(2 * cap, C, generator=g)
+    v = torch.randn(2 * cap, C, generator=g)
+    bank = hip.x6_bank(2, cap, C, 'cuda')
+    slot_dev = torch.zeros(1, dtype=torch.int32, device='cuda')
+    kd, vd = _dev(k), _dev(v)
+    for slot in range(slots):
+        slot_dev.fill_(slot)
+        src_k = torch.cat([kd[b * cap + slot * N:b * cap + (slot + 1) * N] for b in range(2)])
+        src_v = torch.cat([vd[b * cap + slot * N:b * cap + (slot + 1) * N] for b in range(2)])
+        hip.attention_pack_x6(src_k, src_v, bank, N, B=2, src_brows=N, slot=7, slot_dev=slot_dev)     # (the device int wins)
+    T = slots * N - 11
+    q = torch.randn(2 * 97, C, generator=g)
+    out = torch.empty(2 * 97, C, device='cuda')
+    tdev = torch.tensor([T], dtype=torch.int32, device='cuda')
+    hip.attention_x6(_dev(q), bank, out, slots * N, H, 32 ** 0.5, T_dev=tdev, B=2)
+    for b in range(2):
+        _close(out[b * 97:(b + 1) * 97], _mha_ref(q[b * 97:(b + 1) * 97], k[b * cap:b * cap + T], v[b * cap:b * cap + T], H, 32 ** 0.5),
+               2e-5, 'x6 lane %d' % b)
+    # the planes: kv [lane][row / 32][head][K: (plane, sub-step) x 64 lanes x 8 | V: the same]
+    planes, cap_rows = bank
+    pl = planes.view(2, cap_rows // 32, H, 2, 3, 2, 64, 8).cpu().to(torch.int32)
+    as_f32 = lambda t: ((t & 0xffff) << 16).to(torch.int32).view(torch.float32)
+    row, head = 45, 3                                       # bank row 45 of lane 1, head 3
+    kt = as_f32(pl[1, row // 32, head, 0])                  # [plane, c, lane, 8]
+    w = row % 32
+    got_k = torch.stack([torch.cat([kt[p, c, hi * 32 + w] for c in range(2) for hi in range(2)]) for p in range(3)]).sum(0)
+    assert torch.equal(got_k, k[cap + row, head * 32:(head + 1) * 32]), 'K planes do not sum to the fp32 row'
+    vt = as_f32(pl[1, row // 32, head, 1])
+    c, hi, i = w >> 4, (w >> 2) & 1, ((w >> 3) & 1) * 4 + (w & 3)
+    got_v = torch.stack([vt[p, c, hi * 32:(hi + 1) * 32, i] for p in range(3)]).sum(0)
+    assert torch.equal(got_v, v[cap + row, head * 32:(head + 1) * 32]), 'V planes do not sum to the fp32 row'
+
+
+def test_attention_x6_peaky_rescale(hip):
+    """the online-softmax rescale of the x6 kernel: one key per query dominates by > 50 logits and sits in a LATE tile."""
+    g = torch.Generator().manual_seed(29)
+    Nq, T = 64, 640
+    q, k, v = torch.randn(Nq, 256, generator=g), torch.randn(T, 256, generator=g) * 0.1, torch.randn(T, 256, generator=g)
+    for i in range(Nq):
+        k[600 - i, :] = q[i] * 3.0
+    out = torch.empty(Nq, 256, device='cuda')
+    hip.attention_x6(_dev(q), _x6_bank_of(hip, k, v, T), out, T, 8, 32 ** 0.5)
+    _close(out, _mha_ref(q, k, v, 8, 32 ** 0.5), 2e-5, 'x6 peaky')
+
+
+def test_attention_kernels_reproducible_under_load(hip):
+    """Every flash-attention kernel (fp32 d = 32, its bf16x6 twin, the gated form) run eight times on a full-size launch (grids of
+    several dispatch rounds, every SIMD shared by several waves): bit-identical results.  (Guards the hazard class found while
+    building the x6 kernel: inline asm touching MFMA accumulators gave run-to-run differences in sporadic workgroups.)"""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    N, C, H, M = 1674, 256, 8, 6
+    T = M * N - 13
+    q = torch.randn(N, C, device='cuda', generator=g) * 2
+    k = torch.randn(M * N, C, device='cuda', generator=g)
+    v = torch.randn(M * N, C, device='cuda', generator=g)
+    bank = hip.x6_bank(1, M * N, C, 'cuda')
+    hip.attention_pack_x6(k, v, bank, M * N, slot=0)
+    qg = torch.randn(N, 128, device='cuda', generator=g)
+    kg = torch.randn(M * N, 128, device='cuda', generator=g)
+    vg = torch.randn(M * N, 1024, device='cuda', generator=g)
+    gate = torch.randn(N, 1024, device='cuda', generator=g)
+    for ns in (1, 3, 5):
+        part = torch.empty(ns * N * (C + 2 * H), device='cuda')
+        partg = torch.empty(ns * N * (1024 + 2 * 4), device='cuda')
+        runs = {'fp32': lambda o: hip.attention(q, k, v, o, T, H, 32 ** 0.5, part=part, nsplit=ns),
+                'bf16x6': lambda o: hip.attention_x6(q, bank, o, T, H, 32 ** 0.5, part=part, nsplit=ns)}
+        for name, run in runs.items():
+            first = torch.empty(N, C, device='cuda')
+            run(first)
+            for _ in range(7):
+                again = torch.empty(N, C, device='cuda')
+                run(again)
+                assert torch.equal(first, again), '%s attention, nsplit %d: results differ from run to run' % (name, ns)
+        first = torch.empty(N, 1024, device='cuda')
+        hip.gated_attention(qg, kg, vg, gate, first, T, 128 ** 0.5, part=partg, nsplit=ns)
+        for _ in range(7):
+            again = torch.empty(N, 1024, device='cuda')
+            hip.gated_attention(qg, kg, vg, gate, again, T, 128 ** 0.5, part=partg, nsplit=ns)
+            assert torch.equal(first, again), 'gated attention, nsplit %d: results differ from run to run' % ns
+
+
 def test_attention_properties_full_bank(hip):
     """BASELINE size (N=1674 queries, bank of 14 frames): rows of softmax sum to one, V-linearity, key order and
     split-count invariance."""
