@@ -35,6 +35,8 @@ _SIGS = {
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
     'aot_attn_pack_x6_f32': [_P] * 3 + [_I, _L, _I, _L, _I, _I, _L, _P, _I, _P],
     'aot_attn_x6_f32': [_P] * 4 + [_I, _L, _I, _I, _P] + [_I] * 4 + [_F, _I, _P],
+    'aot_attn_pack_x6_part_f32': [_P, _P, _I, _L, _I, _L, _I, _L, _P, _I, _I, _P],
+    'aot_gated_attn_x6_f32': [_P] * 6 + [_I, _L, _I, _I, _P] + [_I] * 5 + [_F, _I, _P],
     'aot_preprocess_f32': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     'aot_fuse_probs_f32': [_P] * 5 + [_I] * 5 + [_P],
     'aot_label_resize_f32': [_P, _P] + [_I] * 5 + [_P],
@@ -389,6 +391,41 @@ def attention_x6(q, bank, out, T, H, scale_div, part=None, nsplit=1, T_dev=None,
     if nsplit > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), None, _dev(out), q.shape[0], H, H * 32, 0, out.stride(0), nsplit, s),
              'aot_attn_merge_f32')
+    return out
+
+
+def x6_gated_bank(B, rows, dqk, dv, device):
+    """Packed bank of the gated (DeAOT) bf16x6 attention kernel: (K planes, V planes, cap_rows), zero-filled."""
+    cap = (rows + 31) // 32 * 32
+    return (torch.zeros(B * cap * dqk * 3, dtype=torch.int16, device=device),
+            torch.zeros(B * cap * dv * 3, dtype=torch.int16, device=device), cap)
+
+
+def gated_pack_x6(k, v, bank, rows, B=1, src_brows=None, slot=0, slot_dev=None, stream=None):
+    """Rows [b*src_brows, + rows) of k [., 128] / v [., 1024] (either may be None) into lane b's packed gated bank at rows
+    slot*rows .. (aot_attn_pack_x6_part_f32, K-style / V-style)."""
+    kp, vp, cap = bank
+    s = stream if stream is not None else stream_ptr()
+    for x, planes, tr in ((k, kp, 0), (v, vp, 1)):
+        if x is not None:
+            _chk(load().aot_attn_pack_x6_part_f32(_dev(x), _dev(planes), B, rows, x.shape[1], rows if src_brows is None else src_brows,
+                                                  x.stride(0), cap, _opt(slot_dev), slot, tr, s), 'aot_attn_pack_x6_part_f32')
+    return bank
+
+
+def gated_attention_x6(q, bank, gate, out, T, scale_div, part=None, nsplit=1, T_dev=None, B=1, stream=None):
+    """aot_hip.gated_attention on a packed bank: the bf16x6 member (dqk = 128, dv = 1024)."""
+    kp, vp, cap = bank
+    s = stream if stream is not None else stream_ptr()
+    lib = load()
+    dv = out.shape[1]
+    nq = q.shape[0] // B
+    _chk(lib.aot_gated_attn_x6_f32(_dev(q), _dev(kp), _dev(vp), _opt(gate), _dev(out), _opt(part), B, cap, nq, T, _opt(T_dev),
+                                   q.shape[1], dv, q.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0),
+                                   scale_div, nsplit, s), 'aot_gated_attn_x6_f32')
+    if nsplit > 1:
+        _chk(lib.aot_attn_merge_f32(_dev(part), _opt(gate), _dev(out), q.shape[0], dv // 256, dv,
+                                    gate.stride(0) if gate is not None else 0, out.stride(0), nsplit, s), 'aot_attn_merge_f32')
     return out
 
 

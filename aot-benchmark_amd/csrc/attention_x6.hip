@@ -288,6 +288,234 @@ __global__ void __launch_bounds__(256) attn_pack_x6_kernel(const float* __restri
   }
 }
 
+// ---- one operand of a packed bank: x [B lanes][rows][C] fp32 -> planes[lane][row / 32][C / 32][3 planes x 2 sub-steps x 64 lanes x 8]
+// K-style (transpose = 0: lane = row of the tile, eight dims per chunk) or V-style (transpose = 1: lane = channel, eight rows per
+// chunk in the C/D order of the score tile).  The gated (DeAOT) kernel keeps K (128 wide) and V (1024 wide) in two such buffers.
+__global__ void __launch_bounds__(256) attn_pack_x6_part_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, int B,
+                                                                long rows, int C, long src_brows, int ldx, long cap_rows,
+                                                                const int* __restrict__ slot_dev, int slot, int transpose) {
+  const int C4 = C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = rows * C4;
+  if (idx >= per * B) return;
+  const int b = (int)(idx / per);
+  const long rem = idx - (long)b * per;
+  const long r = rem / C4;
+  const int c = (int)(rem - r * C4) * 4;
+  const long t = (long)(slot_dev ? *slot_dev : slot) * rows + r;
+  const int NB = C >> 5, blk_i = c >> 5, d = c & 31, w = (int)(t & 31);
+  const float4 xx = *reinterpret_cast<const float4*>(x + ((long)b * src_brows + r) * ldx + c);
+  float xr[4] = {xx.x, xx.y, xx.z, xx.w};
+  unsigned short* blk = planes + (((long)b * (cap_rows >> 5) + (t >> 5)) * NB + blk_i) * 3072;
+  if (!transpose) {
+    unsigned short* dst = blk + ((d >> 4) * 64 + ((d >> 3) & 1) * 32 + w) * 8 + (d & 7);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      unsigned short hb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned u = __float_as_uint(xr[e]) & 0xffff0000u;
+        hb[e] = (unsigned short)(u >> 16);
+        xr[e] -= __uint_as_float(u);
+      }
+      *reinterpret_cast<uint2*>(dst + pl * 1024) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+    }
+  } else {
+    unsigned short* dst = blk + ((w >> 4) * 64 + ((w >> 2) & 1) * 32 + d) * 8 + ((w >> 3) & 1) * 4 + (w & 3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned u = __float_as_uint(xr[e]) & 0xffff0000u;
+        dst[pl * 1024 + e * 8] = (unsigned short)(u >> 16);
+        xr[e] -= __uint_as_float(u);
+      }
+  }
+}
+
+// ---- gated-propagation form (DeAOT, attention.py:672-707) in the bf16x6 family: the twin of attn_fwd_wide_coop_kernel<8> ----------
+// One 4-wave workgroup owns 32 queries; wave w contracts channels [32 w, 32 w + 32) of q . k (12 MFMAs, partial score tiles meet in
+// LDS in wave order) and owns value chunk w = eight 32-channel blocks of the 1024-wide [V | ID_V] (96 MFMAs per key tile against
+// 128 fp32 MFMAs of twice the length).  K planes [lane][tile][4 blocks][3072], V planes [lane][tile][32 blocks][3072].
+#ifndef AOT_GX6_NVB
+#define AOT_GX6_NVB 5
+#endif
+struct GatedX6Params {
+  const float* q;
+  const unsigned short* kp;
+  const unsigned short* vp;
+  const float* gate;
+  float* out;
+  float* part;
+  const int* T_dev;
+  int Nq, T, ldq, ldg, ldo, nsplit, B;
+  long cap_rows;
+  float scale_div;
+};
+
+__global__ void __launch_bounds__(256, 1) attn_x6_wide_coop_kernel(const GatedX6Params p) {
+  constexpr int NDV = 8;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int split = blockIdx.x, bz = blockIdx.y;
+  const int b = bz / ntq, qt = bz - b * ntq;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int t0 = min(T, split * tps * 32);
+  const int t1 = min(T, t0 + tps * 32);
+  const int qrow = min(qt * 32 + j, p.Nq - 1);
+  const long qrow0 = (long)b * p.Nq;
+  const long cap_tiles = p.cap_rows >> 5;
+  __shared__ float part[2][4][16][64];     // [buffer][wave][score register][lane]
+
+  bf16x8 qp[2][3];
+  {
+    const float* src = p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
+                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
+      split3(x, qp[c]);
+    }
+  }
+  const unsigned short* kbase = p.kp + ((long)b * cap_tiles * 4 + wave) * 3072 + lane * 8;
+  const unsigned short* vbase = p.vp + ((long)b * cap_tiles * 32 + wave * NDV) * 3072 + lane * 8;
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[NDV];
+#pragma unroll
+  for (int d = 0; d < NDV; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
+    const unsigned short* src = kbase + min((long)(kt >> 5), cap_tiles - 1) * (4 * 3072);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto load_v = [&](bf16x8 (&vf)[2][3], int kt, int d) {
+    const unsigned short* src = vbase + min((long)(kt >> 5), cap_tiles - 1) * (32 * 3072) + d * 3072;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto qk_part = [&](const bf16x8 (&kf)[2][3], int buf) {
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    mfma6(kf[0], qp[0], sc);
+    mfma6(kf[1], qp[1], sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[buf][wave][r][lane] = sc[r];
+  };
+
+  constexpr int NVB = AOT_GX6_NVB;      // rotating V register sets: a block's fetch is issued NVB - 1 blocks ahead of its MFMAs
+  bf16x8 ka[2][3], vb[NVB][2][3];
+  if (t0 < t1) {
+    load_k(ka, t0);
+    qk_part(ka, 0);
+    load_k(ka, t0 + 32);
+  }
+  __syncthreads();
+  int it = 0;
+  auto step = [&](int kt, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
+    const int buf = it & 1;
+#pragma unroll
+    for (int d = 0; d < NVB - 1; ++d) load_v(vb[d], kt, d);
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)      // fixed wave order: every wave of the workgroup gets the same bits
+      sc[r] = ((part[buf][0][r][lane] + part[buf][1][r][lane]) + part[buf][2][r][lane]) + part[buf][3][r][lane];
+    qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of the softmax below
+    if (TAIL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    const float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                          max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    const bool moved = mnew > m;
+    m = mnew;
+    l *= alpha;
+    float pf[16], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -m));
+      ps += pf[r];
+    }
+    l += ps;
+    load_k(ka, kt + 64);
+    if (__any(moved)) {              // (rare after the first tiles of a range)
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    bf16x8 pp[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float x8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+      split3(x8, pp[c]);
+    }
+#pragma unroll
+    for (int d = 0; d < NDV; ++d) {
+      if (d + NVB - 1 < NDV) load_v(vb[(d + NVB - 1) % NVB], kt, d + NVB - 1);
+      mfma6(vb[d % NVB][0], pp[0], o[d]);
+      mfma6(vb[d % NVB][1], pp[1], o[d]);
+    }
+    ++it;
+    __syncthreads();
+  };
+  int kt = t0;
+  for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
+  if (kt < t1) step(kt, std::true_type{});
+
+  l += __shfl_xor(l, 32);
+  if (qt * 32 + j >= p.Nq) return;
+  const long qi = qrow0 + qt * 32 + j;
+  const long prow = (long)p.B * p.Nq;
+  const int cbase = wave * 32 * NDV + 4 * hi;
+  constexpr int CV = 32 * NDV * 4;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        const int c = cbase + d * 32 + 8 * g;
+        if (p.gate) {
+          const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
+          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
+        }
+        *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = t;
+      }
+  } else {
+    float* dst = p.part + ((long)split * prow + qi) * CV;
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
+            make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
+    if (hi == 0) {
+      float* ml = p.part + (long)p.nsplit * prow * CV + (((long)split * prow + qi) * 4 + wave) * 2;
+      ml[0] = m;
+      ml[1] = l;
+    }
+  }
+}
+
 }  // namespace
 
 // ===== C ABI ==============================================================================================================
@@ -316,5 +544,35 @@ extern "C" int aot_attn_x6_f32(const float* q, const void* kv, float* out, float
   p.Nq = Nq; p.T = T; p.H = H; p.ldq = ldq; p.ldo = ldo; p.nsplit = nsplit; p.B = B; p.cap_rows = cap_rows;
   p.scale_div = scale_div;
   hipLaunchKernelGGL(attn_x6_d32_kernel, dim3(H, B * cdiv(Nq, 32), nsplit), dim3(256), 0, (hipStream_t)stream, p);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_attn_pack_x6_part_f32(const float* x, void* planes, int B, long rows, int C, long src_brows, int ldx, long cap_rows,
+                                         const int* slot_dev, int slot, int transpose, void* stream) {
+  if (!x || !planes || B <= 0 || rows <= 0 || C <= 0 || (C & 31) || (ldx & 3) || cap_rows <= 0 || (cap_rows & 31) || slot < 0 ||
+      src_brows < 0 || ((uintptr_t)x & 15) || ((uintptr_t)planes & 15))
+    return AOT_ERR_BADARG;
+  if (!slot_dev && ((long)slot + 1) * rows > cap_rows) return AOT_ERR_BADARG;
+  const long n = (long)B * rows * (C / 4);
+  hipLaunchKernelGGL(attn_pack_x6_part_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, B,
+                     rows, C, src_brows, ldx, cap_rows, slot_dev, slot, transpose);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_gated_attn_x6_f32(const float* q, const void* kp, const void* vp, const float* gate, float* out, float* part, int B,
+                                     long cap_rows, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldg, int ldo,
+                                     float scale_div, int nsplit, void* stream) {
+  if (dqk != 128 || dv != 1024) return AOT_ERR_UNSUPPORTED;
+  if (!q || !kp || !vp || !out || Nq <= 0 || T <= 0 || B <= 0 || cap_rows < T || (cap_rows & 31)) return AOT_ERR_BADARG;
+  if ((long)B * cdiv(Nq, 32) > 65535) return AOT_ERR_UNSUPPORTED;
+  if ((ldq & 3) || (ldo & 3) || (gate && (ldg & 3)) || ((uintptr_t)q & 15) || ((uintptr_t)out & 15) || ((uintptr_t)kp & 15) ||
+      ((uintptr_t)vp & 15))
+    return AOT_ERR_BADARG;
+  if (nsplit < 1 || (nsplit > 1 && !part)) return AOT_ERR_BADARG;
+  GatedX6Params p;
+  p.q = q; p.kp = (const unsigned short*)kp; p.vp = (const unsigned short*)vp; p.out = out; p.part = part; p.T_dev = T_dev;
+  p.gate = (nsplit == 1) ? gate : nullptr;     // with splits the gate is applied by aot_attn_merge_f32
+  p.Nq = Nq; p.T = T; p.ldq = ldq; p.ldg = ldg; p.ldo = ldo; p.nsplit = nsplit; p.B = B; p.cap_rows = cap_rows; p.scale_div = scale_div;
+  hipLaunchKernelGGL(attn_x6_wide_coop_kernel, dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

@@ -108,8 +108,13 @@ class AOTEngine(nn.Module):
         # mfma = 'bf16x6', AOT's 32-wide heads: the bank also exists pre-split into bf16 planes (aot_attn_pack_x6_f32), which is
         # what the long-term attention of that kernel family reads (aot_attn_x6_f32); per layer (planes, rows per lane)
         self._bank_x6 = None
-        self._x6_attn = (mfma == 'bf16x6' and type(aot_model.LSTT).__name__ != 'DualBranchGPM'
-                         and all(l.long_term_attn.hidden_dim == 32 and l.long_term_attn.top_k <= 0 for l in aot_model.LSTT.layers))
+        self._x6_gated = mfma == 'bf16x6' and type(aot_model.LSTT).__name__ == 'DualBranchGPM'
+        if not self._x6_gated:
+            self._x6_attn = (mfma == 'bf16x6' and all(l.long_term_attn.hidden_dim == 32 and l.long_term_attn.top_k <= 0
+                                                      for l in aot_model.LSTT.layers))
+        else:           # DeAOT: one 128-wide head, value [V | ID_V] 1024 wide (aot_gated_attn_x6_f32)
+            self._x6_attn = all(l.long_term_attn.num_head == 1 and l.d_att == 128 and 2 * l.expand_d_model == 1024
+                                and l.long_term_attn.top_k <= 0 for l in aot_model.LSTT.layers)
         self._ring = None            # rotating scratch sets for frames whose K/V do not live in a bank slot; survives too
         self.losses = None           # built by the first forward() (training only)
         self.restart_engine()
@@ -352,7 +357,7 @@ class AOTEngine(nn.Module):
             self._bank = [(torch.empty(B, cap * N, ck, dtype=torch.float32, device=dev),
                            torch.empty(B, cap * N, cv, dtype=torch.float32, device=dev)) for ck, cv in widths]
             self._bank_geom = geom
-            self._bank_x6 = [aot_hip.x6_bank(B, cap * N, ck, dev) for ck, _ in widths] if self._x6_attn else None
+            self._bank_x6 = [self._new_x6(B, cap * N, ck, cv, dev) for ck, cv in widths] if self._x6_attn else None
         cap = self._bank[0][0].shape[1] // N
         if frames_needed > cap:
             new_cap = max(4 * cap, frames_needed)
@@ -366,11 +371,11 @@ class AOTEngine(nn.Module):
                 grown.append((k2, v2))
             self._bank = grown
             if self._x6_attn:            # the packed copy: re-split what the bank holds
-                self._bank_x6 = [aot_hip.x6_bank(B, new_cap * N, k.shape[2], dev) for k, _ in grown]
+                self._bank_x6 = [self._new_x6(B, new_cap * N, k.shape[2], v.shape[2], dev) for k, v in grown]
                 if used:
+                    pack = aot_hip.gated_pack_x6 if self._x6_gated else aot_hip.attention_pack_x6
                     for (k, v), xb in zip(grown, self._bank_x6):
-                        aot_hip.attention_pack_x6(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), xb, used, B=B,
-                                                  src_brows=k.shape[1])
+                        pack(k.view(-1, k.shape[2]), v.view(-1, v.shape[2]), xb, used, B=B, src_brows=k.shape[1])
 
     def _next_slot(self):
         """Bank slot the next memorised frame goes to (append; a bounded bank overwrites its oldest non-first frame)."""
@@ -424,9 +429,12 @@ class AOTEngine(nn.Module):
         if not self._x6_attn:
             return
         stream = aot_hip.stream_ptr()
+        pack = aot_hip.gated_pack_x6 if self._x6_gated else aot_hip.attention_pack_x6
         for xb, (k, v) in zip(self._bank_x6, kv):
-            aot_hip.attention_pack_x6(k, v, xb, self.enc_hw, B=self.lanes, src_brows=src_brows, slot=slot, slot_dev=slot_dev,
-                                      stream=stream)
+            pack(k, v, xb, self.enc_hw, B=self.lanes, src_brows=src_brows, slot=slot, slot_dev=slot_dev, stream=stream)
+
+    def _new_x6(self, B, rows, ck, cv, dev):
+        return aot_hip.x6_gated_bank(B, rows, ck, cv, dev) if self._x6_gated else aot_hip.x6_bank(B, rows, ck, dev)
 
     def _dev_int(self, i, value):
         """Device int i (0: bank length in tokens, 1: bank slot of the frame being memorised) set to `value` on the current

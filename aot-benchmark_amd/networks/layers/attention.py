@@ -42,15 +42,16 @@ def attn_splits(nq, units, t, occ=4, c0=3.0, wg_waves=1):
     return best
 
 
-def gated_splits(nq, t):
+def gated_splits(nq, t, slots=512):
     """Grid-level key split of the gated (DeAOT) attention kernel: one 4-wave workgroup per (32 queries, key range), two
     resident per CU (two waves per SIMD) = 512 slots.  Measured on MI355X (tools/dev/mb_gated.py, profiles/r03g_mb_gated.txt,
     N = 1674, bank of 1..14 frames): the fastest split at EVERY bank size is the largest one whose grid still fits one
     dispatch round (9 x 53 = 477 workgroups: 909 us = 99 TF at M = 14 against 1131 us for 14 splits) -- a second round
-    costs more than longer key ranges.  At least four key tiles per range, at most 16 ranges (the partial-slab scratch)."""
+    costs more than longer key ranges.  At least four key tiles per range, at most 16 ranges (the partial-slab scratch).
+    slots = 256 for the bf16x6 twin (one workgroup per CU; the same rule holds there: profiles/r03r_gated_x6_nvb.txt)."""
     qt = (nq + 31) // 32
     tiles = (t + 31) // 32
-    return max(1, min(512 // max(qt, 1), tiles // 4, 16))
+    return max(1, min(slots // max(qt, 1), tiles // 4, 16))
 
 
 def _planned_len(t, nq, kv_brows):
@@ -208,9 +209,10 @@ class GatedPropagation(nn.Module):
             self._p = p
         return self._p
 
-    def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None, B=1, kv_brows=0):
+    def core(self, q, k, v, gate, out, t, ws, stream, t_dev=None, B=1, kv_brows=0, x6=None):
         """(softmax((q/T) k^T) v) * gate : q [B*Nq,128], k [.,128], v [.,E], gate/out [B*Nq,E]; lane b reads rows
-        b*kv_brows .. + t of k/v."""
+        b*kv_brows .. + t of k/v.  x6 = (K planes, V planes, rows per lane): the same bank pre-split for the bf16x6 kernel
+        (aot_gated_attn_x6_f32), used instead of k / v."""
         nq = q.shape[0] // B
         scale_div = self.T
         if self.max_mem_len_ratio > 0:       # Q *= log(ratio)/log(max ratio), folded into the divisor (attention.py:674-679)
@@ -220,10 +222,18 @@ class GatedPropagation(nn.Module):
         if 0 < self.top_k < t:
             return self._core_topk(q, k, v, gate, out, t, scale_div, ws, stream, B, kv_brows)
         t_plan = _planned_len(t, nq, kv_brows)
-        ns = gated_splits(nq * B, t_plan) if out.shape[1] == 1024 else attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
+        use_x6 = x6 is not None and out.shape[1] == 1024 and q.shape[1] == 128
+        if use_x6:
+            ns = gated_splits(nq * B, t_plan, slots=256)
+        else:
+            ns = gated_splits(nq * B, t_plan) if out.shape[1] == 1024 else attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
         part = None
         if ns > 1:
             part = ws.get('gattn_part', (16 * B * nq * (out.shape[1] + 2 * (out.shape[1] // 256)),), q.device)
+        if use_x6:
+            aot_hip.gated_attention_x6(q, x6, gate, out, t if t_dev is None else t_plan, scale_div, part=part, nsplit=ns,
+                                       T_dev=t_dev, B=B, stream=stream)
+            return out
         aot_hip.gated_attention(q, k, v, gate, out, t if t_dev is None else t_plan, scale_div, part=part, nsplit=ns,
                                 T_dev=t_dev, B=B, kv_brows=kv_brows, stream=stream)
         return out

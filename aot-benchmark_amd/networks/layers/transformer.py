@@ -319,7 +319,7 @@ class GatedPropagationModule(nn.Module):
             aot_hip.linear(id_emb, p['idv_w_id'], None, dst, res=tmp, act=aot_hip.ACT_SILU, stream=stream)
         return vcat
 
-    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
+    def run(self, X, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
         """X [B*N, 2D] = [tgt | tgt_id] (tgt_id = 0 into layer 0), B lanes.  long_mem = (K, Vcat, T, kv_brows), short_mem =
         (K, Vcat, kv_brows); dst = (k_out [B*N, d_att], vcat_out [B*N, 2E]) for this frame's K and [V | ID_V].
         Returns (X_out, curr_K, curr_Vcat, curr_ID_V_input)."""
@@ -361,7 +361,7 @@ class GatedPropagationModule(nn.Module):
             lk, lv, l_brows = short_mem
         raw = ws.get('gpm_raw', (M, 2 * E), dev)
         self.long_term_attn.core(qc, gk, gv, U, raw, t, ws, stream, t_dev=t_dev[0] if t_dev else None, B=B,
-                                 kv_brows=g_brows)
+                                 kv_brows=g_brows, x6=x6 if id_emb is None else None)
         Xm = ws.get('gpm_Xm', (M, 2 * D), dev)
         self.long_term_attn.tail(raw, Xm, size_2d, ws, stream, res=X, B=B)      # X + lt
         self.short_term_attn.core(qc, lk, lv, U, raw, size_2d, ws, stream, B=B, kv_brows=l_brows)
@@ -417,7 +417,7 @@ class DualBranchGPM(nn.Module):
         if intermediate_norm:
             raise NotImplementedError('DeAOT decodes the last GPM output only (default_deaot.py:12)')
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None):
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
         """B lanes on the shared feature x0 [N, D].  Returns (dec_in [B*N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last
         layer, mems): mems[i] = (curr_K, curr_Vcat, curr_ID_V_input) of layer i."""
         N, D = x0.shape
@@ -430,7 +430,7 @@ class DualBranchGPM(nn.Module):
             X, ck, cv, xi = layer.run(X, long_mems[i] if long_mems is not None else None,
                                       short_mems[i] if short_mems is not None else None,
                                       id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
-                                      keep=keep)
+                                      keep=keep, x6=x6[i] if x6 is not None else None)
             mems.append((ck, cv, xi))
         if keep is not None:
             out = keep.get('gpm_dec_in', (B * N, 2 * D), dev)

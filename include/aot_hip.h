@@ -156,6 +156,18 @@ int aot_attn_pack_x6_f32(const float* k, const float* v, void* kv, int B, long r
 int aot_attn_x6_f32(const float* q, const void* kv, float* out, float* part, int B, long cap_rows, int Nq, int T,
                     const int* T_dev, int H, int d, int ldq, int ldo, float scale_div, int nsplit, void* stream);
 
+/* The gated-propagation form in the bf16x6 family (twin of aot_gated_attn_f32; dqk = 128, dv = 1024): K and V are kept in two
+ * packed buffers of the layout above -- planes [B][cap_rows / 32][C / 32][3 planes x 2 sub-steps x 64 lanes x 8] bf16 -- filled
+ * by aot_attn_pack_x6_part_f32 (transpose = 0: K-style, lane = row of the tile; transpose = 1: V-style, lane = channel, rows in
+ * the score tile's C/D order).  Same split / merge protocol as aot_gated_attn_f32 (H := 4 groups; with nsplit > 1 pass the gate
+ * to aot_attn_merge_f32).  Replaces GatedPropagation.forward's core, networks/layers/attention.py:672-707, and the packed
+ * copy of the bank append of networks/engines/deaot_engine.py:20-56. */
+int aot_attn_pack_x6_part_f32(const float* x, void* planes, int B, long rows, int C, long src_brows, int ldx, long cap_rows,
+                              const int* slot_dev, int slot, int transpose, void* stream);
+int aot_gated_attn_x6_f32(const float* q, const void* kp, const void* vp, const float* gate, float* out, float* part, int B,
+                          long cap_rows, int Nq, int T, const int* T_dev, int dqk, int dv, int ldq, int ldg, int ldo,
+                          float scale_div, int nsplit, void* stream);
+
 /* Top-k sparse form of aot_attn_f32 (MultiheadAttention with top_k > 0, networks/layers/attention.py:102-105, a
  * default-off long-video knob): per query row and head only the top_k largest scores enter the softmax and the
  * value sum.  `scores` is caller-owned scratch of H*Nq*((T+3)&~3) floats (the materialised score matrix).

@@ -562,7 +562,7 @@ def test_attention_x6_peaky_rescale(hip):
 
 
 def test_attention_kernels_reproducible_under_load(hip):
-    """Every flash-attention kernel (fp32 d = 32, its bf16x6 twin, the gated form) run eight times on a full-size launch (grids of
+    """Every flash-attention kernel (fp32 d = 32, the gated form, and their bf16x6 twins) run eight times on a full-size launch (grids of
     several dispatch rounds, every SIMD shared by several waves): bit-identical results.  (Guards the hazard class found while
     building the x6 kernel: inline asm touching MFMA accumulators gave run-to-run differences in sporadic workgroups.)"""
     g = torch.Generator(device='cuda').manual_seed(3)
@@ -577,6 +577,8 @@ def test_attention_kernels_reproducible_under_load(hip):
     kg = torch.randn(M * N, 128, device='cuda', generator=g)
     vg = torch.randn(M * N, 1024, device='cuda', generator=g)
     gate = torch.randn(N, 1024, device='cuda', generator=g)
+    gbank = hip.x6_gated_bank(1, M * N, 128, 1024, 'cuda')
+    hip.gated_pack_x6(kg, vg, gbank, M * N)
     for ns in (1, 3, 5):
         part = torch.empty(ns * N * (C + 2 * H), device='cuda')
         partg = torch.empty(ns * N * (1024 + 2 * 4), device='cuda')
@@ -589,12 +591,15 @@ def test_attention_kernels_reproducible_under_load(hip):
                 again = torch.empty(N, C, device='cuda')
                 run(again)
                 assert torch.equal(first, again), '%s attention, nsplit %d: results differ from run to run' % (name, ns)
-        first = torch.empty(N, 1024, device='cuda')
-        hip.gated_attention(qg, kg, vg, gate, first, T, 128 ** 0.5, part=partg, nsplit=ns)
-        for _ in range(7):
-            again = torch.empty(N, 1024, device='cuda')
-            hip.gated_attention(qg, kg, vg, gate, again, T, 128 ** 0.5, part=partg, nsplit=ns)
-            assert torch.equal(first, again), 'gated attention, nsplit %d: results differ from run to run' % ns
+        gruns = {'fp32': lambda o: hip.gated_attention(qg, kg, vg, gate, o, T, 128 ** 0.5, part=partg, nsplit=ns),
+                 'bf16x6': lambda o: hip.gated_attention_x6(qg, gbank, gate, o, T, 128 ** 0.5, part=partg, nsplit=ns)}
+        for name, run in gruns.items():
+            first = torch.empty(N, 1024, device='cuda')
+            run(first)
+            for _ in range(7):
+                again = torch.empty(N, 1024, device='cuda')
+                run(again)
+                assert torch.equal(first, again), '%s gated attention, nsplit %d: results differ from run to run' % (name, ns)
 
 
 def test_attention_properties_full_bank(hip):
@@ -676,6 +681,62 @@ def test_gated_attention_vs_fp64(hip, Nq, T, nsplit):
     part = torch.empty(nsplit * Nq * (1024 + 8), device='cuda') if nsplit > 1 else None
     hip.gated_attention(_dev(q), _dev(k), _dev(v), _dev(u), out, T, 128 ** 0.5, part=part, nsplit=nsplit)
     _close(out, ref, 3e-5, 'gated attention')
+
+
+@pytest.mark.parametrize('Nq,T,nsplit', [(1674, 1674, 1), (1674, 2 * 1674 + 7, 4), (100, 45, 1), (289, 289, 3),
+                                         (1674, 14 * 1674, 4), (1590, 14 * 1590 + 3, 9)])
+def test_gated_attention_x6_vs_fp64(hip, Nq, T, nsplit):
+    """aot_gated_attn_x6_f32 on banks packed by aot_attn_pack_x6_part_f32 (the bf16x6 member of the gated form): the cases and
+    the 3e-5 bar of the fp32 kernel (test_gated_attention_vs_fp64), within 4x its own error, bit-identical when repeated; the
+    bank appended in two pieces through a device-side slot where it divides."""
+    g = torch.Generator().manual_seed(Nq * 7 + T)
+    q, k = torch.randn(Nq, 128, generator=g), torch.randn(T, 128, generator=g)
+    v, u = torch.randn(T, 1024, generator=g), torch.randn(Nq, 1024, generator=g)
+    dev = 'cuda' if T > 8000 else 'cpu'
+    ref = (torch.softmax((q.to(dev).double() / 128 ** 0.5) @ k.to(dev).double().t(), -1) @ v.to(dev).double()
+           * u.to(dev).double()).float()
+    bank = hip.x6_gated_bank(1, T + 50, 128, 1024, 'cuda')
+    kd, vd = _dev(k), _dev(v)
+    if T % 2 == 0:
+        slot_dev = torch.zeros(1, dtype=torch.int32, device='cuda')
+        for slot in range(2):
+            slot_dev.fill_(slot)
+            hip.gated_pack_x6(kd[slot * (T // 2):(slot + 1) * (T // 2)], vd[slot * (T // 2):(slot + 1) * (T // 2)], bank, T // 2,
+                              slot_dev=slot_dev)
+    else:
+        hip.gated_pack_x6(kd, vd, bank, T)
+    out = torch.full((Nq, 1024), float('nan'), device='cuda')
+    out32 = torch.empty(Nq, 1024, device='cuda')
+    part = torch.empty(nsplit * Nq * (1024 + 8), device='cuda') if nsplit > 1 else None
+    hip.gated_attention_x6(_dev(q), bank, _dev(u), out, T, 128 ** 0.5, part=part, nsplit=nsplit)
+    hip.gated_attention(_dev(q), kd, vd, _dev(u), out32, T, 128 ** 0.5, part=part, nsplit=nsplit)
+    _close(out, ref, 3e-5, 'gated attention x6')
+    e6, e32 = float((out.cpu() - ref.cpu()).abs().max()), float((out32.cpu() - ref.cpu()).abs().max())
+    assert e6 <= 4 * e32 + 1e-7, 'x6 error %g against the fp32 kernel\'s %g' % (e6, e32)
+    again = torch.empty_like(out)
+    hip.gated_attention_x6(_dev(q), bank, _dev(u), again, T, 128 ** 0.5, part=part, nsplit=nsplit)
+    assert torch.equal(out, again), 'not reproducible run to run'
+
+
+def test_gated_attention_x6_lanes_and_device_length(hip):
+    """two lanes (object groups), the bank length in a device int, a bank with more capacity than content."""
+    g = torch.Generator().manual_seed(77)
+    N, cap, T = 97, 4 * 130, 3 * 130 - 9
+    k, v = torch.randn(2 * cap, 128, generator=g), torch.randn(2 * cap, 1024, generator=g)
+    q, u = torch.randn(2 * N, 128, generator=g), torch.randn(2 * N, 1024, generator=g)
+    bank = hip.x6_gated_bank(2, cap, 128, 1024, 'cuda')
+    kd, vd = _dev(k), _dev(v)
+    for slot in range(3):
+        src_k = torch.cat([kd[b * cap + slot * 130:b * cap + (slot + 1) * 130] for b in range(2)])
+        src_v = torch.cat([vd[b * cap + slot * 130:b * cap + (slot + 1) * 130] for b in range(2)])
+        hip.gated_pack_x6(src_k, src_v, bank, 130, B=2, src_brows=130, slot=slot)
+    out = torch.empty(2 * N, 1024, device='cuda')
+    tdev = torch.tensor([T], dtype=torch.int32, device='cuda')
+    hip.gated_attention_x6(_dev(q), bank, _dev(u), out, 3 * 130, 128 ** 0.5, T_dev=tdev, B=2)
+    for b in range(2):
+        ref = (torch.softmax((q[b * N:(b + 1) * N].double() / 128 ** 0.5) @ k[b * cap:b * cap + T].double().t(), -1)
+               @ v[b * cap:b * cap + T].double() * u[b * N:(b + 1) * N].double()).float()
+        _close(out[b * N:(b + 1) * N], ref, 3e-5, 'gated x6 lane %d' % b)
 
 
 def test_gated_attention_properties_full_bank(hip):
