@@ -49,6 +49,7 @@ class SwinTransformerBlock(nn.Module):
         self.attn = WindowAttention(dim, window_size, num_heads)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.drop_path_p = 0.       # stochastic depth (training-time only: models/train_forward.py), set by SwinTransformer
         self._p = None
 
     def pack(self):
@@ -127,7 +128,7 @@ class PatchEmbed(nn.Module):
 
 class SwinTransformer(nn.Module):
     def __init__(self, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.,
-                 out_indices=(0, 1, 2)):
+                 out_indices=(0, 1, 2), drop_path_rate=0.2):
         super().__init__()
         self.num_layers = len(depths) - 1                     # the reference drops the last stage (:560)
         self.embed_dim, self.out_indices = embed_dim, out_indices
@@ -136,6 +137,11 @@ class SwinTransformer(nn.Module):
             BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio,
                        PatchMerging if i < self.num_layers - 1 else None) for i in range(self.num_layers)])
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        # stochastic-depth decay rule over the blocks of ALL four stages (swin_transformer.py:601-604), the dropped one included
+        dpr = torch.linspace(0, drop_path_rate, sum(depths)).tolist()
+        for i, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                blk.drop_path_p = dpr[sum(depths[:i]) + bi]
         for i in out_indices:
             self.add_module('norm%d' % i, nn.LayerNorm(self.num_features[i]))
         self._pe = None
@@ -185,6 +191,8 @@ def _freeze_stages(net, frozen_stages):
         last = None
         for i in range(frozen_stages - 1):
             last = net.layers[i]
+            for blk in last.blocks:
+                blk.drop_path_p = 0.
             for p in last.parameters():
                 p.requires_grad = False
         if last is not None and last.downsample is not None:
@@ -195,7 +203,7 @@ def _freeze_stages(net, frozen_stages):
 def build_swin_model(model_type, freeze_at=0):
     if model_type == 'swin_base':       # reference swin/build.py:11-27
         net = SwinTransformer(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7,
-                              out_indices=(0, 1, 2))
+                              out_indices=(0, 1, 2), drop_path_rate=0.3)
         _freeze_stages(net, freeze_at)
         return net
     raise NotImplementedError('Unknown model: %s' % model_type)

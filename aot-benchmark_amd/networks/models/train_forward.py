@@ -12,8 +12,8 @@ modules' `nn.Parameter`s, so that `loss.backward()` fills `.grad` exactly as it 
     the engine's frame recurrence: reference frame, optional second self-memorising frame, propagated frames with
     ground-truth / prediction / probability feedback (back-propagation through time comes from autograd)
 
-Scope: the MobileNetV2 and ResNet-50 / 101 models (AOT-T/S/B/L, DeAOT-T/S/B/L, R50-/R101-AOTL, R50-/R101-DeAOTL: BASELINE
-config 5 trains R50-DeAOTL); the Swin trunk raises NotImplementedError here.  One sample at a time (the reference batches; every op on this
+Scope: every trunk the package has -- MobileNetV2, ResNet-50 / 101, Swin-B (AOT-T/S/B/L, DeAOT-T/S/B/L, R50-/R101-AOTL,
+R50-/R101-DeAOTL, SwinB-AOTL, SwinB-DeAOTL; BASELINE config 5 trains R50-DeAOTL).  One sample at a time (the reference batches; every op on this
 path is per-sample).  Drop-path / Dropout2d follow the modules' `training` flag with torch's generator (they are
 identities in eval mode, which is how the gradient goldens were made)."""
 import torch
@@ -130,6 +130,72 @@ def resnet_features(enc, img):
     return feats
 
 
+def swin_features(enc, img):
+    """Swin trunk, three stages (encoders/swin/swin_transformer.py:684-716): img [1, 3, H, W] -> [(f4, h, w), (f8, h, w),
+    (f16, h, w)] token-major.  Window partition / cyclic shift / padding are index plumbing (views, roll, pad, permute); the
+    arithmetic -- LayerNorm, the qkv / proj / MLP linears, QK^T + relative-position bias (+ shift mask) -> softmax -> PV per
+    window and head, GELU -- runs on the differentiable primitives."""
+    _, _, H, W = img.shape
+    pe = enc.patch_embed
+    ps = pe.patch_size
+    if H % ps or W % ps:          # sides that are not multiples of the patch: zero-padded right / bottom (:501-509)
+        img = F.pad(img.float(), (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
+    x, h, w = T.conv2d(T.to_nhwc(img.float(), 4), pe.proj.weight, pe.proj.bias, 1, img.shape[2], img.shape[3], ps, 0, 1)
+    x = T.layernorm(x, pe.norm.weight, pe.norm.bias)
+    feats = []
+    for li, layer in enumerate(enc.layers):
+        C = x.shape[1]
+        ws = layer.blocks[0].window_size
+        shift = ws // 2
+        hp, wp = -(-h // ws) * ws, -(-w // ws) * ws
+        nw = (hp // ws) * (wp // ws)
+        # BasicLayer.forward :392-411: region labels of the shifted map -> additive -100 mask between tokens of different regions
+        reg = torch.zeros(hp, wp, device=x.device)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                reg[hs, wsl] = cnt
+                cnt += 1
+        mw = reg.view(hp // ws, ws, wp // ws, ws).permute(0, 2, 1, 3).reshape(nw, ws * ws)
+        amask = (mw.unsqueeze(1) != mw.unsqueeze(2)).float() * -100.0                         # [nw, 49, 49]
+        for blk in layer.blocks:
+            nh, sh, Nt = blk.num_heads, blk.shift_size, ws * ws
+            at = blk.attn
+            y = T.layernorm(x, blk.norm1.weight, blk.norm1.bias).view(h, w, C)
+            y = F.pad(y, (0, 0, 0, wp - w, 0, hp - h))
+            if sh:
+                y = torch.roll(y, shifts=(-sh, -sh), dims=(0, 1))
+            win = y.view(hp // ws, ws, wp // ws, ws, C).permute(0, 2, 1, 3, 4).reshape(nw * Nt, C)
+            qkv = T.linear(win, at.qkv.weight, at.qkv.bias).view(nw, Nt, 3, nh, C // nh).permute(2, 0, 3, 1, 4)   # [3, nw, nh, 49, d]
+            q, k, v = (t.reshape(nw * nh, Nt, C // nh) for t in (qkv[0], qkv[1], qkv[2]))
+            att = T.matmul(q, k.transpose(1, 2), alpha=at.scale)                               # (q * scale) k^T, :181-182
+            rpb = at.relative_position_bias_table[at.relative_position_index.view(-1)].view(Nt, Nt, nh).permute(2, 0, 1)
+            att = att.view(nw, nh, Nt, Nt) + rpb.unsqueeze(0)
+            if sh:
+                att = att + amask.unsqueeze(1)
+            o = T.matmul(T.softmax_rows(att.reshape(nw * nh, Nt, Nt)), v)                      # [nw*nh, 49, d]
+            o = o.view(nw, nh, Nt, C // nh).permute(0, 2, 1, 3).reshape(nw * Nt, C)
+            o = T.linear(o, at.proj.weight, at.proj.bias)
+            o = o.view(hp // ws, wp // ws, ws, ws, C).permute(0, 2, 1, 3, 4).reshape(hp, wp, C)
+            if sh:
+                o = torch.roll(o, shifts=(sh, sh), dims=(0, 1))
+            x = x + _drop_path(o[:h, :w].reshape(h * w, C), blk.drop_path_p, blk.training)
+            f = T.act(T.linear(T.layernorm(x, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight, blk.mlp.fc1.bias), 'gelu')
+            x = x + _drop_path(T.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.drop_path_p, blk.training)
+        if li in enc.out_indices:
+            nm = getattr(enc, 'norm%d' % li)
+            feats.append((T.layernorm(x, nm.weight, nm.bias), h, w))
+        if layer.downsample is not None:                                                       # PatchMerging :338-359
+            ds = layer.downsample
+            y = x.view(h, w, C)
+            if h % 2 or w % 2:
+                y = F.pad(y, (0, 0, 0, w % 2, 0, h % 2))
+            y = torch.cat([y[0::2, 0::2], y[1::2, 0::2], y[0::2, 1::2], y[1::2, 1::2]], -1)
+            h, w = (h + 1) // 2, (w + 1) // 2
+            x = T.linear(T.layernorm(y.reshape(h * w, 4 * C), ds.norm.weight, ds.norm.bias), ds.reduction.weight)
+    return feats
+
+
 def encoder_features(enc, img):
     """-> ([f4, f8, f16] shortcuts, (top, h, w) the map the projector reads), aot.py:81-84."""
     kind = type(enc).__name__
@@ -139,7 +205,10 @@ def encoder_features(enc, img):
     if kind == 'ResNet':
         feats = resnet_features(enc, img)
         return feats, feats[2]
-    raise NotImplementedError('the differentiable training forward covers the MobileNetV2 and ResNet trunks; got %s' % kind)
+    if kind == 'SwinTransformer':
+        feats = swin_features(enc, img)
+        return feats, feats[2]
+    raise NotImplementedError('the differentiable training forward covers the MobileNetV2, ResNet and Swin trunks; got %s' % kind)
 
 
 def _heads(t, H):

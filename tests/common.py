@@ -194,12 +194,15 @@ TRAIN_FWD_CASES = {
     # the model BASELINE config 5 trains (R50-DeAOTL: ResNet-50 trunk, three GPM layers), second self-memorising frame, shuffled
     'tf_r50_deaotl': dict(model='r50_deaotl', size=(129, 161), frames=5, objs=(3, 2), step=50000, enable_prev_frame=True,
                           shuffle=True),
+    # BASELINE config 3's model (Swin-B trunk: windows padded 32 x 40 -> 35 x 42, shifted-window masks; MODEL_ALIGN_CORNERS = False: sizes in multiples of 16), prediction feedback
+    'tf_swinb_deaotl': dict(model='swinb_deaotl', size=(128, 160), frames=4, objs=(2, 3), step=20000, use_prev_pred=True,
+                            shuffle=True),
 }
 
 
 # gradient goldens (tests/golden/train_grads.npz, make_golden.make_train_grads): the cases, the parameters stored in full, and
 # the fixed subsample of every other parameter's gradient
-TRAIN_GRAD_CASES = ('tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl')
+TRAIN_GRAD_CASES = ('tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl')
 TRAIN_GRAD_FULL = ('patch_wise_id_bank.bias', 'decoder.conv_out.weight', 'decoder.conv_out.bias', 'LSTT.layers.0.norm1.weight',
                    'encoder_projector.bias')
 

@@ -220,7 +220,7 @@ def test_oracle_gated_propagation_knobs_match_reference(case):
     assert np.abs(out.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_oracle_training_forward_matches_reference(case):
     """aot_engine.py:33-108 of the real reference (train_forward.npz): ground-truth / prediction / probability feedback,
     second self-memorising frame, shuffled identities; losses per frame and sample, masks outside the reference's near-ties."""
@@ -244,7 +244,7 @@ def test_oracle_training_forward_matches_reference(case):
     np.testing.assert_allclose(float(loss), float(g[case + '.loss']), rtol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_oracle_training_gradients_match_reference(case):
     """The BACKWARD of the training step: gradients of the loss of aot_engine.py:33-108 with respect to every trainable
     parameter, from the real reference's `loss.backward()` (tests/golden/train_grads.npz: 105 / 108 parameters -- L2 norm, sum,

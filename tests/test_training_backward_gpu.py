@@ -168,7 +168,7 @@ def _train_engine(case, train_mode=False):
     return c, cfg, model, engine, frames.cuda(), masks.cuda(), objs, kw
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_training_step_matches_reference(T, case):
     """One training step on the device against the REAL reference (train_grads.npz): AOTEngine.forward with autograd on (every
     graph node a HIP kernel), `loss.backward()`, the gradient clip, one AdamW step over the reference's parameter groups.
@@ -226,7 +226,7 @@ def test_training_step_matches_reference(T, case):
           % (case, float(loss.detach()), worst, worst_upd))
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_training_steps_reduce_the_loss(T, case):
     """Six steps of the trainer's loop in train mode (drop-path / Dropout2d drawing, trainer.py:460-519: forward -> backward ->
     clip 5.0 -> AdamW -> EMA) on one batch: the loss of the deterministic network -- measured by the OTHER form of

@@ -94,7 +94,7 @@ def test_ema_update_matches_reference(hip):
     assert not torch.equal(p[0].data, ema.shadow_params[0])
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_training_forward_matches_reference(hip, case):
     """AOTEngine.forward / DeAOTEngine.forward (aot_engine.py:33-108) against the REAL reference's training engine on the same
     seeded batch (tests/golden/train_forward.npz): ground-truth, prediction and probability feedback, the second

@@ -114,7 +114,7 @@ def test_bucketed_allreduce_gloo_world2():
                 assert torch.allclose(got, w, rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_aott_prev', 'tf_aott_shuffle', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_training_forward_orchestration_vs_reference(case, monkeypatch):
     """AOTEngine.forward's own logic -- frame order, which map is fed back, identity shuffle and its reversal, per-sample
     slicing, loss combination -- checked on CPU against the REAL reference's training engine (train_forward.npz) with the
@@ -295,7 +295,7 @@ def test_random_helpers_match_reference_streams():
     assert torch.allclose(t, torch.tensor(gold['trunc_normal']), atol=0, rtol=0) and (t - 0.1).abs().max() < 1.0
 
 
-@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl'])
+@pytest.mark.parametrize('case', ['tf_aott', 'tf_deaott_prob', 'tf_r50_deaotl', 'tf_swinb_deaotl'])
 def test_training_graph_glue_vs_reference_gradients(case, monkeypatch):
     """The differentiable training forward (networks/models/train_forward.py, reached through AOTEngine.forward with autograd
     on) against the REAL reference's `loss.backward()` (tests/golden/train_grads.npz): loss and the gradient of every trainable
