@@ -337,9 +337,6 @@ __global__ void __launch_bounds__(256) attn_pack_x6_part_kernel(const float* __r
 // One 4-wave workgroup owns 32 queries; wave w contracts channels [32 w, 32 w + 32) of q . k (12 MFMAs, partial score tiles meet in
 // LDS in wave order) and owns value chunk w = eight 32-channel blocks of the 1024-wide [V | ID_V] (96 MFMAs per key tile against
 // 128 fp32 MFMAs of twice the length).  K planes [lane][tile][4 blocks][3072], V planes [lane][tile][32 blocks][3072].
-#ifndef AOT_GX6_NVB
-#define AOT_GX6_NVB 5
-#endif
 struct GatedX6Params {
   const float* q;
   const unsigned short* kp;
@@ -414,7 +411,9 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide_coop_kernel(const GatedX6
     for (int r = 0; r < 16; ++r) part[buf][wave][r][lane] = sc[r];
   };
 
-  constexpr int NVB = AOT_GX6_NVB;      // rotating V register sets: a block's fetch is issued NVB - 1 blocks ahead of its MFMAs
+  // rotating V register sets: a block's fetch is issued NVB - 1 = 4 blocks ahead of its MFMAs (one wave per SIMD: nothing else hides
+  // the latency; 2 / 3 / 4 / 5 / 6 sets measured: 891 / 841 / 713 / 673 / 718 us at a bank of 14 frames, profiles/r03r_gated_x6_nvb.txt)
+  constexpr int NVB = 5;
   bf16x8 ka[2][3], vb[NVB][2][3];
   if (t0 < t1) {
     load_k(ka, t0);
