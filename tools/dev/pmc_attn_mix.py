@@ -2,7 +2,7 @@
 frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
 rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams).
     python tools/dev/pmc_attn_mix.py [aot|gated|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel), gated: R50-DeAOTL
-    (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel at M = 14 (SQ counter passes)
+    (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel -- fp32 and bf16x6 forms -- at M = 14 (SQ counter passes)
 AOT_HIP_LIB selects a variant build of the library."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,10 +29,24 @@ def gated(T, brows):
     aot_hip.gated_attention(gq, gk, gv, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
 
 
+def d32_x6(T, brows):
+    ns = attn_splits(N, H, _planned_len(T, N, brows), wg_waves=4)
+    aot_hip.attention_x6(q, xbank, out, T, H, 32 ** 0.5, part=part if ns > 1 else None, nsplit=ns)
+
+
+def gated_x6(T, brows):
+    ns = gated_splits(N, _planned_len(T, N, brows), slots=256)
+    aot_hip.gated_attention_x6(gq, gbank, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
+
+
 n = 0
 if mode == 'm14':
+    xbank = aot_hip.x6_bank(1, 14 * N, C, 'cuda')
+    aot_hip.attention_pack_x6(k, v, xbank, 14 * N)
+    gbank = aot_hip.x6_gated_bank(1, 14 * N, 128, E, 'cuda')
+    aot_hip.gated_pack_x6(gk, gv, gbank, 14 * N)
     for _ in range(3):
-        d32(14 * N, CAP * N); gated(14 * N, CAP * N); n += 2
+        d32(14 * N, CAP * N); gated(14 * N, CAP * N); d32_x6(14 * N, CAP * N); gated_x6(14 * N, CAP * N); n += 4
 else:
     fn = d32 if mode == 'aot' else gated
     for t in range(1, 70):
