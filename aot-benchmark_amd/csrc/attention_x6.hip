@@ -247,90 +247,104 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
   }
 }
 
-// position of bank row w (of its 32-row tile) in the value product: sub-step c = w >> 4, lane half hi = (w >> 2) & 1, element
-// i = ((w >> 3) & 1) * 4 + (w & 3) -- the order the score tile's C/D layout holds the keys in
-// k / v [B lanes][rows][C] fp32 -> planes of the packed bank at rows row0 .. row0 + rows of each lane.  One thread per
-// (row, 4 channels): K planes go out as 8-byte pieces, V planes (transposed) as 2-byte scatters.
-__global__ void __launch_bounds__(256) attn_pack_x6_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                           unsigned short* __restrict__ kv, int B, long rows, int C, long src_brows,
-                                                           int ldk, int ldv, long cap_rows, const int* __restrict__ slot_dev,
-                                                           int slot) {
-  const int C4 = C >> 2;
+// ---- packing: x [B lanes][rows][ldx] fp32 -> the 16-byte operand chunks of a packed bank ---------------------------------------
+// One thread per CHUNK (the eight values one lane contracts in one MFMA sub-step): it gathers its eight fp32 values, splits them
+// and stores three 16-byte pieces (one per plane) -- coalesced on both sides.  K-style (TR = false): lane (row j of the tile, half
+// hi) holds dims 16 c + 8 hi .. + 8 of bank row 32 tile + j.  V-style (TR = true): lane (channel j, half hi) holds the eight bank
+// rows 32 tile + 16 c + 8 (i >> 2) + 4 hi + (i & 3), i = 0..7 -- the order the score tile's C/D layout keeps the keys in.  Rows
+// are appended frame by frame at offsets that are no multiple of 8, so a V chunk can straddle two appends: the rows this call
+// does not cover keep what the chunk holds (read-modify-write; zero in a fresh bank).
+// Block (tile, nb) of a lane's bank sits at ((lane * cap_tiles + tile) * NB + nb) * blk_stride + blk_off ushorts (the d = 32 bank
+// interleaves K and V blocks: stride 6144, V at offset 3072; the gated banks are separate: stride 3072).
+template <bool TR>
+__device__ __forceinline__ void pack_chunk(const float* __restrict__ x, unsigned short* __restrict__ planes, int B, long rows, int NB,
+                                           long src_brows, int ldx, long cap_tiles, const int* __restrict__ slot_dev, int slot,
+                                           int blk_stride, int blk_off, int ntiles_max) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long per = rows * C4;
+  const long per = (long)ntiles_max * NB * 128;
   if (idx >= per * B) return;
   const int b = (int)(idx / per);
-  const long rem = idx - (long)b * per;
-  const long r = rem / C4;
-  const int c = (int)(rem - r * C4) * 4;
-  const long t = (long)(slot_dev ? *slot_dev : slot) * rows + r;
-  const int H = C >> 5, hh = c >> 5, d = c & 31, w = (int)(t & 31);
-  const float4 kk = *reinterpret_cast<const float4*>(k + ((long)b * src_brows + r) * ldk + c);
-  const float4 vv = *reinterpret_cast<const float4*>(v + ((long)b * src_brows + r) * ldv + c);
-  float kr[4] = {kk.x, kk.y, kk.z, kk.w}, vr[4] = {vv.x, vv.y, vv.z, vv.w};
-  unsigned short* blk = kv + (((long)b * (cap_rows >> 5) + (t >> 5)) * H + hh) * 6144;
-  // K: lane (row w, half (d >> 3) & 1), sub-step d >> 4, elements d & 7 .. + 3
-  unsigned short* kdst = blk + ((d >> 4) * 64 + ((d >> 3) & 1) * 32 + w) * 8 + (d & 7);
-  // V: lane (dim d + e, half (w >> 2) & 1), sub-step w >> 4, element ((w >> 3) & 1) * 4 + (w & 3)
-  unsigned short* vdst = blk + 3072 + ((w >> 4) * 64 + ((w >> 2) & 1) * 32 + d) * 8 + ((w >> 3) & 1) * 4 + (w & 3);
+  long rem = idx - (long)b * per;
+  const int lane = (int)(rem & 63), c = (int)((rem >> 6) & 1);
+  rem >>= 7;
+  const int nb = (int)(rem % NB);
+  const long t0 = (long)(slot_dev ? *slot_dev : slot) * rows, t1 = t0 + rows;
+  const long tile = (t0 >> 5) + rem / NB;
+  if (tile > ((t1 - 1) >> 5)) return;
+  const int j = lane & 31, hi = lane >> 5;
+  unsigned short* dst = planes + (((long)b * cap_tiles + tile) * NB + nb) * blk_stride + blk_off + (c * 64 + lane) * 8;
+  float xr[8];
+  if (!TR) {
+    const long row = tile * 32 + j;
+    if (row < t0 || row >= t1) return;
+    const float4* src = reinterpret_cast<const float4*>(x + ((long)b * src_brows + row - t0) * ldx + nb * 32 + 16 * c + 8 * hi);
+    const float4 u0 = src[0], u1 = src[1];
+    xr[0] = u0.x; xr[1] = u0.y; xr[2] = u0.z; xr[3] = u0.w; xr[4] = u1.x; xr[5] = u1.y; xr[6] = u1.z; xr[7] = u1.w;
+  } else {
+    const long r0 = tile * 32 + 16 * c + 4 * hi;
+    unsigned covered = 0;
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    unsigned short kb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned ku = __float_as_uint(kr[e]) & 0xffff0000u, vu = __float_as_uint(vr[e]) & 0xffff0000u;
-      kb[e] = (unsigned short)(ku >> 16);
-      vdst[pl * 1024 + e * 8] = (unsigned short)(vu >> 16);
-      kr[e] -= __uint_as_float(ku);
-      vr[e] -= __uint_as_float(vu);
+    for (int i = 0; i < 8; ++i) {
+      const long r = r0 + 8 * (i >> 2) + (i & 3);
+      xr[i] = 0.f;
+      if (r >= t0 && r < t1) {
+        covered |= 1u << i;
+        xr[i] = x[((long)b * src_brows + r - t0) * ldx + nb * 32 + j];
+      }
     }
-    *reinterpret_cast<uint2*>(kdst + pl * 1024) = make_uint2(kb[0] | ((unsigned)kb[1] << 16), kb[2] | ((unsigned)kb[3] << 16));
+    if (!covered) return;
+    if (covered != 0xffu) {        // rows of another append: rebuild their fp32 values from the planes the chunk holds
+      u32x4 old[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) old[pl] = *reinterpret_cast<const u32x4*>(dst + pl * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!(covered & (1u << i))) {
+          float acc = 0.f;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned w = old[pl][i >> 1];
+            acc += __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));       // exact: the planes are the fp32 number's pieces
+          }
+          xr[i] = acc;
+        }
+    }
   }
+  bf16x8 pl3[3];
+  split3(xr, pl3);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * 1024) = __builtin_bit_cast(u32x4, pl3[pl]);
 }
 
-// ---- one operand of a packed bank: x [B lanes][rows][C] fp32 -> planes[lane][row / 32][C / 32][3 planes x 2 sub-steps x 64 lanes x 8]
-// K-style (transpose = 0: lane = row of the tile, eight dims per chunk) or V-style (transpose = 1: lane = channel, eight rows per
-// chunk in the C/D order of the score tile).  The gated (DeAOT) kernel keeps K (128 wide) and V (1024 wide) in two such buffers.
-__global__ void __launch_bounds__(256) attn_pack_x6_part_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, int B,
-                                                                long rows, int C, long src_brows, int ldx, long cap_rows,
-                                                                const int* __restrict__ slot_dev, int slot, int transpose) {
-  const int C4 = C >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long per = rows * C4;
-  if (idx >= per * B) return;
-  const int b = (int)(idx / per);
-  const long rem = idx - (long)b * per;
-  const long r = rem / C4;
-  const int c = (int)(rem - r * C4) * 4;
-  const long t = (long)(slot_dev ? *slot_dev : slot) * rows + r;
-  const int NB = C >> 5, blk_i = c >> 5, d = c & 31, w = (int)(t & 31);
-  const float4 xx = *reinterpret_cast<const float4*>(x + ((long)b * src_brows + r) * ldx + c);
-  float xr[4] = {xx.x, xx.y, xx.z, xx.w};
-  unsigned short* blk = planes + (((long)b * (cap_rows >> 5) + (t >> 5)) * NB + blk_i) * 3072;
-  if (!transpose) {
-    unsigned short* dst = blk + ((d >> 4) * 64 + ((d >> 3) & 1) * 32 + w) * 8 + (d & 7);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      unsigned short hb[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned u = __float_as_uint(xr[e]) & 0xffff0000u;
-        hb[e] = (unsigned short)(u >> 16);
-        xr[e] -= __uint_as_float(u);
-      }
-      *reinterpret_cast<uint2*>(dst + pl * 1024) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
-    }
-  } else {
-    unsigned short* dst = blk + ((w >> 4) * 64 + ((w >> 2) & 1) * 32 + d) * 8 + ((w >> 3) & 1) * 4 + (w & 3);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned u = __float_as_uint(xr[e]) & 0xffff0000u;
-        dst[pl * 1024 + e * 8] = (unsigned short)(u >> 16);
-        xr[e] -= __uint_as_float(u);
-      }
-  }
+template <bool TR>
+__global__ void __launch_bounds__(256) attn_pack_chunks_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, int B,
+                                                               long rows, int NB, long src_brows, int ldx, long cap_tiles,
+                                                               const int* __restrict__ slot_dev, int slot, int blk_stride,
+                                                               int blk_off, int ntiles_max) {
+  pack_chunk<TR>(x, planes, B, rows, NB, src_brows, ldx, cap_tiles, slot_dev, slot, blk_stride, blk_off, ntiles_max);
+}
+// K and V of the d = 32 bank in one launch: blockIdx.y = 0 packs k (K-style, block offset 0), 1 packs v (V-style, offset 3072)
+__global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                           unsigned short* __restrict__ planes, int B, long rows, int NB, long src_brows,
+                                                           int ldk, int ldv, long cap_tiles, const int* __restrict__ slot_dev, int slot,
+                                                           int ntiles_max) {
+  if (blockIdx.y == 0) pack_chunk<false>(k, planes, B, rows, NB, src_brows, ldk, cap_tiles, slot_dev, slot, 6144, 0, ntiles_max);
+  else pack_chunk<true>(v, planes, B, rows, NB, src_brows, ldv, cap_tiles, slot_dev, slot, 6144, 3072, ntiles_max);
+}
+
+static int launch_pack(bool tr, const float* x, unsigned short* planes, int B, long rows, int C, long src_brows, int ldx, long cap_rows,
+                       const int* slot_dev, int slot, hipStream_t s) {
+  const int NB = C >> 5;
+  const int ntiles_max = (int)(rows / 32 + 2);
+  const long n = (long)B * ntiles_max * NB * 128;
+  if (tr)
+    hipLaunchKernelGGL((attn_pack_chunks_kernel<true>), dim3(cdiv(n, 256)), dim3(256), 0, s, x, planes, B, rows, NB, src_brows, ldx,
+                       cap_rows >> 5, slot_dev, slot, 3072, 0, ntiles_max);
+  else
+    hipLaunchKernelGGL((attn_pack_chunks_kernel<false>), dim3(cdiv(n, 256)), dim3(256), 0, s, x, planes, B, rows, NB, src_brows, ldx,
+                       cap_rows >> 5, slot_dev, slot, 3072, 0, ntiles_max);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? AOT_OK : (int)e;
 }
 
 // ---- gated-propagation form (DeAOT, attention.py:672-707) in the bf16x6 family: the twin of attn_fwd_wide_coop_kernel<8> ----------
@@ -524,9 +538,10 @@ extern "C" int aot_attn_pack_x6_f32(const float* k, const float* v, void* kv, in
       (cap_rows & 31) || slot < 0 || src_brows < 0 || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)kv & 15))
     return AOT_ERR_BADARG;
   if (!slot_dev && ((long)slot + 1) * rows > cap_rows) return AOT_ERR_BADARG;
-  const long n = (long)B * rows * (C / 4);
-  hipLaunchKernelGGL(attn_pack_x6_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k, v, (unsigned short*)kv,
-                     B, rows, C, src_brows, ldk, ldv, cap_rows, slot_dev, slot);
+  const int NB = C >> 5, ntiles_max = (int)(rows / 32 + 2);
+  const long n = (long)B * ntiles_max * NB * 128;
+  hipLaunchKernelGGL(attn_pack_kv_kernel, dim3(cdiv(n, 256), 2), dim3(256), 0, (hipStream_t)stream, k, v, (unsigned short*)kv, B, rows, NB,
+                     src_brows, ldk, ldv, cap_rows >> 5, slot_dev, slot, ntiles_max);
   AOT_LAUNCH_CHECK();
 }
 
@@ -552,10 +567,7 @@ extern "C" int aot_attn_pack_x6_part_f32(const float* x, void* planes, int B, lo
       src_brows < 0 || ((uintptr_t)x & 15) || ((uintptr_t)planes & 15))
     return AOT_ERR_BADARG;
   if (!slot_dev && ((long)slot + 1) * rows > cap_rows) return AOT_ERR_BADARG;
-  const long n = (long)B * rows * (C / 4);
-  hipLaunchKernelGGL(attn_pack_x6_part_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, B,
-                     rows, C, src_brows, ldx, cap_rows, slot_dev, slot, transpose);
-  AOT_LAUNCH_CHECK();
+  return launch_pack(transpose != 0, x, (unsigned short*)planes, B, rows, C, src_brows, ldx, cap_rows, slot_dev, slot, (hipStream_t)stream);
 }
 
 extern "C" int aot_gated_attn_x6_f32(const float* q, const void* kp, const void* vp, const float* gate, float* out, float* part, int B,

@@ -115,7 +115,14 @@ class LongShortTermTransformerBlock(nn.Module):
         sv = ws.get('sa_v', (M, C), dev)
         aot_hip.linear(x1, p['sa_v_w'], p['sa_v_b'], sv, stream=stream)
         so = ws.get('sa_o', (M, C), dev)
-        self.self_attn.core(qk[:, :C], qk[:, C:], sv, so, N, ws, stream, B=B, kv_brows=N)
+        sx6 = None
+        if x6 is not None and self.self_attn.hidden_dim == 32:
+            # bf16x6 family: the frame's own K / V split into a scratch bank of one frame per lane (aot_attn_pack_x6_f32), then the
+            # same kernel as the long-term attention
+            cap = (N + 31) // 32 * 32
+            sx6 = (ws.get_zeroed('sa_x6', (B * cap * C * 6,), dev, torch.int16), cap)
+            aot_hip.attention_pack_x6(qk[:, C:], sv, sx6, N, B=B, src_brows=N, stream=stream)
+        self.self_attn.core(qk[:, :C], qk[:, C:], sv, so, N, ws, stream, B=B, kv_brows=N, x6=sx6)
         xa = ws.get('xa', (M, C), dev)
         aot_hip.linear(so, p['sa_o_w'], p['sa_o_b'], xa, res=x, stream=stream)
 

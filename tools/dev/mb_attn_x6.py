@@ -58,7 +58,7 @@ if QUICK:
     sys.exit(0)
 # pack cost, two lanes, device-side slot
 us = timed(lambda: aot_hip.attention_pack_x6(k[:N], v[:N], bank, N, slot=3))
-print('pack of one frame (%d x %d): %.1f us' % (N, C, us))
+print('pack of one frame (%d x %d): %.1f us (appended at slot 3: chunks straddling the neighbours are merged)' % (N, C, us))
 bank2 = aot_hip.x6_bank(2, 3 * N, C, 'cuda')
 kk = torch.randn(2 * 3 * N, C, device='cuda', generator=g); vv = torch.randn(2 * 3 * N, C, device='cuda', generator=g)
 slot_dev = torch.zeros(1, dtype=torch.int32, device='cuda')
