@@ -71,10 +71,18 @@ __device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3]
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
-// NO inline asm in this kernel: hipcc inserts the wait states gfx950 needs between an MFMA and a vector instruction that reads or
-// writes one of its registers only for instructions it knows; an asm statement touching a score / output accumulator
-// (v_max3_f32 on the scores, a v_mul on the accumulator) gave results that changed from run to run in some instruction orders
-// (tools/dev/dbg_attn_x6.py: sporadic workgroups with a wrong O for 16 of their 32 queries, row maxima and sums intact).
+// ORDER MATTERS HERE, beyond speed.  Builds of this kernel in which a vector instruction touches an MFMA chain's accumulator right
+// behind the chain gave wrong O tiles in sporadic workgroups, different from run to run (row maxima and sums intact):
+//   * inline asm on score / output accumulators (v_max3_f32, v_mul_f32, a v_mov "anchor") in some instruction orders
+//     (profiles/r03n_attn_x6_variants.txt, r03q_attn_x6_determinism.txt);
+//   * the NON-pipelined order -- softmax of a tile directly behind its own score MFMAs, plain C++ -- (r03u_attn_x6_occ.txt);
+//   * an explicit dependency of the K / V reloads on the chain's result through v_readfirstlane (r03u_attn_x6_dep.txt).
+// What has been bit-identical over every repeat and shape tried is the order below: the scores of tile i + 1 are issued, then the
+// softmax reads the scores of tile i (a whole chain old), the accumulator is rescaled a whole chain after its last MFMA, and no
+// inline asm touches an MFMA register.  An operand-overwrite (WAR) probe did not reproduce the effect
+// (tools/dev/mfma_war_probe.hip); the working hypothesis is that with several waves sharing a SIMD's matrix pipe the wait states
+// hipcc inserts between an MFMA and a vector access to its destination do not cover the time the MFMA waits for the pipe.
+// tests/test_parity_gpu.py::test_attention_kernels_reproducible_under_load guards it (eight repeats, full-size grids).
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // Variants measured on MI355X and dropped (tools/dev/mb_attn_x6.py, profiles/r03n_attn_x6_variants.txt; N = 1674, 8 heads,
