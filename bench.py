@@ -562,8 +562,9 @@ def main(argv=None):
             ex, fx, _ = median_run(xruns)
             x6 = {'dtype': 'f32 via bf16x6 split', 'value': round(fx / ex, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in xruns],
                   'n_gpus': 1, 'what': 'conv / linear layers with >= %d tiles of 64x64 on aot_conv2d_bf16x6_f32 (three truncated '
-                                       'bf16 planes per operand, six of the nine partial products, fp32 accumulation); attention '
-                                       'and everything else unchanged' % aot_hip_x6_min_tiles()}
+                                       'bf16 planes per operand, six of the nine partial products, fp32 accumulation); long-term and '
+                                       'self-attention on aot_attn_x6_f32 (aot_gated_attn_x6_f32 for DeAOT) over the memory bank kept '
+                                       'pre-split by aot_attn_pack_x6_f32; everything else unchanged' % aot_hip_x6_min_tiles()}
             del xl
         peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
         stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
