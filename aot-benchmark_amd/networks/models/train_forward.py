@@ -3,19 +3,24 @@ trainer.py:460-519 drives it: `loss.backward()` -> clip -> AdamW -> EMA).
 
 The inference path runs fused kernels on packed weights and keeps no activations; a training step needs the autograd
 graph.  Here the same networks are written once more over the few differentiable primitives of
-`networks/layers/train_ops.py` (every graph node = one C-ABI kernel with a hand-written backward), directly on the
+`networks/layers/train_ops.py` (every compute node = one C-ABI kernel with a hand-written backward), directly on the
 modules' `nn.Parameter`s, so that `loss.backward()` fills `.grad` exactly as it does for the reference:
 
-    MobileNetV2 trunk (FrozenBN folded on the fly; frozen stages record no graph)      mobilenetv2.py:219-224
+    MobileNetV2 / ResNet / Swin trunks (FrozenBN folded on the fly; frozen stages record no graph)
     LongShortTermTransformerBlock / GatedPropagationModule and their attentions        transformer.py:312-367,582-665
     FPNSegmentationHead, the identity bank, the sine position embedding                fpn.py:34-58, aot.py:50-79
     the engine's frame recurrence: reference frame, optional second self-memorising frame, propagated frames with
     ground-truth / prediction / probability feedback (back-propagation through time comes from autograd)
 
 Scope: every trunk the package has -- MobileNetV2, ResNet-50 / 101, Swin-B (AOT-T/S/B/L, DeAOT-T/S/B/L, R50-/R101-AOTL,
-R50-/R101-DeAOTL, SwinB-AOTL, SwinB-DeAOTL; BASELINE config 5 trains R50-DeAOTL).  One sample at a time (the reference batches; every op on this
-path is per-sample).  Drop-path / Dropout2d follow the modules' `training` flag with torch's generator (they are
-identities in eval mode, which is how the gradient goldens were made)."""
+R50-/R101-DeAOTL, SwinB-AOTL, SwinB-DeAOTL; BASELINE config 5 trains R50-DeAOTL).
+
+The SAMPLES OF A BATCH ARE LANES, as the object groups are on the inference path: every activation is token-major
+[B * N, C] with sample b in rows [b * N, (b + 1) * N), and every kernel launch serves the whole batch (the convolution /
+normalisation / resize primitives take B maps, the attention products B * heads matrices); only what differs per sample --
+the identity permutation, the number of objects the loss looks at -- is sliced per sample.  Drop-path / Dropout2d draw per
+sample, as the reference's do along its batch axis, and follow the modules' `training` flag (identities in eval mode,
+which is how the gradient goldens were made)."""
 import torch
 import torch.nn.functional as F
 
@@ -31,12 +36,13 @@ def _fold_bn(weight, bn):
     return weight * scale.view(-1, *([1] * (weight.dim() - 1))), shift
 
 
-def _drop_path(x, p, training):
-    """DropPath of one sample (basic.py:129-148, batch_dim = 1): the whole branch dropped with probability p."""
+def _drop_path(x, p, training, B):
+    """DropPath (basic.py:129-148, one draw per sample of the batch): a sample's whole branch dropped with probability p."""
     if not training or not p:
         return x
     keep = 1. - p
-    return x * ((torch.rand((), device=x.device) < keep).to(x.dtype) / keep)
+    mask = (torch.rand(B, 1, 1, device=x.device) < keep).to(x.dtype) / keep
+    return (x.view(B, -1, x.shape[1]) * mask).view(x.shape)
 
 
 def _dropout(x, p, training):
@@ -47,12 +53,13 @@ def _dropout(x, p, training):
     return x * ((torch.rand_like(x) < keep).to(x.dtype) / keep)
 
 
-def _dropout2d(x, p, training):
-    """nn.Dropout2d on a token-major map [N, C]: whole channels dropped (basic.py:46,55)."""
+def _dropout2d(x, p, training, B):
+    """nn.Dropout2d on B token-major maps [B * N, C]: whole channels of a sample dropped (basic.py:46,55)."""
     if not training or not p:
         return x
     keep = 1. - p
-    return x * ((torch.rand(1, x.shape[1], device=x.device) < keep).to(x.dtype) / keep)
+    mask = (torch.rand(B, 1, x.shape[1], device=x.device) < keep).to(x.dtype) / keep
+    return (x.view(B, -1, x.shape[1]) * mask).view(x.shape)
 
 
 def _no_attn_dropout(m):
@@ -61,68 +68,76 @@ def _no_attn_dropout(m):
                                   'config) is not part of the differentiable forward')
 
 
-def _cbr(x, seq, H, W):
+def _maps_nhwc(maps, cpad):
+    """[B, C, H, W] planar -> token-major [B * H * W, cpad] (channels >= C zero)."""
+    if maps.shape[0] == 1:
+        return T.to_nhwc(maps.float(), cpad)
+    return torch.cat([T.to_nhwc(maps[b:b + 1].float(), cpad) for b in range(maps.shape[0])], 0)
+
+
+def _cbr(x, seq, B, H, W):
     """ConvBNActivation (conv / depthwise conv + FrozenBN + ReLU6), mobilenetv2.py:30-46."""
     conv, bn = seq[0], seq[1]
     w, b = _fold_bn(conv.weight, bn)
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
     if conv.groups == 1:
-        y, OH, OW = T.conv2d(x, w, b, 1, H, W, s, p, d)
+        y, OH, OW = T.conv2d(x, w, b, B, H, W, s, p, d)
     else:
-        y, OH, OW = T.dwconv2d(x, w, 1, H, W, s, p, d)
+        y, OH, OW = T.dwconv2d(x, w, B, H, W, s, p, d)
         y = y + b
     return T.act(y, 'relu6'), OH, OW
 
 
 def mobilenetv2_features(enc, img):
-    """img [1, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w), (top, h, w)] token-major (mobilenetv2.py:219-224)."""
-    _, _, H, W = img.shape
-    x = T.to_nhwc(img.float(), 4)
-    x, h, w = _cbr(x, enc.features[0], H, W)
+    """img [B, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w), (top, h, w)] token-major (mobilenetv2.py:219-224)."""
+    B, _, H, W = img.shape
+    x = _maps_nhwc(img, 4)
+    x, h, w = _cbr(x, enc.features[0], B, H, W)
     feats = []
     for idx in range(1, 18):
         blk = enc.features[idx]
         y, hh, ww = x, h, w
         j = 0
         if blk.expand:
-            y, hh, ww = _cbr(y, blk.conv[0], hh, ww)
+            y, hh, ww = _cbr(y, blk.conv[0], B, hh, ww)
             j = 1
-        y, hh, ww = _cbr(y, blk.conv[j], hh, ww)
+        y, hh, ww = _cbr(y, blk.conv[j], B, hh, ww)
         wpl, bpl = _fold_bn(blk.conv[j + 1].weight, blk.conv[j + 2])
-        y, hh, ww = T.conv2d(y, wpl, bpl, 1, hh, ww)
+        y, hh, ww = T.conv2d(y, wpl, bpl, B, hh, ww)
         x = x + y if blk.use_res_connect else y
         h, w = hh, ww
         if idx in (3, 6, 13):
             feats.append((x, h, w))
-    x, h, w = _cbr(x, enc.features[18], h, w)
+    x, h, w = _cbr(x, enc.features[18], B, h, w)
     feats.append((x, h, w))
     return feats
 
 
 def resnet_features(enc, img):
-    """ResNet-50 / 101 trunk (encoders/resnet.py:140-157): img [1, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w)] token-major.
+    """ResNet-50 / 101 trunk (encoders/resnet.py:140-157): img [B, 3, H, W] -> [(f4, h, w), (f8, h, w), (f16, h, w)] token-major.
     conv + FrozenBN folded per call; the stem's max pool has no backward kernel -- with the stem frozen
     (TRAIN_ENCODER_FREEZE_AT >= 1, every reference recipe) nothing asks for one."""
-    _, _, H, W = img.shape
-    x = T.to_nhwc(img.float(), 4)
+    B, _, H, W = img.shape
+    x = _maps_nhwc(img, 4)
     w, b = _fold_bn(enc.conv1.weight, enc.bn1)
-    x, h, wd = T.conv2d(x, w, b, 1, H, W, 2, 3, 1)
+    x, h, wd = T.conv2d(x, w, b, B, H, W, 2, 3, 1)
     x = T.act(x, 'relu')
-    x, h, wd = T.maxpool3x3s2(x, h, wd)
+    pooled = [T.maxpool3x3s2(x[i * h * wd:(i + 1) * h * wd], h, wd) for i in range(B)]
+    x, h, wd = (pooled[0][0] if B == 1 else torch.cat([q[0] for q in pooled], 0)), pooled[0][1], pooled[0][2]
     feats = []
     for layer in (enc.layer1, enc.layer2, enc.layer3):
         for blk in layer:
             s, d = blk.stride, blk.dilation
             w1, b1 = _fold_bn(blk.conv1.weight, blk.bn1)
-            y = T.act(T.conv2d(x, w1, b1, 1, h, wd)[0], 'relu')
+            y = T.act(T.conv2d(x, w1, b1, B, h, wd)[0], 'relu')
             w2, b2 = _fold_bn(blk.conv2.weight, blk.bn2)
-            y, oh, ow = T.conv2d(y, w2, b2, 1, h, wd, s, d, d)
+            y, oh, ow = T.conv2d(y, w2, b2, B, h, wd, s, d, d)
             y = T.act(y, 'relu')
             w3, b3 = _fold_bn(blk.conv3.weight, blk.bn3)
-            y = T.conv2d(y, w3, b3, 1, oh, ow)[0]
+            y = T.conv2d(y, w3, b3, B, oh, ow)[0]
             if blk.downsample is not None:
                 wds, bds = _fold_bn(blk.downsample[0].weight, blk.downsample[1])
-                res = T.conv2d(x, wds, bds, 1, h, wd, s, 0, 1)[0]                # (stride 2: im2col of a 1x1 window = every 2nd pixel)
+                res = T.conv2d(x, wds, bds, B, h, wd, s, 0, 1)[0]                # (stride 2: im2col of a 1x1 window = every 2nd pixel)
             else:
                 res = x
             x, h, wd = T.act(y + res, 'relu'), oh, ow
@@ -131,16 +146,16 @@ def resnet_features(enc, img):
 
 
 def swin_features(enc, img):
-    """Swin trunk, three stages (encoders/swin/swin_transformer.py:684-716): img [1, 3, H, W] -> [(f4, h, w), (f8, h, w),
+    """Swin trunk, three stages (encoders/swin/swin_transformer.py:684-716): img [B, 3, H, W] -> [(f4, h, w), (f8, h, w),
     (f16, h, w)] token-major.  Window partition / cyclic shift / padding are index plumbing (views, roll, pad, permute); the
     arithmetic -- LayerNorm, the qkv / proj / MLP linears, QK^T + relative-position bias (+ shift mask) -> softmax -> PV per
     window and head, GELU -- runs on the differentiable primitives."""
-    _, _, H, W = img.shape
+    B, _, H, W = img.shape
     pe = enc.patch_embed
     ps = pe.patch_size
     if H % ps or W % ps:          # sides that are not multiples of the patch: zero-padded right / bottom (:501-509)
         img = F.pad(img.float(), (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
-    x, h, w = T.conv2d(T.to_nhwc(img.float(), 4), pe.proj.weight, pe.proj.bias, 1, img.shape[2], img.shape[3], ps, 0, 1)
+    x, h, w = T.conv2d(_maps_nhwc(img, 4), pe.proj.weight, pe.proj.bias, B, img.shape[2], img.shape[3], ps, 0, 1)
     x = T.layernorm(x, pe.norm.weight, pe.norm.bias)
     feats = []
     for li, layer in enumerate(enc.layers):
@@ -161,38 +176,38 @@ def swin_features(enc, img):
         for blk in layer.blocks:
             nh, sh, Nt = blk.num_heads, blk.shift_size, ws * ws
             at = blk.attn
-            y = T.layernorm(x, blk.norm1.weight, blk.norm1.bias).view(h, w, C)
+            y = T.layernorm(x, blk.norm1.weight, blk.norm1.bias).view(B, h, w, C)
             y = F.pad(y, (0, 0, 0, wp - w, 0, hp - h))
             if sh:
-                y = torch.roll(y, shifts=(-sh, -sh), dims=(0, 1))
-            win = y.view(hp // ws, ws, wp // ws, ws, C).permute(0, 2, 1, 3, 4).reshape(nw * Nt, C)
-            qkv = T.linear(win, at.qkv.weight, at.qkv.bias).view(nw, Nt, 3, nh, C // nh).permute(2, 0, 3, 1, 4)   # [3, nw, nh, 49, d]
-            q, k, v = (t.reshape(nw * nh, Nt, C // nh) for t in (qkv[0], qkv[1], qkv[2]))
+                y = torch.roll(y, shifts=(-sh, -sh), dims=(1, 2))
+            win = y.view(B, hp // ws, ws, wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nw * Nt, C)
+            qkv = T.linear(win, at.qkv.weight, at.qkv.bias).view(B * nw, Nt, 3, nh, C // nh).permute(2, 0, 3, 1, 4)   # [3, B nw, nh, 49, d]
+            q, k, v = (t.reshape(B * nw * nh, Nt, C // nh) for t in (qkv[0], qkv[1], qkv[2]))
             att = T.matmul(q, k.transpose(1, 2), alpha=at.scale)                               # (q * scale) k^T, :181-182
             rpb = at.relative_position_bias_table[at.relative_position_index.view(-1)].view(Nt, Nt, nh).permute(2, 0, 1)
-            att = att.view(nw, nh, Nt, Nt) + rpb.unsqueeze(0)
+            att = att.view(B, nw, nh, Nt, Nt) + rpb.view(1, 1, nh, Nt, Nt)
             if sh:
-                att = att + amask.unsqueeze(1)
-            o = T.matmul(T.softmax_rows(att.reshape(nw * nh, Nt, Nt)), v)                      # [nw*nh, 49, d]
-            o = o.view(nw, nh, Nt, C // nh).permute(0, 2, 1, 3).reshape(nw * Nt, C)
+                att = att + amask.view(1, nw, 1, Nt, Nt)
+            o = T.matmul(T.softmax_rows(att.reshape(B * nw * nh, Nt, Nt)), v)                  # [B nw nh, 49, d]
+            o = o.view(B * nw, nh, Nt, C // nh).permute(0, 2, 1, 3).reshape(B * nw * Nt, C)
             o = T.linear(o, at.proj.weight, at.proj.bias)
-            o = o.view(hp // ws, wp // ws, ws, ws, C).permute(0, 2, 1, 3, 4).reshape(hp, wp, C)
+            o = o.view(B, hp // ws, wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, hp, wp, C)
             if sh:
-                o = torch.roll(o, shifts=(sh, sh), dims=(0, 1))
-            x = x + _drop_path(o[:h, :w].reshape(h * w, C), blk.drop_path_p, blk.training)
+                o = torch.roll(o, shifts=(sh, sh), dims=(1, 2))
+            x = x + _drop_path(o[:, :h, :w].reshape(B * h * w, C), blk.drop_path_p, blk.training, B)
             f = T.act(T.linear(T.layernorm(x, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight, blk.mlp.fc1.bias), 'gelu')
-            x = x + _drop_path(T.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.drop_path_p, blk.training)
+            x = x + _drop_path(T.linear(f, blk.mlp.fc2.weight, blk.mlp.fc2.bias), blk.drop_path_p, blk.training, B)
         if li in enc.out_indices:
             nm = getattr(enc, 'norm%d' % li)
             feats.append((T.layernorm(x, nm.weight, nm.bias), h, w))
         if layer.downsample is not None:                                                       # PatchMerging :338-359
             ds = layer.downsample
-            y = x.view(h, w, C)
+            y = x.view(B, h, w, C)
             if h % 2 or w % 2:
                 y = F.pad(y, (0, 0, 0, w % 2, 0, h % 2))
-            y = torch.cat([y[0::2, 0::2], y[1::2, 0::2], y[0::2, 1::2], y[1::2, 1::2]], -1)
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
             h, w = (h + 1) // 2, (w + 1) // 2
-            x = T.linear(T.layernorm(y.reshape(h * w, 4 * C), ds.norm.weight, ds.norm.bias), ds.reduction.weight)
+            x = T.linear(T.layernorm(y.reshape(B * h * w, 4 * C), ds.norm.weight, ds.norm.bias), ds.reduction.weight)
     return feats
 
 
@@ -211,68 +226,75 @@ def encoder_features(enc, img):
     raise NotImplementedError('the differentiable training forward covers the MobileNetV2, ResNet and Swin trunks; got %s' % kind)
 
 
-def _heads(t, H):
-    """[N, H*d] -> [H, N, d] view."""
-    n, c = t.shape
-    return t.view(n, H, c // H).permute(1, 0, 2)
+def _heads(t, H, B):
+    """[B * n, H * d] -> [B * H, n, d] view (a matrix per sample and head)."""
+    n, c = t.shape[0] // B, t.shape[1]
+    return t.view(B, n, H, c // H).permute(0, 2, 1, 3).reshape(B * H, n, c // H)
 
 
-def _attention(q, k, v, H, scale):
-    """softmax((q / scale) k^T) v per head (attention.py:82-117): q [N, C], k / v [T, C] -> [N, C]."""
-    n, c = q.shape
-    s = T.matmul(_heads(q / scale, H), _heads(k, H).transpose(1, 2))          # [H, N, T]
-    p = T.softmax_rows(s)
-    o = T.matmul(p, _heads(v, H))                                              # [H, N, d]
-    return o.permute(1, 0, 2).reshape(n, c)
+def _unheads(o, H, B):
+    """[B * H, n, d] -> [B * n, H * d]."""
+    n, d = o.shape[1], o.shape[2]
+    return o.view(B, H, n, d).permute(0, 2, 1, 3).reshape(B * n, H * d)
 
 
-def _local_attention(m, q, k, v, size_2d):
-    """MultiheadLocalAttentionV2 core (attention.py:308-376): q, k, v [N, C] of the current / previous frame."""
+def _per_sample(p, B):
+    """a per-head parameter [H, a, b] as the [B * H, a, b] operand of a batched product (the gradient sums over the samples)."""
+    return p if B == 1 else p.unsqueeze(0).expand(B, *p.shape).reshape(B * p.shape[0], *p.shape[1:])
+
+
+def _attention(q, k, v, H, scale, B):
+    """softmax((q / scale) k^T) v per sample and head (attention.py:82-117): q [B * N, C], k / v [B * T, C] -> [B * N, C]."""
+    s = T.matmul(_heads(q / scale, H, B), _heads(k, H, B).transpose(1, 2))       # [B H, N, T]
+    return _unheads(T.matmul(T.softmax_rows(s), _heads(v, H, B)), H, B)
+
+
+def _local_attention(m, q, k, v, size_2d, B):
+    """MultiheadLocalAttentionV2 core (attention.py:308-376): q, k, v [B * N, C] of the current / previous frame."""
     h, w = size_2d
     H, d, R = m.num_head, m.hidden_dim, m.max_dis
-    n, c = q.shape
     W2 = m.window_size * m.window_size
-    qh = _heads(q, H)                                                          # UNSCALED q for the relative-position term (:327)
-    rel = T.matmul(qh, m.relative_emb_k.weight.view(H, W2, d).transpose(1, 2)) + m.relative_emb_k.bias.view(H, 1, W2)
-    dense = T.matmul(_heads(q / m.T, H), _heads(k, H).transpose(1, 2))         # [H, N, N]
+    qh = _heads(q, H, B)                                                        # UNSCALED q for the relative-position term (:327)
+    rel = T.matmul(qh, _per_sample(m.relative_emb_k.weight.view(H, W2, d).transpose(1, 2), B))
+    rel = (rel.view(B, H, -1, W2) + m.relative_emb_k.bias.view(1, H, 1, W2)).view(B * H, -1, W2)
+    dense = T.matmul(_heads(q / m.T, H, B), _heads(k, H, B).transpose(1, 2))     # [B H, N, N]
     s = T.window_gather(dense, h, w, R, float('-inf')) + rel                   # outside the image: -inf (the reference's -1e8)
-    a = T.softmax_rows(s)                                                      # [H, N, 225]
-    o = T.matmul(T.window_scatter(a, h, w, R, 0.0), _heads(v, H)) + T.matmul(a, m.relative_emb_v.transpose(1, 2))
-    return o.permute(1, 0, 2).reshape(n, c)
+    a = T.softmax_rows(s)                                                      # [B H, N, 225]
+    o = T.matmul(T.window_scatter(a, h, w, R, 0.0), _heads(v, H, B)) + T.matmul(a, _per_sample(m.relative_emb_v.transpose(1, 2), B))
+    return _unheads(o, H, B)
 
 
-def _gated_tail(m, agg, u, size_2d):
+def _gated_tail(m, agg, u, size_2d, B):
     """(agg * u) -> depthwise 5x5 -> projection (attention.py:707-710, 855-860)."""
     h, w = size_2d
     x = agg * u
-    x, _, _ = T.dwconv2d(x, m.dw_conv.conv.weight, 1, h, w, 1, 2, 1)
-    x = _dropout2d(x, getattr(m.dw_conv, 'dropout_p', 0.), m.training)
+    x, _, _ = T.dwconv2d(x, m.dw_conv.conv.weight, B, h, w, 1, 2, 1)
+    x = _dropout2d(x, m.dw_conv.dropout_p, m.training, B)
     return T.linear(x, m.projection.weight, m.projection.bias)
 
 
-def _gated_global(m, q, k, v, u, size_2d):
-    """GatedPropagation core (attention.py:672-710), single head: q, k [., 128], v [T, E], u [N, E]."""
-    s = T.matmul((q / m.T).unsqueeze(0), k.t().unsqueeze(0))                   # [1, N, T]
-    p = T.softmax_rows(s)
-    agg = T.matmul(p, v.unsqueeze(0))[0]
-    return _gated_tail(m, agg, u, size_2d)
+def _gated_global(m, q, k, v, u, size_2d, B):
+    """GatedPropagation core (attention.py:672-710), single head: q [B * N, 128], k [B * T, 128], v [B * T, E], u [B * N, E]."""
+    s = T.matmul((q / m.T).view(B, -1, q.shape[1]), k.view(B, -1, k.shape[1]).transpose(1, 2))       # [B, N, T]
+    agg = T.matmul(T.softmax_rows(s), v.view(B, -1, v.shape[1])).reshape(-1, v.shape[1])
+    return _gated_tail(m, agg, u, size_2d, B)
 
 
-def _gated_local(m, q, k, v, u, size_2d):
+def _gated_local(m, q, k, v, u, size_2d, B):
     """LocalGatedPropagation core (attention.py:814-860), single head."""
     h, w = size_2d
     R = m.max_dis
     W2 = m.window_size * m.window_size
-    rel = T.linear(q, m.relative_emb_k.weight.view(W2, -1), m.relative_emb_k.bias).unsqueeze(0)      # unscaled q (:814)
-    dense = T.matmul((q / m.T).unsqueeze(0), k.t().unsqueeze(0))               # [1, N, N]
+    rel = T.linear(q, m.relative_emb_k.weight.view(W2, -1), m.relative_emb_k.bias).view(B, -1, W2)      # unscaled q (:814)
+    dense = T.matmul((q / m.T).view(B, -1, q.shape[1]), k.view(B, -1, k.shape[1]).transpose(1, 2))     # [B, N, N]
     a = T.softmax_rows(T.window_gather(dense, h, w, R, float('-inf')) + rel)
-    agg = T.matmul(T.window_scatter(a, h, w, R, 0.0), v.unsqueeze(0))[0]
-    return _gated_tail(m, agg, u, size_2d)
+    agg = T.matmul(T.window_scatter(a, h, w, R, 0.0), v.view(B, -1, v.shape[1])).reshape(-1, v.shape[1])
+    return _gated_tail(m, agg, u, size_2d, B)
 
 
 # ---- LSTT block (AOT) --------------------------------------------------------------------------------------------------
-def lstt_block(blk, x, long_mem, short_mem, id_emb, pos, size_2d):
-    """LongShortTermTransformerBlock.forward (transformer.py:312-362) on token-major x [N, C].  long_mem / short_mem = (K, V);
+def lstt_block(blk, x, long_mem, short_mem, id_emb, pos, size_2d, B):
+    """LongShortTermTransformerBlock.forward (transformer.py:312-362) on token-major x [B * N, C].  long_mem / short_mem = (K, V);
     id_emb given: the frame memorises itself.  Returns (x, [K, V_normed], [K_g, V_g])."""
     h, w = size_2d
     sa = blk.self_attn
@@ -284,8 +306,8 @@ def lstt_block(blk, x, long_mem, short_mem, id_emb, pos, size_2d):
     q = T.linear(qk, sa.linear_Q.weight, sa.linear_Q.bias)
     k = T.linear(qk, sa.linear_K.weight, sa.linear_K.bias)
     v = T.linear(x1, sa.linear_V.weight, sa.linear_V.bias)
-    o = _attention(q, k, v, sa.num_head, sa.T)
-    x = x + _drop_path(T.linear(o, sa.projection.weight, sa.projection.bias), dp, tr)
+    o = _attention(q, k, v, sa.num_head, sa.T, B)
+    x = x + _drop_path(T.linear(o, sa.projection.weight, sa.projection.bias), dp, tr, B)
     x2 = T.layernorm(x, blk.norm2.weight, blk.norm2.bias)
     qc = T.linear(x2, blk.linear_Q.weight, blk.linear_Q.bias)
     kc, vc = qc, x2
@@ -296,15 +318,15 @@ def lstt_block(blk, x, long_mem, short_mem, id_emb, pos, size_2d):
         kg, vg = long_mem
         kl, vl = short_mem
     lt = blk.long_term_attn
-    a_lt = T.linear(_attention(qc, kg, vg, lt.num_head, lt.T), lt.projection.weight, lt.projection.bias)
+    a_lt = T.linear(_attention(qc, kg, vg, lt.num_head, lt.T, B), lt.projection.weight, lt.projection.bias)
     st = blk.short_term_attn
-    a_st = T.linear(_local_attention(st, qc, kl, vl, size_2d), st.projection.weight, st.projection.bias)
-    x = x + (_drop_path(a_lt + a_st, dp, tr) if blk.droppath_lst else _dropout(a_lt + a_st, blk.lst_dropout_p, tr))     # :350-353
+    a_st = T.linear(_local_attention(st, qc, kl, vl, size_2d, B), st.projection.weight, st.projection.bias)
+    x = x + (_drop_path(a_lt + a_st, dp, tr, B) if blk.droppath_lst else _dropout(a_lt + a_st, blk.lst_dropout_p, tr))     # :350-353
     x3 = T.layernorm(x, blk.norm3.weight, blk.norm3.bias)
     f = T.linear(x3, blk.linear1.weight, blk.linear1.bias)
-    f = T.act(T.groupnorm(f, blk.activation.gn.weight, blk.activation.gn.bias, blk.activation.gn.num_groups), 'gelu')
-    f, _, _ = T.dwconv2d(f, blk.activation.conv.weight, 1, h, w, 1, 2, 1)
-    x = x + _drop_path(T.linear(f, blk.linear2.weight, blk.linear2.bias), dp, tr)
+    f = T.act(T.groupnorm(f, blk.activation.gn.weight, blk.activation.gn.bias, blk.activation.gn.num_groups, B), 'gelu')
+    f, _, _ = T.dwconv2d(f, blk.activation.conv.weight, B, h, w, 1, 2, 1)
+    x = x + _drop_path(T.linear(f, blk.linear2.weight, blk.linear2.bias), dp, tr, B)
     return x, [kc, vc], [kg, vg]
 
 
@@ -320,10 +342,10 @@ def gpm_fuse_id(blk, idv, id_emb):
     return T.act(T.linear(z, blk.linear_ID_V.weight, blk.linear_ID_V.bias), 'silu')
 
 
-def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d):
+def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d, B):
     """GatedPropagationModule.forward (transformer.py:582-657).  Memories = (K, V, ID_V).  Returns (x, x_id, [K, V, ID_V in],
     [K_g, V_g, ID_V_g])."""
-    D, E, da = blk.d_model, blk.expand_d_model, blk.d_att * blk.att_nhead
+    D, da = blk.d_model, blk.d_att * blk.att_nhead
     for m in (blk.self_attn, blk.long_term_attn, blk.short_term_attn):
         _no_attn_dropout(m)
         if m.num_head != 1:
@@ -348,11 +370,11 @@ def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d):
     else:
         kg, vg, idvg = long_mem
         kl, vl, idvl = short_mem
-    lt = _gated_global(blk.long_term_attn, qc, kg, torch.cat([vg, idvg], 1), u, size_2d)
-    st = _gated_local(blk.short_term_attn, qc, kl, torch.cat([vl, idvl], 1), u, size_2d)
+    lt = _gated_global(blk.long_term_attn, qc, kg, torch.cat([vg, idvg], 1), u, size_2d, B)
+    st = _gated_local(blk.short_term_attn, qc, kl, torch.cat([vl, idvl], 1), u, size_2d, B)
     y = lt + st
     if blk.droppath_lst:                                                       # :633-638: the two halves draw separately
-        ya, yb = _drop_path(y[:, :D], dp, tr), _drop_path(y[:, D:], dp, tr)
+        ya, yb = _drop_path(y[:, :D], dp, tr, B), _drop_path(y[:, D:], dp, tr, B)
     else:
         ya, yb = _dropout(y[:, :D], blk.lst_dropout_p, tr), _dropout(y[:, D:], blk.lst_dropout_p, tr)
     x = x + ya
@@ -364,44 +386,45 @@ def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d):
     qk = T.linear(z, sa.linear_QK.weight, sa.linear_QK.bias)
     sv = T.act(torch.cat([T.linear(z1, sa.linear_V1.weight, sa.linear_V1.bias), T.linear(z2, sa.linear_V2.weight, sa.linear_V2.bias)], 1), 'silu')
     su = T.act(torch.cat([T.linear(z1, sa.linear_U1.weight, sa.linear_U1.bias), T.linear(z2, sa.linear_U2.weight, sa.linear_U2.bias)], 1), 'silu')
-    y = _gated_global(sa, qk, qk, sv, su, size_2d)
-    return x + _drop_path(y[:, :D], dp, tr), x_id + _drop_path(y[:, D:], dp, tr), [kc, vc, idvc], [kg, vg, idvg]
+    y = _gated_global(sa, qk, qk, sv, su, size_2d, B)
+    return x + _drop_path(y[:, :D], dp, tr, B), x_id + _drop_path(y[:, D:], dp, tr, B), [kc, vc, idvc], [kg, vg, idvg]
 
 
 # ---- decoder -----------------------------------------------------------------------------------------------------------
-def fpn_decoder(dec, x_in, shortcuts, size_2d):
-    """FPNSegmentationHead.forward (fpn.py:34-58): x_in [N16, in_dim], shortcuts = [(f4, h, w), (f8, h, w), (f16, h, w)] ->
-    logits [h4*w4, out_dim], h4, w4."""
+def fpn_decoder(dec, x_in, shortcuts, size_2d, B):
+    """FPNSegmentationHead.forward (fpn.py:34-58): x_in [B * N16, in_dim], shortcuts = [(f4, h, w), (f8, h, w), (f16, h, w)] ->
+    logits [B * h4 * w4, out_dim], h4, w4."""
     (s4, h4, w4), (s8, h8, w8), (s16, h16, w16) = shortcuts
 
     def cgn(m, x, hh, ww):      # ConvGN (basic.py:75-85) + ReLU
         k = m.conv.kernel_size[0]
-        y, _, _ = T.conv2d(x, m.conv.weight, m.conv.bias, 1, hh, ww, 1, k // 2, 1)
-        return T.act(T.groupnorm(y, m.gn.weight, m.gn.bias, m.gn.num_groups), 'relu')
+        y, _, _ = T.conv2d(x, m.conv.weight, m.conv.bias, B, hh, ww, 1, k // 2, 1)
+        return T.act(T.groupnorm(y, m.gn.weight, m.gn.bias, m.gn.num_groups, B), 'relu')
 
     def adapter(m, s, hh, ww):
-        return T.conv2d(s, m.weight, m.bias, 1, hh, ww)[0]
+        return T.conv2d(s, m.weight, m.bias, B, hh, ww)[0]
     x = cgn(dec.conv_in, x_in, h16, w16) + adapter(dec.adapter_16x, s16, h16, w16)
     x = cgn(dec.conv_16x, x, h16, w16)
-    x = T.bilinear(x, 1, h16, w16, h8, w8, dec.align_corners) + adapter(dec.adapter_8x, s8, h8, w8)
+    x = T.bilinear(x, B, h16, w16, h8, w8, dec.align_corners) + adapter(dec.adapter_8x, s8, h8, w8)
     x = cgn(dec.conv_8x, x, h8, w8)
-    x = T.bilinear(x, 1, h8, w8, h4, w4, dec.align_corners) + adapter(dec.adapter_4x, s4, h4, w4)
+    x = T.bilinear(x, B, h8, w8, h4, w4, dec.align_corners) + adapter(dec.adapter_4x, s4, h4, w4)
     x = cgn(dec.conv_4x, x, h4, w4)
-    return T.conv2d(x, dec.conv_out.weight, dec.conv_out.bias, 1, h4, w4)[0], h4, w4
+    return T.conv2d(x, dec.conv_out.weight, dec.conv_out.bias, B, h4, w4)[0], h4, w4
 
 
-# ---- one clip's recurrence ---------------------------------------------------------------------------------------------
+# ---- the clips of a batch, frame by frame ----------------------------------------------------------------------------------
 class ClipGraph:
-    """The frame recurrence of one sample (aot_engine.py:188-354 under autograd): memories are graph tensors, the long-term
-    bank is the concatenation of the memorised frames."""
+    """The frame recurrence of B clips at once (aot_engine.py:188-354 under autograd): memories are graph tensors, the
+    long-term bank of a sample is the concatenation of its memorised frames."""
 
-    def __init__(self, model, long_term_mem_gap=9999):
+    def __init__(self, model, batch, long_term_mem_gap=9999):
         self.m = model
+        self.B = int(batch)
         self.deaot = isinstance(model.LSTT, DualBranchGPM)
         self.gap = long_term_mem_gap
         self.frame_step = 0
         self.last_mem_step = -1
-        self.long = None           # per layer: list of per-frame memories (concatenated at use)
+        self.long = None           # per layer: list over the memorised frames of per-frame memories ([B * N, .] each)
         self.short = None
         self.curr = None
         self.pos = None
@@ -412,23 +435,28 @@ class ClipGraph:
     def _encode(self, img):
         self.feats, (top, h, w) = encoder_features(self.m.encoder, img)
         proj = self.m.encoder_projector
-        x16 = T.conv2d(top, proj.weight, proj.bias, 1, h, w)[0]
+        x16 = T.conv2d(top, proj.weight, proj.bias, self.B, h, w)[0]
         if self.size_2d is None:
             self.size_2d = (h, w)
             with torch.no_grad():
                 pe = self.m.get_pos_emb(torch.zeros(1, x16.shape[1], h, w, device=img.device))
-            self.pos = pe[0].permute(1, 2, 0).reshape(h * w, -1).contiguous()
+            self.pos = pe[0].permute(1, 2, 0).reshape(h * w, -1).repeat(self.B, 1).contiguous()
         return x16
 
     def id_emb(self, one_hot):
-        """one-hot or probability map [1, L, H, W] -> identity embedding [N, C] (aot.py:76-79, deaot.py:51-55)."""
+        """one-hot or probability maps [B, L, H, W] -> identity embedding [B * N, C] (aot.py:76-79, deaot.py:51-55)."""
         bank = self.m.patch_wise_id_bank
         H, W = one_hot.shape[-2:]
-        x = T.to_nhwc(one_hot.float(), (one_hot.shape[1] + 3) // 4 * 4)
-        e, _, _ = T.conv2d(x, bank.weight, bank.bias, 1, H, W, bank.stride[0], bank.padding[0], 1)
+        x = _maps_nhwc(one_hot, (one_hot.shape[1] + 3) // 4 * 4)
+        e, _, _ = T.conv2d(x, bank.weight, bank.bias, self.B, H, W, bank.stride[0], bank.padding[0], 1)
         if self.deaot:
             e = T.layernorm(e, self.m.id_norm.weight, self.m.id_norm.bias)
         return _dropout(e, self.m.id_dropout_p, self.m.training)
+
+    def _bank(self, i):
+        """The long-term memory of layer i: per component, the samples' memorised frames side by side ([B * T, .])."""
+        B = self.B
+        return [torch.cat([t.view(B, -1, t.shape[1]) for t in comp], 1).reshape(-1, comp[0].shape[1]) for comp in zip(*self.long[i])]
 
     def _lstt(self, x16, id_emb):
         """LongShortTermTransformer.forward / DualBranchGPM.forward (transformer.py:94-140, 205-255) and the decoder's input
@@ -441,20 +469,20 @@ class ClipGraph:
         curr, new_long, outs = [], [], []
         x_id = None
         for i, blk in enumerate(layers):
-            long_m = None if ref else [torch.cat(t, 0) for t in zip(*self.long[i])]
+            long_m = None if ref else self._bank(i)
             short_m = None if ref else self.short[i]
             if self.deaot:
-                x, x_id, c, g = gpm_block(blk, x, x_id, long_m, short_m, id_emb, self.size_2d)
+                x, x_id, c, g = gpm_block(blk, x, x_id, long_m, short_m, id_emb, self.size_2d, self.B)
                 outs.append(torch.cat([x, x_id], 1))
             else:
-                x, c, g = lstt_block(blk, x, long_m, short_m, id_emb, self.pos, self.size_2d)
+                x, c, g = lstt_block(blk, x, long_m, short_m, id_emb, self.pos, self.size_2d, self.B)
                 outs.append(x)
             curr.append(c)
             new_long.append(g)
 
         def norm(n, t):
             if self.deaot:
-                return T.groupnorm(t, n.gn.weight, n.gn.bias, n.gn.num_groups)
+                return T.groupnorm(t, n.gn.weight, n.gn.bias, n.gn.num_groups, self.B)
             return T.layernorm(t, n.weight, n.bias)
         if stack.decoder_norms is not None:
             if stack.final_norm:
@@ -484,14 +512,12 @@ class ClipGraph:
         self.frame_step += 1
         self._lstt(self._encode(img), None)
 
-    def decode_logits(self, out_size, obj_num):
-        """decode_current_logits (aot_engine.py:356-380): stride-4 logits -> output size, [1, L, H, W]; the channels of unused
-        identities are constants (-1e10) that carry no gradient."""
-        logits, h4, w4 = fpn_decoder(self.m.decoder, self.dec_in, self.feats, self.size_2d)
+    def decode_logits(self, out_size):
+        """decode_current_logits (aot_engine.py:356-380): stride-4 logits -> output size; token-major [B * H * W, L]."""
+        logits, h4, w4 = fpn_decoder(self.m.decoder, self.dec_in, self.feats, self.size_2d, self.B)
         L = logits.shape[1]
         lp = F.pad(logits, (0, (L + 3) // 4 * 4 - L))
-        up = T.bilinear(lp, 1, h4, w4, out_size[0], out_size[1], self.m.cfg.MODEL_ALIGN_CORNERS)[:, :L]
-        return T.to_nchw(up, out_size[0], out_size[1])
+        return T.bilinear(lp, self.B, h4, w4, out_size[0], out_size[1], self.m.cfg.MODEL_ALIGN_CORNERS)[:, :L]
 
     def update_memory(self, one_hot):
         """update_short_term_memory (aot_engine.py:307-338 / deaot_engine.py:20-56) with the frame's identity embedding."""
@@ -527,47 +553,59 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
     n_aux = 2 if enable_prev_frame else 1
     frames = all_frames.view(T_, bs, *all_frames.shape[1:])
     masks = all_masks.view(T_, bs, *all_masks.shape[1:]).float()
+    size = tuple(masks.shape[-2:])
+    HW = size[0] * size[1]
     losses = [[None] * bs for _ in range(T_)]
     preds = [[None] * bs for _ in range(T_)]
-    for b in range(bs):
-        clip = ClipGraph(model, engine.long_term_mem_gap)
-        objs = int(obj_nums[b])
-        perm = engine.id_shuffle[b] if engine.enable_id_shuffle else None       # identity o is moved to channel perm[o]
-        inv = None if perm is None else torch.argsort(perm)
+    clip = ClipGraph(model, bs, engine.long_term_mem_gap)
+    objs = [int(n) for n in obj_nums]
+    # identity o of sample b is moved to channel perm[b][o] (trainer.py:457; reversed on the logits, aot_engine.py:364-367)
+    perms = engine.id_shuffle if engine.enable_id_shuffle else [None] * bs
+    invs = [None if p is None else torch.argsort(p) for p in perms]
 
-        def ident(m):           # what assign_identity sees (aot_engine.py:168-179): the (shuffled) one-hot / probability map
+    def ident(maps):
+        """what assign_identity sees (aot_engine.py:168-179): per sample the (shuffled) one-hot / probability map -> [bs, L, H, W]"""
+        out = []
+        for b, m in enumerate(maps):
             oh = m if m.shape[1] == L else one_hot(m, model.max_obj_num)
-            return oh if perm is None else oh[:, inv]
+            out.append(oh if invs[b] is None else oh[:, invs[b]])
+        return torch.cat(out, 0)
 
-        def score(t):
+    def score(t):
+        """generate_loss_mask (aot_engine.py:398-430) of frame t: per sample, shuffled identities back in place, the channels of
+        unused identities at -1e10 (constants: no gradient), loss on the first objs + 1 channels, prediction / probabilities."""
+        lg_all = clip.decode_logits(size)
+        feedback = []
+        for b in range(bs):
             gt = masks[t, b:b + 1]
-            size = tuple(gt.shape[-2:])
-            lg = clip.decode_logits(size, objs)
-            if perm is not None:
-                lg = lg[:, perm]
-            lg = torch.cat([lg[:, :objs + 1], torch.full_like(lg[:, objs + 1:], -1e10)], 1)
-            scored = [lg[:, :objs + 1].contiguous()]
+            lg = lg_all[b * HW:(b + 1) * HW]
+            if perms[b] is not None:
+                lg = lg[:, perms[b]]
+            lg = torch.cat([lg[:, :objs[b] + 1], lg.new_full((HW, L - objs[b] - 1), -1e10)], 1)
+            scored = [T.to_nchw(lg[:, :objs[b] + 1], *size)]
             label = [gt.view(1, *size)]
             loss = 0
             for fn, wgt in zip(engine.losses, engine.loss_weights):
                 loss = loss + wgt * fn(scored, label, step)
             losses[t][b] = loss
-            preds[t][b] = lg.detach().argmax(1)
-            return torch.softmax(lg, 1) if use_prev_prob else preds[t][b].view(1, 1, *size).float()
+            preds[t][b] = lg.detach().argmax(1).view(1, *size)
+            feedback.append(T.to_nchw(T.softmax_rows(lg), *size) if use_prev_prob else preds[t][b].view(1, 1, *size).float())
+        return feedback
 
-        clip.add_reference_frame(frames[0, b:b + 1], ident(masks[0, b:b + 1]), frame_step=0)
-        score(0)
-        t = 1
-        if enable_prev_frame:
-            clip.add_reference_frame(frames[1, b:b + 1], ident(masks[1, b:b + 1]), frame_step=1)
-            score(1)
-            t = 2
-        while t < T_:
-            clip.match_propogate_one_frame(frames[t, b:b + 1])
-            pred = score(t)
-            if t < T_ - 1:
-                clip.update_memory(ident(pred if use_prev_pred else masks[t, b:b + 1]))
-            t += 1
+    truth = lambda t: [masks[t, b:b + 1] for b in range(bs)]
+    clip.add_reference_frame(frames[0], ident(truth(0)), frame_step=0)
+    score(0)
+    t = 1
+    if enable_prev_frame:
+        clip.add_reference_frame(frames[1], ident(truth(1)), frame_step=1)
+        score(1)
+        t = 2
+    while t < T_:
+        clip.match_propogate_one_frame(frames[t])
+        pred = score(t)
+        if t < T_ - 1:
+            clip.update_memory(ident(pred if use_prev_pred else truth(t)))
+        t += 1
     frame_loss = [torch.cat(l, 0) for l in losses]
     frame_mask = [torch.cat(m, 0) for m in preds]
     aux_loss = torch.cat(frame_loss[:n_aux], 0).mean(0)

@@ -143,6 +143,24 @@ def test_window_gather_and_scatter(T):
     _check('window_gather big', lambda t: T.window_gather(t[0], h, w, R, 0.0), lambda t: S.window_gather(t[0], h, w, R, 0.0), [d])
 
 
+def test_batched_maps(T):
+    """B = 2 maps per launch (the samples of a training batch are lanes): convolution through im2col / col2im, depthwise
+    convolution, GroupNorm (statistics per sample and group), bilinear resize -- value and every gradient."""
+    B, H, W = 2, 17, 21
+    x, w, b = _r(B * H * W, 64), _r(48, 64, 3, 3, seed=1, scale=0.1), _r(48, seed=2)
+    _check('conv2d B=2', lambda t: T.conv2d(t[0], t[1], t[2], B, H, W, 1, 1, 1)[0], lambda t: S.conv2d(t[0], t[1], t[2], B, H, W, 1, 1, 1)[0],
+           [x, w, b])
+    x, w = _r(B * H * W, 96), _r(96, 1, 5, 5, seed=3)
+    _check('dwconv2d B=2', lambda t: T.dwconv2d(t[0], t[1], B, H, W, 1, 2, 1)[0], lambda t: S.dwconv2d(t[0], t[1], B, H, W, 1, 2, 1)[0], [x, w])
+    x, g, bt = _r(B * 437, 256, scale=2.0, seed=4), _r(256, seed=5), _r(256, seed=6)
+    x = (x.detach() + torch.arange(B, device='cuda').repeat_interleave(437).view(-1, 1) * 3.0).requires_grad_(True)   # distinct statistics
+    _check('groupnorm B=2', lambda t: T.groupnorm(t[0], t[1], t[2], 8, B), lambda t: S.groupnorm(t[0], t[1], t[2], 8, B), [x, g, bt], tol=5e-5)
+    x = _r(B * 9 * 11, 128, seed=7)
+    _check('bilinear B=2', lambda t: T.bilinear(t[0], B, 9, 11, 17, 21, True), lambda t: S.bilinear(t[0], B, 9, 11, 17, 21, True), [x])
+    d = _r(B * 8, 9 * 11, 9 * 11, seed=8)
+    _check('window_gather G=16', lambda t: T.window_gather(t[0], 9, 11, 7, 0.0), lambda t: S.window_gather(t[0], 9, 11, 7, 0.0), [d])
+
+
 def test_layout_changes(T):
     x = _r(33 * 41, 12)
     _check('to_nchw', lambda t: T.to_nchw(t[0], 33, 41), lambda t: S.to_nchw(t[0], 33, 41), [x])
