@@ -306,27 +306,30 @@ __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const float* __restr
   }
 }
 
-// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy over R rows of [R, C]: one workgroup per 64 channels, 4 row slices,
-// fp64 partials in fixed order
+// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy over R rows of [R, C]: one workgroup per 16 channels (so that a few hundred
+// channels already make a few dozen workgroups), 16 row slices, fp64 partials summed in fixed order
 __global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
                                                                int C) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[2][16][16];
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (long r = part; r < R; r += 4) {
+    for (long r = part; r < R; r += 16) {
       const float g = dy[r * C + c];
       a += (double)g * xhat[r * C + c];
       b += g;
     }
-  red[0][part][threadIdx.x & 63] = a;
-  red[1][part][threadIdx.x & 63] = b;
+  red[0][part][cl] = a;
+  red[1][part][cl] = b;
   __syncthreads();
   if (part == 0 && c < C) {
-    const int l = threadIdx.x;
-    dgamma[c] = (float)(((red[0][0][l] + red[0][1][l]) + red[0][2][l]) + red[0][3][l]);
-    dbeta[c] = (float)(((red[1][0][l] + red[1][1][l]) + red[1][2][l]) + red[1][3][l]);
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { sa += red[0][q][cl]; sb += red[1][q][cl]; }
+    dgamma[c] = (float)sa;
+    dbeta[c] = (float)sb;
   }
 }
 
@@ -569,7 +572,7 @@ extern "C" int aot_groupnorm_bwd_f32(const float* x, const float* dy, const doub
 extern "C" int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C,
                                         void* stream) {
   if (!dy || !xhat || !dgamma || !dbeta || R <= 0 || C <= 0) return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C);
+  hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C);
   AOT_LAUNCH_CHECK();
 }
 

@@ -3,8 +3,10 @@
 ATen ops (networks/engines/aot_engine.py:33-108 under loss.backward(), trainer.py:460-519); here every node of the
 graph is one of the few primitives below, each with a hand-written backward:
 
-    matmul      C = alpha * A . B (+ bias) on arbitrarily strided 3-D views (nn.Linear, 1x1 convs, QK^T, PV and -- on
-                transposed views -- every one of their gradients)
+    matmul      C = alpha * A . B (+ bias) on arbitrarily strided 3-D views (QK^T, PV, the relative-position products and -- on
+                transposed views -- every one of their gradients; small or odd-shaped linears)
+    linear      nn.Linear / 1x1 convs / the matmul half of KxK convs: forward, dgrad and wgrad on the LDS-direct fp32 GEMM kernels
+                of the inference path (aot_conv2d_nhwc_f32)
     im2col      KxK convolutions = im2col + matmul (adjoint: col2im)
     dwconv2d    depthwise KxK
     act, layernorm, groupnorm, softmax_rows, bilinear, window_gather / window_scatter, to_nchw, maxpool3x3s2 (forward only)
@@ -73,8 +75,78 @@ def matmul(a, b, bias=None, alpha=1.0):
     return _Matmul.apply(a, b, bias, alpha)
 
 
+# ---- nn.Linear on the LDS-direct GEMM kernels ---------------------------------------------------------------------------------
+# y = x W^T + b, dx = dy W, dW = dy^T x are plain row-major GEMMs: they run on the fp32 tile kernels of the inference path
+# (aot_conv2d_nhwc_f32, csrc/gemm_lds.hip: both operands by LDS-DMA) instead of the strided general kernel whenever the shapes allow
+# it.  That entry takes the second operand twice -- k-major [K, N] for its general kernels and as k-contiguous rows [N, K] for the
+# tile kernel -- so: forward = (W^T copy, W), dgrad = (W, the same W^T copy), wgrad = (x, x^T) with dy^T as the first operand and the
+# row count (the reduction length) zero-padded to the split-K granule; bias gradient = column sums (aot_norm_param_grads_f32).
+_LEAN_MIN_ROWS = 64
+
+
+def _lean_ok(M, K, N):
+    return M >= _LEAN_MIN_ROWS and K % 32 == 0 and N % 4 == 0 and N > 32
+
+
+def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1):
+    """a [M, K] @ w_kn [K, N] (+ bias) with w_nk = w_kn^T; ks > 1: split-K through a scratch slab (K / 32 divisible by ks)."""
+    M, K = a.shape
+    N = w_kn.shape[1]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(ks * M * N, dtype=torch.float32, device=a.device) if ks > 1 else None
+    aot_hip.conv2d_cfg(a, w_kn, bias, out, 1, M, K, 1, M, N, cfg=-2 if ks == 1 else 196 + ks, wt=w_nk, scratch=scratch)
+    return out
+
+
+def _colsum(x):
+    """column sums of x [R, C] (fp64 partials, fixed order)."""
+    R, C = x.shape
+    dg, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+    _chk(load().aot_norm_param_grads_f32(_dev(x), _dev(x), _dev(dg), _dev(db), R, C, stream_ptr()), 'aot_norm_param_grads_f32')
+    return db
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _f32c(x), _f32c(weight)
+        w_kn = weight.t().contiguous()
+        ctx.save_for_backward(x, weight, w_kn)
+        ctx.has_bias = bias is not None
+        return _gemm_lean(x, w_kn, weight, _f32c(bias) if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, w_kn = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, K = x.shape
+        N = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if _lean_ok(M, N, K):
+                dx = _gemm_lean(dy, weight, w_kn)                                     # dy [M, N] . W [N, K]
+            else:
+                dx = _matmul_raw(dy.unsqueeze(0), weight.unsqueeze(0))[0]
+        if ctx.needs_input_grad[1]:
+            ks = max(1, min(15, 256 // max(1, -(-N // 64) * -(-K // 64))))              # enough workgroups for 256 CUs
+            Mp = -(-M // (32 * ks)) * (32 * ks)
+            if M >= 1024 and _lean_ok(N, Mp, K) and (Mp // 32) % ks == 0:
+                dyt = torch.zeros(N, Mp, dtype=torch.float32, device=dy.device)
+                dyt[:, :M] = dy.t()
+                xp = x if Mp == M else torch.cat([x, torch.zeros(Mp - M, K, dtype=torch.float32, device=x.device)], 0)
+                dw = _gemm_lean(dyt, xp, xp.t().contiguous(), ks=ks)                 # dy^T [N, M] . x [M, K]
+            else:
+                dw = _matmul_raw(dy.t().unsqueeze(0), x.unsqueeze(0))[0]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy)
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None):
     """nn.Linear on token-major x [M, in]: weight [out, in] as the parameter holds it."""
+    M, K = x.shape
+    if _lean_ok(M, K, weight.shape[0]):
+        return _Linear.apply(x, weight, bias)
     return matmul(x.unsqueeze(0), weight.t().unsqueeze(0), bias)[0]
 
 

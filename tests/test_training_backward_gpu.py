@@ -72,6 +72,19 @@ def test_matmul_on_strided_views(T):
     _check('small odd', lambda t: T.matmul(t[0], t[1]), lambda t: S.matmul(t[0], t[1]), [a1, b1])
 
 
+@pytest.mark.parametrize('M,K,N', [(437, 256, 96), (5000, 1152, 128), (3000, 256, 1024), (1674, 1024, 256), (2100, 64, 48),
+                                   (437, 100, 96), (40, 256, 96), (2000, 256, 11)])
+def test_linear_on_the_tile_kernels(T, M, K, N):
+    """nn.Linear: forward, dgrad and wgrad on the LDS-direct fp32 GEMM kernels of the inference path (split-K wgrad with the row
+    count zero-padded to the granule; column-sum bias gradient) where the shapes allow, the strided general kernel elsewhere
+    (K not a multiple of 32, few rows, a narrow output)."""
+    x, w, b = _r(M, K), _r(N, K, seed=1, scale=0.2), _r(N, seed=2)
+    _check('linear %dx%dx%d' % (M, K, N), lambda t: T.linear(*t), lambda t: S.linear(*t), [x, w, b], tol=3e-5)
+    xs = _r(M, K + 32, seed=3)                      # a column slice of a wider buffer as the input
+    _check('linear on a slice', lambda t: T.linear(t[0][:, 16:16 + K], t[1], None), lambda t: S.linear(t[0][:, 16:16 + K], t[1], None),
+           [xs, w], tol=3e-5)
+
+
 @pytest.mark.parametrize('geom', [
     # (H, W, Cin of the map, Cin of the weight, Cout, K, stride, pad, dil)
     (33, 41, 4, 3, 32, 3, 2, 1, 1),         # stem: image padded 3 -> 4 channels
