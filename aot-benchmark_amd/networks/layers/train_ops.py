@@ -32,13 +32,25 @@ def _f32c(t):
 
 # ---- matmul ------------------------------------------------------------------------------------------------------------
 def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
-    """a [bt, m, k], b [bt, k, n]: any strides (views welcome) -> contiguous [bt, m, n]."""
+    """a [bt, m, k], b [bt, k, n]: any strides (views welcome) -> contiguous [bt, m, n].  A few large matrices (the gated
+    propagation's QK^T / PV and their gradients: one per sample) go to the LDS-direct GEMM kernels, the reduction length
+    zero-padded to a multiple of 32; everything else -- many small matrices per head / window, odd widths -- to the strided kernel."""
     bt, m, k = a.shape
     n = b.shape[2]
     if b.shape[0] != bt or b.shape[1] != k:
         raise aot_hip.AotHipError('matmul shapes %s x %s' % (tuple(a.shape), tuple(b.shape)))
     if a.dtype != torch.float32 or b.dtype != torch.float32:
         raise aot_hip.AotHipError('matmul operands must be float32')
+    if out is None and alpha == 1.0 and bt <= 4 and k >= 64 and _lean_ok(m, 32, n) and 2.0 * m * n * k >= 2e8:
+        kp = -(-k // 32) * 32
+        res = []
+        for i in range(bt):
+            ai, bi = a[i], b[i]
+            if kp != k:
+                ai = torch.nn.functional.pad(ai, (0, kp - k))
+                bi = torch.nn.functional.pad(bi, (0, 0, 0, kp - k))
+            res.append(_gemm_lean(ai.contiguous(), bi.contiguous(), bi.t().contiguous(), bias))
+        return res[0].unsqueeze(0) if bt == 1 else torch.stack(res)
     c = out if out is not None else torch.empty(bt, m, n, dtype=torch.float32, device=a.device)
     sa, sb = a.stride(), b.stride()
     _chk(load().aot_matmul_strided_f32(_dev(a), _dev(b), _opt(bias), _dev(c), bt, m, n, k, sa[0], sa[1], sa[2], sb[0], sb[1],

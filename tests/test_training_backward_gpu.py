@@ -72,6 +72,19 @@ def test_matmul_on_strided_views(T):
     _check('small odd', lambda t: T.matmul(t[0], t[1]), lambda t: S.matmul(t[0], t[1]), [a1, b1])
 
 
+def test_matmul_few_large_matrices_on_the_tile_kernels(T):
+    """The gated propagation's products, one matrix per sample (QK^T with the keys as a transposed view, PV, a reduction length that
+    is no multiple of 32) and their gradients: the LDS-direct GEMM path of matmul()."""
+    B, N, Tk = 2, 900, 2 * 900 + 37
+    q, k = _r(B, N, 128), _r(B, Tk, 128, seed=1)
+    _check('gated qk^t', lambda t: T.matmul(t[0], t[1].transpose(1, 2)), lambda t: S.matmul(t[0], t[1].transpose(1, 2)), [q, k], tol=3e-5)
+    p, v = _r(B, N, Tk, seed=2, scale=0.05), _r(B, Tk, 1024, seed=3)
+    _check('gated pv', lambda t: T.matmul(t[0], t[1]), lambda t: S.matmul(t[0], t[1]), [p, v], tol=3e-5)
+    x, w, b = _r(1, 1674, 3468, seed=4, scale=0.1), _r(256, 3468, seed=5, scale=0.1), _r(256, seed=6)
+    _check('id bank as a matmul', lambda t: T.matmul(t[0], t[1].t().unsqueeze(0), t[2]), lambda t: S.matmul(t[0], t[1].t().unsqueeze(0), t[2]),
+           [x, w, b], tol=3e-5)
+
+
 @pytest.mark.parametrize('M,K,N', [(437, 256, 96), (5000, 1152, 128), (3000, 256, 1024), (1674, 1024, 256), (2100, 64, 48),
                                    (437, 100, 96), (40, 256, 96), (2000, 256, 11)])
 def test_linear_on_the_tile_kernels(T, M, K, N):
