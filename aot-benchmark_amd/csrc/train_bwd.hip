@@ -306,17 +306,17 @@ __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const float* __restr
   }
 }
 
-// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy over R rows of [R, C]: one workgroup per 16 channels (so that a few hundred
-// channels already make a few dozen workgroups), 16 row slices, fp64 partials summed in fixed order
+// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy over R rows of [R, C]: one workgroup per 8 channels (a few hundred channels
+// already make a few dozen workgroups), 32 row slices, fp64 partials summed in fixed order
 __global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
                                                                int C) {
-  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  __shared__ double red[2][32][8];
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (long r = part; r < R; r += 16) {
+    for (long r = part; r < R; r += 32) {
       const float g = dy[r * C + c];
       a += (double)g * xhat[r * C + c];
       b += g;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* __re
   if (part == 0 && c < C) {
     double sa = 0.0, sb = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { sa += red[0][q][cl]; sb += red[1][q][cl]; }
+    for (int q = 0; q < 32; ++q) { sa += red[0][q][cl]; sb += red[1][q][cl]; }
     dgamma[c] = (float)sa;
     dbeta[c] = (float)sb;
   }
@@ -572,7 +572,7 @@ extern "C" int aot_groupnorm_bwd_f32(const float* x, const float* dy, const doub
 extern "C" int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C,
                                         void* stream) {
   if (!dy || !xhat || !dgamma || !dbeta || R <= 0 || C <= 0) return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C);
+  hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C);
   AOT_LAUNCH_CHECK();
 }
 

@@ -32,8 +32,8 @@ class AdamW:
         if not grads:
             return 0.0, 1.0
         acc = torch.zeros(1, dtype=torch.float64, device=grads[0].device)
-        for gr in grads:
-            aot_hip.sumsq_accum(gr.contiguous(), acc)
+        # one launch over all gradients laid end to end (a launch per tensor was ~5 % of a training step's kernel time)
+        aot_hip.sumsq_accum(torch.cat([gr.reshape(-1) for gr in grads]) if len(grads) > 1 else grads[0].contiguous(), acc)
         total = float(acc.item()) ** 0.5
         return total, min(1.0, max_norm / (total + 1e-6))
 
