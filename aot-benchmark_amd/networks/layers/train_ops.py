@@ -41,15 +41,21 @@ def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
         raise aot_hip.AotHipError('matmul shapes %s x %s' % (tuple(a.shape), tuple(b.shape)))
     if a.dtype != torch.float32 or b.dtype != torch.float32:
         raise aot_hip.AotHipError('matmul operands must be float32')
-    if out is None and alpha == 1.0 and bt <= 4 and k >= 64 and _lean_ok(m, 32, n) and 2.0 * m * n * k >= 2e8:
-        kp = -(-k // 32) * 32
+    if out is None and alpha == 1.0 and bt <= 4 and (k >= 64 or n > 32) and 2.0 * m * n * k >= 5e7:
+        # zero-padding makes any shape fit the tile kernels: the reduction length to the split-K granule, a narrow output (the
+        # decoder's 11 logits) to 64 columns; long reductions into few output tiles (weight gradients) are split over K
+        tiles = -(-m // 64) * -(-max(n, 64) // 64)
+        ks = max(1, min(15, 256 // tiles)) if k >= 4096 else 1
+        kp = -(-k // (32 * ks)) * (32 * ks)
+        npad = n if (n % 4 == 0 and n > 32) else max(64, -(-n // 4) * 4)
+        pad = torch.nn.functional.pad
+        bias_p = bias if (bias is None or npad == n) else pad(bias, (0, npad - n))
         res = []
         for i in range(bt):
-            ai, bi = a[i], b[i]
-            if kp != k:
-                ai = torch.nn.functional.pad(ai, (0, kp - k))
-                bi = torch.nn.functional.pad(bi, (0, 0, 0, kp - k))
-            res.append(_gemm_lean(ai.contiguous(), bi.contiguous(), bi.t().contiguous(), bias))
+            ai = a[i] if kp == k else pad(a[i], (0, kp - k))
+            bi = b[i] if (kp == k and npad == n) else pad(b[i], (0, npad - n, 0, kp - k))
+            ci = _gemm_lean(ai.contiguous(), bi.contiguous(), bi.t().contiguous(), bias_p, ks=ks)
+            res.append(ci if npad == n else ci[:, :n].contiguous())
         return res[0].unsqueeze(0) if bt == 1 else torch.stack(res)
     c = out if out is not None else torch.empty(bt, m, n, dtype=torch.float32, device=a.device)
     sa, sb = a.stride(), b.stride()

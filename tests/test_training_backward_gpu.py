@@ -83,6 +83,8 @@ def test_matmul_few_large_matrices_on_the_tile_kernels(T):
     x, w, b = _r(1, 1674, 3468, seed=4, scale=0.1), _r(256, 3468, seed=5, scale=0.1), _r(256, seed=6)
     _check('id bank as a matmul', lambda t: T.matmul(t[0], t[1].t().unsqueeze(0), t[2]), lambda t: S.matmul(t[0], t[1].t().unsqueeze(0), t[2]),
            [x, w, b], tol=3e-5)
+    x, w, b = _r(27378, 128, seed=7), _r(11, 128, seed=8), _r(11, seed=9)       # the decoder's conv_out: narrow output, its weight
+    _check('narrow output', lambda t: T.linear(*t), lambda t: S.linear(*t), [x, w, b], tol=3e-5)      # gradient a long reduction
 
 
 @pytest.mark.parametrize('M,K,N', [(437, 256, 96), (5000, 1152, 128), (3000, 256, 1024), (1674, 1024, 256), (2100, 64, 48),
