@@ -182,17 +182,18 @@ __global__ void __launch_bounds__(256) dwconv_bwd_data_kernel(const float* __res
   *reinterpret_cast<float4*>(dx + idx * 4) = acc;
 }
 
-// dw[(ky, kx)][c] = sum_{b, oy, ox} dy[(b, oy, ox)][c] * x[(b, iy, ix)][c]: one workgroup per (tap, 64 channels), its 4 waves
+// dw[(ky, kx)][c] = sum_{b, oy, ox} dy[(b, oy, ox)][c] * x[(b, iy, ix)][c]: one workgroup per (tap, 16 channels), its 16 thread rows
 // split the output pixels; per-thread fp64 partials, fixed order (deterministic)
 __global__ void __launch_bounds__(256) dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 float* __restrict__ dw, const ColParams p) {
-  const int tap = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int tap = blockIdx.x, c = blockIdx.y * 16 + cl;
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
-  __shared__ double red[4][64];
+  __shared__ double red[16][16];
   double acc = 0.0;
   if (c < p.C) {
     const long npix = (long)p.B * p.OH * p.OW;
-    for (long q = part; q < npix; q += 4) {
+    for (long q = part; q < npix; q += 16) {
       const int ox = (int)(q % p.OW);
       long t = q / p.OW;
       const int oy = (int)(t % p.OH);
@@ -202,10 +203,14 @@ __global__ void __launch_bounds__(256) dwconv_bwd_weight_kernel(const float* __r
       acc += (double)dy[q * p.C + c] * (double)x[(((long)b * p.H + iy) * p.W + ix) * p.C + c];
     }
   }
-  red[part][threadIdx.x & 63] = acc;
+  red[part][cl] = acc;
   __syncthreads();
-  if (part == 0 && c < p.C)
-    dw[(long)tap * p.C + c] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+  if (part == 0 && c < p.C) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][cl];
+    dw[(long)tap * p.C + c] = (float)s;
+  }
 }
 
 // ---- activations ------------------------------------------------------------------------------------------------------
@@ -538,7 +543,7 @@ extern "C" int aot_dwconv2d_bwd_weight_f32(const float* dy, const float* x, floa
                                            int KH, int KW, int stride, int pad, int dil, void* stream) {
   ColParams p;
   if (!dy || !x || !dw || fill_col(p, B, H, W, C, OH, OW, KH, KW, stride, pad, dil)) return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(KH * KW, cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, p);
+  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(KH * KW, cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, p);
   AOT_LAUNCH_CHECK();
 }
 
