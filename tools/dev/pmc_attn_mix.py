@@ -1,7 +1,7 @@
 """The attention launches of one 70-frame clip (bench.py's mix: per propagated frame and layer one self-attention over the
 frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
 rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams).
-    python tools/dev/pmc_attn_mix.py [aot|gated|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel), gated: R50-DeAOTL
+    python tools/dev/pmc_attn_mix.py [aot|aotx6|gated|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel; aotx6: attn_x6_d32_kernel), gated: R50-DeAOTL
     (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel -- fp32 and bf16x6 forms -- at M = 14 (SQ counter passes)
 AOT_HIP_LIB selects a variant build of the library."""
 import sys, os
@@ -48,7 +48,18 @@ if mode == 'm14':
     for _ in range(3):
         d32(14 * N, CAP * N); gated(14 * N, CAP * N); d32_x6(14 * N, CAP * N); gated_x6(14 * N, CAP * N); n += 4
 else:
-    fn = d32 if mode == 'aot' else gated
+    if mode == 'aotx6':                                    # the bf16x6 twin over the same launch mix: the bank appended frame by frame
+        xbank = aot_hip.x6_bank(1, CAP * N, C, 'cuda')
+        for slot in range(14):
+            aot_hip.attention_pack_x6(k[slot * N:(slot + 1) * N], v[slot * N:(slot + 1) * N], xbank, N, slot=slot)
+        sbank = aot_hip.x6_bank(1, N, C, 'cuda')
+        aot_hip.attention_pack_x6(k[:N], v[:N], sbank, N)
+
+        def fn(T, brows):
+            ns = attn_splits(N, H, _planned_len(T, N, brows), wg_waves=4)
+            aot_hip.attention_x6(q, sbank if brows == N else xbank, out, T, H, 32 ** 0.5, part=part if ns > 1 else None, nsplit=ns)
+    else:
+        fn = d32 if mode == 'aot' else gated
     for t in range(1, 70):
         M = 1 + (t - 1) // 5
         for layer in range(3):
