@@ -593,3 +593,41 @@ def test_infer_engine_builds_cohorts_with_every_option(name):
         assert (c.lanes, c.group0, c.first_group, c.long_term_mem_gap, c.short_term_mem_skip, c.long_term_mem_max, c.use_graph) \
             == (3, 1, 1, 5, 2, 4, graph)
     assert DeAOTEngine(model, 0, 7, 1, 3.).layer_loss_scaling_ratio == 3. if name == 'deaott' else True
+
+
+def test_bf16x6_split_arithmetic_emulated():
+    """The arithmetic claim of the bf16x6 kernel family, checked on CPU by emulation: an fp32 number IS the sum of its three
+    truncated bf16 pieces (8 + 8 + 8 significand bits), and an attention product built from the six partial products of order
+    <= 2 of such pieces (each exact in fp32, as in the accumulator of v_mfma_f32_32x32x16_bf16) stays at the level of one fp32
+    rounding of the plain fp32 product: softmax(QK^T)V within 4e-6 of fp64, no worse than 2x plain fp32."""
+    import torch
+
+    def split3(x):
+        pieces, r = [], x.clone()
+        for _ in range(3):
+            hi = (r.view(torch.int32) & -65536).view(torch.float32)
+            pieces.append(hi)
+            r = r - hi
+        assert torch.equal(r, torch.zeros_like(r)), 'three truncated pieces do not exhaust an fp32 number'
+        return pieces
+
+    def matmul6(a, b):          # a [m, k], b [k, n]: the six kept products, smallest first, fp32 accumulation
+        ap, bp = split3(a), split3(b)
+        acc = torch.zeros(a.shape[0], b.shape[1])
+        for i, j in ((1, 1), (0, 2), (2, 0), (0, 1), (1, 0), (0, 0)):
+            acc = acc + (ap[i].double() @ bp[j].double()).float()      # each partial product exact, each sum rounded to fp32
+        return acc
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4096, generator=g) * torch.logspace(-20, 20, 4096)
+    assert torch.equal(sum(split3(x)), x)
+    q, k, v = torch.randn(64, 32, generator=g) * 2, torch.randn(777, 32, generator=g) * 2, torch.randn(777, 32, generator=g)
+    ref = torch.softmax((q.double() / 32 ** 0.5) @ k.double().t(), -1) @ v.double()
+    s6 = matmul6(q / 32 ** 0.5, k.t().contiguous())
+    p6 = torch.exp(s6 - s6.max(1, keepdim=True).values)
+    o6 = matmul6(p6, v) / p6.sum(1, keepdim=True)
+    s32 = (q / 32 ** 0.5) @ k.t()
+    p32 = torch.exp(s32 - s32.max(1, keepdim=True).values)
+    o32 = (p32 @ v) / p32.sum(1, keepdim=True)
+    e6, e32 = float((o6.double() - ref).abs().max()), float((o32.double() - ref).abs().max())
+    assert e6 < 4e-6 and e6 <= 2 * e32 + 1e-7, (e6, e32)
