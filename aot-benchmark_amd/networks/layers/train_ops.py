@@ -41,7 +41,9 @@ def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
         raise aot_hip.AotHipError('matmul shapes %s x %s' % (tuple(a.shape), tuple(b.shape)))
     if a.dtype != torch.float32 or b.dtype != torch.float32:
         raise aot_hip.AotHipError('matmul operands must be float32')
-    if out is None and alpha == 1.0 and bt <= 4 and (k >= 64 or n > 32) and 2.0 * m * n * k >= 5e7:
+    small = lambda r, c: 4 * r * (c + 64) < 2 ** 31           # the tile kernels address an operand with 32-bit byte offsets
+    if out is None and alpha == 1.0 and bt <= 4 and (k >= 64 or n > 32) and 2.0 * m * n * k >= 5e7 and small(m, k) and small(k, n) \
+            and small(m, n):
         # zero-padding makes any shape fit the tile kernels: the reduction length to the split-K granule, a narrow output (the
         # decoder's 11 logits) to 64 columns; long reductions into few output tiles (weight gradients) are split over K
         tiles = -(-m // 64) * -(-max(n, 64) // 64)
@@ -148,7 +150,7 @@ class _Linear(Function):
         if ctx.needs_input_grad[1]:
             ks = max(1, min(15, 256 // max(1, -(-N // 64) * -(-K // 64))))              # enough workgroups for 256 CUs
             Mp = -(-M // (32 * ks)) * (32 * ks)
-            if M >= 1024 and _lean_ok(N, Mp, K) and (Mp // 32) % ks == 0:
+            if M >= 1024 and _lean_ok(N, Mp, K) and (Mp // 32) % ks == 0 and 4 * Mp * max(N, K) < 2 ** 31:
                 dyt = torch.zeros(N, Mp, dtype=torch.float32, device=dy.device)
                 dyt[:, :M] = dy.t()
                 xp = x if Mp == M else torch.cat([x, torch.zeros(Mp - M, K, dtype=torch.float32, device=x.device)], 0)
