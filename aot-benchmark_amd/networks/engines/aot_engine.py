@@ -735,7 +735,12 @@ def _decode(owner, cohorts, output_size):
                 buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
                 r += lg.shape[0]
             logits = buf[:, :parts[0].shape[1]]
-        return _finalize(owner, cohorts, logits, h4, w4, output_size, stream)
+        osz = output_size
+        if osz is None and sum(c.lanes for c in cohorts) > 1:
+            # several object groups, no output size: the reference aggregates the groups' stride-4 logits themselves
+            # (aot_engine.py:565-582, 618-628) -- the same aggregation kernel with the resize an identity
+            osz = (h4, w4)
+        return _finalize(owner, cohorts, logits, h4, w4, osz, stream)
 
     if len(cohorts) == 1 and first.use_graph:
         key = ptr_key('decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
@@ -749,9 +754,7 @@ def _decode(owner, cohorts, output_size):
         g += c.lanes
     if out is not None:
         return out
-    if out4.shape[0] == 1:
-        return out4
-    raise NotImplementedError('stride-4 aggregation of several object groups: pass an output_size')
+    return out4
 
 
 class DeAOTEngine(AOTEngine):

@@ -1362,6 +1362,10 @@ def test_more_than_ten_objects_vs_oracle(hip):
             lg, lo = eng.decode_current_logits(out_size), ora.decode_current_logits(out_size)
             assert lg.shape == lo.shape == (1, 21, 128, 160)       # bg + 10 slots per group (aot_engine.py:577-579)
             _close(lg, lo, 1e-3, 'aggregated logits frame %d' % t)
+            if t == 2:      # no output size: the groups' stride-4 logits aggregated as they are (aot_engine.py:618-623)
+                l4, o4 = eng.decode_current_logits(), ora.decode_current_logits()
+                assert l4.shape == o4.shape == (1, 21, 33, 41)
+                _close(l4, o4, 1e-3, 'stride-4 aggregated logits')
             fb = F.interpolate(torch.argmax(lo, 1, keepdim=True).float(), size=ora.input_size_2d, mode='nearest')
             eng.update_memory(fb.cuda())
             ora.update_memory(fb)
