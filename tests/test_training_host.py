@@ -399,3 +399,33 @@ def test_data_parallel_step_averages_model_gradients_gloo_world2(case):
     # (a parameter no rank has a gradient for -- LSTT.mask_token, unused -- comes out of the all-reduce as zeros)
     check_grads_against_golden(case, {k: torch.from_numpy(v) for k, v in grads.items() if v.any()},
                                np.load(os.path.join(GOLD, 'train_grads.npz')))
+
+
+def test_training_regularisers_draw_per_sample():
+    """The training-time regularisers of the differentiable forward (reference basic.py:46-55,129-148): DropPath drops a SAMPLE's
+    whole branch with probability p and rescales the kept ones by 1 / (1 - p); Dropout2d drops whole channels of a sample; both
+    are identities in eval mode; the stochastic-depth rates follow the reference's rules (constant, or growing linearly over the
+    layers with TRAIN_LSTT_DROPPATH_SCALING; Swin: linspace(0, 0.3) over the blocks of all four stages, frozen blocks 0)."""
+    from networks.models import train_forward as tf
+    from networks.layers.transformer import _droppath_rate
+    torch.manual_seed(0)
+    B, N, C = 64, 5, 8
+    x = torch.ones(B * N, C)
+    assert tf._drop_path(x, 0.3, False, B) is x and tf._dropout2d(x, 0.1, False, B) is x and tf._drop_path(x, 0.0, True, B) is x
+    y = tf._drop_path(x, 0.25, True, B).view(B, N * C)
+    kept = y[:, 0] != 0
+    assert bool(((y == 0).all(1) | (y == 1 / 0.75).all(1)).all()), 'a sample is kept or dropped as a whole'
+    assert 0.55 < kept.float().mean() < 0.95
+    z = tf._dropout2d(x, 0.5, True, B).view(B, N, C)
+    assert bool((z == z[:, :1]).all()), 'a channel of a sample is kept or dropped over the whole map'
+    assert set(z.unique().tolist()) == {0.0, 2.0} and not bool((z[0] == z[1]).all() and (z[1] == z[2]).all())
+    assert [_droppath_rate(0.1, i, 3, False) for i in range(3)] == [0.1, 0.1, 0.1]
+    assert [_droppath_rate(0.2, i, 3, True) for i in range(3)] == [0.0, 0.1, 0.2] and _droppath_rate(0.2, 0, 1, True) == 0
+    from common import model_cfg
+    from networks.models import build_vos_model
+    cfg = model_cfg('swinb_deaotl')
+    enc = build_vos_model(cfg.MODEL_VOS, cfg).encoder
+    rates = [blk.drop_path_p for layer in enc.layers for blk in layer.blocks]
+    want = torch.linspace(0, 0.3, 24).tolist()[:22]
+    frozen = sum(len(l.blocks) for l in enc.layers[:max(0, cfg.TRAIN_ENCODER_FREEZE_AT - 1)]) if cfg.TRAIN_ENCODER_FREEZE_AT >= 2 else 0
+    assert rates[:frozen] == [0.0] * frozen and rates[frozen:] == pytest.approx(want[frozen:])
