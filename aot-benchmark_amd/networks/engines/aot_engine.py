@@ -477,8 +477,8 @@ class AOTEngine(nn.Module):
         to the split-K summation order of the GEMM dispatch (parity against the reference: the whole-clip golden tests run
         with look-ahead on and off).  No-op for encoders that take one image per call."""
         self._ahead = {}
-        if not imgs or not getattr(self.AOT.encoder, 'batched', False):
-            return
+        if not imgs or len(imgs) < 2 or not getattr(self.AOT.encoder, 'batched', False):
+            return           # (one frame: nothing to batch -- and a B = 1 encode would share the in-line encoder's scratch)
         k = len(imgs)
         key = ('imgs_ahead', k, tuple(imgs[0].shape))
         src = self._static.get(key)          # the batch is gathered into one [k,3,H,W] buffer (stable address: replayable)
@@ -491,11 +491,16 @@ class AOTEngine(nn.Module):
         else:
             feats = self.AOT.encode_tokens(src)
         for b, img in enumerate(imgs):
-            self._ahead[_img_key(img)] = [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats]
+            # the entry holds the image: its storage cannot be freed and re-used for another frame of the same shape while the
+            # features wait, so (address, shape, version) identifies the frame for as long as the entry lives
+            self._ahead[_img_key(img)] = (img, [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats])
 
     def _take_ahead(self, img):
         """Features of a frame encoded by encode_ahead(), if `img` is the same memory, unmodified since."""
-        return self._ahead.pop(_img_key(img), None) if img is not None and self._ahead else None
+        if img is None or not self._ahead:
+            return None
+        hit = self._ahead.pop(_img_key(img), None)
+        return hit[1] if hit is not None else None
 
     # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):

@@ -417,9 +417,10 @@ class ClipGraph:
     """The frame recurrence of B clips at once (aot_engine.py:188-354 under autograd): memories are graph tensors, the
     long-term bank of a sample is the concatenation of its memorised frames."""
 
-    def __init__(self, model, batch, long_term_mem_gap=9999):
+    def __init__(self, model, batch, long_term_mem_gap=9999, freeze_id=False):
         self.m = model
         self.B = int(batch)
+        self.freeze_id = bool(freeze_id)      # aot_engine.py:46,176-177: with prediction feedback the identity bank gets no gradient
         self.deaot = isinstance(model.LSTT, DualBranchGPM)
         self.gap = long_term_mem_gap
         self.frame_step = 0
@@ -451,7 +452,10 @@ class ClipGraph:
         e, _, _ = T.conv2d(x, bank.weight, bank.bias, self.B, H, W, bank.stride[0], bank.padding[0], 1)
         if self.deaot:
             e = T.layernorm(e, self.m.id_norm.weight, self.m.id_norm.bias)
-        return _dropout(e, self.m.id_dropout_p, self.m.training)
+        e = _dropout(e, self.m.id_dropout_p, self.m.training)
+        # assign_identity (aot_engine.py:176-177): `if self.training and self.freeze_id: id_emb = id_emb.detach()` -- no gradient
+        # into patch_wise_id_bank / id_norm, and none through a probability feedback into the earlier frames
+        return e.detach() if self.freeze_id else e
 
     def _bank(self, i):
         """The long-term memory of layer i: per component, the samples' memorised frames side by side ([B * T, .])."""
@@ -557,7 +561,10 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
     HW = size[0] * size[1]
     losses = [[None] * bs for _ in range(T_)]
     preds = [[None] * bs for _ in range(T_)]
-    clip = ClipGraph(model, bs, engine.long_term_mem_gap)
+    if getattr(engine, 'short_term_mem_skip', 1) != 1:
+        raise NotImplementedError('training_forward keeps one short-term frame (short_term_mem_skip = 1, every reference recipe); '
+                                  'aot_engine.py:329-332 would read short_term_memories_list[-skip:][0]')
+    clip = ClipGraph(model, bs, engine.long_term_mem_gap, freeze_id=bool(engine.training and use_prev_pred))
     objs = [int(n) for n in obj_nums]
     # identity o of sample b is moved to channel perm[b][o] (trainer.py:457; reversed on the logits, aot_engine.py:364-367)
     perms = engine.id_shuffle if engine.enable_id_shuffle else [None] * bs
@@ -596,12 +603,17 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
         return feedback
 
     truth = lambda t: [masks[t, b:b + 1] for b in range(bs)]
+    # the auxiliary decodes record no graph once their weight has faded to 0 (aot_engine.py:55-58,66-69: `grad_state`): no wasted
+    # decoder backward, and a non-finite auxiliary loss cannot reach the gradients through 0 * nan
+    aux_grad = torch.no_grad if aux_weight == 0 else torch.enable_grad
     clip.add_reference_frame(frames[0], ident(truth(0)), frame_step=0)
-    score(0)
+    with aux_grad():
+        score(0)
     t = 1
     if enable_prev_frame:
         clip.add_reference_frame(frames[1], ident(truth(1)), frame_step=1)
-        score(1)
+        with aux_grad():
+            score(1)
         t = 2
     while t < T_:
         clip.match_propogate_one_frame(frames[t])

@@ -57,12 +57,22 @@ def synth_tensor(key, ref, all_keys):
     sib = stem + '.weight'
     if leaf == 'bias':
         is_lin = sib in all_keys and all_keys[sib].dim() >= 2
-        return (0.02 if is_lin else 0.1) * torch.randn(shape, generator=g)
+        return (0.02 if is_lin else 0.1) * torch.randn(shape, generator=g) * _swin_out_norm_gain(stem)
     w = 1.0 + 0.1 * torch.randn(shape, generator=g)
     # damp the residual branch of every encoder block so activations stay O(1) through the backbone
     if key.startswith('encoder.') and (stem.endswith('.bn3') or _is_mbv2_last_bn(stem, all_keys)):
         w = w * 0.25
-    return w
+    return w * _swin_out_norm_gain(stem)
+
+
+def _swin_out_norm_gain(stem):
+    """Round 4 calibration of the Swin trunk.  The per-stage output LayerNorms of the Swin
+    encoder (`encoder.norm0/1/2`, swin_transformer.py:630-633) hand the decoder unit-variance shortcuts, where the ResNet
+    trunks hand it a residual stream of std 4-8.  With unit-variance shortcuts the decoder's logits respond ~10x more
+    strongly to the memory read-out, and a one-pixel change of a fed-back mask changes ~5 pixels of the next mask: the
+    free-running clip is chaotic for the reference itself (`tools/dev/chaos_probe.py`, `profiles/r04_swinb_chaos_probe.txt`).
+    Weight AND bias of those three norms x3 puts the Swin models in the ResNet models' regime (growth factor < 1)."""
+    return 3.0 if stem in ('encoder.norm0', 'encoder.norm1', 'encoder.norm2') else 1.0
 
 
 def _is_mbv2_last_bn(stem, all_keys):

@@ -49,6 +49,54 @@ def aot_hip_x6_min_tiles():
     return aot_hip.X6_MIN_TILES
 
 
+COLLECTIVES = {'all_gather': 0, 'all_reduce': 0, 'barrier': 0}      # what this rank issued (the sharding tests read it in --dry-run)
+
+
+def pin_host(rank, world, local_rank, dry=False):
+    """One Python thread drives one GPU (three graph launches per frame and stream): keep it -- and the torch CPU threads of the
+    rank-0-only legs -- on the cores of the GPU's own NUMA node, split evenly between the ranks that share the node, so that eight
+    ranks do not migrate over each other and rank 0's CPU legs cannot spill onto the cores of a rank that is still being timed.
+    Best effort: returns a description, never raises."""
+    ncpu = os.cpu_count() or 1
+    info = {'threads': max(1, ncpu // max(world, 1)), 'affinity': 'unchanged'}
+    try:
+        torch.set_num_threads(info['threads'])
+        if world == 1 or dry or not hasattr(os, 'sched_setaffinity'):
+            return info
+        prop = torch.cuda.get_device_properties(local_rank)
+        bdf = '%04x:%02x:%02x.0' % (getattr(prop, 'pci_domain_id', 0), prop.pci_bus_id, prop.pci_device_id)
+        node = -1
+        pth = '/sys/bus/pci/devices/%s/numa_node' % bdf
+        if os.path.exists(pth):
+            node = int(open(pth).read().strip())
+        cpus = sorted(os.sched_getaffinity(0))
+        if node >= 0 and os.path.exists('/sys/devices/system/node/node%d/cpulist' % node):
+            lst = []
+            for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+                a, _, b = part.partition('-')
+                lst += list(range(int(a), int(b or a) + 1))
+            cpus = sorted(set(lst) & set(cpus)) or cpus
+        # the ranks whose GPUs hang off this node share its cores in rank order (GPUs assumed evenly spread over the nodes;
+        # node unknown: all ranks share all cores evenly)
+        per_node = world if node < 0 else max(1, world // _numa_nodes())
+        share = max(1, len(cpus) // per_node)
+        k = local_rank % per_node
+        mine = cpus[k * share:(k + 1) * share] or cpus
+        os.sched_setaffinity(0, mine)
+        info.update(affinity='numa node %d, cpus %d-%d (%d)' % (node, mine[0], mine[-1], len(mine)), threads=min(info['threads'], len(mine)))
+        torch.set_num_threads(info['threads'])
+    except Exception as e:           # noqa: BLE001
+        info['affinity'] = 'unchanged (%s)' % type(e).__name__
+    return info
+
+
+def _numa_nodes():
+    try:
+        return max(1, len([d for d in os.listdir('/sys/devices/system/node') if d.startswith('node') and d[4:].isdigit()]))
+    except OSError:
+        return 1
+
+
 def shard_clips(num_clips, rank, world):
     """clip i -> rank i mod world (equal-length synthetic clips)."""
     return [i for i in range(num_clips) if i % world == rank]
@@ -59,6 +107,7 @@ def gather_stats(stats, world):
     if world == 1:
         return stats.unsqueeze(0).cpu()
     out = [torch.zeros_like(stats) for _ in range(world)]
+    COLLECTIVES['all_gather'] += 1
     dist.all_gather(out, stats)
     return torch.stack(out).cpu()
 
@@ -210,8 +259,13 @@ def attention_roofline(engine, clip, device):
     # WRITE_SIZE, MI355X_MICROARCH.md); a PMC pass cannot run inside this process, so the figure is read from the committed
     # record of that run and `traffic_source` names it -- it is NOT measured in this run
     traffic = src = None
-    tp = os.path.join('profiles', 'r03_attn_traffic.json' if not deaot else 'r03_gated_attn_traffic.json')
-    if os.path.exists(os.path.join(ROOT, tp)):
+    tp = None
+    for rnd in ('r04', 'r03'):        # the newest committed record of the kernel as built
+        cand = os.path.join('profiles', '%s_%sattn_traffic.json' % (rnd, 'gated_' if deaot else ''))
+        if os.path.exists(os.path.join(ROOT, cand)):
+            tp = cand
+            break
+    if tp:
         with open(os.path.join(ROOT, tp)) as f:
             traffic = round(json.load(f)['traffic_bytes_per_launch'])
         src = tp + ' (separate rocprofv3 --pmc passes, same launch mix; not measured in this run)'
@@ -223,13 +277,11 @@ def attention_roofline(engine, clip, device):
             'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n)}
 
 
-# golden clips of the real reference, whole 70-frame clips (tests/golden/make_golden.py): model -> (fixture, synthetic clip id,
-# tie-synchronised feedback).  SwinB-DeAOTL with the synthetic weights is chaotic on its clip: one near-tie flip at frame 11 is
-# amplified by the mask feedback into thousands of pixels -- for the CPU oracle exactly as for the HIP path
-# (profiles/r03_swinb_free_running_oracle.txt) -- so its pass feeds the engine's own labels back everywhere EXCEPT on the
-# reference's near-tie pixels of the frame, which take the reference's label; pixels differing outside the near-ties stay errors.
-JF_GOLDEN = {'r50_aotl': ('c2_r50_aotl_70', 0, False), 'r50_deaotl': ('c3b_r50_deaotl_70', 2, False),
-             'swinb_deaotl': ('c3_swinb_deaotl_480_70', 10, True)}
+# golden clips of the real reference, whole 70-frame clips (tests/golden/make_golden.py): model -> (fixture, synthetic clip id).
+# All three run free-running on the engine's own labels (round 3 had to tie-synchronise SwinB-DeAOTL; round 4 calibrated the
+# Swin trunk of the synthetic weights, utils/synth.py::_swin_out_norm_gain, so that the reference itself is stable there).
+JF_GOLDEN = {'r50_aotl': ('c2_r50_aotl_70', 0), 'r50_deaotl': ('c3b_r50_deaotl_70', 2),
+             'swinb_deaotl': ('c3_swinb_deaotl_480_70', 10)}
 
 
 def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f32'):
@@ -244,7 +296,7 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
     from utils.synth import synth_clip
     if MODEL not in JF_GOLDEN:
         return None
-    name, clip_id, sync_ties = JF_GOLDEN[MODEL]
+    name, clip_id = JF_GOLDEN[MODEL]
     gp = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
     if not os.path.exists(gp):
         return None
@@ -260,11 +312,7 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
     npix = gold.shape[1] * gold.shape[2]
     on_device = True         # the metric's reductions and dilations run where the masks are; host fallback if the device refuses
     tie_of = lambda t: torch.from_numpy(np.unpackbits(g['gapmask_%d' % t])[:npix].reshape(gold.shape[1:]).astype(bool)).to(device)
-    now = [0]
-    if sync_ties:
-        run.feedback = lambda label: torch.where(tie_of(now[0]), refs[now[0] - 1].float(), label[0, 0]).view_as(label)
     for t in range(1, len(frames)):
-        now[0] = t
         label = run.step(len(frames) - t)[0, 0].long()
         ref = refs[t - 1]
         if on_device:
@@ -288,7 +336,7 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
             'gemm_table': gemm_table, 'mfma': mfma, 'launch': 'hipGraph replay' if graph else 'host launches',
             'labels': 'aot_hip.fuse_probs',
             'encode_ahead_frames': ahead,
-            'feedback': 'own labels; reference labels on its near-tie pixels (chaotic clip)' if sync_ties else 'own labels',
+            'feedback': 'own labels',
             'clip': 'tests/golden/%s.npz (free-running, masks of the real reference; near-tie = top-2 logit gap < 2e-4 in the '
                     'reference)' % name}
 
@@ -323,6 +371,39 @@ def cpu_baseline(sd, budget_s=20.0, max_frames=12):
             'sample': 'frames 1..%d of clip 0 (%dx%d, %d objects) with the long-term gap set to 1: bank M = 1..%d, mean %.1f (the '
                       'timed GPU frames: see config.timed_M_mean); oracle/aot_oracle.py fp32, %d torch threads'
                       % (done, IN_SIZE[0], IN_SIZE[1], NUM_OBJ, done, msum / max(done, 1), threads)}
+
+
+def other_config_legs(args):
+    """BASELINE configs[2] (SwinB-DeAOTL, 480x848) and R50-DeAOTL measured like the headline model, each in a process of its own
+    (`bench.py --model ... --leg`: own weights, banks and graphs; a failure there cannot take the headline line down).  Returns
+    {model: summary of that run's JSON line}."""
+    import subprocess
+    out = {}
+    for name in ('swinb_deaotl', 'r50_deaotl'):
+        cmd = [sys.executable, os.path.abspath(__file__), '--model', name, '--leg', '--gpus', '1', '--steps', str(args.steps),
+               '--warmup', str(args.warmup), '--streams', str(args.streams), '--graph', str(args.graph), '--repeats', str(args.repeats),
+               '--encode-ahead', str(args.encode_ahead)]
+        for flag in ('no_cpu_baseline', 'no_roofline', 'no_jf', 'no_whole_clip'):
+            if getattr(args, flag):
+                cmd.append('--' + flag.replace('_', '-'))
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            rows = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+            if not rows:
+                raise RuntimeError('no JSON line (rc %d): %s' % (pr.returncode, pr.stderr.strip()[-300:]))
+            d = json.loads(rows[-1])
+            c = d['config']
+            out[name] = {'workload': c['workload'], 'fps': d['value'], 'repeat_fps': c['repeat_fps'], 'ms_per_step': d['ms_per_step'],
+                         'dtype': d['dtype'], 'timed_M_mean': c['timed_M_mean'],
+                         'single_stream_fps': (c.get('single_stream') or {}).get('fps'),
+                         'whole_clip_fps': (c.get('whole_clip') or {}).get('fps'),
+                         'jf_vs_reference': c.get('jf_vs_reference'), 'roofline': d.get('roofline'),
+                         'cpu_baseline': d.get('cpu_baseline'), 'rc': pr.returncode}
+        except Exception as e:           # noqa: BLE001
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        print('[bench] other_configs.%s: %.1f s' % (name, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    return out
 
 
 def _free_port():
@@ -397,6 +478,14 @@ def main(argv=None):
                     help='the timed window plan of --steps frames is run this many times; `value` is the MEDIAN run, all runs are '
                          'listed in config.repeat_fps (a --steps 20 window is ~40 ms: one run is not the whole story)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip config.other_configs of a default single-GPU run: the same measurement (throughput, one clip at a time, '
+                         'J&F on the whole-clip golden, roofline of the gated kernel, CPU baseline) for BASELINE configs[2] '
+                         '(SwinB-DeAOTL, 480x848) and R50-DeAOTL, each in its own process')
+    ap.add_argument('--no-whole-clip', action='store_true',
+                    help='skip config.whole_clip: the timed plan over WHOLE 70-frame clips (69 propagated frames per stream) next to '
+                         'the --steps window')
+    ap.add_argument('--leg', action='store_true', help=argparse.SUPPRESS)      # this process is an other_configs leg of another run
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-jf', action='store_true', help='skip the J&F pass on the committed reference clip (tuning runs)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (default); gloo only with --dry-run')
@@ -434,16 +523,26 @@ def main(argv=None):
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
     joined = dist.get_world_size() if world > 1 else 1
+    host = pin_host(rank, world, local_rank, dry)
 
     def sync():
         if not dry:
             torch.cuda.synchronize(device)
 
+    events = []                # --dry-run: the order of this rank's phases (tests/test_sharding_gloo.py)
+
     def fence(collective=True):
         sync()
         if world > 1 and collective:
+            COLLECTIVES['barrier'] += 1
             dist.barrier()
         sync()
+
+    def reduce_max(t):
+        if world > 1:
+            COLLECTIVES['all_reduce'] += 1
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
 
     S = max(1, args.streams)
     table = 'throughput' if S > 1 else 'latency'      # several clips per GPU keep the chip saturated: cheapest kernel in SIMD time
@@ -528,10 +627,9 @@ def main(argv=None):
         for r in range(R):
             elapsed, frames_done, msum = run_plan(lanes, passes, lambda pi, i: pi * S + i)
             assert frames_done == args.steps
-            tm = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            if world > 1:
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            tm = reduce_max(torch.tensor([elapsed], dtype=torch.float64, device=device))
             runs.append((float(tm.item()), frames_done, msum))
+            events.append('timed_run_%d' % r)
         tmax, frames_done, msum = median_run(runs)
         elapsed = tmax
         single = None
@@ -547,8 +645,24 @@ def main(argv=None):
                       'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead}
             del one
 
+        whole = None
+        if not args.no_whole_clip and args.steps != S * (CLIP_FRAMES - 1):
+            # the same lanes over whole clips (every propagated frame of a clip timed, M 1 -> 14): what `--steps 207` measures,
+            # carried by every line so that a short --steps window is never the only throughput figure (collective: all ranks)
+            full = plan_windows(S * (CLIP_FRAMES - 1), S)
+            wruns = []
+            for r in range(R):
+                ew, fw, mw = run_plan(lanes, full, lambda pi, i: i)
+                tw = reduce_max(torch.tensor([ew], dtype=torch.float64, device=device))
+                wruns.append((float(tw.item()), fw, mw))
+                events.append('whole_clip_run_%d' % r)
+            ew, fw, mw = median_run(wruns)
+            whole = {'fps': None if dry else round(world * fw / ew, 2),
+                     'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _ in wruns],
+                     'frames_per_gpu': fw, 'ms_per_frame': round(ew / fw * 1e3, 3), 'timed_M_mean': round(mw / fw, 2)}
+
         x6 = None
-        if args.mfma == 'f32' and not args.no_x6 and rank == 0 and not dry:
+        if args.mfma == 'f32' and not args.no_x6 and not args.leg and rank == 0 and not dry:
             try:                                  # (an optional leg: its failure must not cost the fp32 measurement)
                 # the second kernel family on the same plan (same clips, streams, table, graphs): a separate number under its
                 # own dtype string, next to -- never instead of -- the fp32 value
@@ -582,6 +696,7 @@ def main(argv=None):
                 roof = attention_roofline(probe, clips[0], device)
 
     base = jf = None
+    events.append('rank0_legs')          # everything below runs on rank 0 only, after the last timed barrier of every rank
     if rank == 0 and not dry:
         t_ph = time.perf_counter()
         if not args.no_jf:
@@ -594,9 +709,19 @@ def main(argv=None):
                         x6['jf_error'] = '%s: %s' % (type(e).__name__, e)
             print('[bench] J&F pass on the golden clip: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
         t_ph = time.perf_counter()
-        if not args.no_cpu_baseline:
-            base = cpu_baseline(sd)          # rank 0 only, after the timed region; the other ranks wait at the barrier
+        if not args.no_cpu_baseline and world == 1:
+            base = cpu_baseline(sd)          # rank 0 at N = 1 only (it takes every host core), after the timed region
             print('[bench] cpu_baseline: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
+    others = None
+    if rank == 0 and not dry and world == 1 and default_model and not args.leg and not args.no_other_configs:
+        others = other_config_legs(args)
+    trace = None
+    if dry:            # CPU plumbing test only: what every rank did, gathered as objects (not part of a real run)
+        mine = {'rank': rank, 'clips': list(my_ids), 'collectives': dict(COLLECTIVES), 'events': list(events)}
+        trace = [mine]
+        if world > 1:
+            trace = [None] * world
+            dist.all_gather_object(trace, mine)
     if world > 1:
         dist.barrier()
 
@@ -617,7 +742,7 @@ def main(argv=None):
                        'timed_M_mean': round(float(stats[:, 3].sum()) / total_frames, 2),
                        'repeats': R, 'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _ in runs],
                        'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
-                       'single_stream': single,
+                       'single_stream': single, 'whole_clip': whole,
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': table,
@@ -628,7 +753,7 @@ def main(argv=None):
                                        'bank size M is sampled like a whole clip (timed_M_mean; a whole clip is 7.41); '
                                        'restart + reference frame and the fast-forward between windows are untimed '
                                        'set-up, as in the reference FPS (evaluator.py:325-330,444-446)',
-                       'jf_vs_reference': jf, 'bf16x6_split': x6},
+                       'host': host, 'jf_vs_reference': jf, 'bf16x6_split': x6, 'other_configs': others, 'dry_trace': trace},
             'roofline': roof, 'cpu_baseline': base,
         }
         print(json.dumps(line), flush=True)

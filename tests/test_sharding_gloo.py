@@ -101,3 +101,38 @@ def test_window_plan_samples_the_bank_size_distribution():
                     msum += sum(bench.bank_frames_at(t, 5) for t in range(first, first + n))
         assert frames == steps
         assert abs(msum / frames - full) < 0.6, (steps, streams, msum / frames)
+
+
+def test_bench_entry_point_world_8_dry_run():
+    """The driver's 8-GPU launch (`python bench.py --gpus 8`), device work replaced by --dry-run: eight ranks join, the clips are
+    eight disjoint shards (clip i -> rank i mod 8), every rank issues exactly ONE all_gather on the data path's behalf (the stats
+    vector; reference: mp.Queue, evaluator.py:507-531) next to the barriers and the max-over-ranks reductions of the timing
+    protocol, and the rank-0-only legs (J&F, x6 leg, CPU baseline) come after the last timed run of EVERY rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '20', '--warmup', '5',
+                        '--dry-run', '--backend', 'gloo'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and line['value'] is None
+    assert line['cpu_baseline'] is None                                   # N = 1 only
+    tr = line['config']['dry_trace']
+    assert sorted(t['rank'] for t in tr) == list(range(8))
+    shards = [t['clips'] for t in tr]
+    flat = sorted(c for sh in shards for c in sh)
+    assert flat == list(range(len(flat))) and len(set(flat)) == len(flat)     # disjoint cover of the clip set
+    assert len({len(sh) for sh in shards}) == 1                                # equal work per rank: weak scaling
+    for t in tr:
+        assert all(c % 8 == t['rank'] for c in t['clips'])
+        assert t['collectives']['all_gather'] == 1
+        ev = t['events']
+        assert ev[-1] == 'rank0_legs' and ev.index('rank0_legs') > max(i for i, e in enumerate(ev) if e.startswith(('timed', 'whole')))
+        # same protocol on every rank: identical counts (a rank that skipped a barrier would hang, one that added one would differ)
+        assert t['collectives'] == tr[0]['collectives'] and ev == tr[0]['events']
+    assert tr[0]['collectives']['all_reduce'] == line['config']['repeats'] * 2      # the --steps plan and the whole-clip plan

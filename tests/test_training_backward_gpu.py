@@ -315,3 +315,27 @@ def test_training_steps_reduce_the_loss(T, case):
     assert all(np.isfinite(seen))
     moved = max(float((s - p.detach()).abs().max()) for s, p in zip(ema.shadow_params, ema_params))
     assert 0 < moved < 6 * 2e-4 * 1.1
+
+
+@pytest.mark.parametrize('case', ['tf_aott_prev', 'tf_deaott_prob'])
+def test_prediction_feedback_freezes_the_identity_bank(T, case):
+    """aot_engine.py:46,176-177: with `use_prev_pred` a TRAINING engine detaches every identity embedding (`freeze_id`), so the
+    identity bank (and DeAOT's id_norm) receive no gradient and nothing flows back through a fed-back probability map; in eval
+    mode -- how the gradient goldens were made -- the reference does not detach, and neither does this engine."""
+    got = {}
+    for mode in (True, False):
+        c, cfg, model, engine, frames, masks, objs, kw = _train_engine(case, train_mode=mode)
+        assert kw['use_prev_pred']
+        model.zero_grad()
+        loss = engine(frames, masks, len(objs), objs, **kw)[0]
+        loss.backward()
+        g = model.patch_wise_id_bank.weight.grad
+        got[mode] = None if g is None else float(g.abs().max())
+        if mode:
+            assert g is None or float(g.abs().max()) == 0.0, 'the identity bank got a gradient in train mode with use_prev_pred'
+            if hasattr(model, 'id_norm'):
+                assert model.id_norm.weight.grad is None or float(model.id_norm.weight.grad.abs().max()) == 0.0
+            assert float(model.decoder.conv_out.weight.grad.abs().max()) > 0
+        else:
+            assert g is not None and float(g.abs().max()) > 0
+    print('identity-bank gradient max: train mode %s, eval mode %.3g' % (got[True], got[False]))

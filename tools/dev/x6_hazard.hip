@@ -1,0 +1,294 @@
+// Reproducer / A-B harness for the instruction-order dependence of the bf16x6 attention kernel (VERDICT r3 next #1a).
+// Stand-alone binary (no torch): includes the product translation unit for the shipped kernel and the pack kernels, and defines
+// hz_kernel<ORDER, PAD> -- the same arithmetic as attn_x6_d32_kernel in a chosen instruction order with optional padding:
+//   ORDER 0 = the shipped software-pipelined order (scores of tile i + 1 issued before the softmax of tile i)
+//   ORDER 1 = the NON-pipelined order round 3 saw failing: softmax of a tile directly behind its own score MFMAs
+//   PAD bits: 1 = 32 wait states between the score chain and the softmax's first read of it          (XDL write -> VALU read)
+//             2 = 32 wait states between the P split and the value MFMAs                             (VALU write -> XDL SrcB read)
+//             4 = 32 wait states behind the value MFMAs before anything overwrites their operands    (XDL SrcA/B read -> write, WAR)
+//             8 = 32 wait states between the accumulator rescale and the value MFMAs                 (VALU write -> XDL SrcC read)
+//            16 = the scheduling fences of the four sites without the wait states (control: same code motion limits, no padding)
+// Every variant is launched REPS times on the same inputs; each result is compared bit for bit with the shipped kernel's first
+// result.  The arithmetic is order-independent, so any difference is a hazard.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/dev/x6_hazard.hip -o tools/dev/x6_hazard
+//   tools/dev/x6_hazard [reps]
+#include "../../aot-benchmark_amd/csrc/attention_x6.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace {
+
+template <int PAD, int BIT>
+__device__ __forceinline__ void site() {
+  if constexpr ((PAD & BIT) != 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+  } else if constexpr ((PAD & 16) != 0) {
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int ORDER, int PAD>
+__global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
+  __shared__ float red[4][18][64];
+  const int h = blockIdx.x, split = blockIdx.z, bz = blockIdx.y;
+  const int ntq = (p.Nq + 31) >> 5;
+  const int b = bz / ntq, qt = bz - b * ntq;
+  const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int tpw = (tps + 3) >> 2;
+  const int s1 = min(T, (split + 1) * tps * 32);
+  const int t0 = min(s1, (split * tps + wave * tpw) * 32);
+  const int t1 = min(s1, t0 + tpw * 32);
+  const long qrow0 = (long)b * p.Nq;
+  const int C = p.H * 32;
+  const long cap_tiles = p.cap_rows >> 5;
+  bf16x8 qp[2][3];
+  {
+    const int qrow = min(qt * 32 + j, p.Nq - 1);
+    const float* src = p.q + (qrow0 + qrow) * p.ldq + h * 32 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
+                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
+      split3(x, qp[c]);
+    }
+  }
+  const unsigned short* kvbase = p.kv + ((long)b * cap_tiles * p.H + h) * 6144 + lane * 8;
+  const long tile_stride = (long)p.H * 6144;
+  float m = -INFINITY, l = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
+    const unsigned short* src = kvbase + min((long)(kt >> 5), cap_tiles - 1) * tile_stride;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto load_v = [&](bf16x8 (&vf)[2][3], int kt) {
+    const unsigned short* src = kvbase + min((long)(kt >> 5), cap_tiles - 1) * tile_stride + 3072;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto qk = [&](const bf16x8 (&kf)[2][3], f32x16& sc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    mfma6(kf[0], qp[0], sc);
+    mfma6(kf[1], qp[1], sc);
+  };
+  bf16x8 ka[2][3], va[2][3];
+  f32x16 sa, sb;
+  if (t0 < t1) {
+    load_k(ka, t0);
+    load_v(va, t0);
+    if (ORDER == 0) {
+      qk(ka, sa);
+      load_k(ka, t0 + 32);
+    }
+  }
+  auto step = [&](int kt, f32x16& sc, f32x16& scn, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
+    if (ORDER == 0) {
+      qk(ka, scn);
+    } else {
+      qk(ka, sc);           // this tile's own scores, read by the softmax right behind the chain
+    }
+    site<PAD, 1>();
+    if (TAIL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+    }
+    float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                    max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    site<PAD, 8>();
+    float pf[16], ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -m));
+      ps += pf[r];
+    }
+    l += ps;
+    load_k(ka, ORDER == 0 ? kt + 64 : kt + 32);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float x8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+      bf16x8 pp[3];
+      split3(x8, pp);
+      site<PAD, 2>();
+      mfma6(va[c], pp, o);
+      site<PAD, 4>();
+    }
+    load_v(va, kt + 32);
+  };
+  int kt = t0;
+  if (ORDER == 0) {
+    for (; kt + 64 < t1; kt += 32) {
+      step(kt, sa, sb, std::false_type{});
+      sa = sb;
+    }
+    if (kt + 32 < t1) {
+      step(kt, sa, sb, std::false_type{});
+      step(kt + 32, sb, sa, std::true_type{});
+    } else if (kt < t1) {
+      step(kt, sa, sb, std::true_type{});
+    }
+  } else {
+    for (; kt + 32 < t1; kt += 32) step(kt, sa, sb, std::false_type{});
+    if (kt < t1) step(kt, sa, sb, std::true_type{});
+  }
+  {
+    const float lt = l + __shfl_xor(l, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = o[r];
+    red[wave][16][lane] = m;
+    red[wave][17][lane] = lt;
+  }
+  __syncthreads();
+  float mm = fmaxf(fmaxf(red[0][16][lane], red[1][16][lane]), fmaxf(red[2][16][lane], red[3][16][lane]));
+  float f[4], lsum = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; ++w2) {
+    const float mw = red[w2][16][lane];
+    f[w2] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+    lsum += f[w2] * red[w2][17][lane];
+  }
+  float4 acc;
+  {
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * wave + i;
+      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+    }
+    acc = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  const int qi = qt * 32 + j;
+  if (qi >= p.Nq) return;
+  const long grow = qrow0 + qi;
+  const int c = h * 32 + 8 * wave + 4 * hi;
+  if (p.nsplit == 1) {
+    const float inv = 1.f / lsum;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    *reinterpret_cast<float4*>(p.out + grow * p.ldo + c) = acc;
+  } else {
+    const long rows = (long)p.B * p.Nq;
+    *reinterpret_cast<float4*>(p.part + ((long)split * rows + grow) * C + c) = acc;
+    if (wave == 0 && hi == 0) {
+      float* ml = p.part + (long)p.nsplit * rows * C + (((long)split * rows + grow) * p.H + h) * 2;
+      ml[0] = mm;
+      ml[1] = lsum;
+    }
+  }
+}
+
+typedef void (*kern_t)(const AttnX6Params);
+struct Variant { const char* name; kern_t fn; };
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const int reps = argc > 1 ? atoi(argv[1]) : 40;
+  const int N = 1674, H = 8, C = 256, MMAX = 14;
+  const long cap = ((long)MMAX * N + 31) / 32 * 32;
+  std::vector<float> hq((size_t)N * C), hk((size_t)MMAX * N * C), hv((size_t)MMAX * N * C);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.f - 1.f; };
+  for (auto& x : hq) x = 3.f * rnd();
+  for (auto& x : hk) x = 2.f * rnd();
+  for (auto& x : hv) x = 2.f * rnd();
+  float *q, *k, *v, *out, *ref, *part, *pref;
+  unsigned short* kv;
+  const size_t kvbytes = (size_t)(cap / 32) * H * 6144 * 2;
+  const int NSMAX = 5;
+  const size_t partn = (size_t)NSMAX * N * (C + 2 * H);
+  CK(hipMalloc(&q, hq.size() * 4)); CK(hipMalloc(&k, hk.size() * 4)); CK(hipMalloc(&v, hv.size() * 4));
+  CK(hipMalloc(&out, (size_t)N * C * 4)); CK(hipMalloc(&ref, (size_t)N * C * 4)); CK(hipMalloc(&kv, kvbytes));
+  CK(hipMalloc(&part, partn * 4)); CK(hipMalloc(&pref, partn * 4));
+  CK(hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(k, hk.data(), hk.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(v, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(kv, 0, kvbytes));
+  for (int slot = 0; slot < MMAX; ++slot)
+    if (aot_attn_pack_x6_f32(k + (size_t)slot * N * C, v + (size_t)slot * N * C, kv, 1, N, C, 0, C, C, cap, nullptr, slot, nullptr)) {
+      printf("pack failed\n");
+      return 1;
+    }
+  CK(hipDeviceSynchronize());
+  const Variant vs[] = {
+      {"shipped order (copy)        ", hz_kernel<0, 0>},  {"non-pipelined               ", hz_kernel<1, 0>},
+      {"non-pipelined + fences only ", hz_kernel<1, 16>}, {"non-pipelined + pad scores  ", hz_kernel<1, 1>},
+      {"non-pipelined + pad P->B    ", hz_kernel<1, 2>},  {"non-pipelined + pad WAR     ", hz_kernel<1, 4>},
+      {"non-pipelined + pad rescale ", hz_kernel<1, 8>},  {"non-pipelined + all pads    ", hz_kernel<1, 15>},
+      {"shipped order + all pads    ", hz_kernel<0, 15>}};
+  struct Case { int M, ns; } cases[] = {{1, 5}, {4, 3}, {14, 3}, {4, 1}};
+  std::vector<float> h0(partn), h1(partn);
+  for (const Case& cs : cases) {
+    const int T = cs.M * N - (cs.M == 4 ? 13 : 0);
+    AttnX6Params p;
+    p.q = q; p.kv = kv; p.out = ref; p.part = pref; p.T_dev = nullptr; p.Nq = N; p.T = T; p.H = H; p.ldq = C; p.ldo = C;
+    p.nsplit = cs.ns; p.B = 1; p.cap_rows = cap; p.scale_div = 5.656854249492381f;
+    const size_t cmpn = cs.ns == 1 ? (size_t)N * C : (size_t)cs.ns * N * (C + 2 * H);
+    CK(hipMemset(pref, 0, partn * 4));
+    if (aot_attn_x6_f32(q, kv, ref, pref, 1, cap, N, T, nullptr, H, 32, C, C, p.scale_div, cs.ns, nullptr)) { printf("ref launch failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h0.data(), cs.ns == 1 ? ref : pref, cmpn * 4, hipMemcpyDeviceToHost));
+    printf("== bank of %d frames (T = %d), key split %d: %d launches per variant\n", cs.M, T, cs.ns, reps);
+    p.out = out; p.part = part;
+    for (const Variant& var : vs) {
+      int bad_launches = 0, lo = 0, hi16 = 0;
+      size_t bad_vals = 0;
+      float worst = 0.f;
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      float ms_total = 0.f;
+      for (int r = 0; r < reps; ++r) {
+        CK(hipMemsetAsync(part, 0, partn * 4, nullptr));
+        CK(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(var.fn, dim3(H, (N + 31) / 32, cs.ns), dim3(256), 0, nullptr, p);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipMemcpy(h1.data(), cs.ns == 1 ? out : part, cmpn * 4, hipMemcpyDeviceToHost));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms_total += ms;
+        size_t nb = 0;
+        for (size_t i = 0; i < cmpn; ++i)
+          if (memcmp(&h0[i], &h1[i], 4)) {
+            ++nb;
+            const float d = fabsf(h0[i] - h1[i]);
+            if (d > worst || d != d) worst = d;
+            const size_t on = (size_t)cs.ns * N * C;
+            if (cs.ns == 1 || i < on) {
+              const int row = (int)((i / C) % N);
+              ((row & 31) < 16 ? lo : hi16)++;
+            }
+          }
+        if (nb) ++bad_launches;
+        bad_vals += nb;
+      }
+      printf("  %s %6.1f us  launches differing %3d / %d   values %8zu   worst |d| %.3g   O entries of queries j<16: %d  j>=16: %d\n", var.name,
+             ms_total / reps * 1e3, bad_launches, reps, bad_vals, worst, lo, hi16);
+    }
+  }
+  return 0;
+}
