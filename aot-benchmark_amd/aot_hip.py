@@ -23,6 +23,8 @@ _SIGS = {
     'aot_conv2d_nhwc_f32': [_P] * 7 + [_L] + [_I] * 20 + [_P],
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
+    'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
+    'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
@@ -60,6 +62,8 @@ _SIGS = {
     'aot_adamw_step_f32': [_P] * 4 + [_L] + [_F] * 5 + [_I, _F, _P],
     'aot_ema_update_f32': [_P, _P, _L, _F, _P],
     'aot_sumsq_accum_f64': [_P, _L, _P, _P],
+    'aot_sumsq_flat_f64': [_P, _L, _P, _I, _P, _P, _P],
+    'aot_adamw_flat_f32': [_P] * 4 + [_L, _P, _P, _I, _F, _F, _F, _P, _F, _P],
     # training path, differentiable primitives (csrc/train_bwd.hip)
     'aot_matmul_strided_f32': [_P] * 4 + [_I] * 4 + [_L] * 7 + [_I, _F, _I, _P],
     'aot_im2col_f32': [_P, _P] + [_I] * 11 + [_P],
@@ -256,6 +260,24 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     res.stride(0) if res is not None else 0, res_rows, act,
                                     (stack[-1][0] if stack else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
+    return out
+
+
+def gemm_bf16(a, w_kn, bias=None, out=None, stream=None):
+    """Training path, precision 'bf16': out [M, N] = a [M, K] @ w_kn [K, N] (+ bias) with both operands rounded to bf16 (round to
+    nearest even) and fp32 accumulation (aot_pack_bf16_f32 + aot_conv2d_bf16_f32).  K % 32 == 0; a / out row-major fp32."""
+    M, K = a.shape
+    N = w_kn.shape[1]
+    if K % 32 or w_kn.shape[0] != K or a.stride(1) != 1 or w_kn.stride(1) != 1:
+        raise AotHipError('gemm_bf16: a [M, K] @ w [K, N] with K %% 32 == 0, unit inner strides (got %s @ %s)' % (tuple(a.shape), tuple(w_kn.shape)))
+    cout_pad = (N + 63) // 64 * 64
+    wq = torch.empty(K // 32, 4, cout_pad, 8, dtype=torch.int16, device=a.device)
+    st = stream if stream is not None else stream_ptr()
+    _chk(load().aot_pack_bf16_f32(_dev(w_kn), _dev(wq), K, N, w_kn.stride(0), cout_pad, st), 'aot_pack_bf16_f32')
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk(load().aot_conv2d_bf16_f32(_dev(a), _dev(wq), cout_pad, _opt(bias), None, _dev(out), 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 1,
+                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, st), 'aot_conv2d_bf16_f32')
     return out
 
 
@@ -668,6 +690,34 @@ def ema_update(shadow, param, one_minus_decay, stream=None):
         raise AotHipError('ema_update: shadow and parameter differ in size')
     _chk(load().aot_ema_update_f32(_dev(shadow), _dev(param), shadow.numel(), one_minus_decay,
                                    stream if stream is not None else stream_ptr()), 'aot_ema_update_f32')
+
+
+def sumsq_flat(x, scratch, out, stream=None):
+    """out (one fp64 element) = sum(x^2) over a flat fp32 buffer in one launch; scratch = (partials fp64 [nblk], ticket int32 [1],
+    zeroed once)."""
+    _flat_f32(x)
+    part, ticket = scratch
+    if out.dtype != torch.float64 or part.dtype != torch.float64 or ticket.dtype != torch.int32:
+        raise AotHipError('sumsq_flat: fp64 partials / accumulator and an int32 ticket')
+    nblk = min(part.numel(), max(1, (x.numel() + 4095) // 4096))
+    _chk(load().aot_sumsq_flat_f64(_dev(x), x.numel(), _dev(part), nblk, _dev(ticket), _dev(out),
+                                   stream if stream is not None else stream_ptr()), 'aot_sumsq_flat_f64')
+
+
+def adamw_flat(p, g, m, v, seg_off, hyp, beta1, beta2, eps, sumsq=None, max_norm=0.0, stream=None):
+    """torch.optim.AdamW over flat buffers: seg_off int64 [nseg + 1] (device), hyp fp32 [nseg, 4] (device) = lr (< 0: skip), weight
+    decay, 1 - beta1^step, sqrt(1 - beta2^step) per tensor; sumsq (device fp64) + max_norm: the gradient clip, applied in-kernel."""
+    _flat_f32(p, g, m, v, hyp)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise AotHipError('adamw_flat: parameter, gradient and moment buffers differ in size')
+    nseg = hyp.shape[0]
+    if seg_off.dtype != torch.int64 or seg_off.numel() != nseg + 1 or hyp.shape[1] != 4 or not seg_off.is_cuda:
+        raise AotHipError('adamw_flat: seg_off int64 [nseg + 1], hyp fp32 [nseg, 4], both on the device')
+    if sumsq is not None and sumsq.dtype != torch.float64:
+        raise AotHipError('adamw_flat: the sum of squares must be float64')
+    _chk(load().aot_adamw_flat_f32(_dev(p), _dev(g), _dev(m), _dev(v), p.numel(), _dev(seg_off), _dev(hyp), nseg, beta1, beta2, eps,
+                                   _dev(sumsq) if sumsq is not None else None, float(max_norm),
+                                   stream if stream is not None else stream_ptr()), 'aot_adamw_flat_f32')
 
 
 def sumsq_accum(x, out, stream=None):

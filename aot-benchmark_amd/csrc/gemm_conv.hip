@@ -593,6 +593,40 @@ __global__ void __launch_bounds__(256) pack_x6_kernel(const float* __restrict__ 
   }
 }
 
+// one plane, rounded to nearest even: the weight operand of the plain-bf16 (training) form, same tile order as plane 0 above
+__global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wq, int K, int Cout, int ldb,
+                                                        int cout_pad) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)(K / 32) * 4 * cout_pad;
+  if (idx >= total) return;
+  const int n = (int)(idx % cout_pad);
+  const int cc = (int)((idx / cout_pad) & 3);
+  const int kb = (int)(idx / ((long)cout_pad * 4));
+  const int k0 = 32 * kb + 16 * (cc >> 1) + 4 * (cc & 1);
+  unsigned o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned h[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ee = 2 * e + t;
+      const unsigned u = n < Cout ? __float_as_uint(w[(long)(k0 + (ee & 3) + 8 * (ee >> 2)) * ldb + n]) : 0u;
+      // round to nearest even on the dropped 16 bits; NaN / Inf keep their exponent (a quiet NaN stays a NaN)
+      h[t] = ((u & 0x7f800000u) == 0x7f800000u) ? (u >> 16) | ((u & 0xffffu) ? 0x40u : 0u) : (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    o[e] = h[0] | (h[1] << 16);
+  }
+  *reinterpret_cast<uint4*>(wq + idx * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int aot_pack_bf16_f32(const float* w, void* wq, int K, int Cout, int ldb, int cout_pad, void* stream) {
+  if (!w || !wq || K <= 0 || (K % 32) || Cout <= 0 || ldb < Cout || cout_pad < Cout || (cout_pad % 64) || ((uintptr_t)wq & 15))
+    return AOT_ERR_BADARG;
+  const long total = (long)(K / 32) * 4 * cout_pad;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)wq, K, Cout, ldb, cout_pad);
+  AOT_LAUNCH_CHECK();
+}
+
 extern "C" int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream) {
   if (!w || !w6 || K <= 0 || (K % 32) || Cout <= 0 || ldb < Cout || cout_pad < Cout || (cout_pad % 64) || ((uintptr_t)w6 & 15))
     return AOT_ERR_BADARG;
@@ -618,4 +652,21 @@ extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_p
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
   return launch_gemm_x6(p, w6, cout_pad, tile, (hipStream_t)stream);
+}
+
+extern "C" int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
+                                   int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                                   int dil, int lda, int ldc, int ldr, int res_rows, int act, void* stream) {
+  if (!in || !wq || !out) return AOT_ERR_BADARG;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
+  if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
+  return launch_gemm_x6(p, wq, cout_pad, 64, (hipStream_t)stream, 1);
 }

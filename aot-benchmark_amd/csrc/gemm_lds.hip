@@ -837,29 +837,46 @@ __device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, bf16x8 
 
 // asynchronous fragment reads of one ring stage (IMM = its byte offset): four fp32 chunks of the lane's A row, and for each weight
 // plane the lane's two bf16 chunk columns (sub-steps 0 / 1 = pieces 4 pl + half and 4 pl + 2 + half; `half` is in baddr)
-template <int IMM, int PIECE>
+template <int IMM, int PIECE, int NT = 6>
 __device__ __forceinline__ void x6_fetch(f32x4 (&a)[4], bf16x8 (&b)[3][2], const unsigned (&aaddr)[4], unsigned baddr) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(aaddr[j]), "n"(IMM));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[0][0]) : "v"(baddr), "n"(IMM + 0 * PIECE));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[0][1]) : "v"(baddr), "n"(IMM + 2 * PIECE));
+  if (NT == 1) return;        // plain bf16: the first plane is the whole (rounded) weight
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[1][0]) : "v"(baddr), "n"(IMM + 4 * PIECE));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[1][1]) : "v"(baddr), "n"(IMM + 6 * PIECE));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[2][0]) : "v"(baddr), "n"(IMM + 8 * PIECE));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[2][1]) : "v"(baddr), "n"(IMM + 10 * PIECE));
 }
+template <int NT = 6>
 __device__ __forceinline__ void x6_landed(f32x4 (&a)[4], bf16x8 (&b)[3][2]) {
   asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(b[pl][0]), "+v"(b[pl][1]));
+  for (int pl = 0; pl < (NT == 1 ? 1 : 3); ++pl) asm volatile("" : "+v"(b[pl][0]), "+v"(b[pl][1]));
 }
 
-template <bool IS1X1>
+// eight fp32 values -> eight bf16, round to nearest even (v_cvt_pk_bf16_f32, gfx950), element order as split3
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 round8(const f32x4& x0, const f32x4& x1) {
+  u32x4 w;
+  w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x0[0], x0[1]}, hbf16x2));
+  w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x0[2], x0[3]}, hbf16x2));
+  w[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x1[0], x1[1]}, hbf16x2));
+  w[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{x1[2], x1[3]}, hbf16x2));
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// NT = 6: the fp32-equivalent six-term product (inference, mfma = 'bf16x6').  NT = 1: ONE product of operands rounded to bf16 --
+// the training path's `precision = 'bf16'` (train_ops.matmul_precision): weight plane from aot_pack_bf16_f32 (round to nearest
+// even), activations rounded in registers; 2 MFMAs per k-step instead of 12, one weight plane through the ring instead of three.
+template <bool IS1X1, int NT = 6>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq) {
   constexpr int NST = 3;
   constexpr int BM = 64, BN = 64;
   constexpr int AG = BM / 8, AGW = AG / 4;              // A: 8-row groups, two per wave
-  constexpr int BPW = 3;                                // B: one 16-byte chunk column (cc = wave) of each plane per wave
+  constexpr int BPW = NT == 1 ? 1 : 3;                  // B: one 16-byte chunk column (cc = wave) of each plane per wave
   constexpr int LPW = AGW + BPW;
   constexpr int OPA_BYTES = AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 12 * B_PIECE;
   constexpr int STAGE_BYTES = OPA_BYTES + OPB_BYTES;
@@ -896,7 +913,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, BPW * plane_bytes, 0x00020000);
   const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
   const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
   const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
@@ -946,7 +963,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
       }
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < BPW; ++pl)
       dma16(rsrc_b, st + OPA_BYTES + (pl * 4 + wave) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
     s_k += BK * 4;
     s_kb += 4 * wq.cout_pad * 16;
@@ -966,9 +983,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   f32x4 ra[2][4];              // [register set][16-byte chunk j]: sub-step s contracts chunks 2 s and 2 s + 1
   bf16x8 rb[2][3][2];          // [register set][plane][sub-step]
   auto fetch = [&](auto SET, auto SLOT) __attribute__((always_inline)) -> void {
-    x6_fetch<decltype(SLOT)::value * STAGE_BYTES, B_PIECE>(ra[decltype(SET)::value], rb[decltype(SET)::value], aaddr, baddr);
+    x6_fetch<decltype(SLOT)::value * STAGE_BYTES, B_PIECE, NT>(ra[decltype(SET)::value], rb[decltype(SET)::value], aaddr, baddr);
   };
-  auto landed = [&](auto SET) __attribute__((always_inline)) -> void { x6_landed(ra[decltype(SET)::value], rb[decltype(SET)::value]); };
+  auto landed = [&](auto SET) __attribute__((always_inline)) -> void { x6_landed<NT>(ra[decltype(SET)::value], rb[decltype(SET)::value]); };
   f32x16 acc[2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -1069,6 +1086,10 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (NT == 1) {
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(round8(ra[set][2 * s], ra[set][2 * s + 1]), rb[set][0][s], acc[s], 0, 0, 0);
+        continue;
+      }
       bf16x8 ap[3];
       split3(ra[set][2 * s], ra[set][2 * s + 1], ap);
       // smallest terms first; the two sub-steps feed two independent accumulators
@@ -1464,13 +1485,22 @@ bool gemm_x6_eligible(const ConvParams& p) {
          (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL);
 }
 
-int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s) {
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
   X6Weight wq;
   wq.w6 = w6;
   wq.cout_pad = cout_pad;
+  if (terms == 1) {           // plain bf16 (training): the 64x64 tile, two workgroups per CU
+    const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+    const int g1 = nit < 512 ? nit : 512;
+    if (is1x1)
+      hipLaunchKernelGGL((gemm_x6_kernel<true, 1>), dim3(g1), dim3(256), 0, s, p, wq);
+    else
+      hipLaunchKernelGGL((gemm_x6_kernel<false, 1>), dim3(g1), dim3(256), 0, s, p, wq);
+    AOT_LAUNCH_CHECK();
+  }
   const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
   // 128x128 tiles win where they fill the chip: at least 150 of them, and either a single dispatch round or rounds that are
   // >= 70 % full (measured per shape at batch 1 and 3: profiles/r03e_mb_gemm_bf16x6_batch{1,3}.txt)

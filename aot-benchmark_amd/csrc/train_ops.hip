@@ -334,7 +334,108 @@ __global__ void __launch_bounds__(1024) sumsq_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) out[0] += red[0];
 }
 
+// ---- the optimiser over FLAT state (utils/flat_state.py): every trainable tensor is a range of one parameter / gradient /
+// moment buffer, so one step is three launches whatever the number of tensors ----------------------------------------------
+// sum of squares of the whole gradient buffer: per-block partials in fp64, summed in block order by the block that arrives
+// last (ticket) -> deterministic, one launch.  part [gridDim.x] doubles, ticket one unsigned (zero before the first launch; the
+// last arriver re-arms it).
+__global__ void __launch_bounds__(256) sumsq_flat_kernel(const float* __restrict__ x, long n, double* __restrict__ part,
+                                                         unsigned* __restrict__ ticket, double* __restrict__ out) {
+  __shared__ double red[256];
+  __shared__ bool last;
+  double acc = 0.0;
+  const long stride = (long)gridDim.x * 1024;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 t = *reinterpret_cast<const float4*>(x + i);
+      acc += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
+    } else {
+      for (long j = i; j < n; ++j) acc += (double)x[j] * x[j];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0];
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(part + i);     // fixed assignment of blocks to threads
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[0];
+    *ticket = 0u;
+  }
+}
+
+// AdamW over the flat buffers.  seg_off [nseg + 1] element offsets of the tensors (ascending), hyp [nseg][4] = lr, weight decay,
+// bias correction 1, sqrt(bias correction 2) of each tensor at its own step count; lr < 0 marks a tensor that received no
+// gradient this step (torch.optim.AdamW skips `p.grad is None`: no decay, no moment update).  The clip factor is computed here
+// from the device-resident sum of squares (clip_grad_norm_: max_norm / (norm + 1e-6), capped at 1; max_norm <= 0: no clipping),
+// so the step needs no host synchronisation.
+__global__ void __launch_bounds__(256) adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long n, const long* __restrict__ seg_off,
+                                                         const float* __restrict__ hyp, int nseg, float b1, float b2, float eps,
+                                                         const double* __restrict__ sumsq, float max_norm) {
+  const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  float gscale = 1.f;
+  if (max_norm > 0.f && sumsq) gscale = fminf(1.f, max_norm / ((float)sqrt(sumsq[0]) + 1e-6f));
+  // segment of the first element: binary search (the table is a few KB: L1 / L2 resident)
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg_off[mid] <= i0) lo = mid; else hi = mid - 1;
+  }
+  int sg = lo;
+  long end = seg_off[sg + 1];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long i = i0 + e;
+    if (i >= n) return;
+    while (i >= end) end = seg_off[++sg + 1];
+    const float lr = hyp[4 * sg];
+    if (lr < 0.f) continue;
+    const float wd = hyp[4 * sg + 1], bc1 = hyp[4 * sg + 2], bc2_sqrt = hyp[4 * sg + 3];
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi;
+  }
+}
+
 }  // namespace
+
+extern "C" int aot_sumsq_flat_f64(const float* x, long n, double* part, int nblk, unsigned* ticket, double* out, void* stream) {
+  if (!x || !part || !ticket || !out || n <= 0 || nblk <= 0 || nblk > 65535 || ((uintptr_t)x & 15)) return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(sumsq_flat_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n, part, ticket, out);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_adamw_flat_f32(float* p, const float* g, float* m, float* v, long n, const long* seg_off, const float* hyp, int nseg,
+                                  float beta1, float beta2, float eps, const double* sumsq, float max_norm, void* stream) {
+  if (!p || !g || !m || !v || !seg_off || !hyp || n <= 0 || nseg <= 0) return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_off, hyp, nseg, beta1,
+                     beta2, eps, sumsq, max_norm);
+  AOT_LAUNCH_CHECK();
+}
 
 extern "C" int aot_ce_loss_f32(const float* logits, const float* labels, float* loss_px, float* loss, unsigned* thr, float* cnt,
                                int B, int C, long P, long top_k, void* stream) {

@@ -23,6 +23,32 @@ ACT = {'none': aot_hip.ACT_NONE, 'relu': aot_hip.ACT_RELU, 'relu6': aot_hip.ACT_
        'silu': aot_hip.ACT_SILU}
 
 
+# ---- arithmetic of the conv / linear products ------------------------------------------------------------------------------
+# 'f32' (default): exact fp32 products on v_mfma_f32_32x32x2_f32.  'bf16': forward and dgrad on v_mfma_f32_32x32x16_bf16 -- both
+# operands rounded to bf16 (round to nearest even: v_cvt_pk_bf16_f32 for the activations, the weight pre-rounded by
+# aot_pack_bf16_f32), fp32 accumulation, fp32 outputs, fp32 master weights: what `--amp` (trainer.py:460-487, fp16 autocast +
+# GradScaler there) / BASELINE config 5 ask for, without a loss scale (bf16 keeps fp32's exponent range).  The weight gradient
+# (a long reduction into few tiles: split-K) and the attention products stay fp32.  A Function records the mode at forward time
+# and its backward uses the same one, wherever backward() is called from.
+_PRECISION = ['f32']
+
+
+class matmul_precision:
+    def __init__(self, mode):
+        if mode not in ('f32', 'bf16'):
+            raise ValueError("matmul_precision: 'f32' or 'bf16'")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _PRECISION[0]
+        _PRECISION[0] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _PRECISION[0] = self.prev
+        return False
+
+
 def _f32c(t):
     """fp32, contiguous (the streaming kernels walk raw memory)."""
     if t.dtype != torch.float32:
@@ -108,10 +134,13 @@ def _lean_ok(M, K, N):
     return M >= _LEAN_MIN_ROWS and K % 32 == 0 and N % 4 == 0 and N > 32
 
 
-def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1):
-    """a [M, K] @ w_kn [K, N] (+ bias) with w_nk = w_kn^T; ks > 1: split-K through a scratch slab (K / 32 divisible by ks)."""
+def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32'):
+    """a [M, K] @ w_kn [K, N] (+ bias) with w_nk = w_kn^T; ks > 1: split-K through a scratch slab (K / 32 divisible by ks).
+    prec = 'bf16' (and no split): the bf16 matrix cores (aot_hip.gemm_bf16), operands rounded to nearest even."""
     M, K = a.shape
     N = w_kn.shape[1]
+    if prec == 'bf16' and ks == 1 and 4 * M * max(K, N) < 2 ** 31:
+        return aot_hip.gemm_bf16(a, w_kn, bias)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     scratch = torch.empty(ks * M * N, dtype=torch.float32, device=a.device) if ks > 1 else None
     aot_hip.conv2d_cfg(a, w_kn, bias, out, 1, M, K, 1, M, N, cfg=-2 if ks == 1 else 196 + ks, wt=w_nk, scratch=scratch)
@@ -133,7 +162,8 @@ class _Linear(Function):
         w_kn = weight.t().contiguous()
         ctx.save_for_backward(x, weight, w_kn)
         ctx.has_bias = bias is not None
-        return _gemm_lean(x, w_kn, weight, _f32c(bias) if bias is not None else None)
+        ctx.prec = _PRECISION[0]
+        return _gemm_lean(x, w_kn, weight, _f32c(bias) if bias is not None else None, prec=ctx.prec)
 
     @staticmethod
     def backward(ctx, dy):
@@ -144,7 +174,7 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if _lean_ok(M, N, K):
-                dx = _gemm_lean(dy, weight, w_kn)                                     # dy [M, N] . W [N, K]
+                dx = _gemm_lean(dy, weight, w_kn, prec=ctx.prec)                      # dy [M, N] . W [N, K]
             else:
                 dx = _matmul_raw(dy.unsqueeze(0), weight.unsqueeze(0))[0]
         if ctx.needs_input_grad[1]:

@@ -58,10 +58,17 @@ def pin_host(rank, world, local_rank, dry=False):
     ranks do not migrate over each other and rank 0's CPU legs cannot spill onto the cores of a rank that is still being timed.
     Best effort: returns a description, never raises."""
     ncpu = os.cpu_count() or 1
-    info = {'threads': max(1, ncpu // max(world, 1)), 'affinity': 'unchanged'}
+    info = {'threads': torch.get_num_threads(), 'affinity': 'unchanged'}
+    if world == 1:
+        return info                      # a single rank keeps torch's own defaults
+    try:
+        ncpu = len(os.sched_getaffinity(0))          # the cores this process may actually use (cgroup / affinity aware)
+    except (AttributeError, OSError):
+        pass
+    info['threads'] = max(1, min(info['threads'], ncpu // world))    # never more than torch's own default
     try:
         torch.set_num_threads(info['threads'])
-        if world == 1 or dry or not hasattr(os, 'sched_setaffinity'):
+        if dry or not hasattr(os, 'sched_setaffinity'):
             return info
         prop = torch.cuda.get_device_properties(local_rank)
         bdf = '%04x:%02x:%02x.0' % (getattr(prop, 'pci_domain_id', 0), prop.pci_bus_id, prop.pci_device_id)
@@ -608,6 +615,13 @@ def main(argv=None):
         return runs[order[(len(runs) - 1) // 2]]
 
     R = max(1, args.repeats)
+    t_phase = [time.perf_counter()]
+
+    def phase(name):
+        now = time.perf_counter()
+        if rank == 0:
+            print('[bench] %s: %.1f s' % (name, now - t_phase[0]), file=sys.stderr, flush=True)
+        t_phase[0] = now
     with torch.no_grad():
         # priming (set-up, untimed): one full clip per stream so the caching allocator, the per-stream scratch and the
         # memory banks have reached their steady-state size -- a growing allocator calls hipMalloc, which
@@ -617,6 +631,7 @@ def main(argv=None):
         for t in range(1, CLIP_FRAMES):
             for lane in lanes:
                 lane.step()
+        phase('model build + priming (one clip per stream)')
         # warmup: W frames spread over the streams (fresh clip state; the plan below restarts every lane anyway)
         for lane in lanes:
             lane.restart()
@@ -632,6 +647,7 @@ def main(argv=None):
             events.append('timed_run_%d' % r)
         tmax, frames_done, msum = median_run(runs)
         elapsed = tmax
+        phase('warm-up + %d timed runs' % R)
         single = None
         if S > 1 and rank == 0 and not dry:      # the same job one clip at a time (the reference's evaluation mode)
             one = StreamClip(new_engine('latency'), streams[0], clips[0])
@@ -645,6 +661,7 @@ def main(argv=None):
                       'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead}
             del one
 
+        phase('single-stream leg')
         whole = None
         if not args.no_whole_clip and args.steps != S * (CLIP_FRAMES - 1):
             # the same lanes over whole clips (every propagated frame of a clip timed, M 1 -> 14): what `--steps 207` measures,
@@ -661,6 +678,7 @@ def main(argv=None):
                      'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _ in wruns],
                      'frames_per_gpu': fw, 'ms_per_frame': round(ew / fw * 1e3, 3), 'timed_M_mean': round(mw / fw, 2)}
 
+        phase('whole-clip leg')
         x6 = None
         if args.mfma == 'f32' and not args.no_x6 and not args.leg and rank == 0 and not dry:
             try:                                  # (an optional leg: its failure must not cost the fp32 measurement)
@@ -684,6 +702,7 @@ def main(argv=None):
             except Exception as e:           # noqa: BLE001
                 x6 = {'dtype': 'f32 via bf16x6 split', 'error': '%s: %s' % (type(e).__name__, e)}
                 print('[bench] bf16x6 leg failed: %s' % x6['error'], file=sys.stderr, flush=True)
+        phase('bf16x6 leg')
         peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
         stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
                                           device=device), world)
@@ -695,6 +714,7 @@ def main(argv=None):
             with torch.cuda.stream(streams[0]):
                 roof = attention_roofline(probe, clips[0], device)
 
+    phase('roofline pass')
     base = jf = None
     events.append('rank0_legs')          # everything below runs on rank 0 only, after the last timed barrier of every rank
     if rank == 0 and not dry:

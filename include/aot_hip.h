@@ -73,6 +73,16 @@ int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const f
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                           int lda, int ldc, int ldr, int res_rows, int act, int tile, void* stream);
 
+/* Plain bf16 form of the same operation for the TRAINING path (`--amp` of the reference's trainer, trainer.py:123-125,460-487 --
+ * there fp16 autocast + GradScaler; BASELINE config 5: bf16): both operands rounded to bf16 (round to nearest even), ONE
+ * v_mfma_f32_32x32x16_bf16 product, fp32 accumulation and output.  aot_pack_bf16_f32 rounds a weight w [K, ldb] (K % 32 == 0)
+ * into one plane of the tile order above (K * cout_pad * 2 bytes); aot_conv2d_bf16_f32 takes fp32 activations and rounds them in
+ * registers (v_cvt_pk_bf16_f32).  Same arguments and epilogue as aot_conv2d_bf16x6_f32 (64x64 tile). */
+int aot_pack_bf16_f32(const float* w, void* wq, int K, int Cout, int ldb, int cout_pad, void* stream);
+int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
+                        int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                        int lda, int ldc, int ldr, int res_rows, int act, void* stream);
+
 /* Depthwise KxK convolution over B NHWC maps ([B*H*W, C]), w is [KH*KW, C], optional bias, fused activation.
  * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)
  * and the depthwise 3x3 of MobileNetV2 InvertedResidual (mobilenetv2.py:93-98). */
@@ -328,6 +338,17 @@ int aot_ema_update_f32(float* shadow, const float* param, long n, float one_minu
 /* out[0] += sum(x^2) in fp64 (one workgroup, fixed order): the gradient-norm reduction of clip_grad_norm_
  * (trainer.py:501-503). */
 int aot_sumsq_accum_f64(const float* x, long n, double* out, void* stream);
+/* The same three steps over FLAT training state -- every trainable tensor a range of one parameter / gradient / moment buffer
+ * (what DistributedDataParallel's gradient buckets and torch's fused optimisers do for the reference's trainer,
+ * trainer.py:59-74,116-118,501-503) -- so that a step is three launches whatever the number of tensors:
+ * aot_sumsq_flat_f64: out[0] = sum(x^2) in fp64, per-block partials (part [nblk]) summed in block order by the last arriver
+ *   (`ticket`: one zeroed unsigned, re-armed by the kernel) -- deterministic;
+ * aot_adamw_flat_f32: torch.optim.AdamW on tensor s = elements [seg_off[s], seg_off[s+1]) with hyp[s] = {lr, weight decay,
+ *   1 - beta1^step, sqrt(1 - beta2^step)}; lr < 0 skips the tensor (`p.grad is None`); the clip_grad_norm_ factor
+ *   min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) is taken from the device (max_norm <= 0 or sumsq NULL: none): no host sync. */
+int aot_sumsq_flat_f64(const float* x, long n, double* part, int nblk, unsigned* ticket, double* out, void* stream);
+int aot_adamw_flat_f32(float* p, const float* g, float* m, float* v, long n, const long* seg_off, const float* hyp, int nseg,
+                       float beta1, float beta2, float eps, const double* sumsq, float max_norm, void* stream);
 
 /* ---- training path, differentiable primitives (csrc/train_bwd.hip) ----
  * What `loss.backward()` (networks/managers/trainer.py:460-519) derives for the training engine's forward

@@ -429,3 +429,70 @@ def test_training_regularisers_draw_per_sample():
     want = torch.linspace(0, 0.3, 24).tolist()[:22]
     frozen = sum(len(l.blocks) for l in enc.layers[:max(0, cfg.TRAIN_ENCODER_FREEZE_AT - 1)]) if cfg.TRAIN_ENCODER_FREEZE_AT >= 2 else 0
     assert rates[:frozen] == [0.0] * frozen and rates[frozen:] == pytest.approx(want[frozen:])
+
+
+def _flat_worker(rank, world, port, q):
+    """One rank of FlatTrainState over gloo: a small MLP (plain torch modules: the state is backend-agnostic up to step())."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from utils.flat_state import FlatTrainState
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 8))
+    unused = torch.nn.Parameter(torch.ones(5))                 # no rank ever uses it: must stay `grad is None`
+    one_sided = torch.nn.Parameter(torch.ones(8))              # only rank 1 uses it: both ranks get the averaged gradient
+    groups = [{'params': [unused], 'name': 'unused'}, {'params': [one_sided], 'name': 'one_sided'}]
+    groups += [{'params': [p], 'lr': 1e-3, 'weight_decay': 0.0, 'name': k} for k, p in net.named_parameters()]
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    st = FlatTrainState(groups, bucket_mb=512 * 4 / 2 ** 20, group=None)       # 512 elements: one layer per bucket
+    assert all(torch.equal(before[k], p.detach()) for k, p in net.named_parameters())   # re-pointing keeps the values
+    assert all(p.data_ptr() >= st.flat_p.data_ptr() and p.data_ptr() < st.flat_p.data_ptr() + 4 * st.total for p in net.parameters())
+    x = torch.randn(world, 4, 16, generator=torch.Generator().manual_seed(5))
+    st.zero_grad()
+    out = net(x[rank])
+    loss = out.pow(2).mean() + ((out * one_sided).sum() * 0.01 if rank == 1 else 0.0)
+    loss.backward()
+    in_bwd, order = st.launched_in_backward, list(st.launch_order)
+    st.average()
+    res = {'rank': rank, 'in_bwd': in_bwd, 'order': order, 'nbuckets': len(st.buckets),
+           'grads': {k: p.grad.numpy().copy() for k, p in net.named_parameters()},          # (by value: the worker exits)
+           'unused_none': unused.grad is None, 'one_sided': None if one_sided.grad is None else one_sided.grad.numpy().copy(),
+           'views': all(p.grad.data_ptr() >= st.flat_g.data_ptr() and p.grad.data_ptr() < st.flat_g.data_ptr() + 4 * st.total
+                        for p in net.parameters())}
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_train_state_overlaps_and_averages_gloo_world2():
+    """utils/flat_state.py over gloo, world 2 (trainer.py:59-74's DistributedDataParallel): parameters and gradients are views of
+    the flat buffers; a bucket's all-reduce is issued from the post-accumulate-grad hooks WHILE backward runs, first the bucket of
+    the last layers; the averaged gradients equal the full-batch gradients; a tensor no rank used keeps `grad is None` (torch's
+    AdamW skips it), one that a single rank used gets the averaged gradient on both (find_unused_parameters = True)."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # the same computation in one process on the whole batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 8))
+    one_sided = torch.nn.Parameter(torch.ones(8))
+    x = torch.randn(2, 4, 16, generator=torch.Generator().manual_seed(5))
+    o0, o1 = net(x[0]), net(x[1])
+    (0.5 * (o0.pow(2).mean() + o1.pow(2).mean() + (o1 * one_sided).sum() * 0.01)).backward()
+    for r in res:
+        assert r['views'] and r['unused_none']
+        assert r['nbuckets'] >= 3 and r['in_bwd'] >= r['nbuckets'] - 1, 'buckets were not issued from the backward hooks: %s' % r
+        assert r['order'][0] == 0 and r['order'] == sorted(r['order'])            # last layers first, in production order
+        for k, p in net.named_parameters():
+            assert np.allclose(r['grads'][k], p.grad.numpy(), atol=1e-7), k
+        assert np.allclose(r['one_sided'], one_sided.grad.numpy(), atol=1e-8)

@@ -115,7 +115,12 @@ __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
     float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
                     max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
     const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    // bits 32 / 64 / 128: 16 / 4 / 8 wait states between the v_exp_f32 that produces alpha and ANY use of it (the asm's "+v" makes
+    // every consumer depend on the s_nop)
+    if constexpr ((PAD & 32) != 0) asm volatile("s_nop 15" : "+v"(alpha));
+    if constexpr ((PAD & 64) != 0) asm volatile("s_nop 3" : "+v"(alpha));
+    if constexpr ((PAD & 128) != 0) asm volatile("s_nop 7" : "+v"(alpha));
     m = mnew;
     l *= alpha;
 #pragma unroll
@@ -242,8 +247,11 @@ int main(int argc, char** argv) {
       {"non-pipelined + fences only ", hz_kernel<1, 16>}, {"non-pipelined + pad scores  ", hz_kernel<1, 1>},
       {"non-pipelined + pad P->B    ", hz_kernel<1, 2>},  {"non-pipelined + pad WAR     ", hz_kernel<1, 4>},
       {"non-pipelined + pad rescale ", hz_kernel<1, 8>},  {"non-pipelined + all pads    ", hz_kernel<1, 15>},
-      {"shipped order + all pads    ", hz_kernel<0, 15>}};
-  struct Case { int M, ns; } cases[] = {{1, 5}, {4, 3}, {14, 3}, {4, 1}};
+      {"shipped order + all pads    ", hz_kernel<0, 15>},
+      {"pad P->B  + alpha +16 ws    ", hz_kernel<1, 2 | 32>},  {"pad rescale + alpha +16 ws  ", hz_kernel<1, 8 | 32>},
+      {"pad P->B  + alpha +4 ws     ", hz_kernel<1, 2 | 64>},  {"pad rescale + alpha +4 ws   ", hz_kernel<1, 8 | 64>},
+      {"pad P->B  + alpha +8 ws     ", hz_kernel<1, 2 | 128>}, {"pad rescale + alpha +8 ws   ", hz_kernel<1, 8 | 128>}};
+  struct Case { int M, ns; } cases[] = {{1, 5}, {4, 3}};
   std::vector<float> h0(partn), h1(partn);
   for (const Case& cs : cases) {
     const int T = cs.M * N - (cs.M == 4 ? 13 : 0);
