@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--model', default='r50_deaotl')
+    ap.add_argument('--stage', default='pre_ytb_dav', help='engine config module under configs/ (BASELINE config 5: pre_ytb_dav)')
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--batch', type=int, default=2, help='samples per GPU (TRAIN_BATCH_SIZE 16 over 8 GPUs)')
@@ -40,7 +41,9 @@ def main():
                                          env=env))
     import torch
     import torch.distributed as dist
-    from common import TRAIN_CFG, synth_model_state
+    import importlib
+    from networks.models import build_vos_model
+    from utils.synth import synth_state_dict
     from networks.engines import build_engine
     from networks.managers.trainer import TrainStep
     from utils.synth import synth_clip
@@ -48,7 +51,10 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev if a.backend == 'nccl' else None)
-    cfg, model, _ = synth_model_state(a.model, cfg_overrides=TRAIN_CFG)          # the same keyed synthetic weights on every rank
+    # BASELINE config 5's stage (configs/pre_ytb_dav.py) over the model's preset; the same keyed synthetic weights on every rank
+    cfg = importlib.import_module('configs.' + a.stage).EngineConfig('train_ddp', a.model)
+    model = build_vos_model(cfg.MODEL_VOS, cfg)
+    model.load_state_dict(synth_state_dict(model.state_dict()))
     S = a.size if cfg.MODEL_ALIGN_CORNERS else a.size // 16 * 16
     model = model.to(dev).train()
     engine = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=local, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP).train()
