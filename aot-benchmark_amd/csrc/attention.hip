@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * wave + i;
-      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+      t[i] = merge4_scalar(f, red[0][r][lane], red[1][r][lane], red[2][r][lane], red[3][r][lane]);      // (scalar on purpose: common.h)
     }
     acc = make_float4(t[0], t[1], t[2], t[3]);
   }
@@ -272,7 +272,9 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_d32_pipe_kernel(const AttnPar
   const int c = h * 32 + 8 * wave + 4 * hi;
   if (p.nsplit == 1) {
     const float inv = 1.f / lsum;
-    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    // (each product through scalar_fp32: paired, hipcc wrote the result over the register that holds `inv` -- an in-place packed
+    // multiply whose high half reads the overwritten low half; common.h)
+    acc.x = scalar_fp32(acc.x * inv); acc.y = scalar_fp32(acc.y * inv); acc.z = scalar_fp32(acc.z * inv); acc.w = scalar_fp32(acc.w * inv);
     if (p.gate) {
       const float4 u = *reinterpret_cast<const float4*>(p.gate + grow * p.ldg + c);
       acc.x *= u.x; acc.y *= u.y; acc.z *= u.z; acc.w *= u.w;

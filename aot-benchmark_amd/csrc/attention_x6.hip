@@ -71,18 +71,15 @@ __device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3]
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
-// ORDER MATTERS HERE, beyond speed.  Builds of this kernel in which a vector instruction touches an MFMA chain's accumulator right
-// behind the chain gave wrong O tiles in sporadic workgroups, different from run to run (row maxima and sums intact):
-//   * inline asm on score / output accumulators (v_max3_f32, v_mul_f32, a v_mov "anchor") in some instruction orders
-//     (profiles/r03n_attn_x6_variants.txt, r03q_attn_x6_determinism.txt);
-//   * the NON-pipelined order -- softmax of a tile directly behind its own score MFMAs, plain C++ -- (r03u_attn_x6_occ.txt);
-//   * an explicit dependency of the K / V reloads on the chain's result through v_readfirstlane (r03u_attn_x6_dep.txt).
-// What has been bit-identical over every repeat and shape tried is the order below: the scores of tile i + 1 are issued, then the
-// softmax reads the scores of tile i (a whole chain old), the accumulator is rescaled a whole chain after its last MFMA, and no
-// inline asm touches an MFMA register.  An operand-overwrite (WAR) probe did not reproduce the effect
-// (tools/dev/mfma_war_probe.hip); the working hypothesis is that with several waves sharing a SIMD's matrix pipe the wait states
-// hipcc inserts between an MFMA and a vector access to its destination do not cover the time the MFMA waits for the pipe.
-// tests/test_parity_gpu.py::test_attention_kernels_reproducible_under_load guards it (eight repeats, full-size grids).
+// Round 3 shipped this kernel with a warning that its instruction order was part of its correctness: some orders gave wrong O for
+// 16 of the 32 queries of sporadic tiles, and the MFMA wait states were suspected.  Round 4 found the cause, and it is not in the
+// loop (profiles/r04_hazard.txt): the (O, m, l) LDS merge at the end was compiled by hipcc's SLP vectoriser into an IN-PLACE packed
+// add whose op_sel crosses the halves of the overwritten source (v_pk_add_f32 v[0:1], v[18:19], v[0:1] op_sel:[0,1] op_sel_hi:[1,0]),
+// and gfx950 returns a wrong low half for lanes 48-63 of that instruction when other waves are active on the SIMD -- which waves
+// are active when the merge runs is what the loop's instruction order changed.  Probes on the hardware confirmed hipcc's MFMA
+// table on the way (XDL write -> VALU read 12 wait states, VALU write -> XDL SrcA/B 1, trans -> VALU 1, at 1 / 2 / 4 waves per
+// SIMD).  The merge is now scalar (merge4_scalar, common.h), every kernel of the library is audited for the pattern
+// (tests/test_host.py::test_no_inplace_crossed_packed_ops), and tools/dev/x6_hazard.hip keeps the deterministic reproducer.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // Variants measured on MI355X and dropped (tools/dev/mb_attn_x6.py, profiles/r03n_attn_x6_variants.txt; N = 1674, 8 heads,
@@ -232,7 +229,7 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * wave + i;
-      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+      t[i] = merge4_scalar(f, red[0][r][lane], red[1][r][lane], red[2][r][lane], red[3][r][lane]);      // (scalar on purpose: common.h)
     }
     acc = make_float4(t[0], t[1], t[2], t[3]);
   }

@@ -9,8 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'attention.hip', 'attention_x6.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip', 'train_ops.hip', 'train_bwd.hip']
 LIB = os.path.join(HERE, 'libaot_hip.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-         '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
+# Per-file additions.  -fno-slp-vectorize: hipcc's SLP vectoriser pairs scalar fp32 arithmetic into packed (VOP3P) instructions and,
+# depending on the register allocation, emits IN-PLACE forms whose op_sel crosses the halves of the overwritten source -- not safe
+# on gfx950 (common.h: scalar_fp32(); profiles/r04_hazard.txt).  The streaming / glue / training kernels below gain nothing
+# measurable from packed fp32 (they are bound by HBM or launch latency), so they are built without it; the matrix-core kernels
+# keep it (their inner loops use explicit packed asm) and are held to the ISA audit of tests/test_host.py like every other file.
+EXTRA = {'norm_act.hip': ['-fno-slp-vectorize'], 'prepost.hip': ['-fno-slp-vectorize'], 'swin.hip': ['-fno-slp-vectorize'],
+         'attn_topk.hip': ['-fno-slp-vectorize'], 'train_ops.hip': ['-fno-slp-vectorize'], 'train_bwd.hip': ['-fno-slp-vectorize']}
 
 
 def _stale():
@@ -25,11 +31,40 @@ def build_lib(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ['-o', LIB]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    # one object per source (own flags), compiled side by side, then one link
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src[:-4] + '.o')
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ['-c', os.path.join(HERE, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, obj, subprocess.Popen(cmd)))
+    objs = []
+    for src, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, 'hipcc -c ' + src)
+        objs.append(obj)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
     return LIB
+
+
+def device_asm(outdir, sources=None):
+    """gfx950 assembly of every source (the flags of the build), for the ISA audits of tests/test_host.py."""
+    hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')
+    os.makedirs(outdir, exist_ok=True)
+    procs, out = [], []
+    for src in (sources or SOURCES):
+        dst = os.path.join(outdir, src[:-4] + '.s')
+        flags = [f for f in FLAGS if f != '-fPIC'] + EXTRA.get(src, [])
+        procs.append(subprocess.Popen([hipcc] + flags + ['-S', '--cuda-device-only', os.path.join(HERE, src), '-o', dst],
+                                      stderr=subprocess.DEVNULL))
+        out.append(dst)
+    for pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, 'hipcc -S')
+    return out
 
 
 if __name__ == '__main__':

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -32,6 +34,8 @@ __device__ __forceinline__ void site() {
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+__device__ float* g_dbg = nullptr;      // PAD bit 2048: every wave's (o[16], m, l) right before the LDS merge: [workgroup][wave][18][64]
 
 template <int ORDER, int PAD>
 __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
@@ -134,16 +138,40 @@ __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
     }
     l += ps;
     load_k(ka, ORDER == 0 ? kt + 64 : kt + 32);
+    if constexpr ((PAD & 256) != 0) {
+      // bit 256: both halves of P split first, then the twelve value MFMAs strictly back to back (fenced on both sides)
+      bf16x8 pp[2][3];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float x8[8];
+      for (int c = 0; c < 2; ++c) {
+        float x8[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
-      bf16x8 pp[3];
-      split3(x8, pp);
-      site<PAD, 2>();
-      mfma6(va[c], pp, o);
-      site<PAD, 4>();
+        for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+        split3(x8, pp[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(va[0], pp[0], o);
+      mfma6(va[1], pp[1], o);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float x8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+        bf16x8 pp[3];
+        split3(x8, pp);
+        site<PAD, 2>();
+        mfma6(va[c], pp, o);
+        site<PAD, 4>();
+      }
+      if constexpr ((PAD & 512) != 0) {
+        // bit 512: the value MFMAs spread out, SPREAD vector instructions between two dependent MFMAs of the chain
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (PAD >> 12) & 15, 0);
+        }
+      }
     }
     load_v(va, kt + 32);
   };
@@ -162,6 +190,13 @@ __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
   } else {
     for (; kt + 32 < t1; kt += 32) step(kt, sa, sb, std::false_type{});
     if (kt < t1) step(kt, sa, sb, std::true_type{});
+  }
+  if constexpr ((PAD & 2048) != 0) {
+    float* d = g_dbg + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * (18 * 64) + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r * 64] = o[r];
+    d[16 * 64] = m;
+    d[17 * 64] = l;
   }
   {
     const float lt = l + __shfl_xor(l, 32);
@@ -185,7 +220,18 @@ __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * wave + i;
-      t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+      if constexpr ((PAD & 65536) != 0) {
+        // bit 65536: the merge in scalar fp32 -- an opaque asm on every product keeps hipcc's SLP vectoriser from forming v_pk_* ops
+        float a0 = f[0] * red[0][r][lane], a1 = f[1] * red[1][r][lane], a2 = f[2] * red[2][r][lane], a3 = f[3] * red[3][r][lane];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        float u = a0 + a1;
+        asm volatile("" : "+v"(u));
+        u += a2;
+        asm volatile("" : "+v"(u));
+        t[i] = u + a3;
+      } else {
+        t[i] = ((f[0] * red[0][r][lane] + f[1] * red[1][r][lane]) + f[2] * red[2][r][lane]) + f[3] * red[3][r][lane];
+      }
     }
     acc = make_float4(t[0], t[1], t[2], t[3]);
   }
@@ -207,6 +253,116 @@ __global__ void __launch_bounds__(256, 2) hz_kernel(const AttnX6Params p) {
     }
   }
 }
+
+// Host emulation (double) of one workgroup's partial O for one (key split, query row, head, channel): per wave the online softmax
+// over its key tiles, then the LDS merge.  For a value the device got wrong it prints which single dropped / doubled / stale term
+// explains the number: candidates are, per (wave, key tile, half c of the tile = 16 keys = one mfma6 group), the group's whole
+// contribution to the partial.
+struct Emul {
+  const float *q, *k, *v;
+  int N, H, C, T, ns;
+  // one wave's un-normalised (o, m, l) for (query row, head, channel) against what the device held before the merge
+  void wave(int split, int row, int h, int ch, int w, double o_dev, double m_dev, double l_dev) const {
+    const int ntile = (T + 31) / 32, tps = (ntile + ns - 1) / ns, tpw = (tps + 3) / 4;
+    const int s1 = std::min(T, (split + 1) * tps * 32);
+    const double L2E = 1.4426950408889634;
+    const int t0 = std::min(s1, (split * tps + w * tpw) * 32), t1 = std::min(s1, t0 + tpw * 32);
+    double m = -INFINITY, o = 0.0, l = 0.0;
+    std::vector<double> terms, alphas;
+    for (int kt = t0; kt < t1; kt += 32) {
+      double sc[32], mx = -INFINITY;
+      for (int j = 0; j < 32; ++j) {
+        const int key = kt + j;
+        if (key >= t1) { sc[j] = -INFINITY; continue; }
+        double d = 0.0;
+        for (int e = 0; e < 32; ++e) d += (double)(q[(size_t)row * C + h * 32 + e] / 5.656854249492381f) * k[(size_t)key * C + h * 32 + e];
+        sc[j] = d;
+        mx = std::max(mx, d);
+      }
+      const double mnew = std::max(m, mx * L2E), alpha = exp2(m - mnew);
+      m = mnew;
+      o *= alpha;
+      l *= alpha;
+      alphas.push_back(alpha);
+      for (int c = 0; c < 2; ++c) {
+        double t = 0.0;
+        for (int j = 16 * c; j < 16 * c + 16; ++j)
+          if (kt + j < t1) { const double pj = exp2(sc[j] * L2E - m); t += pj * v[(size_t)(kt + j) * C + h * 32 + ch]; l += pj; }
+        o += t;
+        terms.push_back(t);
+      }
+    }
+    printf("        wave %d (keys %d..%d): o device %.7g emulated %.7g %s | m %.6g / %.6g | l %.6g / %.6g | alphas", w, t0, t1, o_dev, o,
+           fabs(o_dev - o) > 1e-4 * (fabs(o) + 1.0) ? "<-- WRONG" : "", m_dev, m, l_dev, l);
+    for (double a : alphas) printf(" %.4g", a);
+    printf(" | group terms");
+    for (double t : terms) printf(" %.5g", t);
+    printf("\n");
+  }
+
+  void run(int split, int row, int h, int ch, double got, double want_dev) const {
+    const int ntile = (T + 31) / 32, tps = (ntile + ns - 1) / ns, tpw = (tps + 3) / 4;
+    const int s1 = std::min(T, (split + 1) * tps * 32);
+    const double L2E = 1.4426950408889634;
+    double mw[4], ow[4];
+    std::vector<std::vector<double>> terms(4);      // per wave: contribution of every (tile, c) group to o_w, BEFORE later rescales
+    std::vector<std::vector<double>> resc(4);       // per wave: product of the alphas applied after that group
+    for (int w = 0; w < 4; ++w) {
+      const int t0 = std::min(s1, (split * tps + w * tpw) * 32), t1 = std::min(s1, t0 + tpw * 32);
+      double m = -INFINITY, o = 0.0;
+      for (int kt = t0; kt < t1; kt += 32) {
+        double sc[32], mx = -INFINITY;
+        for (int j = 0; j < 32; ++j) {
+          const int key = kt + j;
+          if (key >= t1) { sc[j] = -INFINITY; continue; }
+          double d = 0.0;
+          for (int e = 0; e < 32; ++e) d += (double)(q[(size_t)row * C + h * 32 + e] / 5.656854249492381f) * k[(size_t)key * C + h * 32 + e];
+          sc[j] = d;
+          mx = std::max(mx, d);
+        }
+        const double mnew = std::max(m, mx * L2E), alpha = exp2(m - mnew);
+        m = mnew;
+        o *= alpha;
+        for (auto& r : resc[w]) r *= alpha;
+        // the kernel's halves: c = 0 holds accumulator registers 0..7 = keys {0-3, 8-11} + 4 hi ... the MFMA contracts, per c, the keys
+        // 16 c + 8 (i >> 2) + 4 hi + (i & 3) over BOTH lane halves = keys 16 c .. 16 c + 15
+        for (int c = 0; c < 2; ++c) {
+          double t = 0.0;
+          for (int j = 16 * c; j < 16 * c + 16; ++j)
+            if (kt + j < t1) t += exp2(sc[j] * L2E - m) * v[(size_t)(kt + j) * C + h * 32 + ch];
+          o += t;
+          terms[w].push_back(t);
+          resc[w].push_back(1.0);
+        }
+      }
+      mw[w] = m;
+      ow[w] = o;
+    }
+    const double mm = std::max(std::max(mw[0], mw[1]), std::max(mw[2], mw[3]));
+    double want = 0.0, f[4];
+    for (int w = 0; w < 4; ++w) { f[w] = mw[w] == -INFINITY ? 0.0 : exp2(mw[w] - mm); want += f[w] * ow[w]; }
+    printf("        emulation: want %.6g (device reference %.6g), device got %.6g, difference %.6g\n", want, want_dev, got, got - want_dev);
+    double best = 1e30; int bw = -1, bi = -1, bkind = 0;
+    for (int w = 0; w < 4; ++w)
+      for (size_t i = 0; i < terms[w].size(); ++i) {
+        const double contrib = f[w] * resc[w][i] * terms[w][i];
+        const double cand[3] = {want - contrib, want + contrib, 0};
+        for (int kd = 0; kd < 2; ++kd) {
+          const double e = fabs(cand[kd] - got);
+          if (e < best) { best = e; bw = w; bi = (int)i; bkind = kd; }
+        }
+        // a group whose P was the PREVIOUS group's P (stale B planes): replace this group's term by sum over the previous keys' weights x this V?
+      }
+    if (bw >= 0)
+      printf("        closest single-term explanation: the (wave %d, tile %d of its range, keys %d..%d) group %s -> %.6g (residual %.3g; %zu groups per wave)\n",
+             bw, bi / 2, 16 * (bi & 1), 16 * (bi & 1) + 15, bkind == 0 ? "MISSING" : "counted TWICE", bkind == 0 ? want - f[bw] * resc[bw][bi] * terms[bw][bi] : want + f[bw] * resc[bw][bi] * terms[bw][bi], best, terms[bw].size());
+    // a missed accumulator rescale: o_w *= alpha skipped for this granule at some tile (everything accumulated before it too large by 1/alpha)
+    for (int w = 0; w < 4; ++w) {
+      const int t0 = std::min(s1, (split * tps + w * tpw) * 32), t1 = std::min(s1, t0 + tpw * 32);
+      (void)t0; (void)t1;
+    }
+  }
+};
 
 typedef void (*kern_t)(const AttnX6Params);
 struct Variant { const char* name; kern_t fn; };
@@ -242,15 +398,26 @@ int main(int argc, char** argv) {
       return 1;
     }
   CK(hipDeviceSynchronize());
+  float* dbg;
+  const size_t dbgn = (size_t)H * ((N + 31) / 32) * NSMAX * 4 * 18 * 64;
+  CK(hipMalloc(&dbg, dbgn * 4));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg, sizeof dbg));
+  std::vector<float> hd(dbgn);
   const Variant vs[] = {
       {"shipped order (copy)        ", hz_kernel<0, 0>},  {"non-pipelined               ", hz_kernel<1, 0>},
       {"non-pipelined + fences only ", hz_kernel<1, 16>}, {"non-pipelined + pad scores  ", hz_kernel<1, 1>},
       {"non-pipelined + pad P->B    ", hz_kernel<1, 2>},  {"non-pipelined + pad WAR     ", hz_kernel<1, 4>},
       {"non-pipelined + pad rescale ", hz_kernel<1, 8>},  {"non-pipelined + all pads    ", hz_kernel<1, 15>},
       {"shipped order + all pads    ", hz_kernel<0, 15>},
-      {"pad P->B  + alpha +16 ws    ", hz_kernel<1, 2 | 32>},  {"pad rescale + alpha +16 ws  ", hz_kernel<1, 8 | 32>},
-      {"pad P->B  + alpha +4 ws     ", hz_kernel<1, 2 | 64>},  {"pad rescale + alpha +4 ws   ", hz_kernel<1, 8 | 64>},
-      {"pad P->B  + alpha +8 ws     ", hz_kernel<1, 2 | 128>}, {"pad rescale + alpha +8 ws   ", hz_kernel<1, 8 | 128>}};
+      {"scalar merge: pad P->B      ", hz_kernel<1, 2 | 65536>}, {"scalar merge: pad rescale   ", hz_kernel<1, 8 | 65536>},
+      {"scalar merge: b2b value MFMA", hz_kernel<1, 256 | 65536>}, {"scalar merge: 6 VALU apart  ", hz_kernel<1, 512 | (6 << 12) | 65536>},
+      {"DBG non-pipelined           ", hz_kernel<1, 2048>},    {"DBG pad P->B                ", hz_kernel<1, 2 | 2048>},
+      {"DBG pad rescale             ", hz_kernel<1, 8 | 2048>}, {"DBG b2b value MFMAs        ", hz_kernel<1, 256 | 2048>},
+      {"value MFMAs back to back    ", hz_kernel<1, 256>},     {"pad rescale + b2b value MFMA", hz_kernel<1, 8 | 256>},
+      {"pad scores + b2b value MFMAs", hz_kernel<1, 1 | 256>},
+      {"value MFMAs 2 VALU apart    ", hz_kernel<1, 512 | (2 << 12)>}, {"value MFMAs 4 VALU apart    ", hz_kernel<1, 512 | (4 << 12)>},
+      {"value MFMAs 6 VALU apart    ", hz_kernel<1, 512 | (6 << 12)>}, {"value MFMAs 7 VALU apart    ", hz_kernel<1, 512 | (7 << 12)>},
+      {"value MFMAs 8 VALU apart    ", hz_kernel<1, 512 | (8 << 12)>}, {"value MFMAs 10 VALU apart   ", hz_kernel<1, 512 | (10 << 12)>}};
   struct Case { int M, ns; } cases[] = {{1, 5}, {4, 3}};
   std::vector<float> h0(partn), h1(partn);
   for (const Case& cs : cases) {
@@ -266,7 +433,8 @@ int main(int argc, char** argv) {
     printf("== bank of %d frames (T = %d), key split %d: %d launches per variant\n", cs.M, T, cs.ns, reps);
     p.out = out; p.part = part;
     for (const Variant& var : vs) {
-      int bad_launches = 0, lo = 0, hi16 = 0;
+      int bad_launches = 0, lo = 0, hi16 = 0, shown_emul = 0;
+      bool analysed = false, dumped = false;
       size_t bad_vals = 0;
       float worst = 0.f;
       hipEvent_t e0, e1;
@@ -282,6 +450,14 @@ int main(int argc, char** argv) {
         size_t nb = 0;
         for (size_t i = 0; i < cmpn; ++i)
           if (memcmp(&h0[i], &h1[i], 4)) {
+            if (!analysed && cs.ns > 1 && i < (size_t)cs.ns * N * C && shown_emul < 3) {
+              const int c = (int)(i % C), row = (int)((i / C) % N), sp = (int)(i / ((size_t)C * N));
+              printf("      %s launch %d: split %d query row %d (tile %d, j = %d) head %d channel %d:\n", var.name, r, sp, row, row / 32, row & 31, c / 32, c & 31);
+              Emul em{hq.data(), hk.data(), hv.data(), N, H, C, T, cs.ns};
+              em.run(sp, row, c / 32, c & 31, h1[i], h0[i]);
+              ++shown_emul;
+              if (shown_emul >= 3) analysed = true;
+            }
             ++nb;
             const float d = fabsf(h0[i] - h1[i]);
             if (d > worst || d != d) worst = d;
@@ -291,6 +467,29 @@ int main(int argc, char** argv) {
               ((row & 31) < 16 ? lo : hi16)++;
             }
           }
+        if (nb && !dumped && !strncmp(var.name, "DBG", 3) && cs.ns > 1) {
+          dumped = true;
+          CK(hipMemcpy(hd.data(), dbg, dbgn * 4, hipMemcpyDeviceToHost));
+          // per-wave accumulators against the emulation, for the tiles that differ: report every (wave, register, 16-lane quarter)
+          // whose un-normalised o deviates, with the emulated per-group terms
+          int reported = 0;
+          const int ntq = (N + 31) / 32;
+          for (size_t i = 0; i < (size_t)cs.ns * N * C && reported < 4; ++i)
+            if (memcmp(&h0[i], &h1[i], 4)) {
+              const int c = (int)(i % C), row = (int)((i / C) % N), sp = (int)(i / ((size_t)C * N));
+              const int h = c / 32, ch = c & 31, qt = row / 32, j = row & 31;
+              if (j != 16) continue;                       // one report per bad granule (its first query row)
+              const int hi = (ch >> 2) & 1, rr = (ch & 3) + 4 * (ch >> 3);      // channel = (r & 3) + 8 (r >> 2) + 4 hi
+              printf("      %s: partial of split %d, query tile %d, head %d, channel %d (register %d, lane half %d) is wrong; per-wave accumulators of lane j = 16:\n",
+                     var.name, sp, qt, h, ch, rr, hi);
+              for (int w = 0; w < 4; ++w) {
+                const float* d = hd.data() + ((((size_t)sp * ntq + qt) * H + h) * 4 + w) * (18 * 64);
+                Emul em{hq.data(), hk.data(), hv.data(), N, H, C, T, cs.ns};
+                em.wave(sp, row, h, ch, w, d[rr * 64 + 32 * hi + 16], d[16 * 64 + 32 * hi + 16], d[17 * 64 + 32 * hi + 16] + d[17 * 64 + 32 * (1 - hi) + 16]);
+              }
+              ++reported;
+            }
+        }
         if (nb) ++bad_launches;
         bad_vals += nb;
       }
