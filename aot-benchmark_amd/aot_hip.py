@@ -263,6 +263,32 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
     return out
 
 
+def pack_bf16(w_kn, stream=None):
+    """w [K, N] fp32 (K % 32 == 0, unit column stride) -> one bf16 plane in the tile order of the matrix-core kernels, rounded to
+    nearest even (aot_pack_bf16_f32): int16 [K/32, 4, cout_pad, 8]."""
+    K, N = w_kn.shape
+    if K % 32 or w_kn.stride(1) != 1:
+        raise AotHipError('pack_bf16: w [K, N] with K %% 32 == 0 and unit column stride (got %s)' % (tuple(w_kn.shape),))
+    cout_pad = (N + 63) // 64 * 64
+    wq = torch.empty(K // 32, 4, cout_pad, 8, dtype=torch.int16, device=w_kn.device)
+    _chk(load().aot_pack_bf16_f32(_dev(w_kn), _dev(wq), K, N, w_kn.stride(0), cout_pad, stream if stream is not None else stream_ptr()),
+         'aot_pack_bf16_f32')
+    return wq
+
+
+def gemm_bf16_packed(a, wq, N, bias=None, out=None, stream=None):
+    """a [M, K] fp32 @ the packed weight of pack_bf16 (N real columns) (+ bias) -> fp32 [M, N]."""
+    M, K = a.shape
+    if a.stride(1) != 1 or wq.shape[0] * 32 != K:
+        raise AotHipError('gemm_bf16_packed: a [M, K] against a weight packed for K = %d' % (wq.shape[0] * 32))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk(load().aot_conv2d_bf16_f32(_dev(a), _dev(wq), wq.shape[2], _opt(bias), None, _dev(out), 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 1,
+                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, stream if stream is not None else stream_ptr()),
+         'aot_conv2d_bf16_f32')
+    return out
+
+
 def gemm_bf16(a, w_kn, bias=None, out=None, stream=None):
     """Training path, precision 'bf16': out [M, N] = a [M, K] @ w_kn [K, N] (+ bias) with both operands rounded to bf16 (round to
     nearest even) and fp32 accumulation (aot_pack_bf16_f32 + aot_conv2d_bf16_f32).  K % 32 == 0; a / out row-major fp32."""

@@ -49,6 +49,33 @@ class matmul_precision:
         return False
 
 
+# Within one optimiser step a weight is used once per frame and sample group (forward) and once more per use in backward (dgrad):
+# its k-major copy and its bf16 planes are made once per step.  The cache lives only inside `with weight_cache():` (TrainStep opens
+# one per step): the optimiser's kernels update parameters behind torch's version counters, so nothing may outlive a step.
+_WCACHE = [None]
+
+
+class weight_cache:
+    def __enter__(self):
+        self.prev = _WCACHE[0]
+        _WCACHE[0] = {}
+        return self
+
+    def __exit__(self, *exc):
+        _WCACHE[0] = self.prev
+        return False
+
+
+def _cached(key, make):
+    c = _WCACHE[0]
+    if c is None or key is None:
+        return make()
+    v = c.get(key)
+    if v is None:
+        v = c[key] = make()
+    return v
+
+
 def _f32c(t):
     """fp32, contiguous (the streaming kernels walk raw memory)."""
     if t.dtype != torch.float32:
@@ -134,13 +161,15 @@ def _lean_ok(M, K, N):
     return M >= _LEAN_MIN_ROWS and K % 32 == 0 and N % 4 == 0 and N > 32
 
 
-def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32'):
+def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32', key=None):
     """a [M, K] @ w_kn [K, N] (+ bias) with w_nk = w_kn^T; ks > 1: split-K through a scratch slab (K / 32 divisible by ks).
-    prec = 'bf16' (and no split): the bf16 matrix cores (aot_hip.gemm_bf16), operands rounded to nearest even."""
+    prec = 'bf16' (and no split): the bf16 matrix cores, operands rounded to nearest even; `key` names w_kn for the per-step cache
+    of its packed plane."""
     M, K = a.shape
     N = w_kn.shape[1]
     if prec == 'bf16' and ks == 1 and 4 * M * max(K, N) < 2 ** 31:
-        return aot_hip.gemm_bf16(a, w_kn, bias)
+        wq = _cached(None if key is None else (key, 'bf16'), lambda: aot_hip.pack_bf16(w_kn))
+        return aot_hip.gemm_bf16_packed(a, wq, N, bias)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     scratch = torch.empty(ks * M * N, dtype=torch.float32, device=a.device) if ks > 1 else None
     aot_hip.conv2d_cfg(a, w_kn, bias, out, 1, M, K, 1, M, N, cfg=-2 if ks == 1 else 196 + ks, wt=w_nk, scratch=scratch)
@@ -157,13 +186,15 @@ def _colsum(x):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, wkey):
         x, weight = _f32c(x), _f32c(weight)
-        w_kn = weight.t().contiguous()
+        w_kn = _cached(None if wkey is None else (wkey, 'kn'), lambda: weight.t().contiguous())
         ctx.save_for_backward(x, weight, w_kn)
         ctx.has_bias = bias is not None
         ctx.prec = _PRECISION[0]
-        return _gemm_lean(x, w_kn, weight, _f32c(bias) if bias is not None else None, prec=ctx.prec)
+        ctx.wkey = wkey
+        return _gemm_lean(x, w_kn, weight, _f32c(bias) if bias is not None else None, prec=ctx.prec,
+                          key=None if wkey is None else (wkey, 'fwd'))
 
     @staticmethod
     def backward(ctx, dy):
@@ -174,7 +205,8 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if _lean_ok(M, N, K):
-                dx = _gemm_lean(dy, weight, w_kn, prec=ctx.prec)                      # dy [M, N] . W [N, K]
+                dx = _gemm_lean(dy, weight, w_kn, prec=ctx.prec,                      # dy [M, N] . W [N, K]
+                                key=None if ctx.wkey is None else (ctx.wkey, 'dgrad'))
             else:
                 dx = _matmul_raw(dy.unsqueeze(0), weight.unsqueeze(0))[0]
         if ctx.needs_input_grad[1]:
@@ -189,14 +221,17 @@ class _Linear(Function):
                 dw = _matmul_raw(dy.t().unsqueeze(0), x.unsqueeze(0))[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
-    """nn.Linear on token-major x [M, in]: weight [out, in] as the parameter holds it."""
+def linear(x, weight, bias=None, wkey=None):
+    """nn.Linear on token-major x [M, in]: weight [out, in] as the parameter holds it.  wkey: what identifies the weight inside a
+    weight_cache() scope (default: the tensor's own address -- right for parameters, not for temporaries)."""
     M, K = x.shape
     if _lean_ok(M, K, weight.shape[0]):
-        return _Linear.apply(x, weight, bias)
+        if wkey is None and isinstance(weight, torch.nn.Parameter):
+            wkey = (weight.data_ptr(), tuple(weight.shape))
+        return _Linear.apply(x, weight, bias, wkey)
     return matmul(x.unsqueeze(0), weight.t().unsqueeze(0), bias)[0]
 
 
@@ -231,14 +266,19 @@ def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, dil=1):
     parameter holds it.  Returns ([B*OH*OW, Cout], OH, OW)."""
     cout, cin, kh, kw = weight.shape
     OH, OW = _osz(H, kh, stride, pad, dil), _osz(W, kw, stride, pad, dil)
+    wkey = getattr(weight, '_aot_wkey', None)
+    if wkey is None and isinstance(weight, torch.nn.Parameter):
+        wkey = (weight.data_ptr(), tuple(weight.shape))
+    if wkey is not None:
+        wkey = wkey + (x.shape[1],)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
-        return linear(x, weight.view(cout, cin), bias), OH, OW
+        return linear(x, weight.view(cout, cin), bias, wkey), OH, OW
     if x.shape[1] != cin:           # channel padding of the input (one-hot maps: 11 -> 12): pad the weight with zeros
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, x.shape[1] - cin))
         cin = x.shape[1]
     cols = _Im2col.apply(x, (B, H, W, cin, kh, kw, stride, pad, dil))
     wmat = weight.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)          # k = (ky, kx, c), as im2col lays the taps out
-    return linear(cols, wmat, bias), OH, OW
+    return linear(cols, wmat, bias, wkey), OH, OW
 
 
 # ---- depthwise convolution ---------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ class TrainStep:
         bs = len(obj_nums)
         self.engine.restart_engine(bs, True)
         self.state.zero_grad()
-        with train_ops.matmul_precision(self.precision):
+        with train_ops.matmul_precision(self.precision), train_ops.weight_cache():
             loss, masks, losses, _ = self.engine(all_frames, all_masks, bs, obj_nums, step=step, use_prev_pred=use_prev_pred,
                                                  enable_prev_frame=cfg.TRAIN_ENABLE_PREV_FRAME if enable_prev_frame is None
                                                  else enable_prev_frame, use_prev_prob=cfg.MODEL_USE_PREV_PROB)

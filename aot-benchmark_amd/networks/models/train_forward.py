@@ -31,9 +31,14 @@ from networks.layers.transformer import DualBranchGPM
 # ---- small pieces ------------------------------------------------------------------------------------------------------
 def _fold_bn(weight, bn):
     """conv weight [Cout, ...] and FrozenBatchNorm2d (constants) -> (weight * scale, shift)."""
-    scale = (bn.weight * (bn.running_var + bn.epsilon).rsqrt()).detach()
-    shift = (bn.bias - bn.running_mean * scale).detach()
-    return weight * scale.view(-1, *([1] * (weight.dim() - 1))), shift
+    def make():
+        scale = (bn.weight * (bn.running_var + bn.epsilon).rsqrt()).detach()
+        shift = (bn.bias - bn.running_mean * scale).detach()
+        w = weight * scale.view(-1, *([1] * (weight.dim() - 1)))
+        w._aot_wkey = (weight.data_ptr(), tuple(weight.shape), 'folded')      # names the weight inside train_ops.weight_cache()
+        return w, shift
+    # inside a weight_cache() scope (one optimiser step) the folded weight is ONE graph node shared by every frame that uses it
+    return T._cached((weight.data_ptr(), id(bn), 'fold'), make)
 
 
 def _drop_path(x, p, training, B):

@@ -42,6 +42,12 @@ import torch.nn.functional as F  # noqa: E402
 MODEL = 'r50_aotl'
 IN_SIZE, OUT_SIZE, NUM_OBJ, CLIP_FRAMES = (481, 849), (480, 854), 10, 70
 FP32_MFMA_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 (same guide)
+
+
+X6_WHAT = ('conv / linear layers with >= %d tiles of 64x64 on aot_conv2d_bf16x6_f32 (three truncated bf16 planes per operand, six of the '
+           'nine partial products, fp32 accumulation); long-term and self-attention on aot_attn_x6_f32 (aot_gated_attn_x6_f32 for DeAOT) '
+           'over the memory bank kept pre-split by aot_attn_pack_x6_f32; everything else as in the fp32 family')
 
 
 def aot_hip_x6_min_tiles():
@@ -230,7 +236,8 @@ def attention_roofline(engine, clip, device):
     import aot_hip
     recs = []
     deaot = 'deaot' in MODEL
-    name = 'gated_attention' if deaot else 'attention'
+    x6 = getattr(engine, 'mfma', 'f32') == 'bf16x6'
+    name = ('gated_attention' if deaot else 'attention') + ('_x6' if x6 else '')
     real = getattr(aot_hip, name)
 
     def timed(*a, **kw):
@@ -238,12 +245,21 @@ def attention_roofline(engine, clip, device):
         e0.record(torch.cuda.current_stream())
         r = real(*a, **kw)
         e1.record(torch.cuda.current_stream())
-        q, v = a[0], a[2]
-        if deaot:       # (q, k, v, gate, out, T, scale): 2*N*T*(128 + dv) FLOP; bytes: K and V rows once, q / gate / out
+        q = a[0]
+        kvb = 6.0 if x6 else 4.0     # bytes per bank element: fp32, or three bf16 planes
+        if deaot and x6:    # (q, bank, gate, out, T, scale)
+            T, dv = a[4], a[3].shape[1]
+            flop = 2.0 * q.shape[0] * T * (q.shape[1] + dv)
+            byts = kvb * T * kw.get('B', 1) * (q.shape[1] + dv) + 4.0 * q.shape[0] * (q.shape[1] + 2 * dv)
+        elif deaot:         # (q, k, v, gate, out, T, scale): 2*N*T*(128 + dv) FLOP; bytes: K and V rows once, q / gate / out
             T, dv = a[5], a[4].shape[1]
             flop = 2.0 * q.shape[0] * T * (q.shape[1] + dv)
             byts = 4.0 * (T * kw.get('B', 1) * (q.shape[1] + dv) + q.shape[0] * (q.shape[1] + 2 * dv))
-        else:           # (q, k, v, out, T, H, scale): 4*N*T*C FLOP; bytes 8*T*C + 8*N*C
+        elif x6:            # (q, bank, out, T, H, scale)
+            T, H = a[3], a[4]
+            flop = 4.0 * q.shape[0] * T * H * 32
+            byts = (2 * kvb * T * kw.get('B', 1) + 8.0 * q.shape[0]) * H * 32
+        else:               # (q, k, v, out, T, H, scale): 4*N*T*C FLOP; bytes 8*T*C + 8*N*C
             T, H = a[4], a[5]
             flop = 4.0 * q.shape[0] * T * H * 32
             byts = 8.0 * (T * kw.get('B', 1) + q.shape[0]) * H * 32
@@ -267,8 +283,8 @@ def attention_roofline(engine, clip, device):
     # record of that run and `traffic_source` names it -- it is NOT measured in this run
     traffic = src = None
     tp = None
-    for rnd in ('r04', 'r03'):        # the newest committed record of the kernel as built
-        cand = os.path.join('profiles', '%s_%sattn_traffic.json' % (rnd, 'gated_' if deaot else ''))
+    for rnd in ('r04', 'r03z', 'r03'):        # the newest committed record of the kernel as built
+        cand = os.path.join('profiles', '%s_%sattn_%straffic.json' % (rnd, 'gated_' if deaot else '', 'x6_' if x6 else ''))
         if os.path.exists(os.path.join(ROOT, cand)):
             tp = cand
             break
@@ -276,8 +292,19 @@ def attention_roofline(engine, clip, device):
         with open(os.path.join(ROOT, tp)) as f:
             traffic = round(json.load(f)['traffic_bytes_per_launch'])
         src = tp + ' (separate rocprofv3 --pmc passes, same launch mix; not measured in this run)'
-    return {'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2), 'peak': FP32_MFMA_PEAK_TF,
-            'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), 'traffic': traffic,
+    tf = flop / (ms * 1e-3) / 1e12
+    if x6:
+        # the bf16x6 kernels issue SIX bf16 MFMA products per fp32-equivalent product: priced against the dense bf16 peak that is
+        # 6 x the algorithmic FLOPs over 2500 TFLOP/s -- the same fraction as the algorithmic rate over 2500 / 6
+        return {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': round(BF16_MFMA_PEAK_TF / 6.0, 1),
+                'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs; the kernel issues 6 bf16 MFMA products per product)',
+                'frac': round(tf * 6.0 / BF16_MFMA_PEAK_TF, 4), 'bf16_mfma_tflops_issued': round(6.0 * tf, 1),
+                'peak_bf16_dense': BF16_MFMA_PEAK_TF, 'traffic': traffic, 'traffic_source': src,
+                'kernel': 'attn_x6_wide_coop_kernel' if deaot else 'attn_x6_d32_kernel', 'launches': n,
+                'avg_launch_us': round(ms * 1e3 / n, 2), 'gflop_per_launch': round(flop / n / 1e9, 3),
+                'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n)}
+    return {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TF,
+            'unit': 'TFLOP/s', 'frac': round(tf / FP32_MFMA_PEAK_TF, 4), 'traffic': traffic,
             'traffic_source': src,
             'kernel': 'attn_fwd_wide_coop_kernel<8>' if deaot else 'attn_fwd_d32_pipe_kernel', 'launches': n,
             'avg_launch_us': round(ms * 1e3 / n, 2), 'gflop_per_launch': round(flop / n / 1e9, 3),
@@ -389,7 +416,7 @@ def other_config_legs(args):
     for name in ('swinb_deaotl', 'r50_deaotl'):
         cmd = [sys.executable, os.path.abspath(__file__), '--model', name, '--leg', '--gpus', '1', '--steps', str(args.steps),
                '--warmup', str(args.warmup), '--streams', str(args.streams), '--graph', str(args.graph), '--repeats', str(args.repeats),
-               '--encode-ahead', str(args.encode_ahead)]
+               '--encode-ahead', str(args.encode_ahead), '--mfma', args.mfma]
         for flag in ('no_cpu_baseline', 'no_roofline', 'no_jf', 'no_whole_clip'):
             if getattr(args, flag):
                 cmd.append('--' + flag.replace('_', '-'))
@@ -476,11 +503,13 @@ def main(argv=None):
                     help='K > 1 (default 3): the encoder runs over the next K frames of a clip as one batch on the clip\'s own '
                          'stream (engine.encode_ahead; the encoder does not depend on the mask feedback), never past the end of '
                          'a timed window and never before its start; 1: every frame is encoded when it is matched')
-    ap.add_argument('--mfma', default='f32', choices=['f32', 'bf16x6'],
-                    help="matrix-core arithmetic of the conv / linear layers for the whole run: 'f32' (default, exact fp32 products) or "
-                         "'bf16x6' (the fp32-equivalent six-term bf16 split; reported as dtype 'f32 via bf16x6 split')")
-    ap.add_argument('--no-x6', action='store_true',
-                    help='skip the extra bf16x6 leg of a default (f32) run (config.bf16x6_split: throughput and J&F of the second kernel family)')
+    ap.add_argument('--mfma', default='bf16x6', choices=['f32', 'bf16x6'],
+                    help="matrix-core arithmetic of the run: 'bf16x6' (default since round 4: the fp32-equivalent six-term bf16 split -- "
+                         "every fp32 operand as three truncated bf16 numbers, six of the nine partial products, fp32 accumulation; dtype "
+                         "'f32 via bf16x6 split') or 'f32' (exact fp32 products on v_mfma_f32_32x32x2_f32).  The OTHER arithmetic is "
+                         "measured on the same plan as a leg of the line (config.fp32_exact / config.bf16x6_split)")
+    ap.add_argument('--no-x6', '--no-second-arithmetic', dest='no_x6', action='store_true',
+                    help='skip the leg that measures the other arithmetic (throughput and J&F of the second kernel family)')
     ap.add_argument('--repeats', type=int, default=3,
                     help='the timed window plan of --steps frames is run this many times; `value` is the MEDIAN run, all runs are '
                          'listed in config.repeat_fps (a --steps 20 window is ~40 ms: one run is not the whole story)')
@@ -680,11 +709,13 @@ def main(argv=None):
 
         phase('whole-clip leg')
         x6 = None
-        if args.mfma == 'f32' and not args.no_x6 and not args.leg and rank == 0 and not dry:
-            try:                                  # (an optional leg: its failure must not cost the fp32 measurement)
-                # the second kernel family on the same plan (same clips, streams, table, graphs): a separate number under its
-                # own dtype string, next to -- never instead of -- the fp32 value
-                xl = [StreamClip(new_engine(table, mfma='bf16x6'), streams[i], clips[i]) for i in range(S)]
+        other = 'f32' if args.mfma == 'bf16x6' else 'bf16x6'
+        other_dtype = 'f32' if other == 'f32' else 'f32 via bf16x6 split'
+        if not args.no_x6 and not args.leg and rank == 0 and not dry:
+            try:                                  # (an optional leg: its failure must not cost the headline measurement)
+                # the other kernel family on the same plan (same clips, streams, table, graphs): a separate number under its
+                # own dtype string, next to -- never instead of -- `value`
+                xl = [StreamClip(new_engine(table, mfma=other), streams[i], clips[i]) for i in range(S)]
                 for lane in xl:
                     lane.ahead = lanes[0].ahead
                     lane.restart()
@@ -693,16 +724,15 @@ def main(argv=None):
                         lane.step()
                 xruns = [run_plan(xl, passes, lambda pi, i: pi * S + i, collective=False) for _ in range(R)]
                 ex, fx, _ = median_run(xruns)
-                x6 = {'dtype': 'f32 via bf16x6 split', 'value': round(fx / ex, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in xruns],
-                      'n_gpus': 1, 'what': 'conv / linear layers with >= %d tiles of 64x64 on aot_conv2d_bf16x6_f32 (three truncated '
-                                           'bf16 planes per operand, six of the nine partial products, fp32 accumulation); long-term and '
-                                           'self-attention on aot_attn_x6_f32 (aot_gated_attn_x6_f32 for DeAOT) over the memory bank kept '
-                                           'pre-split by aot_attn_pack_x6_f32; everything else unchanged' % aot_hip_x6_min_tiles()}
+                x6 = {'dtype': other_dtype, 'value': round(fx / ex, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in xruns],
+                      'n_gpus': 1, 'what': X6_WHAT % aot_hip_x6_min_tiles() if other == 'bf16x6' else
+                      'every product exact in fp32: conv / linear on aot_conv2d_nhwc_f32, attention on aot_attn_f32 / aot_gated_attn_f32 '
+                      '(v_mfma_f32_32x32x2_f32)'}
                 del xl
             except Exception as e:           # noqa: BLE001
-                x6 = {'dtype': 'f32 via bf16x6 split', 'error': '%s: %s' % (type(e).__name__, e)}
-                print('[bench] bf16x6 leg failed: %s' % x6['error'], file=sys.stderr, flush=True)
-        phase('bf16x6 leg')
+                x6 = {'dtype': other_dtype, 'error': '%s: %s' % (type(e).__name__, e)}
+                print('[bench] %s leg failed: %s' % (other, x6['error']), file=sys.stderr, flush=True)
+        phase('second-arithmetic leg (%s)' % other)
         peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
         stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
                                           device=device), world)
@@ -713,6 +743,11 @@ def main(argv=None):
             probe = new_engine(table, graph=False)
             with torch.cuda.stream(streams[0]):
                 roof = attention_roofline(probe, clips[0], device)
+                if not args.no_x6 and not args.leg:
+                    try:            # the same pass for the other arithmetic's attention kernel (sub-object: never the headline)
+                        roof['other_arithmetic'] = attention_roofline(new_engine(table, graph=False, mfma=other), clips[0], device)
+                    except Exception as e:       # noqa: BLE001
+                        roof['other_arithmetic'] = {'error': '%s: %s' % (type(e).__name__, e)}
 
     phase('roofline pass')
     base = jf = None
@@ -724,7 +759,7 @@ def main(argv=None):
                 jf = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead), args.mfma)
                 if x6 is not None and 'error' not in x6:
                     try:
-                        x6['jf_vs_reference'] = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead), 'bf16x6')
+                        x6['jf_vs_reference'] = jf_vs_reference(device, bool(args.graph), table, max(1, args.encode_ahead), other)
                     except Exception as e:       # noqa: BLE001
                         x6['jf_error'] = '%s: %s' % (type(e).__name__, e)
             print('[bench] J&F pass on the golden clip: %.1f s' % (time.perf_counter() - t_ph), file=sys.stderr, flush=True)
@@ -773,14 +808,16 @@ def main(argv=None):
                                        'bank size M is sampled like a whole clip (timed_M_mean; a whole clip is 7.41); '
                                        'restart + reference frame and the fast-forward between windows are untimed '
                                        'set-up, as in the reference FPS (evaluator.py:325-330,444-446)',
-                       'host': host, 'jf_vs_reference': jf, 'bf16x6_split': x6, 'other_configs': others, 'dry_trace': trace},
+                       'host': host, 'jf_vs_reference': jf, ('fp32_exact' if args.mfma == 'bf16x6' else 'bf16x6_split'): x6,
+                       'arithmetic': X6_WHAT % aot_hip_x6_min_tiles() if (args.mfma == 'bf16x6' and not dry) else None,
+                       'other_configs': others, 'dry_trace': trace},
             'roofline': roof, 'cpu_baseline': base,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0 and x6 is not None and x6.get('jf_vs_reference') and x6['jf_vs_reference']['pixels_outside_near_ties'] > 0:
-        print('[bench] bf16x6 leg: %d mask pixels outside the reference near-ties' % x6['jf_vs_reference']['pixels_outside_near_ties'],
+        print('[bench] second-arithmetic leg: %d mask pixels outside the reference near-ties' % x6['jf_vs_reference']['pixels_outside_near_ties'],
               file=sys.stderr, flush=True)
     if rank == 0 and jf is not None and jf['pixels_outside_near_ties'] > 0:
         # a timed configuration whose masks leave the reference's near-ties is not a valid measurement: fail loudly

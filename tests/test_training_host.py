@@ -312,6 +312,7 @@ def test_training_graph_glue_vs_reference_gradients(case, monkeypatch):
     cfg, model, _ = synth_model_state(c['model'], cfg_overrides=TRAIN_CFG)
     model.eval()                                                   # how the fixture was made: regularisers off
     eng = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
+    eng.eval()        # the gradient goldens were made with engine.eval(): no freeze_id detach (aot_engine.py:176-177 needs self.training)
     mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
     eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
                   lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
@@ -355,6 +356,7 @@ def _ddp_worker(rank, world, port, case, q):
     cfg, model, _ = synth_model_state(c['model'], cfg_overrides=TRAIN_CFG)
     model.eval()
     eng = build_engine(cfg.MODEL_ENGINE, phase='train', aot_model=model, gpu_id=0, long_term_mem_gap=cfg.TRAIN_LONG_TERM_MEM_GAP)
+    eng.eval()        # the gradient goldens were made with engine.eval(): no freeze_id detach (aot_engine.py:176-177 needs self.training)
     mining = TRAIN_CFG['TRAIN_HARD_MINING_RATIO'] * TRAIN_CFG['TRAIN_TOTAL_STEPS']
     eng.losses = [lambda lg, lb, step: ce_topk_loss(lg[0], lb[0], step, TRAIN_CFG['TRAIN_TOP_K_PERCENT_PIXELS'], mining),
                   lambda lg, lb, step: soft_jaccard_loss(lg[0], lb[0])]
