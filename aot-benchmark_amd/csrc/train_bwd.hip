@@ -338,6 +338,89 @@ __global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* __re
   }
 }
 
+// The same two column reductions for LONG inputs (the batched step: R = lanes x tokens reaches 1e5 rows): a grid of (32-channel
+// group, row chunk); a workgroup is 8 row lanes x 32 channels (every row read is one 128-byte line), fp64 partials per chunk, the
+// workgroup that arrives last at a channel group's ticket sums the chunks in order -- deterministic, one launch.
+// part [2][nchunk][C] doubles, ticket [ceil(C / 32)] unsigned (zero before the first use; re-armed by the last arriver).
+__global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int C,
+                                                         double* __restrict__ part, unsigned* __restrict__ ticket, int nchunk) {
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, chunk = blockIdx.y;
+  const long per = (R + nchunk - 1) / nchunk;
+  const long r0 = chunk * per, r1 = min(R, r0 + per);
+  __shared__ double red[2][8][32];
+  __shared__ bool last;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long r = r0 + rl; r < r1; r += 8) {
+      const float g = dy[r * C + c];
+      if (xhat) a += (double)g * xhat[r * C + c];
+      b += g;
+    }
+  red[0][rl][cl] = a;
+  red[1][rl][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sa += red[0][q][cl]; sb += red[1][q][cl]; }
+    part[(long)chunk * C + c] = sa;
+    part[((long)nchunk + chunk) * C + c] = sb;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ticket + blockIdx.x, 1u) == (unsigned)nchunk - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (rl == 0 && c < C) {
+    double sa = 0.0, sb = 0.0;
+    for (int q = 0; q < nchunk; ++q) {
+      sa += __builtin_nontemporal_load(part + (long)q * C + c);
+      sb += __builtin_nontemporal_load(part + ((long)nchunk + q) * C + c);
+    }
+    if (dgamma) dgamma[c] = (float)sa;
+    dbeta[c] = (float)sb;
+  }
+  if (threadIdx.x == 0) ticket[blockIdx.x] = 0u;
+}
+
+// dst [C, Rpad] = src [R, C]^T, columns R..Rpad-1 zero (TR) / dst [Rpad, C] = src rows followed by zero rows (!TR): the operand
+// copies of the weight-gradient GEMM (dy^T and x^T with the reduction length padded to the split-K granule) in ONE launch each
+// instead of a fill, a strided copy and a concatenation.  32 x 32 tiles through LDS: both sides coalesced.
+template <bool TR>
+__global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, long R, int C,
+                                                            long lds_, long ldd, long Rpad) {
+  if (!TR) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= Rpad * C) return;
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) v = *reinterpret_cast<const float4*>(src + r * lds_ + c);
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+    return;
+  }
+  __shared__ float tile[32][33];
+  const long rb = (long)blockIdx.x * 32;
+  const int cb = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long r = rb + ty + 8 * k;
+    const int c = cb + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? src[r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cb + ty + 8 * k;
+    const long r = rb + tx;
+    if (c < C && r < Rpad) dst[(long)c * ldd + r] = tile[tx][ty + 8 * k];
+  }
+}
+
 // ---- softmax over rows ------------------------------------------------------------------------------------------------
 // y = softmax(x) per row of length T (entries at -inf give exactly 0); one workgroup per row
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int T) {
@@ -578,6 +661,29 @@ extern "C" int aot_norm_param_grads_f32(const float* dy, const float* xhat, floa
                                         void* stream) {
   if (!dy || !xhat || !dgamma || !dbeta || R <= 0 || C <= 0) return AOT_ERR_BADARG;
   hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_col_reduce_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, double* part,
+                                  unsigned* ticket, int nchunk, void* stream) {
+  if (!dy || !dbeta || !part || !ticket || R <= 0 || C <= 0 || nchunk <= 0 || nchunk > 65535 || (xhat && !dgamma)) return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32), nchunk), dim3(256), 0, (hipStream_t)stream, dy, xhat, dgamma, dbeta, R, C, part,
+                     ticket, nchunk);
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_transpose_pad_f32(const float* src, float* dst, long R, int C, long lds, long ldd, long Rpad, int transpose,
+                                     void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || Rpad < R || lds < C) return AOT_ERR_BADARG;
+  if (transpose) {
+    if (ldd < Rpad || cdiv(C, 32) > 65535) return AOT_ERR_BADARG;
+    hipLaunchKernelGGL((transpose_pad_kernel<true>), dim3(cdiv(Rpad, 32), cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds,
+                       ldd, Rpad);
+  } else {
+    if ((C & 3) || (lds & 3) || (ldd & 3) || ldd < C || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return AOT_ERR_BADARG;
+    hipLaunchKernelGGL((transpose_pad_kernel<false>), dim3(cdiv(Rpad * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds,
+                       ldd, Rpad);
+  }
   AOT_LAUNCH_CHECK();
 }
 

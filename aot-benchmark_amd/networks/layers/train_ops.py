@@ -153,7 +153,8 @@ def matmul(a, b, bias=None, alpha=1.0):
 # (aot_conv2d_nhwc_f32, csrc/gemm_lds.hip: both operands by LDS-DMA) instead of the strided general kernel whenever the shapes allow
 # it.  That entry takes the second operand twice -- k-major [K, N] for its general kernels and as k-contiguous rows [N, K] for the
 # tile kernel -- so: forward = (W^T copy, W), dgrad = (W, the same W^T copy), wgrad = (x, x^T) with dy^T as the first operand and the
-# row count (the reduction length) zero-padded to the split-K granule; bias gradient = column sums (aot_norm_param_grads_f32).
+# row count (the reduction length) zero-padded to the split-K granule; bias gradient = column sums (aot_col_reduce_f32);
+# the operand copies of the weight gradient (dy^T, x^T, zero-padded) are one aot_transpose_pad_f32 launch each.
 _LEAN_MIN_ROWS = 64
 
 
@@ -176,12 +177,38 @@ def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32', key=None):
     return out
 
 
+_REDUCE_WS = {}
+
+
+def _col_reduce(dy, xhat):
+    """(sum_r dy xhat, sum_r dy) over the rows of [R, C] (fp64 partials in fixed order, one launch: aot_col_reduce_f32); xhat None:
+    column sums only.  The scratch (chunk partials, self re-arming tickets) is kept per device and stream."""
+    R, C = dy.shape
+    nchunk = max(1, min(64, R // 512))
+    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+    ws = _REDUCE_WS.get(key)
+    if ws is None or ws[0].numel() < 2 * nchunk * C or ws[1].numel() < (C + 31) // 32:
+        ws = _REDUCE_WS[key] = (torch.empty(2 * 64 * max(C, 2048), dtype=torch.float64, device=dy.device),
+                                torch.zeros(max(64, (max(C, 2048) + 31) // 32), dtype=torch.int32, device=dy.device))
+    dg = torch.empty(C, dtype=torch.float32, device=dy.device) if xhat is not None else None
+    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    _chk(load().aot_col_reduce_f32(_dev(dy), _opt(xhat), _opt(dg), _dev(db), R, C, _dev(ws[0]), _dev(ws[1]), nchunk, stream_ptr()),
+         'aot_col_reduce_f32')
+    return dg, db
+
+
 def _colsum(x):
     """column sums of x [R, C] (fp64 partials, fixed order)."""
+    return _col_reduce(x, None)[1]
+
+
+def _transpose_pad(x, rpad, transpose=True):
+    """x [R, C] -> x^T zero-padded to [C, rpad] (or, transpose = False, x followed by zero rows: [rpad, C]) in one launch."""
     R, C = x.shape
-    dg, db = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
-    _chk(load().aot_norm_param_grads_f32(_dev(x), _dev(x), _dev(dg), _dev(db), R, C, stream_ptr()), 'aot_norm_param_grads_f32')
-    return db
+    out = torch.empty((C, rpad) if transpose else (rpad, C), dtype=torch.float32, device=x.device)
+    _chk(load().aot_transpose_pad_f32(_dev(x), _dev(out), R, C, x.stride(0), out.stride(0), rpad, 1 if transpose else 0, stream_ptr()),
+         'aot_transpose_pad_f32')
+    return out
 
 
 class _Linear(Function):
@@ -213,10 +240,9 @@ class _Linear(Function):
             ks = max(1, min(15, 256 // max(1, -(-N // 64) * -(-K // 64))))              # enough workgroups for 256 CUs
             Mp = -(-M // (32 * ks)) * (32 * ks)
             if M >= 1024 and _lean_ok(N, Mp, K) and (Mp // 32) % ks == 0 and 4 * Mp * max(N, K) < 2 ** 31:
-                dyt = torch.zeros(N, Mp, dtype=torch.float32, device=dy.device)
-                dyt[:, :M] = dy.t()
-                xp = x if Mp == M else torch.cat([x, torch.zeros(Mp - M, K, dtype=torch.float32, device=x.device)], 0)
-                dw = _gemm_lean(dyt, xp, xp.t().contiguous(), ks=ks)                 # dy^T [N, M] . x [M, K]
+                dyt = _transpose_pad(dy, Mp)                                            # dy^T [N, Mp], zero behind column M
+                xp = x if Mp == M else _transpose_pad(x, Mp, transpose=False)
+                dw = _gemm_lean(dyt, xp, _transpose_pad(x, Mp), ks=ks)               # dy^T [N, M] . x [M, K]
             else:
                 dw = _matmul_raw(dy.t().unsqueeze(0), x.unsqueeze(0))[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -375,8 +401,7 @@ class _LayerNorm(Function):
         dx, xhat = torch.empty_like(x), torch.empty_like(x)
         _chk(load().aot_layernorm_bwd_f32(_dev(x), _dev(dy), _dev(gamma), _dev(dx), _dev(xhat), M, C, ctx.eps, stream_ptr()),
              'aot_layernorm_bwd_f32')
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
-        _chk(load().aot_norm_param_grads_f32(_dev(dy), _dev(xhat), _dev(dg), _dev(db), M, C, stream_ptr()), 'aot_norm_param_grads_f32')
+        dg, db = _col_reduce(dy, xhat)
         return dx, dg, db, None
 
 
@@ -408,8 +433,7 @@ class _GroupNorm(Function):
         dx, xhat = torch.empty_like(x), torch.empty_like(x)
         _chk(load().aot_groupnorm_bwd_f32(_dev(x), _dev(dy), _dev(stats), _dev(gamma), _dev(dx), _dev(xhat), ctx.B, R // ctx.B, C,
                                           ctx.groups, stream_ptr()), 'aot_groupnorm_bwd_f32')
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
-        _chk(load().aot_norm_param_grads_f32(_dev(dy), _dev(xhat), _dev(dg), _dev(db), R, C, stream_ptr()), 'aot_norm_param_grads_f32')
+        dg, db = _col_reduce(dy, xhat)
         return dx, dg, db, None, None, None
 
 

@@ -437,11 +437,27 @@ class ClipGraph:
         self.size_2d = None
         self.feats = None
         self.dec_in = None
+        self._pre = None           # encode_all(): per frame ([f4, f8, f16], projected 16x map, h, w)
 
-    def _encode(self, img):
-        self.feats, (top, h, w) = encoder_features(self.m.encoder, img)
+    def encode_all(self, frames_all, n_frames):
+        """The encoder over ALL frames of the step as one batch of n_frames * B lanes (time-major), like the reference's
+        offline_encoder (aot_engine.py:147-166): the trunk does not depend on the memory, and one pass over ten maps costs a fifth
+        of the launches of five passes over two.  _encode(t) then hands out frame t's rows (unbind: one stack in backward)."""
+        B = self.B
+        feats, (top, h, w) = encoder_features(self.m.encoder, frames_all)
         proj = self.m.encoder_projector
-        x16 = T.conv2d(top, proj.weight, proj.bias, self.B, h, w)[0]
+        x16 = T.conv2d(top, proj.weight, proj.bias, n_frames * B, h, w)[0]
+        per = [[(ft, hh, ww) for ft in f.view(n_frames, B * hh * ww, f.shape[1]).unbind(0)] for f, hh, ww in feats]
+        x16s = x16.view(n_frames, B * h * w, x16.shape[1]).unbind(0)
+        self._pre = [([per[k][t] for k in range(len(per))], x16s[t], h, w) for t in range(n_frames)]
+
+    def _encode(self, img, t=None):
+        if self._pre is not None and t is not None:
+            self.feats, x16, h, w = self._pre[t]
+        else:
+            self.feats, (top, h, w) = encoder_features(self.m.encoder, img)
+            proj = self.m.encoder_projector
+            x16 = T.conv2d(top, proj.weight, proj.bias, self.B, h, w)[0]
         if self.size_2d is None:
             self.size_2d = (h, w)
             with torch.no_grad():
@@ -503,11 +519,11 @@ class ClipGraph:
         self.curr = curr
         return new_long
 
-    def add_reference_frame(self, img, one_hot, frame_step=None):
+    def add_reference_frame(self, img, one_hot, frame_step=None, t=None):
         """aot_engine.py:188-251 (also set_prev_frame, :253-289): the frame memorises its own mask."""
         if frame_step is not None:
             self.frame_step = frame_step
-        x16 = self._encode(img)
+        x16 = self._encode(img, t)
         mems = self._lstt(x16, self.id_emb(one_hot))
         if self.long is None:
             self.long = [[m] for m in mems]
@@ -517,9 +533,9 @@ class ClipGraph:
         self.last_mem_step = self.frame_step
         self.short = mems
 
-    def match_propogate_one_frame(self, img):
+    def match_propogate_one_frame(self, img, t=None):
         self.frame_step += 1
-        self._lstt(self._encode(img), None)
+        self._lstt(self._encode(img, t), None)
 
     def decode_logits(self, out_size):
         """decode_current_logits (aot_engine.py:356-380): stride-4 logits -> output size; token-major [B * H * W, L]."""
@@ -611,17 +627,18 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
     # the auxiliary decodes record no graph once their weight has faded to 0 (aot_engine.py:55-58,66-69: `grad_state`): no wasted
     # decoder backward, and a non-finite auxiliary loss cannot reach the gradients through 0 * nan
     aux_grad = torch.no_grad if aux_weight == 0 else torch.enable_grad
-    clip.add_reference_frame(frames[0], ident(truth(0)), frame_step=0)
+    clip.encode_all(all_frames, T_)
+    clip.add_reference_frame(frames[0], ident(truth(0)), frame_step=0, t=0)
     with aux_grad():
         score(0)
     t = 1
     if enable_prev_frame:
-        clip.add_reference_frame(frames[1], ident(truth(1)), frame_step=1)
+        clip.add_reference_frame(frames[1], ident(truth(1)), frame_step=1, t=1)
         with aux_grad():
             score(1)
         t = 2
     while t < T_:
-        clip.match_propogate_one_frame(frames[t])
+        clip.match_propogate_one_frame(frames[t], t)
         pred = score(t)
         if t < T_ - 1:
             clip.update_memory(ident(pred if use_prev_pred else truth(t)))

@@ -387,6 +387,16 @@ int aot_groupnorm_bwd_f32(const float* x, const float* dy, const double* stats, 
                           int M, int C, int G, void* stream);
 /* dgamma[c] = sum_r dy[r][c] * xhat[r][c], dbeta[c] = sum_r dy[r][c] over R rows of [R, C] (both norms). */
 int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, void* stream);
+/* The same column reductions for long inputs (a batched training step reaches 1e5 rows): grid of (32-channel group, row chunk),
+ * fp64 partials `part` [2][nchunk][C], summed in chunk order by the last arriver of each group's `ticket` (ceil(C/32) zeroed
+ * unsigned, re-armed by the kernel) -- deterministic, one launch.  xhat / dgamma may be NULL (bias gradient = column sums:
+ * what autograd derives for nn.Linear / nn.Conv2d biases, trainer.py:460-519). */
+int aot_col_reduce_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, double* part,
+                       unsigned* ticket, int nchunk, void* stream);
+/* Operand copies of the weight-gradient GEMM dW = dy^T x (what autograd derives for nn.Linear, trainer.py:460-519) in one launch:
+ * transpose != 0: dst [C, ldd] = src [R, lds]^T with columns R..Rpad-1 zero; transpose == 0: dst [Rpad, ldd] = the rows of src
+ * followed by zero rows (C % 4 == 0). */
+int aot_transpose_pad_f32(const float* src, float* dst, long R, int C, long lds, long ldd, long Rpad, int transpose, void* stream);
 /* y = softmax(x) over rows of length T (entries at -inf give 0) and dx = y * (dy - sum(dy * y)): attention.py:107,359,703,846. */
 int aot_softmax_rows_f32(const float* x, float* y, long rows, int T, void* stream);
 int aot_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int T, void* stream);
