@@ -74,9 +74,11 @@ _SIGS = {
     'aot_act_bwd_f32': [_P, _P, _P, _L, _I, _P],
     'aot_layernorm_bwd_f32': [_P] * 5 + [_I, _I, _F, _P],
     'aot_groupnorm_bwd_f32': [_P] * 6 + [_I] * 4 + [_P],
+    'aot_groupnorm_bwd2_f32': [_P] * 9 + [_I] * 5 + [_P],
     'aot_norm_param_grads_f32': [_P] * 4 + [_L, _I, _P],
     'aot_col_reduce_f32': [_P] * 4 + [_L, _I, _P, _P, _I, _P],
     'aot_transpose_pad_f32': [_P, _P, _L, _I, _L, _L, _L, _I, _P],
+    'aot_gather_cols_f32': [_P, _P, _P, _L, _I, _I, _P],
     'aot_softmax_rows_f32': [_P, _P, _L, _I, _P],
     'aot_softmax_rows_bwd_f32': [_P, _P, _P, _L, _I, _P],
     'aot_bilinear_bwd_nhwc_f32': [_P, _P] + [_I] * 7 + [_P],

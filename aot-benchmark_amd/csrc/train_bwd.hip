@@ -311,6 +311,85 @@ __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const float* __restr
   }
 }
 
+// The same backward in two well-filled launches (the batched training step: a decoder map is 1e5 tokens x 16 channels per group,
+// which ONE workgroup per (lane, group) walked in ~0.3 ms).  Launch 1: grid (G, B, nchunk), fp64 partials of (s1, s2) per row chunk,
+// summed in chunk order by the last arriver of the (lane, group)'s ticket -> m12 [B][G][2] = (s1 / n, s2 / n).  Launch 2:
+// elementwise dx and xhat, four channels per thread.
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                           double* __restrict__ part, unsigned* __restrict__ ticket, float* __restrict__ m12,
+                                                           int M, int C, int G, int nchunk) {
+  const int g = blockIdx.x, bl = blockIdx.y, chunk = blockIdx.z, t = threadIdx.x;
+  const int cg = C / G;
+  const float mean = (float)stats[((long)bl * G + g) * 2], rstd = (float)stats[((long)bl * G + g) * 2 + 1];
+  const int per = (M + nchunk - 1) / nchunk;
+  const int r0 = chunk * per, r1 = min(M, r0 + per);
+  const long base = (long)bl * M * C + (long)g * cg;
+  const long n = (long)max(0, r1 - r0) * cg;
+  __shared__ double red[2][256];
+  __shared__ bool last;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = t; i < n; i += 256) {
+    const long r = r0 + i / cg;
+    const int c = (int)(i % cg);
+    const long off = base + r * C + c;
+    const float gg = dy[off] * gamma[g * cg + c], xh = (x[off] - mean) * rstd;
+    s1 += gg;
+    s2 += (double)gg * xh;
+  }
+  red[0][t] = s1; red[1][t] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+    __syncthreads();
+  }
+  const long slot = (long)bl * G + g;
+  if (t == 0) {
+    part[(slot * nchunk + chunk) * 2] = red[0][0];
+    part[(slot * nchunk + chunk) * 2 + 1] = red[1][0];
+    __threadfence();
+    last = atomicAdd(ticket + slot, 1u) == (unsigned)nchunk - 1;
+  }
+  __syncthreads();
+  if (!last || t != 0) return;
+  __threadfence();
+  double a = 0.0, b = 0.0;
+  for (int q = 0; q < nchunk; ++q) {
+    a += __builtin_nontemporal_load(part + (slot * nchunk + q) * 2);
+    b += __builtin_nontemporal_load(part + (slot * nchunk + q) * 2 + 1);
+  }
+  const double nn = (double)M * cg;
+  m12[slot * 2] = (float)(a / nn);
+  m12[slot * 2 + 1] = (float)(b / nn);
+  ticket[slot] = 0u;
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ m12, float* __restrict__ dx, float* __restrict__ xhat_out,
+                                                           long total4, int M, int C, int G) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const long e = i4 * 4;
+  const long row = e / C;
+  const int c = (int)(e - row * C);
+  const int bl = (int)(row / M), cg = C / G;
+  const float4 xv = *reinterpret_cast<const float4*>(x + e), dv = *reinterpret_cast<const float4*>(dy + e);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+  float o[4], h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = (c + k) / cg;
+    const long slot = (long)bl * G + g;
+    const float mean = (float)stats[slot * 2], rstd = (float)stats[slot * 2 + 1];
+    const float gg = ds[k] * gamma[c + k], xh = (xs[k] - mean) * rstd;
+    o[k] = rstd * (gg - m12[slot * 2] - xh * m12[slot * 2 + 1]);
+    h[k] = xh;
+  }
+  *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<float4*>(xhat_out + e) = make_float4(h[0], h[1], h[2], h[3]);
+}
+
 // dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy over R rows of [R, C]: one workgroup per 8 channels (a few hundred channels
 // already make a few dozen workgroups), 32 row slices, fp64 partials summed in fixed order
 __global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
@@ -352,12 +431,25 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict
   __shared__ double red[2][8][32];
   __shared__ bool last;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (long r = r0 + rl; r < r1; r += 8) {
+  if (c < C) {
+    long r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {          // four rows in flight per thread
+      float g[4], h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = dy[(r + 8 * u) * C + c];
+      if (xhat) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = xhat[(r + 8 * u) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += (double)g[u] * h[u]; b += g[u]; }
+    }
+    for (; r < r1; r += 8) {
       const float g = dy[r * C + c];
       if (xhat) a += (double)g * xhat[r * C + c];
       b += g;
     }
+  }
   red[0][rl][cl] = a;
   red[1][rl][cl] = b;
   __syncthreads();
@@ -419,6 +511,17 @@ __global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restr
     const long r = rb + tx;
     if (c < C && r < Rpad) dst[(long)c * ldd + r] = tile[tx][ty + 8 * k];
   }
+}
+
+// out[r][t] = x[r][idx[t]] for t < Cout (idx int32, a permutation or a selection of the Cin columns): the identity (un)shuffle of
+// the logits (trainer.py:457, aot_engine.py:364-367) as a column gather instead of a product with a 0 / 1 matrix
+__global__ void __launch_bounds__(256) gather_cols_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out,
+                                                          long R, int Cin, int Cout) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * Cout) return;
+  const long r = i / Cout;
+  const int t = (int)(i - r * Cout);
+  out[i] = x[r * Cin + idx[t]];
 }
 
 // ---- softmax over rows ------------------------------------------------------------------------------------------------
@@ -657,6 +760,19 @@ extern "C" int aot_groupnorm_bwd_f32(const float* x, const float* dy, const doub
   AOT_LAUNCH_CHECK();
 }
 
+extern "C" int aot_groupnorm_bwd2_f32(const float* x, const float* dy, const double* stats, const float* gamma, float* dx, float* xhat,
+                                      double* part, unsigned* ticket, float* m12, int B, int M, int C, int G, int nchunk, void* stream) {
+  if (!x || !dy || !stats || !gamma || !dx || !xhat || !part || !ticket || !m12 || B <= 0 || B > 65535 || M <= 0 || C <= 0 || G <= 0 ||
+      C % G || (C & 3) || nchunk <= 0 || nchunk > 65535)
+    return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(G, B, nchunk), dim3(256), 0, (hipStream_t)stream, x, dy, stats, gamma, part, ticket, m12, M, C,
+                     G, nchunk);
+  const long total4 = (long)B * M * C / 4;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, stats, gamma, m12, dx, xhat,
+                     total4, M, C, G);
+  AOT_LAUNCH_CHECK();
+}
+
 extern "C" int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C,
                                         void* stream) {
   if (!dy || !xhat || !dgamma || !dbeta || R <= 0 || C <= 0) return AOT_ERR_BADARG;
@@ -684,6 +800,12 @@ extern "C" int aot_transpose_pad_f32(const float* src, float* dst, long R, int C
     hipLaunchKernelGGL((transpose_pad_kernel<false>), dim3(cdiv(Rpad * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds,
                        ldd, Rpad);
   }
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_gather_cols_f32(const float* x, const int* idx, float* out, long R, int Cin, int Cout, void* stream) {
+  if (!x || !idx || !out || R <= 0 || Cin <= 0 || Cout <= 0) return AOT_ERR_BADARG;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(R * Cout, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, R, Cin, Cout);
   AOT_LAUNCH_CHECK();
 }
 

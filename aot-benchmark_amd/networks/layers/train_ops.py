@@ -148,6 +148,34 @@ def matmul(a, b, bias=None, alpha=1.0):
     return _Matmul.apply(a, b, bias, alpha)
 
 
+# ---- column permutation -----------------------------------------------------------------------------------------------------------
+class _PermuteCols(Function):
+    @staticmethod
+    def forward(ctx, x, perm, inv):
+        x = _f32c(x)
+        R, C = x.shape
+        out = torch.empty(R, perm.numel(), dtype=torch.float32, device=x.device)
+        _chk(load().aot_gather_cols_f32(_dev(x), _dev(perm), _dev(out), R, C, perm.numel(), stream_ptr()), 'aot_gather_cols_f32')
+        ctx.save_for_backward(inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv, = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = dy.shape
+        dx = torch.empty(R, inv.numel(), dtype=torch.float32, device=dy.device)
+        _chk(load().aot_gather_cols_f32(_dev(dy), _dev(inv), _dev(dx), R, C, inv.numel(), stream_ptr()), 'aot_gather_cols_f32')
+        return dx, None, None
+
+
+def permute_cols(x, perm):
+    """out[:, t] = x[:, perm[t]] for a PERMUTATION perm of the columns of x [R, C] (what a product with the 0 / 1 matrix M[perm[t], t] = 1
+    computes); the gradient is the gather by the inverse permutation."""
+    perm = perm.to(device=x.device, dtype=torch.int32).contiguous()
+    return _PermuteCols.apply(x, perm, torch.argsort(perm).to(torch.int32).contiguous())
+
+
 # ---- nn.Linear on the LDS-direct GEMM kernels ---------------------------------------------------------------------------------
 # y = x W^T + b, dx = dy W, dW = dy^T x are plain row-major GEMMs: they run on the fp32 tile kernels of the inference path
 # (aot_conv2d_nhwc_f32, csrc/gemm_lds.hip: both operands by LDS-DMA) instead of the strided general kernel whenever the shapes allow
@@ -184,7 +212,7 @@ def _col_reduce(dy, xhat):
     """(sum_r dy xhat, sum_r dy) over the rows of [R, C] (fp64 partials in fixed order, one launch: aot_col_reduce_f32); xhat None:
     column sums only.  The scratch (chunk partials, self re-arming tickets) is kept per device and stream."""
     R, C = dy.shape
-    nchunk = max(1, min(64, R // 512))
+    nchunk = max(1, min(64, R // 128))
     key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
     ws = _REDUCE_WS.get(key)
     if ws is None or ws[0].numel() < 2 * nchunk * C or ws[1].numel() < (C + 31) // 32:
@@ -431,8 +459,21 @@ class _GroupNorm(Function):
         dy = _f32c(dy)
         R, C = x.shape
         dx, xhat = torch.empty_like(x), torch.empty_like(x)
-        _chk(load().aot_groupnorm_bwd_f32(_dev(x), _dev(dy), _dev(stats), _dev(gamma), _dev(dx), _dev(xhat), ctx.B, R // ctx.B, C,
-                                          ctx.groups, stream_ptr()), 'aot_groupnorm_bwd_f32')
+        M = R // ctx.B
+        nchunk = max(1, min(64, M // 256))
+        slots = ctx.B * ctx.groups
+        key = ('gn', x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _REDUCE_WS.get(key)
+        if ws is None or ws[1].numel() < slots:
+            ws = _REDUCE_WS[key] = (torch.empty(2 * 64 * max(slots, 256), dtype=torch.float64, device=x.device),
+                                    torch.zeros(max(slots, 256), dtype=torch.int32, device=x.device),
+                                    torch.empty(2 * max(slots, 256), dtype=torch.float32, device=x.device))
+        if C % 4 == 0:
+            _chk(load().aot_groupnorm_bwd2_f32(_dev(x), _dev(dy), _dev(stats), _dev(gamma), _dev(dx), _dev(xhat), _dev(ws[0]), _dev(ws[1]),
+                                               _dev(ws[2]), ctx.B, M, C, ctx.groups, nchunk, stream_ptr()), 'aot_groupnorm_bwd2_f32')
+        else:
+            _chk(load().aot_groupnorm_bwd_f32(_dev(x), _dev(dy), _dev(stats), _dev(gamma), _dev(dx), _dev(xhat), ctx.B, M, C,
+                                              ctx.groups, stream_ptr()), 'aot_groupnorm_bwd_f32')
         dg, db = _col_reduce(dy, xhat)
         return dx, dg, db, None, None, None
 

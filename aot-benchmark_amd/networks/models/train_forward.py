@@ -590,9 +590,6 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
     # identity o of sample b is moved to channel perm[b][o] (trainer.py:457; reversed on the logits, aot_engine.py:364-367)
     perms = engine.id_shuffle if engine.enable_id_shuffle else [None] * bs
     invs = [None if p is None else torch.argsort(p) for p in perms]
-    unshuffle = [None if p is None else torch.zeros(L, L, device=all_frames.device).index_put_((p, torch.arange(L, device=p.device)),
-                                                                                               torch.ones(L, device=p.device))
-                 for p in perms]
 
     def ident(maps):
         """what assign_identity sees (aot_engine.py:168-179): per sample the (shuffled) one-hot / probability map -> [bs, L, H, W]"""
@@ -610,8 +607,8 @@ def training_forward(engine, all_frames, all_masks, batch_size, obj_nums, step=0
         for b in range(bs):
             gt = masks[t, b:b + 1]
             lg = lg_all[b * HW:(b + 1) * HW]
-            if perms[b] is not None:       # channel t <- the channel identity t was moved to: a 0 / 1 matrix (exact; its backward is a matmul too)
-                lg = T.matmul(lg.unsqueeze(0), unshuffle[b].unsqueeze(0))[0]
+            if perms[b] is not None:       # channel t <- the channel identity t was moved to (aot_engine.py:364-367): a column gather
+                lg = T.permute_cols(lg, perms[b])
             lg = torch.cat([lg[:, :objs[b] + 1], lg.new_full((HW, L - objs[b] - 1), -1e10)], 1)
             scored = [T.to_nchw(lg[:, :objs[b] + 1], *size)]
             label = [gt.view(1, *size)]

@@ -385,6 +385,10 @@ int aot_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, f
 /* nn.GroupNorm backward over B lanes of contiguous [M, C] maps with the forward's statistics (aot_groupnorm_stats_f32): dx, xhat. */
 int aot_groupnorm_bwd_f32(const float* x, const float* dy, const double* stats, const float* gamma, float* dx, float* xhat, int B,
                           int M, int C, int G, void* stream);
+/* The same in two well-filled launches for long maps: per-chunk fp64 partials `part` [B*G][nchunk][2], summed in chunk order by the
+ * last arriver of `ticket` [B*G] (zeroed unsigned, re-armed) into m12 [B*G][2]; then dx / xhat elementwise (C % 4 == 0). */
+int aot_groupnorm_bwd2_f32(const float* x, const float* dy, const double* stats, const float* gamma, float* dx, float* xhat,
+                           double* part, unsigned* ticket, float* m12, int B, int M, int C, int G, int nchunk, void* stream);
 /* dgamma[c] = sum_r dy[r][c] * xhat[r][c], dbeta[c] = sum_r dy[r][c] over R rows of [R, C] (both norms). */
 int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, void* stream);
 /* The same column reductions for long inputs (a batched training step reaches 1e5 rows): grid of (32-channel group, row chunk),
@@ -396,6 +400,9 @@ int aot_col_reduce_f32(const float* dy, const float* xhat, float* dgamma, float*
 /* Operand copies of the weight-gradient GEMM dW = dy^T x (what autograd derives for nn.Linear, trainer.py:460-519) in one launch:
  * transpose != 0: dst [C, ldd] = src [R, lds]^T with columns R..Rpad-1 zero; transpose == 0: dst [Rpad, ldd] = the rows of src
  * followed by zero rows (C % 4 == 0). */
+/* out [R, Cout] = the columns idx[0..Cout) (int32) of x [R, Cin]: the identity shuffle / un-shuffle of label maps and logits
+ * (trainer.py:457, aot_engine.py:364-367: einsum with a 0 / 1 matrix there); its adjoint is the gather by the inverse permutation. */
+int aot_gather_cols_f32(const float* x, const int* idx, float* out, long R, int Cin, int Cout, void* stream);
 int aot_transpose_pad_f32(const float* src, float* dst, long R, int C, long lds, long ldd, long Rpad, int transpose, void* stream);
 /* y = softmax(x) over rows of length T (entries at -inf give 0) and dx = y * (dy - sum(dy * y)): attention.py:107,359,703,846. */
 int aot_softmax_rows_f32(const float* x, float* y, long rows, int T, void* stream);

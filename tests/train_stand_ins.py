@@ -103,9 +103,13 @@ def to_nhwc(x, cpad=None):
     return y if cpad is None or cpad == C else F.pad(y, (0, cpad - C))
 
 
+def permute_cols(x, perm):
+    return x[:, perm.to(x.device).long()]
+
+
 def install(monkeypatch):
     """Replaces the primitives of networks.layers.train_ops by the stand-ins above for one test."""
     from networks.layers import train_ops
     for name in ('matmul', 'linear', 'conv2d', 'dwconv2d', 'act', 'layernorm', 'groupnorm', 'softmax_rows', 'bilinear',
-                 'window_gather', 'window_scatter', 'to_nchw', 'to_nhwc', 'maxpool3x3s2'):
+                 'window_gather', 'window_scatter', 'to_nchw', 'to_nhwc', 'maxpool3x3s2', 'permute_cols'):
         monkeypatch.setattr(train_ops, name, globals()[name])
