@@ -27,17 +27,20 @@ def _stale():
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 
-def build_lib(force=False, verbose=True):
-    if not force and not _stale():
+def build_lib(force=False, verbose=True, variant=None, defines=()):
+    """The product library, or (variant='name', defines=['-DX=1', ...]) a variant next to it for A/B runs: libaot_hip_<name>.so,
+    same per-source flags, its own object directory (tools/dev/build_variant.sh)."""
+    lib = LIB if variant is None else os.path.join(HERE, 'libaot_hip_%s.so' % variant)
+    if variant is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')
-    objdir = os.path.join(HERE, 'build')
+    objdir = os.path.join(HERE, 'build' if variant is None else 'build_' + variant)
     os.makedirs(objdir, exist_ok=True)
     # one object per source (own flags), compiled side by side, then one link
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src[:-4] + '.o')
-        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ['-c', os.path.join(HERE, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + list(defines) + ['-c', os.path.join(HERE, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd)))
@@ -46,18 +49,18 @@ def build_lib(force=False, verbose=True):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, 'hipcc -c ' + src)
         objs.append(obj)
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
-    return LIB
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib])
+    return lib
 
 
-def device_asm(outdir, sources=None):
+def device_asm(outdir, sources=None, defines=()):
     """gfx950 assembly of every source (the flags of the build), for the ISA audits of tests/test_host.py."""
     hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')
     os.makedirs(outdir, exist_ok=True)
     procs, out = [], []
     for src in (sources or SOURCES):
         dst = os.path.join(outdir, src[:-4] + '.s')
-        flags = [f for f in FLAGS if f != '-fPIC'] + EXTRA.get(src, [])
+        flags = [f for f in FLAGS if f != '-fPIC'] + EXTRA.get(src, []) + list(defines)
         procs.append(subprocess.Popen([hipcc] + flags + ['-S', '--cuda-device-only', os.path.join(HERE, src), '-o', dst],
                                       stderr=subprocess.DEVNULL))
         out.append(dst)
