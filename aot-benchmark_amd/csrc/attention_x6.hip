@@ -90,8 +90,9 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 // subtractions of the splits as v_pk_add_f32 on register pairs (-16 per tile: 81.7 / 247.2; hipcc's post-RA pass unpacks a third
 // of them again inside MFMA shadows, where packed fp32 cannot co-issue), the exponent's fma packed as well (81.9 / 248.8), two
 // tiles per loop trip without the 16-register score copy (82.9 / 249.4), all three (82.5 / 251.3).  Same for the splits of the
-// GEMM kernels (batch 3: 2413 -> 2424 us per frame set).  The kernel is bound by the dependent chain of a tile at two waves per
-// SIMD, not by the instruction count.
+// GEMM kernels (batch 3: 2413 -> 2424 us per frame set).  Nor do more waves: capped at 128 registers (four waves per SIMD instead
+// of the three its 160 registers allow; the spills stay outside the loop) it is 15 % SLOWER (94.5 / 278 us,
+// profiles/r04_x6_occupancy.txt).
 // One wave = 32 queries x 1 head; the four waves of a workgroup take the four quarters of the workgroup's key range and merge
 // through LDS; blockIdx = (head, lane * query tile, key split) exactly as attn_fwd_d32_pipe_kernel.
 __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params p) {
