@@ -24,7 +24,7 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
-    'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
+    'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
     'aot_nchw_to_nhwc_f32': [_P, _P] + [_I] * 4 + [_P],
@@ -79,6 +79,7 @@ _SIGS = {
     'aot_col_reduce_f32': [_P] * 4 + [_L, _I, _P, _P, _I, _P],
     'aot_transpose_pad_f32': [_P, _P, _L, _I, _L, _L, _L, _I, _P],
     'aot_gather_cols_f32': [_P, _P, _P, _L, _I, _I, _P],
+    'aot_copy2d_pad_f32': [_P, _P, _L, _L, _L, _L, _L, _L, _L, _P],
     'aot_softmax_rows_f32': [_P, _P, _L, _I, _P],
     'aot_softmax_rows_bwd_f32': [_P, _P, _P, _L, _I, _P],
     'aot_bilinear_bwd_nhwc_f32': [_P, _P] + [_I] * 7 + [_P],
@@ -280,15 +281,20 @@ def pack_bf16(w_kn, stream=None):
     return wq
 
 
-def gemm_bf16_packed(a, wq, N, bias=None, out=None, stream=None):
-    """a [M, K] fp32 @ the packed weight of pack_bf16 (N real columns) (+ bias) -> fp32 [M, N]."""
+def gemm_bf16_packed(a, wq, N, bias=None, out=None, stream=None, ks=1):
+    """a [M, K] fp32 @ the packed weight of pack_bf16 (N real columns) (+ bias) -> fp32 [M, N].  ks > 1: split-K (K / 32 divisible
+    by ks) through a scratch slab -- the weight gradients of the training path, whose K is the row count."""
     M, K = a.shape
     if a.stride(1) != 1 or wq.shape[0] * 32 != K:
         raise AotHipError('gemm_bf16_packed: a [M, K] against a weight packed for K = %d' % (wq.shape[0] * 32))
+    if ks > 1 and (K // 32) % ks:
+        raise AotHipError('gemm_bf16_packed: K / 32 = %d is not divisible by the split %d' % (K // 32, ks))
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(ks * M * N, dtype=torch.float32, device=a.device) if ks > 1 else None
     _chk(load().aot_conv2d_bf16_f32(_dev(a), _dev(wq), wq.shape[2], _opt(bias), None, _dev(out), 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 1,
-                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, stream if stream is not None else stream_ptr()),
+                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, ks, _opt(scratch),
+                                    stream if stream is not None else stream_ptr()),
          'aot_conv2d_bf16_f32')
     return out
 
@@ -307,16 +313,17 @@ def gemm_bf16(a, w_kn, bias=None, out=None, stream=None):
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     _chk(load().aot_conv2d_bf16_f32(_dev(a), _dev(wq), cout_pad, _opt(bias), None, _dev(out), 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 1,
-                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, st), 'aot_conv2d_bf16_f32')
+                                    a.stride(0), out.stride(0), 0, 0, ACT_NONE, 1, None, st), 'aot_conv2d_bf16_f32')
     return out
 
 
 def conv2d_cfg(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
                cfg=-1, wt=None, scratch=None, B=1, res_rows=0, stream=None):
     """Tuning / test form: explicit kernel configuration, explicit k-contiguous weight and split-K scratch."""
-    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _dev(w), _opt(wt), _opt(bias), _opt(res), _dev(out), _opt(scratch),
+    _chk(load().aot_conv2d_nhwc_f32(_dev(x), _opt(w), _opt(wt), _opt(bias), _opt(res), _dev(out), _opt(scratch),
                                     scratch.numel() if scratch is not None else 0, B, H, W, Cin, OH, OW, Cout, KH, KW,
-                                    stride, pad, dil, x.stride(0), w.stride(0), wt.stride(0) if wt is not None else 0,
+                                    stride, pad, dil, x.stride(0), w.stride(0) if w is not None else 0,
+                                    wt.stride(0) if wt is not None else 0,
                                     out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out

@@ -128,7 +128,11 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
   }
   // K: lane = key row j of the tile; V: lane = value channel j; chunk (plane, c) of either = 64 lanes x 16 bytes
   const unsigned short* kvbase = p.kv + ((long)b * cap_tiles * p.H + h) * 6144 + lane * 8;
+#ifdef AOT_X6_PROBE_SAMETILE      // timing probe only (wrong results): every key tile reads the bank's first tile -> all fetches hit L1
+  const long tile_stride = 0;
+#else
   const long tile_stride = (long)p.H * 6144;
+#endif
 
   float m = -INFINITY, l = 0.f;
   f32x16 o;

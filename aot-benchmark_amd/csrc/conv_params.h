@@ -25,4 +25,4 @@ bool gemm_lean_eligible(const ConvParams& p);
 // [3][K/32][4][cout_pad][8] (aot_pack_bf16x6_f32)
 bool gemm_x6_eligible(const ConvParams& p);
 // tile: 0 = chosen by shape, 64 / 128 = forced (the 128x128 eight-wave form / the 64x64 form)
-int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms = 6);
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms = 6, int ksplit = 1, float* scratch = nullptr);

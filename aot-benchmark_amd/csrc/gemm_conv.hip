@@ -499,6 +499,7 @@ static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
 // hide under fp32 MFMAs: with three clips per GPU the lean tile kernel everywhere is +4..14 % frames/s.
 static int auto_cfg(const ConvParams& p, long scratch_floats, bool throughput) {
   (void)scratch_floats;
+  if (!p.w) return gemm_lean_eligible(p) ? 196 + 1 : 4;      // only the k-contiguous twin given: the LDS-direct kernel or nothing
   const bool direct_ok = (p.Cin % 32 == 0) && (p.K % 32 == 0);
   const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const bool kxk = p.KH * p.KW > 1;
@@ -517,10 +518,11 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
                                    float* out, float* scratch, long scratch_floats, int B, int H, int W, int Cin, int OH,
                                    int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int lda, int ldb,
                                    int ldwt, int ldc, int ldr, int res_rows, int act, int cfg, void* stream) {
-  if (!in || !w || !out) return AOT_ERR_BADARG;
+  if (!in || (!w && !wt) || !out) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
-  if ((Cin & 3) || (lda & 3) || (ldb & 3) || ldb < Cout || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
-  if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return AOT_ERR_BADARG;
+  if ((Cin & 3) || (lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
+  if (w && ((ldb & 3) || ldb < Cout || ((uintptr_t)w & 15))) return AOT_ERR_BADARG;
+  if ((uintptr_t)in & 15) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
   if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   ConvParams p;
@@ -534,6 +536,7 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
   hipStream_t s = (hipStream_t)stream;
   if (!scratch) scratch_floats = 0;
   if (cfg < 0) cfg = auto_cfg(p, scratch_floats, cfg == -2);
+  if (cfg < 100 && !w) return AOT_ERR_UNSUPPORTED;      // every kernel but the LDS-direct ones reads w [K, ldb]
   if (cfg >= 100) {      // LDS-direct kernel: variant (cfg - 100) / 16, split-K factor (cfg - 100) % 16
     const int variant = (cfg - 100) / 16, ks = (cfg - 100) % 16;
     if (ks > 1 && (long)ks * p.M * p.Cout > scratch_floats) return AOT_ERR_BADARG;
@@ -656,8 +659,8 @@ extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_p
 
 extern "C" int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
                                    int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
-                                   int dil, int lda, int ldc, int ldr, int res_rows, int act, void* stream) {
-  if (!in || !wq || !out) return AOT_ERR_BADARG;
+                                   int dil, int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, void* stream) {
+  if (!in || !wq || !out || ksplit < 1 || ksplit > 64 || (ksplit > 1 && !scratch)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
@@ -668,5 +671,5 @@ extern "C" int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  return launch_gemm_x6(p, wq, cout_pad, 64, (hipStream_t)stream, 1);
+  return launch_gemm_x6(p, wq, cout_pad, 64, (hipStream_t)stream, 1, ksplit, scratch);
 }

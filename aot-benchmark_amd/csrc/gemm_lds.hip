@@ -871,8 +871,11 @@ __device__ __forceinline__ bf16x8 round8(const f32x4& x0, const f32x4& x1) {
 // NT = 6: the fp32-equivalent six-term product (inference, mfma = 'bf16x6').  NT = 1: ONE product of operands rounded to bf16 --
 // the training path's `precision = 'bf16'` (train_ops.matmul_precision): weight plane from aot_pack_bf16_f32 (round to nearest
 // even), activations rounded in registers; 2 MFMAs per k-step instead of 12, one weight plane through the ring instead of three.
-template <bool IS1X1, int NT = 6>
-__global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq) {
+// SK (with NT = 1, 1x1 only): split-K for the weight gradients of the training path -- item = (tile, k-slice), the partial tile goes
+// raw to its fp32 slab of `scratch` [ksplit][M][Cout] and splitk_reduce_kernel sums the slabs in order (+ bias / residual / act).
+template <bool IS1X1, int NT = 6, bool SK = false>
+__global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
+  static_assert(!SK || (IS1X1 && NT == 1), "split-K: the plain bf16 1x1 member only");
   constexpr int NST = 3;
   constexpr int BM = 64, BN = 64;
   constexpr int AG = BM / 8, AGW = AG / 4;              // A: 8-row groups, two per wave
@@ -887,8 +890,8 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int nk = p.K / BK;
-  const int nitems = nbm * nbn;
+  const int nk = SK ? (p.K / BK) / ksplit : p.K / BK;            // k-steps per item (host guarantees divisibility)
+  const int nitems = nbm * nbn * (SK ? ksplit : 1);
   const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
   const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
   const int q8 = nitems >> 3, r8 = nitems & 7;
@@ -901,8 +904,14 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     const int it = chunk0 + li + i * nwg_x;
     Item r;
     r.bn = it % nbn;
-    r.bm = it / nbn;
-    r.kt0 = 0;
+    if (SK) {            // item = ((bm * ksplit) + slice) * nbn + bn, as in gemm_lean_kernel
+      const int t = it / nbn;
+      r.kt0 = (t % ksplit) * nk;
+      r.bm = t / ksplit;
+    } else {
+      r.bm = it / nbn;
+      r.kt0 = 0;
+    }
     return r;
   };
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -917,7 +926,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
   const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
   const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
-  const int n_res = p.res ? 16 : 0, n_bias = p.bias ? 1 : 0;
+  const int n_res = (!SK && p.res) ? 16 : 0, n_bias = (!SK && p.bias) ? 1 : 0;      // (split-K: the reduce pass adds them)
 
   // ---- issue side --------------------------------------------------------------------------------------------------
   int is_i = 0, is_kt = 0;
@@ -942,8 +951,8 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
       if (IS1X1 && !a_ok[g]) a_off[g] = (int)OOB;
     }
     b_off = live ? (unsigned)((wave * wq.cout_pad + it.bn * BN + lane) * 16) : OOB;    // chunk column cc = wave of k-block 0
-    s_k = 0;
-    s_kb = 0;
+    s_k = SK ? it.kt0 * BK * 4 : 0;                      // (split-K: the slice's first k-step)
+    s_kb = SK ? it.kt0 * 4 * wq.cout_pad * 16 : 0;
     if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
   };
   auto issue = [&](auto SLOT) __attribute__((always_inline)) -> void {
@@ -1028,6 +1037,20 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     const bool col_ok = n < p.Cout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] += acc[1][r]; acc[1][r] = 0.f; }
+    if (SK) {            // the raw partial tile -> the slice's slab [M][Cout] (sixteen stores, counted like the fused form's)
+      const int mlane_s = it.bm * BM + wm + 4 * half;
+      const i32x4 desc_slab = raw_desc(scratch + (long)(it.kt0 / nk) * p.M * p.Cout, (long)p.M * p.Cout * 4);
+      const int vbase_s = col_ok ? (mlane_s * p.Cout + n) * 4 : (int)OOB;
+      const int rows_left_s = p.M - mlane_s, lds4 = p.Cout * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        buf_store_s(desc_slab, c < rows_left_s ? vbase_s : (int)OOB, c * lds4, acc[0][r]);
+        acc[0][r] = 0.f;
+      }
+      stores_pending = 16;
+      return;
+    }
     // residual and bias were fetched under the tile's last k-step: older than the DMA pieces issued in that step
     __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));
     if (n_bias) asm volatile("" : "+v"(bv));
@@ -1485,20 +1508,29 @@ bool gemm_x6_eligible(const ConvParams& p) {
          (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL);
 }
 
-int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms) {
+int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms, int ksplit, float* scratch) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
   X6Weight wq;
   wq.w6 = w6;
   wq.cout_pad = cout_pad;
+  if (ksplit < 1 || (ksplit > 1 && terms != 1)) return AOT_ERR_BADARG;
   if (terms == 1) {           // plain bf16 (training): the 64x64 tile, two workgroups per CU
     const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
     const int g1 = nit < 512 ? nit : 512;
+    if (ksplit > 1) {         // split-K (weight gradients): 1x1 only, K / 32 divisible, partial slabs + the reduce pass
+      if (!is1x1 || (p.K / BK) % ksplit != 0 || !scratch || (long)p.M * p.Cout * 4 >= 0x7fffffffL) return AOT_ERR_BADARG;
+      const int gk = nit * ksplit < 512 ? nit * ksplit : 512;
+      hipLaunchKernelGGL((gemm_x6_kernel<true, 1, true>), dim3(gk), dim3(256), 0, s, p, wq, ksplit, scratch);
+      const long n = (long)p.M * ((p.Cout + 3) >> 2);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+      AOT_LAUNCH_CHECK();
+    }
     if (is1x1)
-      hipLaunchKernelGGL((gemm_x6_kernel<true, 1>), dim3(g1), dim3(256), 0, s, p, wq);
+      hipLaunchKernelGGL((gemm_x6_kernel<true, 1>), dim3(g1), dim3(256), 0, s, p, wq, 1, nullptr);
     else
-      hipLaunchKernelGGL((gemm_x6_kernel<false, 1>), dim3(g1), dim3(256), 0, s, p, wq);
+      hipLaunchKernelGGL((gemm_x6_kernel<false, 1>), dim3(g1), dim3(256), 0, s, p, wq, 1, nullptr);
     AOT_LAUNCH_CHECK();
   }
   const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
@@ -1517,9 +1549,9 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
   const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nitems < 512 ? nitems : 512;             // two workgroups per CU
   if (is1x1)
-    hipLaunchKernelGGL((gemm_x6_kernel<true>), dim3(grid), dim3(256), 0, s, p, wq);
+    hipLaunchKernelGGL((gemm_x6_kernel<true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
   else
-    hipLaunchKernelGGL((gemm_x6_kernel<false>), dim3(grid), dim3(256), 0, s, p, wq);
+    hipLaunchKernelGGL((gemm_x6_kernel<false>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
   AOT_LAUNCH_CHECK();
 }
 

@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(256) dwconv_bwd_data_kernel(const float* __res
 }
 
 // dw[(ky, kx)][c] = sum_{b, oy, ox} dy[(b, oy, ox)][c] * x[(b, iy, ix)][c]: one workgroup per (tap, 16 channels), its 16 thread rows
-// split the output pixels; per-thread fp64 partials, fixed order (deterministic)
+// split the output pixels; per-thread fp64 partials, fixed order (deterministic).  (Round 4 tried two levels -- workgroup = (pixel
+// chunk, 64 channels), all 25 taps of a channel in registers, chunk partials summed by the last arriver: 152 us against this
+// kernel's 128 us on the GPM's 5x5 convolutions, dropped.)
 __global__ void __launch_bounds__(256) dwconv_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 float* __restrict__ dw, const ColParams p) {
   const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
@@ -513,6 +515,37 @@ __global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restr
   }
 }
 
+// dst [Rpad, ldd] (columns < Cpad written) = the 2-D view src[r * s_r + c * s_c] (r < R, c < C; ANY strides, zero strides included),
+// zeros outside: the operands of the matrix-core GEMMs made from whatever view autograd hands over -- a row-major matrix, a
+// transposed view, a broadcast -- with the reduction length padded to the kernels' granule, in ONE launch instead of torch's
+// fill + strided copy (+ transpose copy).  32 x 32 tiles; a view whose ROWS are contiguous (s_r == 1: a transposed row-major
+// matrix) is read along r and turned through LDS, so that both sides stay coalesced.
+__global__ void __launch_bounds__(256) copy2d_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, long R, long C, long s_r,
+                                                         long s_c, long Rpad, long Cpad, long ldd) {
+  __shared__ float tile[32][33];
+  const long rb = (long)blockIdx.x * 32, cb = (long)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (s_r == 1 && s_c != 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long c = cb + ty + 8 * k, r = rb + tx;
+      tile[ty + 8 * k][tx] = (r < R && c < C) ? src[r + c * s_c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long r = rb + ty + 8 * k, c = cb + tx;
+      if (r < Rpad && c < Cpad) dst[r * ldd + c] = tile[tx][ty + 8 * k];
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long r = rb + ty + 8 * k, c = cb + tx;
+    if (r < Rpad && c < Cpad) dst[r * ldd + c] = (r < R && c < C) ? src[r * s_r + c * s_c] : 0.f;
+  }
+}
+
 // out[r][t] = x[r][idx[t]] for t < Cout (idx int32, a permutation or a selection of the Cin columns): the identity (un)shuffle of
 // the logits (trainer.py:457, aot_engine.py:364-367) as a column gather instead of a product with a 0 / 1 matrix
 __global__ void __launch_bounds__(256) gather_cols_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out,
@@ -800,6 +833,15 @@ extern "C" int aot_transpose_pad_f32(const float* src, float* dst, long R, int C
     hipLaunchKernelGGL((transpose_pad_kernel<false>), dim3(cdiv(Rpad * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C, lds,
                        ldd, Rpad);
   }
+  AOT_LAUNCH_CHECK();
+}
+
+extern "C" int aot_copy2d_pad_f32(const float* src, float* dst, long R, long C, long s_r, long s_c, long Rpad, long Cpad, long ldd,
+                                  void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || s_r < 0 || s_c < 0 || Rpad < R || Cpad < C || ldd < Cpad) return AOT_ERR_BADARG;
+  if (cdiv(Cpad, 32) > 65535 || cdiv(Rpad, 32) > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(copy2d_pad_kernel, dim3((unsigned)cdiv(Rpad, 32), (unsigned)cdiv(Cpad, 32)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     R, C, s_r, s_c, Rpad, Cpad, ldd);
   AOT_LAUNCH_CHECK();
 }
 

@@ -76,6 +76,17 @@ def _cached(key, make):
     return v
 
 
+def _dense(x2, rpad, cpad):
+    """A 2-D fp32 view (any strides) as a dense [rpad, cpad] matrix, zero beyond its own extent: the view itself when it already is
+    one (16-byte aligned), else one launch of aot_copy2d_pad_f32."""
+    R, C = x2.shape
+    if rpad == R and cpad == C and x2.stride(1) == 1 and x2.stride(0) == C and x2.data_ptr() % 16 == 0:
+        return x2
+    out = torch.empty(rpad, cpad, dtype=torch.float32, device=x2.device)
+    _chk(load().aot_copy2d_pad_f32(_dev(x2), _dev(out), R, C, x2.stride(0), x2.stride(1), rpad, cpad, cpad, stream_ptr()), 'aot_copy2d_pad_f32')
+    return out
+
+
 def _f32c(t):
     """fp32, contiguous (the streaming kernels walk raw memory)."""
     if t.dtype != torch.float32:
@@ -84,6 +95,9 @@ def _f32c(t):
 
 
 # ---- matmul ------------------------------------------------------------------------------------------------------------
+MATMUL_LOG = None      # a dict: shapes of the products that take the strided kernel are counted into it
+
+
 def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
     """a [bt, m, k], b [bt, k, n]: any strides (views welcome) -> contiguous [bt, m, n].  A few large matrices (the gated
     propagation's QK^T / PV and their gradients: one per sample) go to the LDS-direct GEMM kernels, the reduction length
@@ -98,20 +112,26 @@ def _matmul_raw(a, b, bias=None, alpha=1.0, out=None):
     if out is None and alpha == 1.0 and bt <= 4 and (k >= 64 or n > 32) and 2.0 * m * n * k >= 5e7 and small(m, k) and small(k, n) \
             and small(m, n):
         # zero-padding makes any shape fit the tile kernels: the reduction length to the split-K granule, a narrow output (the
-        # decoder's 11 logits) to 64 columns; long reductions into few output tiles (weight gradients) are split over K
+        # decoder's 11 logits) to 64 columns; long reductions into few output tiles (weight gradients) are split over K.  Each
+        # operand view (row-major, transposed, broadcast) becomes a dense padded matrix in ONE launch (aot_copy2d_pad_f32) -- or is
+        # used where it lies; the product lands in its slab of the result.
         tiles = -(-m // 64) * -(-max(n, 64) // 64)
         ks = max(1, min(15, 256 // tiles)) if k >= 4096 else 1
         kp = -(-k // (32 * ks)) * (32 * ks)
         npad = n if (n % 4 == 0 and n > 32) else max(64, -(-n // 4) * 4)
-        pad = torch.nn.functional.pad
-        bias_p = bias if (bias is None or npad == n) else pad(bias, (0, npad - n))
-        res = []
+        bias_p = bias if (bias is None or npad == n) else torch.nn.functional.pad(bias, (0, npad - n))
+        c = torch.empty(bt, m, n, dtype=torch.float32, device=a.device)
+        direct = npad == n and (m * n) % 4 == 0
         for i in range(bt):
-            ai = a[i] if kp == k else pad(a[i], (0, kp - k))
-            bi = b[i] if (kp == k and npad == n) else pad(b[i], (0, npad - n, 0, kp - k))
-            ci = _gemm_lean(ai.contiguous(), bi.contiguous(), bi.t().contiguous(), bias_p, ks=ks)
-            res.append(ci if npad == n else ci[:, :n].contiguous())
-        return res[0].unsqueeze(0) if bt == 1 else torch.stack(res)
+            ai, bti = _dense(a[i], m, kp), _dense(b[i].t(), npad, kp)      # (the kernel reads B through its k-contiguous twin only)
+            if direct:
+                _gemm_lean(ai, None, bti, bias_p, ks=ks, out=c[i])
+            else:
+                c[i].copy_(_gemm_lean(ai, None, bti, bias_p, ks=ks)[:, :n])
+        return c
+    if MATMUL_LOG is not None:          # (tools/dev: which products stay on the strided kernel)
+        key = (bt, m, k, n, float(alpha), tuple(a.stride()), tuple(b.stride()))
+        MATMUL_LOG[key] = MATMUL_LOG.get(key, 0) + 1
     c = out if out is not None else torch.empty(bt, m, n, dtype=torch.float32, device=a.device)
     sa, sb = a.stride(), b.stride()
     _chk(load().aot_matmul_strided_f32(_dev(a), _dev(b), _opt(bias), _dev(c), bt, m, n, k, sa[0], sa[1], sa[2], sb[0], sb[1],
@@ -137,9 +157,7 @@ class _Matmul(Function):
         if ctx.needs_input_grad[1]:
             db = _matmul_raw(a.transpose(1, 2), dc, alpha=ctx.alpha)            # A^T . dC
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            rows = dc.shape[0] * dc.shape[1]
-            ones = torch.ones(1, dtype=torch.float32, device=dc.device).expand(1, 1, rows)   # stride-0 view: no buffer
-            dbias = _matmul_raw(ones, dc.view(1, rows, dc.shape[2])).view(-1)
+            dbias = _colsum(dc.view(dc.shape[0] * dc.shape[1], dc.shape[2]))      # (a 1-row product on the strided kernel took 440 us)
         return da, db, dbias, None
 
 
@@ -190,18 +208,20 @@ def _lean_ok(M, K, N):
     return M >= _LEAN_MIN_ROWS and K % 32 == 0 and N % 4 == 0 and N > 32
 
 
-def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32', key=None):
+def _gemm_lean(a, w_kn, w_nk, bias=None, ks=1, prec='f32', key=None, out=None):
     """a [M, K] @ w_kn [K, N] (+ bias) with w_nk = w_kn^T; ks > 1: split-K through a scratch slab (K / 32 divisible by ks).
     prec = 'bf16' (and no split): the bf16 matrix cores, operands rounded to nearest even; `key` names w_kn for the per-step cache
-    of its packed plane."""
+    of its packed plane.  w_kn may be None on the fp32 path (the LDS-direct kernels read the k-contiguous twin only)."""
     M, K = a.shape
-    N = w_kn.shape[1]
+    N = w_nk.shape[0]
     if prec == 'bf16' and ks == 1 and 4 * M * max(K, N) < 2 ** 31:
         wq = _cached(None if key is None else (key, 'bf16'), lambda: aot_hip.pack_bf16(w_kn))
         return aot_hip.gemm_bf16_packed(a, wq, N, bias)
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     scratch = torch.empty(ks * M * N, dtype=torch.float32, device=a.device) if ks > 1 else None
-    aot_hip.conv2d_cfg(a, w_kn, bias, out, 1, M, K, 1, M, N, cfg=-2 if ks == 1 else 196 + ks, wt=w_nk, scratch=scratch)
+    aot_hip.conv2d_cfg(a, w_kn, bias, out, 1, M, K, 1, M, N, cfg=(-2 if w_kn is not None else 197) if ks == 1 else 196 + ks, wt=w_nk,
+                       scratch=scratch)
     return out
 
 
@@ -269,8 +289,12 @@ class _Linear(Function):
             Mp = -(-M // (32 * ks)) * (32 * ks)
             if M >= 1024 and _lean_ok(N, Mp, K) and (Mp // 32) % ks == 0 and 4 * Mp * max(N, K) < 2 ** 31:
                 dyt = _transpose_pad(dy, Mp)                                            # dy^T [N, Mp], zero behind column M
-                xp = x if Mp == M else _transpose_pad(x, Mp, transpose=False)
-                dw = _gemm_lean(dyt, xp, _transpose_pad(x, Mp), ks=ks)               # dy^T [N, M] . x [M, K]
+                if ctx.prec == 'bf16' and 4 * N * K < 2 ** 31:
+                    # bf16 products: x packed (rounded) into the tile order instead of transposed, split-K on the bf16 kernel
+                    xp = x if Mp == M else _transpose_pad(x, Mp, transpose=False)
+                    dw = aot_hip.gemm_bf16_packed(dyt, aot_hip.pack_bf16(xp), K, ks=ks)
+                else:
+                    dw = _gemm_lean(dyt, None, _transpose_pad(x, Mp), ks=ks)         # dy^T [N, M] . x [M, K]: x through its twin x^T
             else:
                 dw = _matmul_raw(dy.t().unsqueeze(0), x.unsqueeze(0))[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:

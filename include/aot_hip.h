@@ -41,7 +41,8 @@ const char* aot_hip_version(void);
  * w is [KH*KW*Cin, ldb] row-major (ldb >= Cout, multiple of 4; FrozenBN already folded in by the host);
  * wt (optional) is the same weight with k-contiguous rows, [Cout, ldwt] (ldwt >= KH*KW*Cin): when it is given and
  * Cin % 32 == 0 the LDS-direct tile kernel (csrc/gemm_lds.hip) runs, otherwise the register-staged one
- * (csrc/gemm_conv.hip).  bias / res may be NULL; res_rows = 0 means one residual row per output row, otherwise the
+ * (csrc/gemm_conv.hip); w may then be NULL (the LDS-direct kernels read wt only: AOT_ERR_UNSUPPORTED if the shape would need another
+ * kernel) -- the training graph's products of two activations hand over one operand layout, not two.  bias / res may be NULL; res_rows = 0 means one residual row per output row, otherwise the
  * residual is a [res_rows, ldr] map shared by the images (row m % res_rows).  A linear layer is the 1x1 case with
  * B = 1, H = 1, W = M.  `scratch` (optional, scratch_floats floats) enables split-K for shapes with too few tiles
  * (partials summed in slice order: deterministic).  cfg = -1: kernel chosen for the lowest latency of this launch on
@@ -77,11 +78,13 @@ int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const f
  * there fp16 autocast + GradScaler; BASELINE config 5: bf16): both operands rounded to bf16 (round to nearest even), ONE
  * v_mfma_f32_32x32x16_bf16 product, fp32 accumulation and output.  aot_pack_bf16_f32 rounds a weight w [K, ldb] (K % 32 == 0)
  * into one plane of the tile order above (K * cout_pad * 2 bytes); aot_conv2d_bf16_f32 takes fp32 activations and rounds them in
- * registers (v_cvt_pk_bf16_f32).  Same arguments and epilogue as aot_conv2d_bf16x6_f32 (64x64 tile). */
+ * registers (v_cvt_pk_bf16_f32).  Same arguments and epilogue as aot_conv2d_bf16x6_f32 (64x64 tile).  ksplit > 1 (1x1 only, K / 32
+ * divisible by it; the weight gradients dW = dY^T X of the training path, whose K is the row count): every k-slice writes its
+ * partial tile to a slab of `scratch` [ksplit][M][Cout] floats and one more launch sums the slabs in order (+ bias / residual / act). */
 int aot_pack_bf16_f32(const float* w, void* wq, int K, int Cout, int ldb, int cout_pad, void* stream);
 int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
                         int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                        int lda, int ldc, int ldr, int res_rows, int act, void* stream);
+                        int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, void* stream);
 
 /* Depthwise KxK convolution over B NHWC maps ([B*H*W, C]), w is [KH*KW, C], optional bias, fused activation.
  * Replaces: GNActDWConv2d.conv / DWConv2d.conv (networks/layers/basic.py:19-25,33,41-47,54)
@@ -397,13 +400,18 @@ int aot_norm_param_grads_f32(const float* dy, const float* xhat, float* dgamma, 
  * what autograd derives for nn.Linear / nn.Conv2d biases, trainer.py:460-519). */
 int aot_col_reduce_f32(const float* dy, const float* xhat, float* dgamma, float* dbeta, long R, int C, double* part,
                        unsigned* ticket, int nchunk, void* stream);
-/* Operand copies of the weight-gradient GEMM dW = dy^T x (what autograd derives for nn.Linear, trainer.py:460-519) in one launch:
- * transpose != 0: dst [C, ldd] = src [R, lds]^T with columns R..Rpad-1 zero; transpose == 0: dst [Rpad, ldd] = the rows of src
- * followed by zero rows (C % 4 == 0). */
 /* out [R, Cout] = the columns idx[0..Cout) (int32) of x [R, Cin]: the identity shuffle / un-shuffle of label maps and logits
  * (trainer.py:457, aot_engine.py:364-367: einsum with a 0 / 1 matrix there); its adjoint is the gather by the inverse permutation. */
 int aot_gather_cols_f32(const float* x, const int* idx, float* out, long R, int Cin, int Cout, void* stream);
+/* Operand copies of the weight-gradient GEMM dW = dy^T x (what autograd derives for nn.Linear, trainer.py:460-519) in one launch:
+ * transpose != 0: dst [C, ldd] = src [R, lds]^T with columns R..Rpad-1 zero; transpose == 0: dst [Rpad, ldd] = the rows of src
+ * followed by zero rows (C % 4 == 0). */
 int aot_transpose_pad_f32(const float* src, float* dst, long R, int C, long lds, long ldd, long Rpad, int transpose, void* stream);
+/* The general form: dst [Rpad, ldd] (columns < Cpad written) = the 2-D VIEW src[r * s_r + c * s_c] (element strides, any values >= 0:
+ * row-major, transposed, broadcast), zeros outside R x C -- the operands of the attention products QK^T / PV of the training graph
+ * and of their gradients (attention.py:99-110, 672-707 under autograd: torch.matmul on views), made dense and padded to the
+ * GEMM kernels' reduction granule in one launch. */
+int aot_copy2d_pad_f32(const float* src, float* dst, long R, long C, long s_r, long s_c, long Rpad, long Cpad, long ldd, void* stream);
 /* y = softmax(x) over rows of length T (entries at -inf give 0) and dx = y * (dy - sum(dy * y)): attention.py:107,359,703,846. */
 int aot_softmax_rows_f32(const float* x, float* y, long rows, int T, void* stream);
 int aot_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int T, void* stream);

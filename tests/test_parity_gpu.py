@@ -562,9 +562,12 @@ def test_attention_x6_peaky_rescale(hip):
 
 
 def test_attention_kernels_reproducible_under_load(hip):
-    """Every flash-attention kernel (fp32 d = 32, the gated form, and their bf16x6 twins) run eight times on a full-size launch (grids of
-    several dispatch rounds, every SIMD shared by several waves): bit-identical results.  (Guards the hazard class found while
-    building the x6 kernel: inline asm touching MFMA accumulators gave run-to-run differences in sporadic workgroups.)"""
+    """Every flash-attention kernel (fp32 d = 32, the gated form, and their bf16x6 twins) launched 132 times each -- 528 full-size
+    launches, grid-level key splits 1 / 3 / 5 in turn, grids of several dispatch rounds -- WHILE a second stream keeps the chip busy
+    with GEMM and attention launches of its own: every result bit-identical to the first of its kind.  (The hazard class this
+    guards: an in-place packed add with crossed halves in the (O, m, l) merge gave wrong values in sporadic workgroups depending on
+    what the CU's other waves were doing -- profiles/r04_hazard.txt; the ISA audit of tests/test_host.py guards the cause, this
+    test the symptom.)  Differences are counted on the device: no host synchronisation between launches."""
     g = torch.Generator(device='cuda').manual_seed(3)
     N, C, H, M = 1674, 256, 8, 6
     T = M * N - 13
@@ -579,27 +582,53 @@ def test_attention_kernels_reproducible_under_load(hip):
     gate = torch.randn(N, 1024, device='cuda', generator=g)
     gbank = hip.x6_gated_bank(1, M * N, 128, 1024, 'cuda')
     hip.gated_pack_x6(kg, vg, gbank, M * N)
-    for ns in (1, 3, 5):
-        part = torch.empty(ns * N * (C + 2 * H), device='cuda')
-        partg = torch.empty(ns * N * (1024 + 2 * 4), device='cuda')
-        runs = {'fp32': lambda o: hip.attention(q, k, v, o, T, H, 32 ** 0.5, part=part, nsplit=ns),
-                'bf16x6': lambda o: hip.attention_x6(q, bank, o, T, H, 32 ** 0.5, part=part, nsplit=ns)}
-        for name, run in runs.items():
-            first = torch.empty(N, C, device='cuda')
-            run(first)
-            for _ in range(7):
-                again = torch.empty(N, C, device='cuda')
-                run(again)
-                assert torch.equal(first, again), '%s attention, nsplit %d: results differ from run to run' % (name, ns)
-        gruns = {'fp32': lambda o: hip.gated_attention(qg, kg, vg, gate, o, T, 128 ** 0.5, part=partg, nsplit=ns),
-                 'bf16x6': lambda o: hip.gated_attention_x6(qg, gbank, gate, o, T, 128 ** 0.5, part=partg, nsplit=ns)}
-        for name, run in gruns.items():
-            first = torch.empty(N, 1024, device='cuda')
-            run(first)
-            for _ in range(7):
-                again = torch.empty(N, 1024, device='cuda')
-                run(again)
-                assert torch.equal(first, again), '%s gated attention, nsplit %d: results differ from run to run' % (name, ns)
+    SPLITS, REPS = (1, 3, 5), 44                 # 3 x 44 = 132 launches per kernel
+    part = {ns: torch.empty(ns * N * (C + 2 * H), device='cuda') for ns in SPLITS}
+    partg = {ns: torch.empty(ns * N * (1024 + 2 * 4), device='cuda') for ns in SPLITS}
+    kernels = {
+        'fp32 attention': (C, lambda o, ns: hip.attention(q, k, v, o, T, H, 32 ** 0.5, part=part[ns], nsplit=ns)),
+        'bf16x6 attention': (C, lambda o, ns: hip.attention_x6(q, bank, o, T, H, 32 ** 0.5, part=part[ns], nsplit=ns)),
+        'fp32 gated attention': (1024, lambda o, ns: hip.gated_attention(qg, kg, vg, gate, o, T, 128 ** 0.5, part=partg[ns], nsplit=ns)),
+        'bf16x6 gated attention': (1024, lambda o, ns: hip.gated_attention_x6(qg, gbank, gate, o, T, 128 ** 0.5, part=partg[ns], nsplit=ns)),
+    }
+    # the load: its own operands and outputs, on its own stream; one load launch is queued per launch under test
+    side = torch.cuda.Stream()
+    xa = torch.randn(20000, 512, device='cuda', generator=g)
+    wa = hip.attach_wt(torch.randn(512, 512, device='cuda', generator=g) / 512 ** 0.5, 512)
+    ya = torch.empty(20000, 512, device='cuda')
+    q2, k2, v2 = q.clone(), k.clone(), v.clone()
+    o2 = torch.empty(N, C, device='cuda')
+    part2 = torch.empty(3 * N * (C + 2 * H), device='cuda')
+    bank2 = hip.x6_bank(1, M * N, C, 'cuda')
+    hip.attention_pack_x6(k2, v2, bank2, M * N, slot=0)
+    torch.cuda.synchronize()
+
+    def load(i):
+        with torch.cuda.stream(side):
+            if i % 3 == 0:
+                hip.linear(xa, wa, None, ya)
+            elif i % 3 == 1:
+                hip.attention(q2, k2, v2, o2, T, H, 32 ** 0.5, part=part2, nsplit=3)
+            else:
+                hip.attention_x6(q2, bank2, o2, T, H, 32 ** 0.5, part=part2, nsplit=3)
+
+    launches = 0
+    for name, (width, run) in kernels.items():
+        bad = torch.zeros((), dtype=torch.int64, device='cuda')
+        first = {}
+        for ns in SPLITS:
+            first[ns] = torch.empty(N, width, device='cuda')
+            run(first[ns], ns)
+        again = torch.empty(N, width, device='cuda')
+        for i in range(REPS * len(SPLITS)):
+            ns = SPLITS[i % len(SPLITS)]
+            load(i)
+            run(again, ns)
+            bad += (again != first[ns]).sum()
+            launches += 1
+        side.synchronize()
+        assert int(bad) == 0, '%s: %d values differ from the first launch over %d launches under load' % (name, int(bad), REPS * len(SPLITS))
+    assert launches >= 500
 
 
 def test_attention_properties_full_bank(hip):

@@ -72,6 +72,23 @@ def test_matmul_on_strided_views(T):
     _check('small odd', lambda t: T.matmul(t[0], t[1]), lambda t: S.matmul(t[0], t[1]), [a1, b1])
 
 
+def test_copy2d_pad_makes_any_view_dense(T):
+    """aot_copy2d_pad_f32 (train_ops._dense): row-major slices, transposed views, broadcasts and ragged extents become the dense
+    zero-padded matrix the GEMM kernels take, bit for bit; a matrix that already is one is passed through untouched."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    base = torch.randn(301, 517, device='cuda', generator=g)
+    views = {'row-major': base, 'column slice': base[:, 13:400], 'row slice': base[7:300:3], 'transposed': base.t(),
+             'transposed slice': base[5:205, 11:76].t(), 'broadcast row': base[3:4].expand(77, 517), 'scalar': base[2:3, 4:5].expand(40, 90)}
+    for name, v in views.items():
+        R, C = v.shape
+        for rpad, cpad in ((R, C), (R + 19, C), (R, -(-C // 32) * 32), (-(-R // 64) * 64, -(-C // 32) * 32 + 32)):
+            d = T._dense(v, rpad, cpad)
+            ref = torch.zeros(rpad, cpad, device='cuda')
+            ref[:R, :C] = v
+            assert d.shape == (rpad, cpad) and d.is_contiguous() and torch.equal(d, ref), '%s -> [%d, %d]' % (name, rpad, cpad)
+    assert T._dense(base, 301, 517).data_ptr() == base.data_ptr()
+
+
 def test_matmul_few_large_matrices_on_the_tile_kernels(T):
     """The gated propagation's products, one matrix per sample (QK^T with the keys as a transposed view, PV, a reduction length that
     is no multiple of 32) and their gradients: the LDS-direct GEMM path of matmul()."""
@@ -363,9 +380,29 @@ def test_gemm_bf16_is_the_rounded_product(T, M, K, N):
     assert 1e-4 < rel < 1e-2, 'bf16 rounding error %.2e is not at the bf16 level' % rel
 
 
+@pytest.mark.parametrize('M,K,N,ks', [(256, 4096, 256, 4), (200, 137 * 32 * 3, 130, 3), (64, 32 * 15, 64, 15), (512, 960 * 32, 64, 15)])
+def test_gemm_bf16_split_k(T, M, K, N, ks):
+    """The split-K form of aot_conv2d_bf16_f32 (weight gradients: K is the row count): the same rounded-operand product, the
+    k-slices summed in order by the reduce pass; ragged M / N, bias added once."""
+    import aot_hip
+    g = torch.Generator(device='cuda').manual_seed(M + K + N)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(K, N, device='cuda', generator=g) * 0.1
+    bias = torch.randn(N, device='cuda', generator=g)
+    out = aot_hip.gemm_bf16_packed(a, aot_hip.pack_bf16(w), N, bias, ks=ks)
+    one = aot_hip.gemm_bf16_packed(a, aot_hip.pack_bf16(w), N, bias)
+    ref = a.bfloat16().double() @ w.bfloat16().double() + bias.double()
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) / scale < 2e-6
+    assert float((out - one).abs().max()) / scale < 2e-6
+    with pytest.raises(aot_hip.AotHipError):
+        aot_hip.gemm_bf16_packed(a, aot_hip.pack_bf16(w), N, bias, ks=7 if (K // 32) % 7 else 11)
+
+
 def test_linear_bf16_forward_and_dgrad(T):
-    """nn.Linear under train_ops.matmul_precision('bf16'): forward and dgrad on the bf16 matrix cores (the mode is recorded at
-    forward time and used by backward wherever it runs), wgrad and bias gradient in fp32."""
+    """nn.Linear under train_ops.matmul_precision('bf16'): forward, dgrad and (split-K) wgrad on the bf16 matrix cores -- each
+    exactly the product of its operands rounded to bf16, fp32 accumulation (the mode is recorded at forward time and used by
+    backward wherever it runs); bias gradient in fp32."""
     x, w, b = _r(1800, 512, seed=1), _r(256, 512, seed=2, scale=0.05), _r(256, seed=3)
     with T.matmul_precision('bf16'):
         y = T.linear(x, w, b)
@@ -375,8 +412,8 @@ def test_linear_bf16_forward_and_dgrad(T):
     assert float((y.detach().double() - yr).abs().max()) / float(yr.abs().max()) < 2e-6
     dxr = ct.bfloat16().double() @ w.detach().bfloat16().double()
     assert float((x.grad.double() - dxr).abs().max()) / float(dxr.abs().max()) < 2e-6
-    dwr = ct.double().t() @ x.detach().double()                                  # fp32 split-K wgrad: no operand rounding
-    assert float((w.grad.double() - dwr).abs().max()) / float(dwr.abs().max()) < 2e-5
+    dwr = ct.bfloat16().double().t() @ x.detach().bfloat16().double()            # split-K over the 1800 rows (padded to a multiple of 32 ks)
+    assert float((w.grad.double() - dwr).abs().max()) / float(dwr.abs().max()) < 2e-6
     assert float((b.grad.double() - ct.double().sum(0)).abs().max()) / float(ct.double().sum(0).abs().max()) < 2e-5
 
 

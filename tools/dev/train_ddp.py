@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--size', type=int, default=465)
     ap.add_argument('--bucket-mb', type=float, default=32.0)
     ap.add_argument('--backend', default='nccl')
+    ap.add_argument('--profile', default=None, help='after the timed steps: one more step under torch.profiler; device kernels by '
+                    'the Python line / autograd node that launched them -> this text file')
     a = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ:
         import socket
@@ -92,7 +94,69 @@ def main():
                           'params_m': round(st.total / 1e6, 2), 'replicas_identical': bool(float(lo) == float(hi)),
                           'losses': [round(float(x), 4) for x in losses], 'grad_norm_last': round(st.grad_norm(), 3),
                           'peak_mem_gib': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}))
+    if a.profile and rank == 0:
+        from networks.layers import train_ops
+        train_ops.MATMUL_LOG = {}
+        profile_step(lambda: step_fn(all_frames, all_masks, objs, a.steps + 1), a.profile)
+        with open(a.profile, 'a') as f:
+            f.write('\nproducts on the strided kernel in that step (count x [bt, m, k, n], alpha, strides; GFLOP each):\n')
+            for (bt, m, k, n, alpha, sa, sb), cnt in sorted(train_ops.MATMUL_LOG.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2] * kv[0][3]):
+                f.write('%4d x [%d, %d, %d, %d] alpha %g  a%s b%s  %.3f GF\n' % (cnt, bt, m, k, n, alpha, sa, sb, 2e-9 * bt * m * k * n))
+        train_ops.MATMUL_LOG = None
     dist.destroy_process_group()
+
+
+def profile_step(run, path):
+    """One step under torch.profiler (CPU + device, Python stacks): every device kernel attributed to what launched it -- in
+    forward the innermost frame inside aot-benchmark_amd, in backward the autograd node -- and summed: which glue costs what."""
+    import collections
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        run()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        ks = getattr(e, 'kernels', None)
+        if not ks:
+            continue
+        node, p = None, e
+        while p is not None:
+            if p.name.startswith('autograd::engine::evaluate_function'):
+                node = p.name.split(': ')[-1]
+                break
+            p = p.cpu_parent
+        site = node
+        if site is None:
+            site = '?'
+            q = e
+            while q is not None and site == '?':
+                for fr in (q.stack or []):
+                    if 'aot-benchmark_amd' in fr:
+                        site = fr.split('aot-benchmark_amd/')[-1][:70]
+                        break
+                q = q.cpu_parent
+        for k in ks:
+            name = k.name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-60:]
+            if 'elementwise' in name or 'Functor' in k.name:
+                name = 'torch:' + e.name
+            a = agg[(name, site)]
+            a[0] += 1
+            a[1] += k.duration
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    total = sum(v[1] for _, v in rows)
+    with open(path, 'w') as f:
+        f.write('device time of one step by (kernel, launching site): %.1f ms in %d launches\n' % (total / 1e3, sum(v[0] for _, v in rows)))
+        for (name, site), (n, us) in rows[:150]:
+            f.write('%8.1f us %5d x  %-46s %s\n' % (us, n, name[:46], site))
+        by_site = collections.defaultdict(lambda: [0, 0.0])
+        for (name, site), (n, us) in rows:
+            if name.startswith('torch:'):
+                by_site[site][0] += n
+                by_site[site][1] += us
+        f.write('\ntorch glue only, by site: %.1f ms\n' % (sum(v[1] for v in by_site.values()) / 1e3))
+        for site, (n, us) in sorted(by_site.items(), key=lambda kv: -kv[1][1])[:60]:
+            f.write('%8.1f us %5d x  %s\n' % (us, n, site))
 
 
 if __name__ == '__main__':
