@@ -1,7 +1,7 @@
 """The attention launches of one 70-frame clip (bench.py's mix: per propagated frame and layer one self-attention over the
 frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
 rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams).
-    python tools/dev/pmc_attn_mix.py [aot|aotx6|gated|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel; aotx6: attn_x6_d32_kernel), gated: R50-DeAOTL
+    python tools/dev/pmc_attn_mix.py [aot|aotx6|gated|gatedx6|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel; aotx6: attn_x6_d32_kernel), gated: R50-DeAOTL
     (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel -- fp32 and bf16x6 forms -- at M = 14 (SQ counter passes)
 AOT_HIP_LIB selects a variant build of the library."""
 import sys, os
@@ -58,6 +58,16 @@ else:
         def fn(T, brows):
             ns = attn_splits(N, H, _planned_len(T, N, brows), wg_waves=4)
             aot_hip.attention_x6(q, sbank if brows == N else xbank, out, T, H, 32 ** 0.5, part=part if ns > 1 else None, nsplit=ns)
+    elif mode == 'gatedx6':                                # DeAOT's bf16x6 twin: packed K / V banks appended frame by frame
+        gbank = aot_hip.x6_gated_bank(1, CAP * N, 128, E, 'cuda')
+        for slot in range(14):
+            aot_hip.gated_pack_x6(gk[slot * N:(slot + 1) * N], gv[slot * N:(slot + 1) * N], gbank, N, slot=slot)
+        gsbank = aot_hip.x6_gated_bank(1, N, 128, E, 'cuda')
+        aot_hip.gated_pack_x6(gk[:N], gv[:N], gsbank, N)
+
+        def fn(T, brows):
+            ns = gated_splits(N, _planned_len(T, N, brows), slots=256)
+            aot_hip.gated_attention_x6(gq, gsbank if brows == N else gbank, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
     else:
         fn = d32 if mode == 'aot' else gated
     for t in range(1, 70):
