@@ -453,7 +453,7 @@ def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: re-exec this file under torch.distributed.run, one rank per GPU
     (what tools/eval.py:100-106 does with mp.spawn).  Fails loudly when fewer than N devices are visible."""
     import subprocess
-    if not args.dry_run:
+    if not args.dry_run and not args.share_gpu:
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit('bench.py --gpus %d: only %d ROCm device(s) visible' % (args.gpus, have))
@@ -526,6 +526,9 @@ def main(argv=None):
     ap.add_argument('--no-jf', action='store_true', help='skip the J&F pass on the committed reference clip (tuning runs)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL (default); gloo only with --dry-run')
     ap.add_argument('--dry-run', action='store_true', help='launcher / sharding / gather plumbing only, no device work (CPU tests)')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='development only: every rank on GPU 0, collectives over gloo -- walks the N > 1 control flow WITH device '
+                         'work on a one-GPU box (tools/dev/r04_call27.sh); the numbers of such a run mean nothing and say so')
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1:
         raise SystemExit('bench.py: --gpus and --steps must be >= 1')
@@ -549,13 +552,13 @@ def main(argv=None):
     dry = args.dry_run
     if not dry and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the AOT hot path has no CPU fallback')
-    device = torch.device('cpu') if dry else torch.device('cuda', local_rank)
+    device = torch.device('cpu') if dry else torch.device('cuda', 0 if args.share_gpu else local_rank)
     if not dry:
         torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if dry:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if dry or args.share_gpu:
+            dist.init_process_group('gloo' if args.share_gpu else args.backend, rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
     joined = dist.get_world_size() if world > 1 else 1
@@ -788,7 +791,8 @@ def main(argv=None):
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.mfma == 'f32' else 'f32 via bf16x6 split',
-            'data': 'dry-run (no device work)' if dry else 'synthetic',
+            'data': 'dry-run (no device work)' if dry else ('synthetic -- ALL RANKS ON ONE GPU (--share-gpu smoke run of the N > 1 control '
+                                                            'flow): the numbers mean nothing') if args.share_gpu else 'synthetic',
             'config': {'workload': ('R50-AOTL inference, 480p (481x849 in, 480x854 out) 10-object synthetic clips, '
                                     '70 frames/clip, long-term gap 5 (configs[1])') if default_model else
                                    '%s inference, 480p (%dx%d in, 480x854 out) 10-object synthetic clips, 70 frames/clip'
