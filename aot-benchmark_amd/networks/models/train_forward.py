@@ -45,26 +45,26 @@ def _drop_path(x, p, training, B):
     """DropPath (basic.py:129-148, one draw per sample of the batch): a sample's whole branch dropped with probability p."""
     if not training or not p:
         return x
-    keep = 1. - p
-    mask = (torch.rand(B, 1, 1, device=x.device) < keep).to(x.dtype) / keep
-    return (x.view(B, -1, x.shape[1]) * mask).view(x.shape)
+    return (x.view(B, -1, x.shape[1]) * _keep_mask((B, 1, 1), 1. - p, x)).view(x.shape)
+
+
+def _keep_mask(shape, keep, like):
+    """Bernoulli(keep) / keep (two launches: the draw and the rescale)."""
+    return torch.empty(shape, dtype=like.dtype, device=like.device).bernoulli_(keep).div_(keep)
 
 
 def _dropout(x, p, training):
     """nn.Dropout (elementwise)."""
     if not training or not p:
         return x
-    keep = 1. - p
-    return x * ((torch.rand_like(x) < keep).to(x.dtype) / keep)
+    return x * _keep_mask(x.shape, 1. - p, x)
 
 
 def _dropout2d(x, p, training, B):
     """nn.Dropout2d on B token-major maps [B * N, C]: whole channels of a sample dropped (basic.py:46,55)."""
     if not training or not p:
         return x
-    keep = 1. - p
-    mask = (torch.rand(B, 1, x.shape[1], device=x.device) < keep).to(x.dtype) / keep
-    return (x.view(B, -1, x.shape[1]) * mask).view(x.shape)
+    return (x.view(B, -1, x.shape[1]) * _keep_mask((B, 1, x.shape[1]), 1. - p, x)).view(x.shape)
 
 
 def _no_attn_dropout(m):
@@ -358,8 +358,8 @@ def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d, B):
     dp, tr = blk.droppath_p, blk.training
     x1 = T.layernorm(x, blk.norm1.weight, blk.norm1.bias)
     qv = T.linear(x1, blk.linear_QV.weight, blk.linear_QV.bias)
-    qc = qv[:, :da]
-    vc = T.act(qv[:, da:], 'silu')
+    qc, vraw = qv.split([da, qv.shape[1] - da], 1)        # (one split node: its backward is ONE concatenation, not two zero-fills + copies + an add)
+    vc = T.act(vraw, 'silu')
     kc = qc
     uc = T.linear(x1, blk.linear_U.weight, blk.linear_U.bias)
     if blk.layer_idx == 0:
@@ -377,11 +377,11 @@ def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d, B):
         kl, vl, idvl = short_mem
     lt = _gated_global(blk.long_term_attn, qc, kg, torch.cat([vg, idvg], 1), u, size_2d, B)
     st = _gated_local(blk.short_term_attn, qc, kl, torch.cat([vl, idvl], 1), u, size_2d, B)
-    y = lt + st
+    ya, yb = (lt + st).split([D, lt.shape[1] - D], 1)
     if blk.droppath_lst:                                                       # :633-638: the two halves draw separately
-        ya, yb = _drop_path(y[:, :D], dp, tr, B), _drop_path(y[:, D:], dp, tr, B)
+        ya, yb = _drop_path(ya, dp, tr, B), _drop_path(yb, dp, tr, B)
     else:
-        ya, yb = _dropout(y[:, :D], blk.lst_dropout_p, tr), _dropout(y[:, D:], blk.lst_dropout_p, tr)
+        ya, yb = _dropout(ya, blk.lst_dropout_p, tr), _dropout(yb, blk.lst_dropout_p, tr)
     x = x + ya
     x_id = yb if x_id is None else x_id + yb
     z1 = T.layernorm(x, blk.norm2.weight, blk.norm2.bias)
@@ -391,8 +391,8 @@ def gpm_block(blk, x, x_id, long_mem, short_mem, id_emb, size_2d, B):
     qk = T.linear(z, sa.linear_QK.weight, sa.linear_QK.bias)
     sv = T.act(torch.cat([T.linear(z1, sa.linear_V1.weight, sa.linear_V1.bias), T.linear(z2, sa.linear_V2.weight, sa.linear_V2.bias)], 1), 'silu')
     su = T.act(torch.cat([T.linear(z1, sa.linear_U1.weight, sa.linear_U1.bias), T.linear(z2, sa.linear_U2.weight, sa.linear_U2.bias)], 1), 'silu')
-    y = _gated_global(sa, qk, qk, sv, su, size_2d, B)
-    return x + _drop_path(y[:, :D], dp, tr, B), x_id + _drop_path(y[:, D:], dp, tr, B), [kc, vc, idvc], [kg, vg, idvg]
+    ya, yb = _gated_global(sa, qk, qk, sv, su, size_2d, B).split([D, D], 1)
+    return x + _drop_path(ya, dp, tr, B), x_id + _drop_path(yb, dp, tr, B), [kc, vc, idvc], [kg, vg, idvg]
 
 
 # ---- decoder -----------------------------------------------------------------------------------------------------------
