@@ -24,6 +24,9 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
+    'aot_split3_bf16_f32': [_P, _P, _L, _I, _I, _I, _L, _P],
+    'aot_pack_bf16x6n_f32': [_P, _P, _I, _I, _I, _I, _P],
+    'aot_conv2d_bf16x6p_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
     'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
@@ -265,6 +268,37 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     res.stride(0) if res is not None else 0, res_rows, act,
                                     (stack[-1][0] if stack else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
+    return out
+
+
+def split3(x, C=None):
+    """x [M, ld] fp32 -> its three truncated-bf16 planes, int16 [3, M, ldp] (ldp = C rounded up to 8; aot_split3_bf16_f32): the input
+    format of conv2d_x6p.  Experimental (round 4): what a producing kernel's tile end will write."""
+    M = x.shape[0]
+    C = x.shape[1] if C is None else C
+    ldp = (C + 7) // 8 * 8
+    planes = torch.empty(3, M, ldp, dtype=torch.int16, device=x.device)
+    _chk(load().aot_split3_bf16_f32(_dev(x), _dev(planes), M, C, x.stride(0), ldp, M * ldp, stream_ptr()), 'aot_split3_bf16_f32')
+    return planes
+
+
+def pack_bf16x6n(w):
+    """Weight w [K, ld] -> three bf16 planes with k in natural order (aot_pack_bf16x6n_f32): int16 [3, K/32, 4, cout_pad, 8]."""
+    K, ld = w.shape
+    if K % 32:
+        raise AotHipError('bf16x6 weights need K % 32 == 0')
+    cout_pad = (ld + 63) // 64 * 64
+    w6 = torch.empty(3, K // 32, 4, cout_pad, 8, dtype=torch.int16, device=w.device)
+    _chk(load().aot_pack_bf16x6n_f32(_dev(w), _dev(w6), K, ld, w.stride(0), cout_pad, stream_ptr()), 'aot_pack_bf16x6n_f32')
+    return w6
+
+
+def conv2d_x6p(planes, w6n, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE, B=1,
+               res_rows=0, stream=None):
+    """The bf16x6 convolution / linear layer on PRE-SPLIT activations (planes from split3: [3, B*H*W, lda]); same epilogue as conv2d."""
+    _chk(load().aot_conv2d_bf16x6p_f32(_dev(planes), _dev(w6n), w6n.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dil, planes.stride(1), out.stride(0), res.stride(0) if res is not None else 0,
+                                       res_rows, act, stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6p_f32')
     return out
 
 

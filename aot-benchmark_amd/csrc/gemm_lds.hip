@@ -873,15 +873,23 @@ __device__ __forceinline__ bf16x8 round8(const f32x4& x0, const f32x4& x1) {
 // even), activations rounded in registers; 2 MFMAs per k-step instead of 12, one weight plane through the ring instead of three.
 // SK (with NT = 1, 1x1 only): split-K for the weight gradients of the training path -- item = (tile, k-slice), the partial tile goes
 // raw to its fp32 slab of `scratch` [ksplit][M][Cout] and splitk_reduce_kernel sums the slabs in order (+ bias / residual / act).
-template <bool IS1X1, int NT = 6, bool SK = false>
+// PS (with NT = 6): the activations arrive ALREADY SPLIT -- p.in is three bf16 planes [3][B*H*W][lda] (element stride lda, k in
+// natural order; aot_split3_bf16_f32 or a producer's tile end), the weight planes in natural k order too (aot_pack_bf16x6n_f32).
+// The A tile of a k-step is 3 x 64 rows x 64 bytes: one DMA piece per wave and plane (lane = (row, 16-byte chunk), the chunk
+// XOR-swizzled by the row so that the fragment reads are conflict-free), and the fragment goes from LDS straight into the MFMA: no
+// vector instruction touches it (the split is 7.3 of the 10.7 VALU per MFMA of the fp32-activation form: profiles/r04_x6_gemm_pmc.txt).
+template <bool IS1X1, int NT = 6, bool SK = false, bool PS = false>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
   static_assert(!SK || (IS1X1 && NT == 1), "split-K: the plain bf16 1x1 member only");
+  static_assert(!PS || (NT == 6 && !SK), "pre-split activations: the six-term member only");
   constexpr int NST = 3;
   constexpr int BM = 64, BN = 64;
-  constexpr int AG = BM / 8, AGW = AG / 4;              // A: 8-row groups, two per wave
+  constexpr int AG = BM / 8, AGW = PS ? 1 : AG / 4;     // A: 8-row fp32 groups, two per wave (PS: one 16-row piece per plane)
   constexpr int BPW = NT == 1 ? 1 : 3;                  // B: one 16-byte chunk column (cc = wave) of each plane per wave
-  constexpr int LPW = AGW + BPW;
-  constexpr int OPA_BYTES = AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 12 * B_PIECE;
+  constexpr int LPW = (PS ? 3 : AGW) + BPW;
+  constexpr int A_PLANE = 64 * 64;                      // (PS) bytes of one plane of the A tile: 64 rows x 32 bf16
+  constexpr int AEL = PS ? 2 : 4;                       // bytes per activation element
+  constexpr int OPA_BYTES = PS ? 3 * A_PLANE : AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 12 * B_PIECE;
   constexpr int STAGE_BYTES = OPA_BYTES + OPB_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
@@ -919,8 +927,10 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   const int cofs = (lp ^ lr) << 2;
   const int hw_out = p.OH * p.OW;
   const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const int a_plane_bytes = p.B * p.H * p.W * p.lda * 2;         // (PS) one activation plane
   const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, PS ? 3 * a_plane_bytes : (int)((long)p.B * p.H * p.W * p.lda * 4),
+                                        0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, BPW * plane_bytes, 0x00020000);
   const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
@@ -940,41 +950,56 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     const Item it = item_of(live ? i : 0);
 #pragma unroll
     for (int g = 0; g < AGW; ++g) {
-      const int m = it.bm * BM + 8 * (AGW * wave + g) + lr;
+      // fp32: lane = (row lr of the wave's g-th 8-row group, 16-byte chunk lp); PS: lane = (row lane >> 2 of the wave's 16 rows,
+      // LDS chunk lane & 3, which holds the GLOBAL chunk (lane & 3) ^ ((row >> 1) & 3) of the 32-channel block)
+      const int rowl = PS ? 16 * wave + (lane >> 2) : 8 * (AGW * wave + g) + lr;
+      const int m = it.bm * BM + rowl;
       a_ok[g] = live && m < p.M;
       const int mm = a_ok[g] ? m : 0;
       const int b = mm / hw_out, pix = mm - b * hw_out;
       const int oy = pix / p.OW, ox = pix - oy * p.OW;
       a_iy0[g] = oy * p.stride - p.pad;
       a_ix0[g] = ox * p.stride - p.pad;
-      a_off[g] = (((b * p.H + a_iy0[g]) * p.W + a_ix0[g]) * p.lda + cofs) * 4;
+      const int celem = PS ? 8 * ((lane & 3) ^ ((rowl >> 1) & 3)) : cofs;
+      a_off[g] = (((b * p.H + a_iy0[g]) * p.W + a_ix0[g]) * p.lda + celem) * AEL;
       if (IS1X1 && !a_ok[g]) a_off[g] = (int)OOB;
     }
     b_off = live ? (unsigned)((wave * wq.cout_pad + it.bn * BN + lane) * 16) : OOB;    // chunk column cc = wave of k-block 0
-    s_k = SK ? it.kt0 * BK * 4 : 0;                      // (split-K: the slice's first k-step)
+    s_k = SK ? it.kt0 * BK * AEL : 0;                    // (split-K: the slice's first k-step)
     s_kb = SK ? it.kt0 * 4 * wq.cout_pad * 16 : 0;
     if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
   };
   auto issue = [&](auto SLOT) __attribute__((always_inline)) -> void {
     constexpr int slot = decltype(SLOT)::value;
     if (is_kt == 0) setup_item(is_i);
-    if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4;
+    if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * AEL;
     unsigned char* st = lds + slot * STAGE_BYTES;
+    if (PS) {          // one piece per plane: the wave's 16 rows x 64 bytes, lane-linear in LDS
+      int voff = a_off[0];
+      if (!IS1X1) {
+        const int iy = a_iy0[0] + tap_ky * p.dil, ix = a_ix0[0] + tap_kx * p.dil;
+        const bool in = a_ok[0] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        voff = in ? a_off[0] + s_tap : (int)OOB;
+      }
 #pragma unroll
-    for (int g = 0; g < AGW; ++g) {
-      unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
-      if (IS1X1) {
-        dma16(rsrc_a, dst, a_off[g], s_k);
-      } else {
-        const int iy = a_iy0[g] + tap_ky * p.dil, ix = a_ix0[g] + tap_kx * p.dil;
-        const bool in = a_ok[g] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        dma16(rsrc_a, dst, in ? a_off[g] + s_tap : (int)OOB, 0);
+      for (int pl = 0; pl < 3; ++pl) dma16(rsrc_a, st + pl * A_PLANE + wave * 1024, voff, (IS1X1 ? s_k : 0) + pl * a_plane_bytes);
+    } else {
+#pragma unroll
+      for (int g = 0; g < AGW; ++g) {
+        unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
+        if (IS1X1) {
+          dma16(rsrc_a, dst, a_off[g], s_k);
+        } else {
+          const int iy = a_iy0[g] + tap_ky * p.dil, ix = a_ix0[g] + tap_kx * p.dil;
+          const bool in = a_ok[g] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+          dma16(rsrc_a, dst, in ? a_off[g] + s_tap : (int)OOB, 0);
+        }
       }
     }
 #pragma unroll
     for (int pl = 0; pl < BPW; ++pl)
       dma16(rsrc_b, st + OPA_BYTES + (pl * 4 + wave) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
-    s_k += BK * 4;
+    s_k += BK * AEL;
     s_kb += 4 * wq.cout_pad * 16;
     if (!IS1X1) {
       tap_c += BK;
@@ -991,10 +1016,38 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   const unsigned baddr = lds_base + OPA_BYTES + (half * 64 + wn + l31) * 16;      // chunk column cc = 2 s + half: + 2 s pieces
   f32x4 ra[2][4];              // [register set][16-byte chunk j]: sub-step s contracts chunks 2 s and 2 s + 1
   bf16x8 rb[2][3][2];          // [register set][plane][sub-step]
+  bf16x8 pa[2][3][2];          // (PS) [register set][plane][sub-step]: the A planes as they lie in LDS
+  unsigned paddr[2];           // (PS) the lane's row; chunk 2 s + half at its swizzled place
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx) paddr[sx] = lds_base + (wm + l31) * 64 + (((2 * sx + half) ^ (((wm + l31) >> 1) & 3)) << 4);
   auto fetch = [&](auto SET, auto SLOT) __attribute__((always_inline)) -> void {
-    x6_fetch<decltype(SLOT)::value * STAGE_BYTES, B_PIECE, NT>(ra[decltype(SET)::value], rb[decltype(SET)::value], aaddr, baddr);
+    if (PS) {
+      constexpr int ST = decltype(SLOT)::value * STAGE_BYTES, q = decltype(SET)::value;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][0][0]) : "v"(paddr[0]), "n"(ST));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][0][1]) : "v"(paddr[1]), "n"(ST));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][1][0]) : "v"(paddr[0]), "n"(ST + A_PLANE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][1][1]) : "v"(paddr[1]), "n"(ST + A_PLANE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][2][0]) : "v"(paddr[0]), "n"(ST + 2 * A_PLANE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[q][2][1]) : "v"(paddr[1]), "n"(ST + 2 * A_PLANE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][0][0]) : "v"(baddr), "n"(ST + 0 * B_PIECE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][0][1]) : "v"(baddr), "n"(ST + 2 * B_PIECE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][1][0]) : "v"(baddr), "n"(ST + 4 * B_PIECE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][1][1]) : "v"(baddr), "n"(ST + 6 * B_PIECE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][2][0]) : "v"(baddr), "n"(ST + 8 * B_PIECE));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[q][2][1]) : "v"(baddr), "n"(ST + 10 * B_PIECE));
+    } else {
+      x6_fetch<decltype(SLOT)::value * STAGE_BYTES, B_PIECE, NT>(ra[decltype(SET)::value], rb[decltype(SET)::value], aaddr, baddr);
+    }
   };
-  auto landed = [&](auto SET) __attribute__((always_inline)) -> void { x6_landed<NT>(ra[decltype(SET)::value], rb[decltype(SET)::value]); };
+  auto landed = [&](auto SET) __attribute__((always_inline)) -> void {
+    if (PS) {
+      constexpr int q = decltype(SET)::value;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(pa[q][pl][0]), "+v"(pa[q][pl][1]), "+v"(rb[q][pl][0]), "+v"(rb[q][pl][1]));
+    } else {
+      x6_landed<NT>(ra[decltype(SET)::value], rb[decltype(SET)::value]);
+    }
+  };
   f32x16 acc[2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -1109,6 +1162,15 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (PS) {        // the planes as they came: same six products, same order
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][1][s], rb[set][1][s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][0][s], rb[set][2][s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][2][s], rb[set][0][s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][0][s], rb[set][1][s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][1][s], rb[set][0][s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][0][s], rb[set][0][s], acc[s], 0, 0, 0);
+        continue;
+      }
       if (NT == 1) {
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(round8(ra[set][2 * s], ra[set][2 * s + 1]), rb[set][0][s], acc[s], 0, 0, 0);
         continue;
@@ -1506,6 +1568,27 @@ bool gemm_x6_eligible(const ConvParams& p) {
   return (p.Cin % 32) == 0 && (p.K % 32) == 0 && (p.lda & 3) == 0 && ((uintptr_t)p.in & 15) == 0 &&
          (long)p.B * p.H * p.W * p.lda * 4 < 0x7fffffffL && (long)p.M * p.ldc * 4 < 0x7fffffffL &&
          (!p.res || (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 < 0x7fffffffL);
+}
+
+// the member that takes the activations pre-split (p.in = three bf16 planes [3][B*H*W][lda], natural k order; w6 packed in natural
+// order too): 64x64 tile, two workgroups per CU
+int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s) {
+  if (!w6n || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6n & 15) || ((uintptr_t)p.in & 15)) return AOT_ERR_UNSUPPORTED;
+  if ((p.Cin % 32) || (p.K % 32) || (p.lda & 7)) return AOT_ERR_UNSUPPORTED;
+  if (3L * p.B * p.H * p.W * p.lda * 2 >= 0x7fffffffL || (long)p.M * p.ldc * 4 >= 0x7fffffffL ||
+      (p.res && (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 >= 0x7fffffffL) || 3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL)
+    return AOT_ERR_UNSUPPORTED;
+  const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
+  X6Weight wq;
+  wq.w6 = w6n;
+  wq.cout_pad = cout_pad;
+  const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nitems < 512 ? nitems : 512;
+  if (is1x1)
+    hipLaunchKernelGGL((gemm_x6_kernel<true, 6, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
+  else
+    hipLaunchKernelGGL((gemm_x6_kernel<false, 6, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
+  AOT_LAUNCH_CHECK();
 }
 
 int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms, int ksplit, float* scratch) {

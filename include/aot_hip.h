@@ -74,6 +74,20 @@ int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const f
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                           int lda, int ldc, int ldr, int res_rows, int act, int tile, void* stream);
 
+/* The member of the same family that takes its activations ALREADY SPLIT (experimental in round 4: called by tests and
+ * tools/dev/mb_gemm.py only, no engine stage hands over split activations yet).  aot_split3_bf16_f32: x [M, ldx] fp32 -> three
+ * truncated-bf16 planes [3][M][ldp] (plane stride pstride elements; ldp % 8 == 0; channels in memory order; x = the sum of its
+ * planes exactly) -- what a producing kernel's tile end will write.  aot_pack_bf16x6n_f32: the weight planes with k in natural
+ * order inside a 32-block (same sizes as aot_pack_bf16x6_f32).  aot_conv2d_bf16x6p_f32: same arguments and epilogue as
+ * aot_conv2d_bf16x6_f32 with `in_planes` = the three planes of the B NHWC maps ([3][B*H*W][lda] bf16, lda % 8 == 0, plane stride =
+ * B*H*W*lda) -- the A fragments go from LDS into the matrix cores without touching the vector ALUs, where the split of the fp32
+ * form is 7.3 of its 10.7 VALU instructions per MFMA (profiles/r04_x6_gemm_pmc.txt); bit-identical results (64x64 tile). */
+int aot_split3_bf16_f32(const float* x, void* planes, long M, int C, int ldx, int ldp, long pstride, void* stream);
+int aot_pack_bf16x6n_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
+int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, int cout_pad, const float* bias, const float* res, float* out,
+                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                           int lda, int ldc, int ldr, int res_rows, int act, void* stream);
+
 /* Plain bf16 form of the same operation for the TRAINING path (`--amp` of the reference's trainer, trainer.py:123-125,460-487 --
  * there fp16 autocast + GradScaler; BASELINE config 5: bf16): both operands rounded to bf16 (round to nearest even), ONE
  * v_mfma_f32_32x32x16_bf16 product, fp32 accumulation and output.  aot_pack_bf16_f32 rounds a weight w [K, ldb] (K % 32 == 0)

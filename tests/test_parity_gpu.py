@@ -116,7 +116,7 @@ def test_conv2d_lean_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, cfg):
         assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
 
 
-@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', [
+X6_CASES = [
     (61, 107, 128, 128, 3, 1, 1, 1, 1, False, 1),     # 3x3
     (61, 107, 128, 128, 3, 2, 1, 1, 1, True, 1),      # stride-2 3x3 + residual
     (61, 107, 256, 512, 1, 2, 0, 1, 0, False, 1),     # 1x1 stride-2 downsample
@@ -126,7 +126,53 @@ def test_conv2d_lean_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, cfg):
     (17, 19, 32, 40, 3, 1, 1, 1, 0, False, 1),        # tiny map: fewer tiles than workgroups, ragged rows and columns
     (9, 9, 64, 64, 1, 1, 0, 1, 0, True, 2),           # residual map smaller than a tile (general modulo path)
     (121, 213, 256, 128, 1, 1, 0, 1, 4, False, 1),    # 4x map: 806 tiles on 512 workgroup slots (persistent item walk), SiLU
-])
+]
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
+def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
+    """The member of the bf16x6 family that takes PRE-SPLIT activations (aot_split3_bf16_f32 + aot_pack_bf16x6n_f32 +
+    aot_conv2d_bf16x6p_f32): the planes sum to the fp32 activations exactly; the result is the 64x64 on-the-fly kernel's up to the
+    position of a k inside its MFMA (the planes keep the channels in memory order, the on-the-fly split does not): within 1e-5 of
+    the output scale of it, and within the family's own tolerance of the fp64 result -- every case of the family's own test."""
+    g = torch.Generator().manual_seed(H * 131 + Cout + B)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    OH, OW = (H + 2 * p - d * (K - 1) - 1) // s + 1, (W + 2 * p - d * (K - 1) - 1) // s + 1
+    r = torch.randn(1, Cout, OH, OW, generator=g) if res else None
+    ldb = (Cout + 3) // 4 * 4
+    wk = torch.zeros(K * K * Cin, ldb)
+    wk[:, :Cout] = w.permute(2, 3, 1, 0).reshape(K * K * Cin, Cout)
+    wk = hip.attach_wt(_dev(wk), Cin)
+    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
+    rt = _dev(r[0].permute(1, 2, 0).reshape(OH * OW, Cout)) if res else None
+    planes = hip.split3(xt)
+    back = (planes.to(torch.int32) << 16).view(torch.float32).double().sum(0)
+    assert planes.shape == (3, B * H * W, Cin) and torch.equal(back, xt.double()), 'the activation planes do not sum to the fp32 values'
+    w6n = hip.pack_bf16x6n(wk)
+    want = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+    w6 = hip.pack_bf16x6(wk)
+    bd = _dev(b)
+    rc = hip.load().aot_conv2d_bf16x6_f32(xt.data_ptr(), w6.data_ptr(), w6.shape[3], bd.data_ptr(), rt.data_ptr() if res else None,
+                                          want.data_ptr(), B, H, W, Cin, OH, OW, Cout, K, K, s, p, d, xt.stride(0), want.stride(0),
+                                          rt.stride(0) if res else 0, OH * OW if res else 0, act, 64, hip.stream_ptr())
+    assert rc == 0
+    got = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+    hip.conv2d_x6p(planes, w6n, bd, got, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    if res:
+        ref = ref + r.double()
+    ref = {0: ref, 1: F.relu(ref), 3: F.gelu(ref), 4: F.silu(ref)}[act].float()
+    scale = max(1.0, ref.abs().max().item())
+    gotc = got[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    _close(gotc, ref, 2e-5 * scale, 'pre-split bf16x6 conv')
+    assert float((got[:, :Cout] - want[:, :Cout]).abs().max()) <= 1e-5 * scale, 'pre-split member differs from the on-the-fly split'
+    if ldb > Cout:
+        assert torch.isnan(got[:, Cout:]).all(), 'wrote outside the logical columns'
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
 @pytest.mark.parametrize('tile', [64, 128])
 def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --

@@ -39,7 +39,17 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
     row = []
     ref_out = None
     for c in cfgs:
-        if str(c).startswith('x6'):      # x6 = tile by shape, x6n = 64x64 forced, x6w = 128x128 forced
+        if c in ('x6p', 'x6ps'):         # x6p = the 64x64 kernel on PRE-SPLIT activations (planes made outside the timed loop); x6ps = split pass + kernel
+            if Cin % 32: row.append('      -      -'); continue
+            w6n = aot_hip.pack_bf16x6n(w)
+            planes = aot_hip.split3(x)
+            if c == 'x6p':
+                def run():
+                    aot_hip.conv2d_x6p(planes, w6n, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
+            else:
+                def run():
+                    aot_hip.conv2d_x6p(aot_hip.split3(x), w6n, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
+        elif str(c).startswith('x6'):      # x6 = tile by shape, x6n = 64x64 forced, x6w = 128x128 forced
             aot_hip.X6_TILE = {'x6': 0, 'x6n': 64, 'x6w': 128}[c]
             def run():        # (layers that do not qualify fall back to the fp32 dispatch inside conv2d, as in the engine)
                 with aot_hip.use_gemm_table('throughput', 'bf16x6'):
