@@ -804,6 +804,9 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 //   * the ACTIVATION tile arrives as fp32 exactly as in the lean kernel (im2col through the buffer descriptor) and is split in
 //     registers right before use: 4 VALU per element + 3 v_perm per pair;
 //   * three ring stages of 20.6 KB (two workgroups per CU); a k-step is 12 MFMAs of 32 cycles instead of 16 of 64.
+#ifndef AOT_X6_EARLY
+#define AOT_X6_EARLY 0      // development switch: DMA of step ss+3 issued in step ss (64x64 bf16x6 / bf16 kernels)
+#endif
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1138,21 +1141,26 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  // EARLY (AOT_X6_EARLY): the slot of step ss is dead once its fragments are in registers, i.e. DURING step ss -- the DMA of step
+  // ss+3 goes there right away instead of one step later: two steps of DMA in flight on the same three slots (counted waits).
+  constexpr bool EARLY = AOT_X6_EARLY != 0;
   issue(I0{});
   issue(I1{});
-  __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));          // step 0 has landed
+  if (EARLY) issue(I2{});
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(EARLY ? 2 * LPW : LPW, 15));          // step 0 has landed
   __builtin_amdgcn_s_barrier();
   fetch(I0{}, I0{});
   // step ss (ring stage U % 3, register set U % 2; the loop is unrolled by six): on entry the fragments of step ss are being
   // read into set U % 2, the DMA of step ss+1 is in flight
   auto step = [&](auto U) __attribute__((always_inline)) -> void {
-    constexpr int u = decltype(U)::value, set = u & 1, nslot = (u + 1) % 3, islot = (u + 2) % 3;
-    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished)
+    constexpr int u = decltype(U)::value, set = u & 1, nslot = (u + 1) % 3, islot = EARLY ? u % 3 : (u + 2) % 3;
+    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished;
+    // EARLY: the pieces of step ss+2 may stay in flight)
     if (stores_pending) {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 0));
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm((EARLY ? LPW : 0) + 16, 0));
       stores_pending = 0;
     } else {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(EARLY ? LPW : 0, 0));
     }
     __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 (= of step ss+2) is free
     landed(std::integral_constant<int, set>{});
