@@ -26,7 +26,7 @@ _SIGS = {
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_split3_bf16_f32': [_P, _P, _L, _I, _I, _I, _L, _P],
     'aot_pack_bf16x6n_f32': [_P, _P, _I, _I, _I, _I, _P],
-    'aot_conv2d_bf16x6p_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P],
+    'aot_conv2d_bf16x6p_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P, _I, _P],
     'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
@@ -294,12 +294,15 @@ def pack_bf16x6n(w):
 
 
 def conv2d_x6p(planes, w6n, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE, B=1,
-               res_rows=0, stream=None):
-    """The bf16x6 convolution / linear layer on PRE-SPLIT activations (planes from split3: [3, B*H*W, lda]); same epilogue as conv2d."""
-    _chk(load().aot_conv2d_bf16x6p_f32(_dev(planes), _dev(w6n), w6n.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH, OW, Cout,
-                                       KH, KW, stride, pad, dil, planes.stride(1), out.stride(0), res.stride(0) if res is not None else 0,
-                                       res_rows, act, stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6p_f32')
-    return out
+               res_rows=0, stream=None, out_planes=None):
+    """The bf16x6 convolution / linear layer on PRE-SPLIT activations (planes from split3: [3, B*H*W, lda]); same epilogue as conv2d.
+    out_planes (int16 [3, B*OH*OW, ldp]): the result as planes instead of fp32 (`out` may be None)."""
+    _chk(load().aot_conv2d_bf16x6p_f32(_dev(planes), _dev(w6n), w6n.shape[3], _opt(bias), _opt(res), _opt(out), B, H, W, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dil, planes.stride(1), out.stride(0) if out is not None else 0,
+                                       res.stride(0) if res is not None else 0, res_rows, act, _opt(out_planes),
+                                       out_planes.stride(1) if out_planes is not None else 0,
+                                       stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6p_f32')
+    return out_planes if out_planes is not None else out
 
 
 def pack_bf16(w_kn, stream=None):

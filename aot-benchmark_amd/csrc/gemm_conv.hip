@@ -688,10 +688,11 @@ extern "C" int aot_split3_bf16_f32(const float* x, void* planes, long M, int C, 
 
 extern "C" int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, int cout_pad, const float* bias, const float* res,
                                       float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act, void* stream) {
-  if (!in_planes || !w6n || !out) return AOT_ERR_BADARG;
+                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
+                                      void* out_planes, int ldp, void* stream) {
+  if (!in_planes || !w6n || (!out && !out_planes)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
-  if ((lda & 7) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
+  if ((lda & 7) || lda < Cin || (!out_planes && ldc < Cout)) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
   if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   ConvParams p;
@@ -700,7 +701,7 @@ extern "C" int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, in
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  return launch_gemm_x6_presplit(p, w6n, cout_pad, (hipStream_t)stream);
+  return launch_gemm_x6_presplit(p, w6n, cout_pad, (hipStream_t)stream, out_planes, ldp);
 }
 
 extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,

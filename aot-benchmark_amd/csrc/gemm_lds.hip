@@ -379,6 +379,10 @@ __device__ __forceinline__ float buf_load_s(const i32x4& desc, int voff, int sof
 __device__ __forceinline__ void buf_store_s(const i32x4& desc, int voff, int soff, float v) {
   asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" : : "v"(v), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
+// bits [31:16] of v as one 16-bit store (a truncated-bf16 plane element)
+__device__ __forceinline__ void buf_store_hi16(const i32x4& desc, int voff, int soff, float v) {
+  asm volatile("s_nop 4\n\tbuffer_store_short_d16_hi %0, %1, %2, %3 offen" : : "v"(v), "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
 template <int IMM>
 __device__ __forceinline__ void fetch_one(f32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
@@ -881,10 +885,16 @@ __device__ __forceinline__ bf16x8 round8(const f32x4& x0, const f32x4& x1) {
 // The A tile of a k-step is 3 x 64 rows x 64 bytes: one DMA piece per wave and plane (lane = (row, 16-byte chunk), the chunk
 // XOR-swizzled by the row so that the fragment reads are conflict-free), and the fragment goes from LDS straight into the MFMA: no
 // vector instruction touches it (the split is 7.3 of the 10.7 VALU per MFMA of the fp32-activation form: profiles/r04_x6_gemm_pmc.txt).
-template <bool IS1X1, int NT = 6, bool SK = false, bool PS = false>
+// OP (with PS): the tile end writes the result AS THREE bf16 PLANES [3][M][ldp] (natural channel order: the input format of this very
+// member) instead of fp32 -- the producer side of a conv -> conv chain.  The planes' base arrives in `scratch`, ldp in `ksplit` (the
+// split-K arguments, unused here: the kernel's argument layout stays what the shipped members were validated with).  Three
+// buffer_store_short_d16_hi per value: bits [31:16] of v, of v - hi(v) and of that remainder's remainder (exact).
+template <bool IS1X1, int NT = 6, bool SK = false, bool PS = false, bool OP = false>
 __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
   static_assert(!SK || (IS1X1 && NT == 1), "split-K: the plain bf16 1x1 member only");
   static_assert(!PS || (NT == 6 && !SK), "pre-split activations: the six-term member only");
+  static_assert(!OP || PS, "plane output: the pre-split member only");
+  constexpr int NSTORE = OP ? 48 : 16;                  // stores of a tile end per lane
   constexpr int NST = 3;
   constexpr int BM = 64, BN = 64;
   constexpr int AG = BM / 8, AGW = PS ? 1 : AG / 4;     // A: 8-row fp32 groups, two per wave (PS: one 16-row piece per plane)
@@ -1126,6 +1136,30 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] += rv[r];
     }
+    if (OP) {
+      const int ldp = ksplit;
+      const int oplane = p.M * ldp * 2;                   // bytes of one output plane
+      const i32x4 desc_pl = raw_desc(scratch, 3L * oplane);
+      const int vbase_p = col_ok ? (mlane * ldp + n) * 2 : (int)OOB;
+      const int ldp2 = ldp * 2;
+      with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const int vo = c < rows_left ? vbase_p : (int)OOB;
+          const float v0 = apply_act(acc[0][r], act);
+          const float v1 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u);
+          const float v2 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+          buf_store_hi16(desc_pl, vo, c * ldp2, v0);
+          buf_store_hi16(desc_pl, vo, c * ldp2 + oplane, v1);
+          buf_store_hi16(desc_pl, vo, c * ldp2 + 2 * oplane, v2);
+          acc[0][r] = 0.f;
+        }
+      });
+      stores_pending = NSTORE;
+      return;
+    }
     with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
       constexpr int act = decltype(ACT)::value;
 #pragma unroll
@@ -1157,7 +1191,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
     // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished;
     // EARLY: the pieces of step ss+2 may stay in flight)
     if (stores_pending) {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm((EARLY ? LPW : 0) + 16, 0));
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm((EARLY ? LPW : 0) + NSTORE, 0));
       stores_pending = 0;
     } else {
       __builtin_amdgcn_s_waitcnt(waitcnt_imm(EARLY ? LPW : 0, 0));
@@ -1580,8 +1614,10 @@ bool gemm_x6_eligible(const ConvParams& p) {
 
 // the member that takes the activations pre-split (p.in = three bf16 planes [3][B*H*W][lda], natural k order; w6 packed in natural
 // order too): 64x64 tile, two workgroups per CU
-int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s) {
+int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s, void* out_planes, int ldp) {
   if (!w6n || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6n & 15) || ((uintptr_t)p.in & 15)) return AOT_ERR_UNSUPPORTED;
+  if (out_planes && (ldp < p.Cout || (ldp & 7) || 3L * p.M * ldp * 2 >= 0x7fffffffL || ((uintptr_t)out_planes & 15))) return AOT_ERR_BADARG;
+  if (!out_planes && !p.out) return AOT_ERR_BADARG;
   if ((p.Cin % 32) || (p.K % 32) || (p.lda & 7)) return AOT_ERR_UNSUPPORTED;
   if (3L * p.B * p.H * p.W * p.lda * 2 >= 0x7fffffffL || (long)p.M * p.ldc * 4 >= 0x7fffffffL ||
       (p.res && (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 >= 0x7fffffffL) || 3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL)
@@ -1592,6 +1628,13 @@ int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, 
   wq.cout_pad = cout_pad;
   const int nitems = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nitems < 512 ? nitems : 512;
+  if (out_planes) {        // the tile end writes planes: their base and row stride ride in the split-K arguments
+    if (is1x1)
+      hipLaunchKernelGGL((gemm_x6_kernel<true, 6, false, true, true>), dim3(grid), dim3(256), 0, s, p, wq, ldp, (float*)out_planes);
+    else
+      hipLaunchKernelGGL((gemm_x6_kernel<false, 6, false, true, true>), dim3(grid), dim3(256), 0, s, p, wq, ldp, (float*)out_planes);
+    AOT_LAUNCH_CHECK();
+  }
   if (is1x1)
     hipLaunchKernelGGL((gemm_x6_kernel<true, 6, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
   else

@@ -81,12 +81,14 @@ int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const f
  * order inside a 32-block (same sizes as aot_pack_bf16x6_f32).  aot_conv2d_bf16x6p_f32: same arguments and epilogue as
  * aot_conv2d_bf16x6_f32 with `in_planes` = the three planes of the B NHWC maps ([3][B*H*W][lda] bf16, lda % 8 == 0, plane stride =
  * B*H*W*lda) -- the A fragments go from LDS into the matrix cores without touching the vector ALUs, where the split of the fp32
- * form is 7.3 of its 10.7 VALU instructions per MFMA (profiles/r04_x6_gemm_pmc.txt); bit-identical results (64x64 tile). */
+ * form is 7.3 of its 10.7 VALU instructions per MFMA (profiles/r04_x6_gemm_pmc.txt); results equal up to the position of a k inside
+ * its MFMA (64x64 tile).  out_planes != NULL: the tile end writes the result as three bf16 planes [3][B*OH*OW][ldp] (ldp % 8 == 0,
+ * ldp >= Cout) INSTEAD of fp32 (`out` may be NULL) -- the producer side of a conv -> conv chain. */
 int aot_split3_bf16_f32(const float* x, void* planes, long M, int C, int ldx, int ldp, long pstride, void* stream);
 int aot_pack_bf16x6n_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
 int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, int cout_pad, const float* bias, const float* res, float* out,
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                           int lda, int ldc, int ldr, int res_rows, int act, void* stream);
+                           int lda, int ldc, int ldr, int res_rows, int act, void* out_planes, int ldp, void* stream);
 
 /* Plain bf16 form of the same operation for the TRAINING path (`--amp` of the reference's trainer, trainer.py:123-125,460-487 --
  * there fp16 autocast + GradScaler; BASELINE config 5: bf16): both operands rounded to bf16 (round to nearest even), ONE

@@ -170,6 +170,14 @@ def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, re
     assert float((got[:, :Cout] - want[:, :Cout]).abs().max()) <= 1e-5 * scale, 'pre-split member differs from the on-the-fly split'
     if ldb > Cout:
         assert torch.isnan(got[:, Cout:]).all(), 'wrote outside the logical columns'
+    if Cout % 8 == 0:
+        # the producer side: the tile end writes the result AS PLANES -- bit for bit the split of the fp32 result above
+        ldp = Cout + 8                                    # (a padded row: the padding must stay untouched)
+        op = torch.full((3, B * OH * OW, ldp), 0x7fc1, dtype=torch.int16, device='cuda')
+        hip.conv2d_x6p(planes, w6n, bd, None, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
+                       out_planes=op)
+        assert torch.equal(op[:, :, :Cout], hip.split3(got[:, :Cout].contiguous())), 'plane output differs from the split of the fp32 output'
+        assert bool((op[:, :, Cout:] == 0x7fc1).all()), 'wrote into the row padding of the planes'
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)

@@ -39,7 +39,14 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
     row = []
     ref_out = None
     for c in cfgs:
-        if c in ('x6p', 'x6ps'):         # x6p = the 64x64 kernel on PRE-SPLIT activations (planes made outside the timed loop); x6ps = split pass + kernel
+        if c == 'x6pp':                  # planes in, planes out (the tile end writes the three planes): a link of a conv -> conv chain
+            if Cin % 32 or Cout % 8: row.append('      -      -'); continue
+            w6n = aot_hip.pack_bf16x6n(w)
+            planes = aot_hip.split3(x)
+            oplanes = torch.empty(3, M, Cout, dtype=torch.int16, device='cuda')
+            def run():
+                aot_hip.conv2d_x6p(planes, w6n, b, None, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH, out_planes=oplanes)
+        elif c in ('x6p', 'x6ps'):         # x6p = the 64x64 kernel on PRE-SPLIT activations (planes made outside the timed loop); x6ps = split pass + kernel
             if Cin % 32: row.append('      -      -'); continue
             w6n = aot_hip.pack_bf16x6n(w)
             planes = aot_hip.split3(x)
