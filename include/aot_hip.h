@@ -66,8 +66,8 @@ int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const 
  * (K % 32 == 0; the layout aot_conv2d_nhwc_f32 takes) once into w6 = three bf16 planes in the kernel's tile order,
  * 3 * K * cout_pad * 2 bytes, cout_pad = Cout rounded up to 64.  aot_conv2d_bf16x6_f32 is aot_conv2d_nhwc_f32 on that weight
  * (same arguments and epilogue; needs Cin % 32 == 0; activations are split on the fly; tile = 0: the 128x128 eight-wave
- * kernel where the layer has >= 128 output channels and >= 192 such tiles, else the 64x64 one; 64 / 128 force one).  Not the default: a caller opts in per
- * engine (build_engine(..., mfma='bf16x6')), and results are reported under their own dtype string.
+ * kernel where the layer has >= 128 output channels and >= 192 such tiles, else the 64x64 one; 64 / 128 force one).  An engine opts in
+ * (build_engine(..., mfma='bf16x6'); bench.py times this arithmetic by default since round 4), and results are reported under their own dtype string.
  * Replaces the same reference code as aot_conv2d_nhwc_f32. */
 int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
 int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
