@@ -79,7 +79,12 @@ class FlatTrainState:
         self._in_backward = False
         self._hooks = [g['param'].register_post_accumulate_grad_hook(self._ready) for g in self.groups]
         self._seg_off = torch.tensor(self.offsets, dtype=torch.int64, device=dev)
-        self._hyp_host = torch.zeros(len(self.groups), 4, dtype=torch.float32, pin_memory=dev.type == 'cuda')
+        # the per-tensor table goes to the device asynchronously and the host never waits for a step: two pinned staging buffers
+        # used in turn, each guarded by the event of its last copy (a host that runs a whole step ahead of the device must not
+        # overwrite a table whose copy has not executed yet)
+        self._hyp_hosts = [torch.zeros(len(self.groups), 4, dtype=torch.float32, pin_memory=dev.type == 'cuda') for _ in range(2)]
+        self._hyp_events = [None, None]
+        self._hyp_turn = 0
         self._hyp = torch.zeros(len(self.groups), 4, dtype=torch.float32, device=dev)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._scratch = (torch.zeros(1024, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
@@ -158,17 +163,25 @@ class FlatTrainState:
         import aot_hip
         b1, b2 = self.betas
         touched = self._touched.tolist()
+        turn = self._hyp_turn
+        self._hyp_turn = turn ^ 1
+        if self._hyp_events[turn] is not None:
+            self._hyp_events[turn].synchronize()          # (the copy issued two steps ago: done long since, unless the host ran ahead)
+        host = self._hyp_hosts[turn]
         for i, (g, t) in enumerate(zip(self.groups, touched)):
             if t:
                 g['step'] += 1
                 st = g['step']
-                self._hyp_host[i, 0] = g['lr']
-                self._hyp_host[i, 1] = g['weight_decay']
-                self._hyp_host[i, 2] = 1.0 - b1 ** st
-                self._hyp_host[i, 3] = math.sqrt(1.0 - b2 ** st)
+                host[i, 0] = g['lr']
+                host[i, 1] = g['weight_decay']
+                host[i, 2] = 1.0 - b1 ** st
+                host[i, 3] = math.sqrt(1.0 - b2 ** st)
             else:
-                self._hyp_host[i, 0] = -1.0
-        self._hyp.copy_(self._hyp_host, non_blocking=True)
+                host[i, 0] = -1.0
+        self._hyp.copy_(host, non_blocking=True)
+        if self._hyp.is_cuda:
+            self._hyp_events[turn] = torch.cuda.Event()
+            self._hyp_events[turn].record()
         with torch.no_grad():
             aot_hip.sumsq_flat(self.flat_g, self._scratch, self._sumsq)
             aot_hip.adamw_flat(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self._seg_off, self._hyp, b1, b2, self.eps,
