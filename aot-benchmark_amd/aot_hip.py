@@ -23,6 +23,7 @@ _SIGS = {
     'aot_conv2d_nhwc_f32': [_P] * 7 + [_L] + [_I] * 20 + [_P],
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
+    'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_split3_bf16_f32': [_P, _P, _L, _I, _I, _I, _L, _P],
     'aot_pack_bf16x6n_f32': [_P, _P, _I, _I, _I, _I, _P],
@@ -103,6 +104,7 @@ GEMM_TABLES = {'latency': -1, 'throughput': -2}
 # too (build_engine(..., mfma=)), carried by the same scope.
 MFMA_MODES = ('f32', 'bf16x6')
 X6_TILE = 0                  # 0: tile of the bf16x6 kernels chosen by shape; 64 / 128 force one (tests, tuning)
+X6K_SCRATCH_FLOATS = 8 << 20   # floats of the per-stream split-K scratch (32 MB: every stride-16 layer of a 480p frame at three lanes fits)
 X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
 
 
@@ -268,6 +270,31 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     res.stride(0) if res is not None else 0, res_rows, act,
                                     (stack[-1][0] if stack else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
+    return out
+
+
+_x6k_ws = None
+
+
+def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE, B=1,
+               res_rows=0, ksplit=1, stream=None):
+    """The phase-shifted 128x128 bf16x6 kernel with split-K over the grid (aot_conv2d_bf16x6k_f32); the slabs of the k-slices live in
+    a per-stream scratch buffer that every such call on the stream shares (the calls are stream-ordered)."""
+    global _x6k_ws
+    w6 = getattr(w, '_aot_w6', None)
+    if w6 is None:
+        w6 = pack_bf16x6(w)
+    scratch = None
+    if ksplit > 1:
+        if _x6k_ws is None:
+            from networks.layers.workspace import Workspace
+            _x6k_ws = Workspace()
+        need = ksplit * B * OH * OW * Cout
+        scratch = _x6k_ws.get('x6k', (max(need, X6K_SCRATCH_FLOATS),), x.device)
+    _chk(load().aot_conv2d_bf16x6k_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dil, x.stride(0), out.stride(0), res.stride(0) if res is not None else 0,
+                                       res_rows, act, ksplit, _opt(scratch), scratch.numel() if scratch is not None else 0,
+                                       stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6k_f32')
     return out
 
 

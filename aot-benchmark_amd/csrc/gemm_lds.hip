@@ -1582,6 +1582,343 @@ __global__ void __launch_bounds__(512, 2) gemm_x6w_kernel(const ConvParams p, co
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
 }
 
+// ---- the 128x128 tile in two PHASE-SHIFTED wave groups ("ping-pong"; round 5) ------------------------------------------------
+// gemm_x6w_kernel's eight waves all walk the same sequence inside a k-step -- weight fragments, split, MFMAs -- so the matrix pipe
+// idles while every wave reads and splits, and the vector pipe idles while every wave multiplies: the steady state of that kernel
+// is ~3100 cycles per k-step against 1536 of MFMA per SIMD (dec c4 at batch 3: 203 TF-equivalent once tile quantisation is taken
+// out).  Here the two waves that share a SIMD (w and w + 4: a workgroup's waves go to the SIMDs cyclically) work in OPPOSITE phases,
+// separated by workgroup barriers:
+//     group X (waves 0-3):   LOAD(s) | COMPUTE(s) | LOAD(s+1) | COMPUTE(s+1) | ...
+//     group Y (waves 4-7):     --    | LOAD(s)    | COMPUTE(s)| LOAD(s+1)    | ...
+// LOAD(s) = the wave's 4 + 12 fragment reads of ring stage s, the split of its A rows into the three bf16 planes (88 VALU), and the
+// issue of its five LDS-DMA pieces of step s+2; COMPUTE(s) = its 24 MFMAs (768 cycles), all operands in registers.  In every phase
+// one wave of a SIMD feeds the matrix pipe while its partner uses the LDS and the vector ALUs.  Same tile, LDS image, DMA pieces,
+// six products in the same order per accumulator and tile end as gemm_x6w_kernel: bit-identical results.
+// Ring safety (three stages): stage s is read by X in phase 2s and by Y in phase 2s+1; the DMA of step s+2 goes to the stage of
+// step s-1, whose last read (Y, phase 2s-1) is behind a barrier for both groups.  Every wave retires its own pieces of step s+1
+// (counted vmcnt) before the barrier that ends phase 2s+1: X at the end of COMPUTE(s), Y at the end of LOAD(s).
+// SK: split-K over the grid (item = (tile, k-slice)), raw partial tiles to fp32 slabs, splitk_reduce_kernel sums them in slice
+// order -- for the stride-16 maps, whose 128x128 tiles alone do not fill 256 CUs.
+#ifndef AOT_PP_DMAC
+#define AOT_PP_DMAC 0        // development switch: the DMA pieces of step s+2 are issued in COMPUTE(s) instead of LOAD(s)
+#endif
+#ifndef AOT_PP_PRIO
+#define AOT_PP_PRIO 0        // development switch: s_setprio 1 around the MFMA phase
+#endif
+template <bool IS1X1, bool SK>
+__global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
+  constexpr bool DMAC = AOT_PP_DMAC != 0;
+  constexpr int NST = 3;
+  constexpr int BM = 128, BN = 128;
+  constexpr int AG = BM / 8, AGW = AG / 8;              // A: 8-row groups, two per wave (eight waves)
+  constexpr int BPW = 3;                                // B: one 16-byte chunk column (cc = wave & 3) of each plane per wave
+  constexpr int LPW = AGW + BPW;
+  constexpr int OPA_BYTES = AG * GROUP_STRIDE, B_PIECE = 64 * 16, OPB_BYTES = 24 * B_PIECE;      // piece (pl, cc, column half)
+  constexpr int STAGE_BYTES = OPA_BYTES + OPB_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                                     // 0 = X, 1 = Y (one phase behind)
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nk = SK ? (p.K / BK) / ksplit : p.K / BK;            // k-steps per item (host guarantees divisibility)
+  const int nitems = nbm * nbn * (SK ? ksplit : 1);
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
+  const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int mine = li < chunk_n ? (chunk_n - li + nwg_x - 1) / nwg_x : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  auto item_of = [&](int i) __attribute__((always_inline)) {
+    const int it = chunk0 + li + i * nwg_x;
+    Item r;
+    r.bn = it % nbn;
+    if (SK) {            // item = ((bm * ksplit) + slice) * nbn + bn: the slices of a tile are neighbours (shared A rows in L2)
+      const int t = it / nbn;
+      r.kt0 = (t % ksplit) * nk;
+      r.bm = t / ksplit;
+    } else {
+      r.bm = it / nbn;
+      r.kt0 = 0;
+    }
+    return r;
+  };
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;       // wave tile: 32 rows x 64 columns (two 32-column blocks)
+  const int lr = lane >> 3, lp = lane & 7;
+  const int cofs = (lp ^ lr) << 2;
+  const int hw_out = p.OH * p.OW;
+  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+  const i32x4 desc_out = raw_desc(p.out, (long)p.M * p.ldc * 4);
+  const i32x4 desc_res = raw_desc(p.res, (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4);
+  const i32x4 desc_bias = raw_desc(p.bias, (long)p.Cout * 4);
+  const int n_res = (!SK && p.res) ? 32 : 0, n_bias = (!SK && p.bias) ? 1 : 0;      // (split-K: the reduce pass adds them)
+
+  // ---- issue side (as gemm_x6w_kernel; split-K: the slice's first k-step sets the K offsets and the filter tap) --------
+  int is_i = 0, is_kt = 0;
+  int a_off[AGW], a_iy0[AGW], a_ix0[AGW];
+  bool a_ok[AGW];
+  unsigned b_off = 0;
+  int s_k = 0, s_kb = 0;
+  int tap_c = 0, tap_ky = 0, tap_kx = 0, s_tap = 0;
+  auto setup_item = [&](int i) __attribute__((always_inline)) {
+    const bool live = i < mine;
+    const Item it = item_of(live ? i : 0);
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      const int m = it.bm * BM + 8 * (AGW * wave + g) + lr;
+      a_ok[g] = live && m < p.M;
+      const int mm = a_ok[g] ? m : 0;
+      const int b = mm / hw_out, pix = mm - b * hw_out;
+      const int oy = pix / p.OW, ox = pix - oy * p.OW;
+      a_iy0[g] = oy * p.stride - p.pad;
+      a_ix0[g] = ox * p.stride - p.pad;
+      a_off[g] = (((b * p.H + a_iy0[g]) * p.W + a_ix0[g]) * p.lda + cofs) * 4;
+      if (IS1X1 && !a_ok[g]) a_off[g] = (int)OOB;
+    }
+    b_off = (live && it.bn * BN + (wave >> 2) * 64 < wq.cout_pad)
+                ? (unsigned)(((wave & 3) * wq.cout_pad + it.bn * BN + (wave >> 2) * 64 + lane) * 16) : OOB;
+    s_k = SK ? it.kt0 * BK * 4 : 0;
+    s_kb = SK ? it.kt0 * 4 * wq.cout_pad * 16 : 0;
+    if (!IS1X1) {
+      if (SK) {
+        const int k0 = it.kt0 * BK, tap = k0 / p.Cin;
+        tap_c = k0 - tap * p.Cin;
+        tap_ky = tap / p.KW;
+        tap_kx = tap - tap_ky * p.KW;
+      } else {
+        tap_c = 0; tap_ky = 0; tap_kx = 0;
+      }
+    }
+  };
+  auto issue = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    constexpr int slot = decltype(SLOT)::value;
+    if (is_kt == 0) setup_item(is_i);
+    if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4;
+    unsigned char* st = lds + slot * STAGE_BYTES;
+#pragma unroll
+    for (int g = 0; g < AGW; ++g) {
+      unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
+      if (IS1X1) {
+        dma16(rsrc_a, dst, a_off[g], s_k);
+      } else {
+        const int iy = a_iy0[g] + tap_ky * p.dil, ix = a_ix0[g] + tap_kx * p.dil;
+        const bool in = a_ok[g] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        dma16(rsrc_a, dst, in ? a_off[g] + s_tap : (int)OOB, 0);
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      dma16(rsrc_b, st + OPA_BYTES + ((pl * 4 + (wave & 3)) * 2 + (wave >> 2)) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
+    s_k += BK * 4;
+    s_kb += 4 * wq.cout_pad * 16;
+    if (!IS1X1) {
+      tap_c += BK;
+      if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
+    }
+    if (++is_kt == nk) { is_kt = 0; ++is_i; }
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
+  unsigned aaddr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aaddr[j] = lds_base + chunk_off(wm + l31, 2 * j + half);
+  const unsigned baddr = lds_base + OPA_BYTES + (half * 2 + (wn >> 6)) * B_PIECE + l31 * 16;
+  f32x4 ra[4];                 // the lane's four 16-byte chunks of its A row: sub-step s contracts chunks 2 s and 2 s + 1
+  bf16x8 rb[3][2][2];          // [plane][sub-step][column block]
+  bf16x8 ap[2][3];             // [sub-step][plane]: the A row split, ready for the matrix cores
+  f32x16 acc[4];               // [2 * sub-step + column block]
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  int c_i = 0, c_kt = 0;
+  bool stores_pending = false;
+  float rv[2][16], bv[2] = {0.f, 0.f};
+  auto epi_loads = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int m0 = it.bm * BM;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (n_bias) bv[nb] = buf_load(desc_bias, col_ok ? n * 4 : (int)OOB);
+      if (n_res && p.res_rows == 0) {
+        const int mlane = m0 + wm + 4 * half;
+        const int vbase = col_ok ? (mlane * p.ldr + n) * 4 : (int)OOB;
+        const int rows_left = p.M - mlane, ldr4 = p.ldr * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          rv[nb][r] = buf_load_s(desc_res, c < rows_left ? vbase : (int)OOB, c * ldr4);
+        }
+      } else if (n_res) {
+        const int rr0 = m0 % p.res_rows;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = wm + mfma32_row(r, half);
+          int rr = rr0 + dm;
+          if (p.res_rows >= BM) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+          else rr %= p.res_rows;
+          rv[nb][r] = buf_load(desc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB);
+        }
+      }
+    }
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[nb][r] += acc[2 + nb][r]; acc[2 + nb][r] = 0.f; }
+    const int m0 = it.bm * BM;
+    const int mlane = m0 + wm + 4 * half;
+    const int rows_left = p.M - mlane;
+    if (SK) {            // the raw partial tile -> the slice's slab [M][Cout]
+      const i32x4 desc_slab = raw_desc(scratch + (long)(it.kt0 / nk) * p.M * p.Cout, (long)p.M * p.Cout * 4);
+      const int lds4 = p.Cout * 4;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int n = it.bn * BN + wn + 32 * nb + l31;
+        const int vbase_s = n < p.Cout ? (mlane * p.Cout + n) * 4 : (int)OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          buf_store_s(desc_slab, c < rows_left ? vbase_s : (int)OOB, c * lds4, acc[nb][r]);
+          acc[nb][r] = 0.f;
+        }
+      }
+      stores_pending = true;
+      return;
+    }
+    // residual and bias were fetched at the head of this phase (DMAC: older than the DMA pieces issued in it)
+    if (n_res | n_bias) __builtin_amdgcn_s_waitcnt(waitcnt_imm(DMAC ? LPW : 0, 15));
+    const int ldc4 = p.ldc * 4;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (n_bias) asm volatile("" : "+v"(bv[nb]));
+      if (n_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[nb][r]));
+      }
+      const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      if (n_bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += bv[nb];
+      }
+      if (n_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += rv[nb][r];
+      }
+      with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          buf_store_s(desc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, apply_act(acc[nb][r], act));
+          acc[nb][r] = 0.f;
+        }
+      });
+    }
+    stores_pending = true;
+  };
+
+  auto phase_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);                     // nothing -- MFMAs and splits included -- moves across a phase boundary
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // LOAD(s): fragments of ring stage SLOT -> registers, A rows split; (not DMAC) the DMA of step s+2 -> stage SLOT + 2
+  auto load_phase = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    constexpr int slot = decltype(SLOT)::value, islot = (slot + 2) % 3;
+    x6w_fetch_a(ra, aaddr, (unsigned)(slot * STAGE_BYTES));
+    x6w_fetch_b<B_PIECE>(rb, baddr + (unsigned)(slot * STAGE_BYTES));
+    if (!DMAC) issue(std::integral_constant<int, islot>{});
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 10));       // LDS reads return in order: the four A chunks are the oldest
+    x6w_landed_a(ra);
+    split3(ra[0], ra[1], ap[0]);
+    split3(ra[2], ra[3], ap[1]);
+    // the planes exist HERE, in this phase (hipcc otherwise sinks the split across the barrier to the MFMAs that use it)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(ap[s][0]), "+v"(ap[s][1]), "+v"(ap[s][2]));
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+    x6w_landed_b(rb);
+    if (grp) {           // Y: its pieces of step s+1 have landed before X reads them in the next phase
+      if (DMAC) {
+        if (stores_pending) __builtin_amdgcn_s_waitcnt(waitcnt_imm(32, 15));
+        else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+      } else {
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));
+      }
+      stores_pending = false;
+    }
+  };
+  // COMPUTE(s): 24 MFMAs, the four accumulators in turn (consecutive MFMAs are independent); smallest terms first per accumulator
+  auto compute_phase = [&](auto SLOT) __attribute__((always_inline)) -> void {
+    constexpr int islot = (decltype(SLOT)::value + 2) % 3;
+    if (c_kt == nk - 1 && (n_res | n_bias)) epi_loads();   // last k-step of the tile: its residual and bias fly under the MFMAs
+    if (AOT_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#define AOT_PP_TERM(PA, PB)                                                                                        \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                   \
+      acc[2 * s + nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s][PA], rb[PB][s][nb], acc[2 * s + nb], 0, 0, 0);
+    AOT_PP_TERM(1, 1)
+    AOT_PP_TERM(0, 2)
+    AOT_PP_TERM(2, 0)
+    if (DMAC) issue(std::integral_constant<int, islot>{});
+    AOT_PP_TERM(0, 1)
+    AOT_PP_TERM(1, 0)
+    AOT_PP_TERM(0, 0)
+#undef AOT_PP_TERM
+    if (AOT_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+    bool did_epi = false;
+    if (++c_kt == nk) {
+      epilogue();
+      c_kt = 0;
+      ++c_i;
+      did_epi = true;
+    }
+    if (!grp) {          // X: its pieces of step s+1 have landed before anyone reads them in the next phase
+      if (did_epi) __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW + 32, 15));
+      else __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));
+      stores_pending = false;
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  issue(I0{});
+  issue(I1{});
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));          // step 0 has landed
+  phase_barrier();
+  if (grp) phase_barrier();                                  // Y starts one phase late
+  auto step = [&](auto U) __attribute__((always_inline)) -> void {
+    load_phase(U);
+    phase_barrier();
+    compute_phase(U);
+    phase_barrier();
+  };
+#pragma unroll 1
+  for (int ss = 0; ss < total; ss += 3) {
+    step(I0{});
+    if (ss + 1 < total) step(I1{});
+    if (ss + 2 < total) step(I2{});
+  }
+  if (!grp) phase_barrier();                                 // X waits for Y's last phase (same barrier count in both groups)
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));             // the all-out-of-bounds DMAs past the end still target this LDS
+}
+
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch) {
   const int nq = (p.Cout + 3) >> 2;
@@ -1689,9 +2026,38 @@ int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, 
   AOT_LAUNCH_CHECK();
 }
 
+// the phase-shifted 128x128 form (gemm_x6pp_kernel); ksplit > 1: split-K over the grid, slabs [ksplit][M][Cout] in `scratch`
+int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch) {
+  if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if (ksplit < 1 || (p.K / BK) % ksplit != 0) return AOT_ERR_BADARG;
+  if (ksplit > 1 && (!scratch || (long)p.M * p.Cout * 4 >= 0x7fffffffL)) return AOT_ERR_BADARG;
+  const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 128) * cdiv(p.Cout, 128) * ksplit;
+  const int grid = nit < 256 ? nit : 256;                     // one 8-wave workgroup per CU
+  if (ksplit > 1) {
+    if (is1x1)
+      hipLaunchKernelGGL((gemm_x6pp_kernel<true, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
+    else
+      hipLaunchKernelGGL((gemm_x6pp_kernel<false, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
+    const long n = (long)p.M * ((p.Cout + 3) >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+    AOT_LAUNCH_CHECK();
+  }
+  if (is1x1)
+    hipLaunchKernelGGL((gemm_x6pp_kernel<true, false>), dim3(grid), dim3(512), 0, s, p, wq, 1, nullptr);
+  else
+    hipLaunchKernelGGL((gemm_x6pp_kernel<false, false>), dim3(grid), dim3(512), 0, s, p, wq, 1, nullptr);
+  AOT_LAUNCH_CHECK();
+}
+
 int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms, int ksplit, float* scratch) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if (tile == 256) return terms == 6 ? launch_gemm_x6pp(p, w6, cout_pad, s, ksplit, scratch) : AOT_ERR_BADARG;
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
   X6Weight wq;
   wq.w6 = w6;

@@ -73,6 +73,17 @@ int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, int ldb, int 
 int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                           int lda, int ldc, int ldr, int res_rows, int act, int tile, void* stream);
+/* tile = 256 selects the PHASE-SHIFTED form of the 128x128 tile (gemm_x6pp_kernel, round 5): the two waves that share a SIMD
+ * alternate between a load phase (fragment reads, activation split, DMA issue) and an MFMA phase, so the matrix pipe and the vector
+ * ALUs work at the same time; bit-identical to tile = 128.  aot_conv2d_bf16x6k_f32 is that form with split-K over the grid for
+ * layers whose 128x128 tiles alone do not fill the chip (the stride-16 maps): (K / 32) % ksplit == 0, every k-slice writes its raw
+ * partial tile to a slab of `scratch` ([ksplit][M][Cout] floats, scratch_floats = its size), one more launch sums the slabs in
+ * slice order and applies bias / residual / activation.  ksplit = 1: no scratch needed.
+ * Replaces the same reference code as aot_conv2d_nhwc_f32. */
+int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                           int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
+                           void* stream);
 
 /* The member of the same family that takes its activations ALREADY SPLIT (experimental in round 4: called by tests and
  * tools/dev/mb_gemm.py only, no engine stage hands over split activations yet).  aot_split3_bf16_f32: x [M, ldx] fp32 -> three

@@ -181,7 +181,7 @@ def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, re
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-@pytest.mark.parametrize('tile', [64, 128])
+@pytest.mark.parametrize('tile', [64, 128, 256])
 def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
     the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
@@ -214,7 +214,7 @@ def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, til
     outs = {}
     for mode in ('f32', 'bf16x6'):
         out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-        hip.X6_TILE = tile                  # both tile forms of the family: 64x64 (four waves) and 128x128 (eight waves)
+        hip.X6_TILE = tile                  # the tile forms of the family: 64x64 (four waves), 128x128 (eight waves), 256 = 128x128 phase-shifted
         try:
             with hip.use_gemm_table('throughput', mode):
                 hip.conv2d(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B,
@@ -231,6 +231,62 @@ def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, til
     if tiles >= hip.X6_MIN_TILES:          # (below that the dispatch keeps the fp32 kernels: nothing to compare)
         assert not torch.equal(outs['f32'], outs['bf16x6']), 'the bf16x6 path did not run'
     assert e6 <= 4 * e32 + 1e-6 * scale, 'bf16x6 error %g vs fp32-kernel error %g' % (e6, e32)
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
+def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
+    """gemm_x6pp_kernel (tile = 256; aot_conv2d_bf16x6k_f32): the two waves of a SIMD in opposite load / MFMA phases.  Same tile, same
+    six products in the same order per accumulator as the 128x128 kernel: BIT-IDENTICAL to it; with split-K over the grid (partial
+    slabs summed in slice order by a second launch) within the family's tolerance of fp64 and 1e-5 of the scale from the unsplit result."""
+    g = torch.Generator().manual_seed(H * 131 + Cout + B)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    OH, OW = ref.shape[2:]
+    r = torch.randn(1, Cout, OH, OW, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    ref = {0: ref, 1: F.relu(ref), 3: F.gelu(ref), 4: F.silu(ref)}[act].float()
+    ldb = (Cout + 3) // 4 * 4
+    wk = torch.zeros(K * K * Cin, ldb)
+    wk[:, :Cout] = w.permute(2, 3, 1, 0).reshape(K * K * Cin, Cout)
+    wk = hip.attach_wt(_dev(wk), Cin)
+    w6 = hip.pack_bf16x6(wk)
+    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
+    rt = _dev(r[0].permute(1, 2, 0).reshape(OH * OW, Cout)) if res else None
+    bd = _dev(b)
+
+    def run(tile):
+        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+        rc = hip.load().aot_conv2d_bf16x6_f32(xt.data_ptr(), w6.data_ptr(), w6.shape[3], bd.data_ptr(), rt.data_ptr() if res else None,
+                                              out.data_ptr(), B, H, W, Cin, OH, OW, Cout, K, K, s, p, d, xt.stride(0), out.stride(0),
+                                              rt.stride(0) if res else 0, OH * OW if res else 0, act, tile, hip.stream_ptr())
+        assert rc == 0
+        return out
+    wide, pp = run(128), run(256)
+    assert torch.equal(wide[:, :Cout], pp[:, :Cout]), 'the phase-shifted kernel differs from the 128x128 kernel'
+    if ldb > Cout:
+        assert torch.isnan(pp[:, Cout:]).all(), 'wrote outside the logical columns'
+    scale = max(1.0, ref.abs().max().item())
+    _close(pp[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'phase-shifted bf16x6 conv')
+    nk = K * K * Cin // 32
+    for ks in (1, 2, 3, 4, 8):
+        if nk % ks:
+            continue
+        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+        hip.conv2d_x6k(xt, wk, bd, out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
+                       ksplit=ks)
+        if ks == 1:
+            assert torch.equal(out[:, :Cout], pp[:, :Cout])
+        else:
+            assert float((out[:, :Cout] - pp[:, :Cout]).abs().max()) <= 1e-5 * scale, 'split-K %d differs from the unsplit result' % ks
+            _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'split-K %d' % ks)
+        if ldb > Cout:
+            assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+    # repeats are bit-identical (no order-dependent state between the phase-shifted groups)
+    for _ in range(3):
+        assert torch.equal(run(256)[:, :Cout], pp[:, :Cout])
 
 
 def test_linear_strided_views(hip):
@@ -911,14 +967,14 @@ def test_end_to_end_vs_reference_golden(hip, case):
 
 
 def _record_parity(case, mode, rec):
-    """Appends one entry to gpurun_out/parity_r04.json (copied to profiles/ after the run): the tie-flip counts are an
+    """Appends one entry to gpurun_out/parity_r05.json (copied to profiles/ after the run): the tie-flip counts are an
     asserted, recorded artifact, not a print.  `mode` names the cell: teacher_forced / free_running, and -- for the cases run
     in several engine configurations -- the GEMM table, the launch mode and the label path."""
     import json
     import os
     d = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(d, exist_ok=True)
-    p = os.path.join(d, 'parity_r04.json')
+    p = os.path.join(d, 'parity_r05.json')
     data = json.load(open(p)) if os.path.exists(p) else {}
     data['%s/%s' % (case, mode)] = rec
     with open(p, 'w') as f:
@@ -931,7 +987,7 @@ def test_bf16x6_engine_vs_reference_golden(hip, case, table, graph):
     """build_engine(..., mfma='bf16x6'): every conv / linear layer that qualifies on the six-term bf16 split -- held to EXACTLY
     the bars of the fp32 engine on the whole-clip goldens of the real reference, teacher-forced: stride-4 logits and last
     LSTT / GPM output within 2e-4, every mask equal outside the reference's near-ties; then free-running (R50 models) with
-    zero pixels outside near-ties.  Recorded next to the fp32 cells in parity_r04.json."""
+    zero pixels outside near-ties.  Recorded next to the fp32 cells in parity_r05.json."""
     from common import unpack_gapmask
     c, g = load_case(case)
     _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table, mfma='bf16x6')
@@ -953,7 +1009,7 @@ def test_bf16x6_engine_vs_reference_golden(hip, case, table, graph):
             assert el < 2e-4, 'frame %d last LSTT layer output err %g' % (t, el)
     rec = {'frames': len(res), 'tie_flips': flips, 'max_logit4_err': worst, 'max_lstt_last_rel_err': worst_l,
            'pixels': int(g['masks'].size)}
-    if 'r50' in c['model']:
+    if True:             # (round 4 gated the free-running half on the R50 models; SwinB-DeAOTL runs it too since round 5)
         frames = frames.cuda() if torch.is_tensor(frames) else [f.cuda() for f in frames]
         eng.restart_engine()
         diffs, hard = [], 0
@@ -967,7 +1023,9 @@ def test_bf16x6_engine_vs_reference_golden(hip, case, table, graph):
                 hard += int((bad & ~unpack_gapmask(g, t, bad.shape)).sum())
                 eng.update_memory(F.interpolate(lab, size=eng.input_size_2d, mode='nearest'))
         rec.update({'free_running_pixels_differing': int(sum(diffs)), 'free_running_outside_near_ties': hard})
-        assert hard == 0 and sum(diffs) <= len(diffs) and max(diffs) <= 4, 'bf16x6 free-running: %s' % diffs
+        swin480 = case.startswith('c3_swinb_deaotl_480')        # (the caps of test_free_running_masks_equal_reference)
+        assert hard == 0 and sum(diffs) <= (3 if swin480 else 1) * len(diffs) and max(diffs) <= (10 if swin480 else 4), \
+            'bf16x6 free-running: %s' % diffs
     _record_parity(case, 'bf16x6/%s/%s' % (table, 'graph' if graph else 'eager'), rec)
 
 
@@ -982,17 +1040,27 @@ _CELLS = [(tb, gr, lb) for tb in ('latency', 'throughput') for gr in (False, Tru
 _FULL = ['c2_r50_aotl_70', 'c3b_r50_deaotl_70', 'c3_swinb_deaotl_480_70']
 
 
-@pytest.mark.parametrize('case,table,graph,labels',
-                         [(c, 'latency', False, 'torch') for c in ('c3_swinb_deaotl_480',)] +
-                         [(c, tb, gr, 'fuse_probs' if gr else 'torch') for c in _FULL for tb in ('latency', 'throughput')
-                          for gr in (False, True)])
-def test_end_to_end_full_size_vs_reference_golden(hip, case, table, graph, labels):
+# the arithmetic bench.py times by default is mfma = 'bf16x6' (since round 4); 'f32' is its `fp32_exact` leg.  Both tests below run
+# their cells under BOTH: the bf16x6 cells are the configurations the bench line reports a frames/s for -- three concurrent clips
+# (throughput table, hipGraph replay, aot_hip.fuse_probs labels, encoder look-ahead 3), one clip at a time (latency table, the same
+# otherwise: `single_stream`), plus the eager / torch-label forms -- for ALL three whole-clip goldens.
+_X6_TF_CELLS = [('throughput', True, 'fuse_probs'), ('latency', True, 'fuse_probs'), ('latency', False, 'torch')]
+_X6_FR_CELLS = [('throughput', True, 'fuse_probs', 3), ('latency', True, 'fuse_probs', 3), ('throughput', True, 'fuse_probs', 1),
+                ('latency', False, 'torch', 1)]
+
+
+@pytest.mark.parametrize('case,table,graph,labels,mfma',
+                         [(c, 'latency', False, 'torch', 'f32') for c in ('c3_swinb_deaotl_480',)] +
+                         [(c, tb, gr, 'fuse_probs' if gr else 'torch', 'f32') for c in _FULL for tb in ('latency', 'throughput')
+                          for gr in (False, True)] +
+                         [(c,) + cell + ('bf16x6',) for c in _FULL for cell in _X6_TF_CELLS])
+def test_end_to_end_full_size_vs_reference_golden(hip, case, table, graph, labels, mfma):
     """BASELINE configs 2 and 3 at their full size and R50-DeAOTL, teacher-forced against the REAL reference over whole
     70-frame clips (bank M 1 -> 14; logits and last LSTT / GPM layer output at frames 1 / 35 / 69), under both GEMM dispatch
     tables, with host launches and with hipGraph replay.  Every mask of every frame is compared; flips are only tolerated on
     the reference's own near-ties and their count is recorded."""
     c, g = load_case(case)
-    _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table)
+    _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table, mfma=mfma)
     frames, mask, objs, out_size = case_clip(c, g=g)
     extra = {}
     res = run_teacher_forced(eng, frames, mask, objs, out_size, g, set(c['keep_logits']), to_dev=lambda x: x.cuda(),
@@ -1010,16 +1078,17 @@ def test_end_to_end_full_size_vs_reference_golden(hip, case, table, graph, label
             el = float(np.abs(extra['lstt_last_%d' % t] - ref).max() / max(1.0, np.abs(ref).max()))
             worst_l = max(worst_l, el)
             assert el < 2e-4, 'frame %d last LSTT layer output err %g' % (t, el)
-    _record_parity(case, 'teacher_forced/%s/%s/%s' % (table, 'graph' if graph else 'eager', labels),
+    _record_parity(case, 'teacher_forced/%s%s/%s/%s' % ('bf16x6/' if mfma == 'bf16x6' else '', table, 'graph' if graph else 'eager', labels),
                    {'frames': len(res), 'tie_flips': flips, 'max_logit4_err': worst, 'max_lstt_last_rel_err': worst_l,
-                    'pixels': int(g['masks'].size)})
+                    'pixels': int(g['masks'].size), 'mfma': mfma})
 
 
-@pytest.mark.parametrize('case,table,graph,labels,ahead',
-                         [(c, 'latency', False, 'torch', 1) for c in ('c1_aott', 'c3_swinb_deaotl_480')] +
-                         [(c,) + cell + (1,) for c in _FULL for cell in _CELLS] +
-                         [(c, tb, True, 'fuse_probs', 3) for c in _FULL for tb in ('latency', 'throughput')])
-def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahead):
+@pytest.mark.parametrize('case,table,graph,labels,ahead,mfma',
+                         [(c, 'latency', False, 'torch', 1, 'f32') for c in ('c1_aott', 'c3_swinb_deaotl_480')] +
+                         [(c,) + cell + (1, 'f32') for c in _FULL for cell in _CELLS] +
+                         [(c, tb, True, 'fuse_probs', 3, 'f32') for c in _FULL for tb in ('latency', 'throughput')] +
+                         [(c,) + cell + ('bf16x6',) for c in _FULL for cell in _X6_FR_CELLS])
+def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahead, mfma):
     """BASELINE configs 1 / 2 / 3 and R50-DeAOTL FREE-RUNNING (the engine's own argmax feeds its memory, exactly the demo
     loop, tools/demo.py:187-235): the mask ids of every frame against the real reference's -- for the whole-clip goldens in
     EVERY configuration bench.py can time: GEMM table {latency, throughput} x {host launches, hipGraph replay} x label path
@@ -1027,10 +1096,10 @@ def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahe
     default --encode-ahead).  Any differing pixel must be one of the reference's own argmax near-ties
     (top-2 logit gap < 2e-4: an fp32 summation-order difference decides those, the reference itself flips such pixels
     between fp32 and fp64 -- SURVEY section 7) and there may be at most one per frame on average; the exact per-frame counts
-    of every cell are recorded in parity_r04.json."""
+    of every cell are recorded in parity_r05.json."""
     from common import unpack_gapmask
     c, g = load_case(case)
-    _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table)
+    _, _, eng, _ = _hip_engine(c['model'], graph=graph, gemm_table=table, mfma=mfma)
     frames, mask, objs, out_size = case_clip(c, device='cuda', g=g)
     label_fn = _fuse_label(hip) if labels == 'fuse_probs' else \
         (lambda logit: torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float())
@@ -1052,11 +1121,11 @@ def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahe
             diffs.append(int(bad.sum()))
             hard += int((bad & ~tie).sum())
             eng.update_memory(F.interpolate(lab, size=eng.input_size_2d, mode='nearest'))
-    _record_parity(case, 'free_running/%s/%s/%s%s' % (table, 'graph' if graph else 'eager', labels,
-                                                       '/ahead%d' % ahead if ahead > 1 else ''),
+    _record_parity(case, 'free_running/%s%s/%s/%s%s' % ('bf16x6/' if mfma == 'bf16x6' else '', table, 'graph' if graph else 'eager', labels,
+                                                         '/ahead%d' % ahead if ahead > 1 else ''),
                    {'frames': len(diffs), 'pixels_differing_per_frame': diffs, 'pixels_differing': int(sum(diffs)),
                     'outside_reference_near_ties': hard, 'pixels': int(g['masks'].size),
-                    'feedback': 'own labels'})
+                    'feedback': 'own labels', 'mfma': mfma})
     assert hard == 0, '%s free-running: %d differing pixels are not reference near-ties' % (case, hard)
     # the tie flips must not feed on themselves: bounded per frame, at most one per frame on average, and no growth over the clip.
     # SwinB-DeAOTL at 480x848 has ~40 reference pixels under the 2e-4 gap in EVERY frame (twice the density of the R50 clips;
