@@ -1582,6 +1582,239 @@ __global__ void __launch_bounds__(512, 2) gemm_x6w_kernel(const ConvParams p, co
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));           // the all-out-of-bounds DMAs past the end still target this LDS
 }
 
+// ---- register-staged 64x64 tile ("x6r", round 5) -------------------------------------------------------------------------------
+// What the round-5 probes of the LDS-DMA kernels say (profiles/r05_x6pp_probes.txt): a k-step of those kernels is set by the ISSUE of
+// the LDS-DMA pieces (100-185 cycles each; the global -> LDS path delivers ~13-17 bytes per clock and CU whatever the schedule) and by
+// the activation split, which every wave repeats for the rows it shares with its column neighbours -- not by the matrix pipe.  This
+// member takes the other road:
+//   * operands come through REGISTERS: per k-step a thread loads 8 fp32 activations (its row's two 16-byte chunks of one
+//     (sub-step, lane-half) fragment: buffer_load_dwordx4 x 2) and three 16-byte weight chunks (one per plane), a step ahead;
+//   * the activations are split into the three bf16 planes ONCE per element (44 VALU per thread and step instead of 88) and written to
+//     LDS as planes (ds_write_b128 x 3, rows of 64 bytes, the chunk XOR-swizzled by the row: fragment reads and stage writes are
+//     bank-conflict free); the weight chunks go to the image the DMA kernels use ([plane][chunk][column] x 16 bytes);
+//   * the A fragments go from LDS straight into the MFMAs; two LDS buffers of 24 KB, ONE barrier per k-step, no inline-asm waits
+//     (nothing here is an LDS-DMA, so hipcc's own counted waits are right);
+//   * 48 KB of LDS and <= 168 registers: THREE workgroups per CU (the DMA kernel: two).
+// Same k -> (sub-step, lane-half, element) mapping and the same six products in the same order per accumulator as gemm_x6_kernel:
+// bit-identical results.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+template <bool IS1X1>
+__global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, const X6Weight wq) {
+  constexpr int BM = 64, BN = 64;
+  constexpr int A_PLANE = 64 * 64;                        // bytes: 64 rows x four 16-byte chunks (32 bf16)
+  constexpr int A_BYTES = 3 * A_PLANE, B_PIECE = 64 * 16, B_BYTES = 12 * B_PIECE;
+  constexpr int BUF = A_BYTES + B_BYTES;                  // 24 KB
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nk = p.K / BK;
+  const int nitems = nbm * nbn;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
+  const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int mine = li < chunk_n ? (chunk_n - li + nwg_x - 1) / nwg_x : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  auto item_of = [&](int i) __attribute__((always_inline)) {
+    const int it = chunk0 + li + i * nwg_x;
+    Item r;
+    r.bn = it % nbn;
+    r.bm = it / nbn;
+    r.kt0 = 0;
+    return r;
+  };
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int hw_out = p.OH * p.OW;
+  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_out =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_res =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? (int)((long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_bias =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+  const bool has_res = p.res != nullptr, has_bias = p.bias != nullptr;
+
+  // ---- staging side: thread = (row tid >> 2 of the tile, fragment slot sh = 2 s + h) -----------------------------------------
+  const int srow = tid >> 2, sh = tid & 3;
+  const int c0 = 4 * (sh >> 1) + (sh & 1);                       // its first 16-byte chunk of the row's 128 bytes; the second is c0 + 2
+  const unsigned a_wr = (unsigned)(srow * 64 + ((sh ^ ((srow >> 2) & 3)) << 4));
+  const unsigned b_wr = (unsigned)(A_BYTES + wave * B_PIECE + lane * 16);          // chunk column cc = wave, + pl * 4 pieces
+  int is_i = 0, is_kt = 0;
+  int a_off = 0, a_iy0 = 0, a_ix0 = 0;
+  bool a_ok = false;
+  unsigned b_off = 0;
+  int s_k = 0, s_kb = 0;
+  int tap_c = 0, tap_ky = 0, tap_kx = 0;
+  u32x4v sa[2], sb[3];                                           // the staged step: 8 fp32 activations, three weight chunks
+  auto setup_item = [&](int i) __attribute__((always_inline)) {
+    const bool live = i < mine;
+    const Item it = item_of(live ? i : 0);
+    const int m = it.bm * BM + srow;
+    a_ok = live && m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int b = mm / hw_out, pix = mm - b * hw_out;
+    const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    a_iy0 = oy * p.stride - p.pad;
+    a_ix0 = ox * p.stride - p.pad;
+    a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + 4 * c0) * 4;
+    if (IS1X1 && !a_ok) a_off = (int)OOB;
+    b_off = live ? (unsigned)((wave * wq.cout_pad + it.bn * BN + lane) * 16) : OOB;
+    s_k = 0;
+    s_kb = 0;
+    if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
+  };
+  auto gload = [&]() __attribute__((always_inline)) {            // global -> registers, the next step not yet staged
+    if (is_kt == 0) setup_item(is_i);
+    int voff = a_off;
+    if (!IS1X1) {
+      const int iy = a_iy0 + tap_ky * p.dil, ix = a_ix0 + tap_kx * p.dil;
+      const bool in = a_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      voff = in ? a_off + ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4 : (int)OOB;
+    }
+    sa[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, IS1X1 ? s_k : 0, 0);
+    sa[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff + 32, IS1X1 ? s_k : 0, 0);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) sb[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_off, s_kb + pl * plane_bytes, 0);
+    s_k += BK * 4;
+    s_kb += 4 * wq.cout_pad * 16;
+    if (!IS1X1) {
+      tap_c += BK;
+      if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
+    }
+    if (++is_kt == nk) { is_kt = 0; ++is_i; }
+  };
+  auto stage_write = [&](auto BUFI) __attribute__((always_inline)) {   // registers -> split -> LDS buffer BUFI
+    unsigned char* st = lds + decltype(BUFI)::value * BUF;
+    bf16x8 pl3[3];
+    split3(__builtin_bit_cast(f32x4, sa[0]), __builtin_bit_cast(f32x4, sa[1]), pl3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(st + pl * A_PLANE + a_wr) = pl3[pl];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4v*>(st + b_wr + pl * 4 * B_PIECE) = sb[pl];
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  const int frow = wm + l31;
+  unsigned a_rd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) a_rd[s] = (unsigned)(frow * 64 + (((2 * s + half) ^ ((frow >> 2) & 3)) << 4));
+  const unsigned b_rd = (unsigned)(A_BYTES + (half * 64 + wn + l31) * 16);          // chunk column cc = 2 s + half: + 2 s pieces
+  f32x16 acc[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+  int c_i = 0, c_kt = 0;
+  float rv[16], bv = 0.f;
+  auto epi_loads = [&]() __attribute__((always_inline)) {        // residual and bias of the tile, under its last k-step
+    const Item it = item_of(c_i);
+    const int n = it.bn * BN + wn + l31;
+    const bool col_ok = n < p.Cout;
+    const int m0 = it.bm * BM;
+    if (has_bias) bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_bias, col_ok ? n * 4 : (int)OOB, 0, 0));
+    if (has_res) {
+      const int rr0 = p.res_rows ? m0 % p.res_rows : m0;          // (scalar: once per tile)
+      const bool wrap1 = p.res_rows >= BM;                         // a shared map at least a tile tall: at most one wrap
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = wm + mfma32_row(r, half);
+        int rr = rr0 + dm;
+        if (p.res_rows) {
+          if (wrap1) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+          else rr %= p.res_rows;
+        }
+        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              rsrc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB, 0, 0));
+      }
+    }
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int n = it.bn * BN + wn + l31;
+    const bool col_ok = n < p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] += acc[1][r]; acc[1][r] = 0.f; }
+    const int mlane = it.bm * BM + wm + 4 * half;
+    const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+    const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+    if (has_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += bv;
+    }
+    if (has_res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += rv[r];
+    }
+    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+      constexpr int act = decltype(ACT)::value;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[0][r], act)), rsrc_out,
+                                              c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
+        acc[0][r] = 0.f;
+      }
+    });
+  };
+  auto wg_barrier = [&]() __attribute__((always_inline)) {       // LDS writes of this wave done, then everybody's
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto step = [&](auto BUFI) __attribute__((always_inline)) -> void {
+    constexpr int bi = decltype(BUFI)::value;
+    const unsigned char* st = lds + bi * BUF;
+    bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        fa[pl][s] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + a_rd[s]);
+        fb[pl][s] = *reinterpret_cast<const bf16x8*>(st + b_rd + (pl * 4 + 2 * s) * B_PIECE);
+      }
+    if (c_kt == nk - 1 && (has_res | has_bias)) epi_loads();
+    // smallest terms first per accumulator; the two sub-steps alternate (consecutive MFMAs are independent).  The staging of the
+    // NEXT step (split + LDS writes) and the global loads of the one after sit between the two halves of the MFMA chain.
+#define AOT_X6R_TERM(PA, PB)                                                                         \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
+      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][s], fb[PB][s], acc[s], 0, 0, 0);
+    AOT_X6R_TERM(1, 1)
+    AOT_X6R_TERM(0, 2)
+    AOT_X6R_TERM(2, 0)
+    stage_write(std::integral_constant<int, bi ^ 1>{});          // the step after this one: registers -> the other buffer
+    gload();                                                     // the step after that: global -> registers
+    AOT_X6R_TERM(0, 1)
+    AOT_X6R_TERM(1, 0)
+    AOT_X6R_TERM(0, 0)
+#undef AOT_X6R_TERM
+    if (++c_kt == nk) {
+      epilogue();
+      c_kt = 0;
+      ++c_i;
+    }
+    wg_barrier();
+  };
+  gload();
+  stage_write(std::integral_constant<int, 0>{});
+  gload();
+  wg_barrier();
+#pragma unroll 1
+  for (int ss = 0; ss < total; ss += 2) {
+    step(std::integral_constant<int, 0>{});
+    if (ss + 1 < total) step(std::integral_constant<int, 1>{});
+  }
+}
+
 // ---- the 128x128 tile in two PHASE-SHIFTED wave groups ("ping-pong"; round 5) ------------------------------------------------
 // gemm_x6w_kernel's eight waves all walk the same sequence inside a k-step -- weight fragments, split, MFMAs -- so the matrix pipe
 // idles while every wave reads and splits, and the vector pipe idles while every wave multiplies: the steady state of that kernel
@@ -1604,6 +1837,9 @@ __global__ void __launch_bounds__(512, 2) gemm_x6w_kernel(const ConvParams p, co
 #endif
 #ifndef AOT_PP_PRIO
 #define AOT_PP_PRIO 0        // development switch: s_setprio 1 around the MFMA phase
+#endif
+#ifndef AOT_PP_PROBE
+#define AOT_PP_PROBE 0       // timing probes (WRONG results): 1 no A DMA, 2 no B DMA, 4 no split, 8 no fragment reads, 16 no MFMAs
 #endif
 template <bool IS1X1, bool SK>
 __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
@@ -1706,6 +1942,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, c
 #pragma unroll
     for (int g = 0; g < AGW; ++g) {
       unsigned char* dst = st + (AGW * wave + g) * GROUP_STRIDE;
+      if (AOT_PP_PROBE & 1) continue;
       if (IS1X1) {
         dma16(rsrc_a, dst, a_off[g], s_k);
       } else {
@@ -1715,7 +1952,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, c
       }
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < ((AOT_PP_PROBE & 2) ? 0 : 3); ++pl)
       dma16(rsrc_b, st + OPA_BYTES + ((pl * 4 + (wave & 3)) * 2 + (wave >> 2)) * B_PIECE, (int)b_off, s_kb + pl * plane_bytes);
     s_k += BK * 4;
     s_kb += 4 * wq.cout_pad * 16;
@@ -1842,13 +2079,20 @@ __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, c
   // LOAD(s): fragments of ring stage SLOT -> registers, A rows split; (not DMAC) the DMA of step s+2 -> stage SLOT + 2
   auto load_phase = [&](auto SLOT) __attribute__((always_inline)) -> void {
     constexpr int slot = decltype(SLOT)::value, islot = (slot + 2) % 3;
-    x6w_fetch_a(ra, aaddr, (unsigned)(slot * STAGE_BYTES));
-    x6w_fetch_b<B_PIECE>(rb, baddr + (unsigned)(slot * STAGE_BYTES));
+    if (!(AOT_PP_PROBE & 8)) {
+      x6w_fetch_a(ra, aaddr, (unsigned)(slot * STAGE_BYTES));
+      x6w_fetch_b<B_PIECE>(rb, baddr + (unsigned)(slot * STAGE_BYTES));
+    }
     if (!DMAC) issue(std::integral_constant<int, islot>{});
     __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 10));       // LDS reads return in order: the four A chunks are the oldest
     x6w_landed_a(ra);
-    split3(ra[0], ra[1], ap[0]);
-    split3(ra[2], ra[3], ap[1]);
+    if (AOT_PP_PROBE & 4) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) { ap[0][pl] = __builtin_bit_cast(bf16x8, ra[pl]); ap[1][pl] = __builtin_bit_cast(bf16x8, ra[3 - pl]); }
+    } else {
+      split3(ra[0], ra[1], ap[0]);
+      split3(ra[2], ra[3], ap[1]);
+    }
     // the planes exist HERE, in this phase (hipcc otherwise sinks the split across the barrier to the MFMAs that use it)
 #pragma unroll
     for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(ap[s][0]), "+v"(ap[s][1]), "+v"(ap[s][2]));
@@ -1870,7 +2114,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, c
     if (c_kt == nk - 1 && (n_res | n_bias)) epi_loads();   // last k-step of the tile: its residual and bias fly under the MFMAs
     if (AOT_PP_PRIO) __builtin_amdgcn_s_setprio(1);
 #define AOT_PP_TERM(PA, PB)                                                                                        \
-  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                   \
+  if (!(AOT_PP_PROBE & 16)) _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                   \
       acc[2 * s + nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s][PA], rb[PB][s][nb], acc[2 * s + nb], 0, 0, 0);
     AOT_PP_TERM(1, 1)
     AOT_PP_TERM(0, 2)
@@ -2058,6 +2302,22 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   if (tile == 256) return terms == 6 ? launch_gemm_x6pp(p, w6, cout_pad, s, ksplit, scratch) : AOT_ERR_BADARG;
+  if (tile == 65) {             // the register-staged 64x64 form: three workgroups per CU
+    if (terms != 6 || ksplit != 1) return AOT_ERR_BADARG;
+    X6Weight wr;
+    wr.w6 = w6;
+    wr.cout_pad = cout_pad;
+    const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+#ifndef AOT_X6R_PERCU
+#define AOT_X6R_PERCU 3         // resident workgroups per CU the grid is sized for (development switch: 2)
+#endif
+    const int gr = nit < 256 * AOT_X6R_PERCU ? nit : 256 * AOT_X6R_PERCU;
+    if (p.KH == 1 && p.KW == 1 && p.pad == 0)
+      hipLaunchKernelGGL((gemm_x6r_kernel<true>), dim3(gr), dim3(256), 0, s, p, wr);
+    else
+      hipLaunchKernelGGL((gemm_x6r_kernel<false>), dim3(gr), dim3(256), 0, s, p, wr);
+    AOT_LAUNCH_CHECK();
+  }
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
   X6Weight wq;
   wq.w6 = w6;
