@@ -103,7 +103,7 @@ GEMM_TABLES = {'latency': -1, 'throughput': -2}
 # fp32-equivalent six-term bf16 split (aot_conv2d_bf16x6_f32; include/aot_hip.h) wherever a layer qualifies.  An engine attribute
 # too (build_engine(..., mfma=)), carried by the same scope.
 MFMA_MODES = ('f32', 'bf16x6')
-X6_TILE = 0                  # 0: tile of the bf16x6 kernels chosen by shape; 64 / 128 force one (tests, tuning)
+X6_TILE = int(os.environ.get('AOT_X6_TILE', '0'))   # 0: kernel of the bf16x6 family chosen by shape; 64 / 65 / 128 / 256 force one (tests, tuning); 1: the round-4 rule
 X6K_SCRATCH_FLOATS = 8 << 20   # floats of the per-stream split-K scratch (32 MB: every stride-16 layer of a 480p frame at three lanes fits)
 X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
 
@@ -258,6 +258,10 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
         w6 = getattr(w, '_aot_w6', None)
         if w6 is None:
             w6 = pack_bf16x6(w)
+        ks = x6_ksplit(B * OH * OW, Cout, KH * KW * Cin) if X6_TILE == 0 else 1
+        if ks > 1:
+            return conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, res=res, act=act, B=B,
+                              res_rows=res_rows, ksplit=ks, stream=stream)
         _chk(load().aot_conv2d_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH,
                                           OW, Cout, KH, KW, stride, pad, dil, x.stride(0), out.stride(0),
                                           res.stride(0) if res is not None else 0, res_rows, act, X6_TILE,
@@ -274,6 +278,22 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
 
 
 _x6k_ws = None
+
+
+def x6_ksplit(M, Cout, K):
+    """Split-K factor of the phase-shifted 128x128 kernel for a layer (1 = do not use it): long-K layers (K >= 2304: the 3x3
+    convolutions on 256 channels) whose 128x128 tiles fill less than a third of the chip -- the stride-16 maps, and the stride-8 map
+    one clip at a time -- get the largest split that keeps (tiles x slices) within one dispatch round of 256 workgroups with at least
+    eight k-steps per slice (profiles/r05_x6pp.txt: l3.c2 3x3 at three lanes 60.6 -> 46.5 us, at one lane 48.6 -> 29.2; dec c8 at one
+    lane 49.5 -> 39.5)."""
+    if K < 2304:
+        return 1
+    nwide = -(-M // 128) * -(-Cout // 128)
+    nk = K // 32
+    for ks in (9, 8, 6, 4, 3, 2):
+        if nwide * ks <= 256 and nk % ks == 0 and nk // ks >= 8 and ks * M * Cout <= X6K_SCRATCH_FLOATS:
+            return ks
+    return 1
 
 
 def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE, B=1,

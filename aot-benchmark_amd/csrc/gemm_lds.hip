@@ -2341,10 +2341,16 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     AOT_LAUNCH_CHECK();
   }
   const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  // 128x128 tiles win where they fill the chip: at least 150 of them, and either a single dispatch round or rounds that are
-  // >= 70 % full (measured per shape at batch 1 and 3: profiles/r03e_mb_gemm_bf16x6_batch{1,3}.txt)
+  // Round 5 (profiles/r05_x6r.txt, every conv / linear of the frame at batch 1 and 3): the register-staged 64x64 kernel (tile 65) is
+  // the default of the family -- faster than the LDS-DMA 64x64 kernel on all but two shapes and than the 128x128 kernel on every 1x1
+  // layer; the 128x128 tile keeps the KxK layers that fill the chip with it (>= 200 tiles, rounds >= 70 % full: the 3x3 convolutions
+  // of the decoder at the 4x map), whose activation rows it re-reads half as often across the filter taps.
   const int rounds = (nwide + 255) / 256;
-  const bool wide = tile == 128 || (tile == 0 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
+  const bool wide = tile == 128 || (tile == 0 && p.KH * p.KW > 1 && p.Cout >= 128 && nwide >= 200 &&
+                                    (rounds == 1 || 10 * nwide >= 7 * 256 * rounds)) ||
+                    // tile 1 = the round-4 rule (A/B runs: AOT_X6_TILE=1): 128x128 wherever it fills the chip, else the LDS-DMA 64x64 kernel
+                    (tile == 1 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
+  if (tile == 0 && !wide) return launch_gemm_x6(p, w6, cout_pad, 65, s, terms, ksplit, scratch);
   if (wide) {
     const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
     if (is1x1)
