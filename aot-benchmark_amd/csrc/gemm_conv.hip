@@ -708,7 +708,7 @@ extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_p
                                      float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
                                      int tile, void* stream) {
-  if (!in || !w6 || !out || (tile != 0 && tile != 1 && tile != 64 && tile != 65 && tile != 128 && tile != 256)) return AOT_ERR_BADARG;
+  if (!in || !w6 || !out || (tile != 0 && tile != 1 && tile != 64 && tile != 65 && tile != 128 && tile != 129 && tile != 256)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;

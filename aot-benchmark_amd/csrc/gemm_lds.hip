@@ -1598,13 +1598,18 @@ __global__ void __launch_bounds__(512, 2) gemm_x6w_kernel(const ConvParams p, co
 // Same k -> (sub-step, lane-half, element) mapping and the same six products in the same order per accumulator as gemm_x6_kernel:
 // bit-identical results.
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-template <bool IS1X1>
-__global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, const X6Weight wq) {
-  constexpr int BM = 64, BN = 64;
-  constexpr int A_PLANE = 64 * 64;                        // bytes: 64 rows x four 16-byte chunks (32 bf16)
-  constexpr int A_BYTES = 3 * A_PLANE, B_PIECE = 64 * 16, B_BYTES = 12 * B_PIECE;
-  constexpr int BUF = A_BYTES + B_BYTES;                  // 24 KB
+// WM = waves along M (2: 64-row tile, 4: 128-row tile), NBW = 32-column blocks per wave (two waves along N): <2, 1> = 64x64 on four
+// waves, three workgroups per CU; <4, 2> = 128x128 on eight waves (each 32 rows x 64 columns, as gemm_x6w_kernel), one workgroup per
+// CU -- half the weight bytes per product, for the layers whose 128x128 tiles fill the chip.
+template <bool IS1X1, int WM, int NBW>
+__global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(const ConvParams p, const X6Weight wq) {
+  constexpr int NT = 128 * WM;                            // threads: WM x 2 waves
+  constexpr int BM = 32 * WM, BN = 64 * NBW;
+  constexpr int A_PLANE = BM * 64;                        // bytes: BM rows x four 16-byte chunks (32 bf16)
+  constexpr int A_BYTES = 3 * A_PLANE, B_PIECE = BN * 16, B_BYTES = 12 * B_PIECE;
+  constexpr int BUF = A_BYTES + B_BYTES;                  // 24 KB (64x64) / 48 KB (128x128)
   constexpr unsigned OOB = 0x80000000u;
+  static_assert(NT == 4 * BM && 3 * NT == 12 * BN, "one A fragment and three weight chunks per thread and k-step");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1629,7 +1634,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, co
     r.kt0 = 0;
     return r;
   };
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32 * NBW;
   const int hw_out = p.OH * p.OW;
   const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
   const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -1644,11 +1649,12 @@ __global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, co
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
   const bool has_res = p.res != nullptr, has_bias = p.bias != nullptr;
 
-  // ---- staging side: thread = (row tid >> 2 of the tile, fragment slot sh = 2 s + h) -----------------------------------------
+  // ---- staging side: thread = (row tid >> 2 of the tile, fragment slot sh = 2 s + h); weight chunk (cc = tid / BN, column tid % BN) ----
   const int srow = tid >> 2, sh = tid & 3;
   const int c0 = 4 * (sh >> 1) + (sh & 1);                       // its first 16-byte chunk of the row's 128 bytes; the second is c0 + 2
   const unsigned a_wr = (unsigned)(srow * 64 + ((sh ^ ((srow >> 2) & 3)) << 4));
-  const unsigned b_wr = (unsigned)(A_BYTES + wave * B_PIECE + lane * 16);          // chunk column cc = wave, + pl * 4 pieces
+  const int bcc = tid / BN, bcol = tid % BN;
+  const unsigned b_wr = (unsigned)(A_BYTES + bcc * B_PIECE + bcol * 16);            // + pl * 4 pieces
   int is_i = 0, is_kt = 0;
   int a_off = 0, a_iy0 = 0, a_ix0 = 0;
   bool a_ok = false;
@@ -1668,7 +1674,8 @@ __global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, co
     a_ix0 = ox * p.stride - p.pad;
     a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + 4 * c0) * 4;
     if (IS1X1 && !a_ok) a_off = (int)OOB;
-    b_off = live ? (unsigned)((wave * wq.cout_pad + it.bn * BN + lane) * 16) : OOB;
+    // (a 128-wide tile on a weight padded to 64 columns: the columns past the padded width are masked)
+    b_off = (live && it.bn * BN + bcol < wq.cout_pad) ? (unsigned)((bcc * wq.cout_pad + it.bn * BN + bcol) * 16) : OOB;
     s_k = 0;
     s_kb = 0;
     if (!IS1X1) { tap_c = 0; tap_ky = 0; tap_kx = 0; }
@@ -1708,63 +1715,71 @@ __global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, co
   unsigned a_rd[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) a_rd[s] = (unsigned)(frow * 64 + (((2 * s + half) ^ ((frow >> 2) & 3)) << 4));
-  const unsigned b_rd = (unsigned)(A_BYTES + (half * 64 + wn + l31) * 16);          // chunk column cc = 2 s + half: + 2 s pieces
-  f32x16 acc[2];
+  const unsigned b_rd = (unsigned)(A_BYTES + half * B_PIECE + (wn + l31) * 16);     // chunk column cc = 2 s + half: + 2 s pieces; block nb: + 512
+  f32x16 acc[2][NBW];          // [sub-step][column block]
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.f;
   int c_i = 0, c_kt = 0;
-  float rv[16], bv = 0.f;
+  float rv[NBW][16], bv[NBW];
   auto epi_loads = [&]() __attribute__((always_inline)) {        // residual and bias of the tile, under its last k-step
     const Item it = item_of(c_i);
-    const int n = it.bn * BN + wn + l31;
-    const bool col_ok = n < p.Cout;
     const int m0 = it.bm * BM;
-    if (has_bias) bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_bias, col_ok ? n * 4 : (int)OOB, 0, 0));
-    if (has_res) {
-      const int rr0 = p.res_rows ? m0 % p.res_rows : m0;          // (scalar: once per tile)
-      const bool wrap1 = p.res_rows >= BM;                         // a shared map at least a tile tall: at most one wrap
+    const int rr0 = p.res_rows ? m0 % p.res_rows : m0;            // (scalar: once per tile)
+    const bool wrap1 = p.res_rows >= BM;                          // a shared map at least a tile tall: at most one wrap
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = wm + mfma32_row(r, half);
-        int rr = rr0 + dm;
-        if (p.res_rows) {
-          if (wrap1) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
-          else rr %= p.res_rows;
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (has_bias) bv[nb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_bias, col_ok ? n * 4 : (int)OOB, 0, 0));
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = wm + mfma32_row(r, half);
+          int rr = rr0 + dm;
+          if (p.res_rows) {
+            if (wrap1) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+            else rr %= p.res_rows;
+          }
+          rv[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rsrc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB, 0, 0));
         }
-        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                              rsrc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB, 0, 0));
       }
     }
   };
   auto epilogue = [&]() __attribute__((always_inline)) {
     const Item it = item_of(c_i);
-    const int n = it.bn * BN + wn + l31;
-    const bool col_ok = n < p.Cout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] += acc[1][r]; acc[1][r] = 0.f; }
     const int mlane = it.bm * BM + wm + 4 * half;
-    const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
     const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
-    if (has_bias) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] += bv;
-    }
-    if (has_res) {
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] += rv[r];
-    }
-    with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
-      constexpr int act = decltype(ACT)::value;
+      for (int r = 0; r < 16; ++r) { acc[0][nb][r] += acc[1][nb][r]; acc[1][nb][r] = 0.f; }
+      const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      if (has_bias) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = (r & 3) + 8 * (r >> 2);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[0][r], act)), rsrc_out,
-                                              c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
-        acc[0][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] += bv[nb];
       }
-    });
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] += rv[nb][r];
+      }
+      with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[0][nb][r], act)), rsrc_out,
+                                                c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
+          acc[0][nb][r] = 0.f;
+        }
+      });
+    }
   };
   auto wg_barrier = [&]() __attribute__((always_inline)) {       // LDS writes of this wave done, then everybody's
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1774,20 +1789,22 @@ __global__ void __launch_bounds__(256, 3) gemm_x6r_kernel(const ConvParams p, co
   auto step = [&](auto BUFI) __attribute__((always_inline)) -> void {
     constexpr int bi = decltype(BUFI)::value;
     const unsigned char* st = lds + bi * BUF;
-    bf16x8 fa[3][2], fb[3][2];
+    bf16x8 fa[3][2], fb[3][2][NBW];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         fa[pl][s] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + a_rd[s]);
-        fb[pl][s] = *reinterpret_cast<const bf16x8*>(st + b_rd + (pl * 4 + 2 * s) * B_PIECE);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          fb[pl][s][nb] = *reinterpret_cast<const bf16x8*>(st + b_rd + (pl * 4 + 2 * s) * B_PIECE + nb * 512);
       }
     if (c_kt == nk - 1 && (has_res | has_bias)) epi_loads();
-    // smallest terms first per accumulator; the two sub-steps alternate (consecutive MFMAs are independent).  The staging of the
-    // NEXT step (split + LDS writes) and the global loads of the one after sit between the two halves of the MFMA chain.
-#define AOT_X6R_TERM(PA, PB)                                                                         \
-  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][s], fb[PB][s], acc[s], 0, 0, 0);
+    // smallest terms first per accumulator; sub-steps and column blocks alternate (consecutive MFMAs are independent).  The staging
+    // of the NEXT step (split + LDS writes) and the global loads of the one after sit between the two halves of the MFMA chain.
+#define AOT_X6R_TERM(PA, PB)                                                                                  \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)             \
+      acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][s], fb[PB][s][nb], acc[s][nb], 0, 0, 0);
     AOT_X6R_TERM(1, 1)
     AOT_X6R_TERM(0, 2)
     AOT_X6R_TERM(2, 0)
@@ -2308,14 +2325,24 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     wr.w6 = w6;
     wr.cout_pad = cout_pad;
     const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
-#ifndef AOT_X6R_PERCU
-#define AOT_X6R_PERCU 3         // resident workgroups per CU the grid is sized for (development switch: 2)
-#endif
-    const int gr = nit < 256 * AOT_X6R_PERCU ? nit : 256 * AOT_X6R_PERCU;
+    const int gr = nit < 768 ? nit : 768;
     if (p.KH == 1 && p.KW == 1 && p.pad == 0)
-      hipLaunchKernelGGL((gemm_x6r_kernel<true>), dim3(gr), dim3(256), 0, s, p, wr);
+      hipLaunchKernelGGL((gemm_x6r_kernel<true, 2, 1>), dim3(gr), dim3(256), 0, s, p, wr);
     else
-      hipLaunchKernelGGL((gemm_x6r_kernel<false>), dim3(gr), dim3(256), 0, s, p, wr);
+      hipLaunchKernelGGL((gemm_x6r_kernel<false, 2, 1>), dim3(gr), dim3(256), 0, s, p, wr);
+    AOT_LAUNCH_CHECK();
+  }
+  if (tile == 129) {            // the register-staged 128x128 form: eight waves, one workgroup per CU
+    if (terms != 6 || ksplit != 1) return AOT_ERR_BADARG;
+    X6Weight wr;
+    wr.w6 = w6;
+    wr.cout_pad = cout_pad;
+    const int nit = cdiv(p.M, 128) * cdiv(p.Cout, 128);
+    const int gr = nit < 256 ? nit : 256;
+    if (p.KH == 1 && p.KW == 1 && p.pad == 0)
+      hipLaunchKernelGGL((gemm_x6r_kernel<true, 4, 2>), dim3(gr), dim3(512), 0, s, p, wr);
+    else
+      hipLaunchKernelGGL((gemm_x6r_kernel<false, 4, 2>), dim3(gr), dim3(512), 0, s, p, wr);
     AOT_LAUNCH_CHECK();
   }
   const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);

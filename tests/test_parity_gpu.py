@@ -181,7 +181,7 @@ def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, re
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-@pytest.mark.parametrize('tile', [64, 65, 128, 256])
+@pytest.mark.parametrize('tile', [64, 65, 128, 129, 256])
 def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
     the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
@@ -273,6 +273,13 @@ def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, ac
         assert torch.isnan(t65[:, Cout:]).all(), 'wrote outside the logical columns'
     for _ in range(3):
         assert torch.equal(run(65)[:, :Cout], t65[:, :Cout])
+    # ... and its 128x128 form (tile = 129) against the LDS-DMA 128x128 kernel
+    t129 = run(129)
+    assert torch.equal(wide[:, :Cout], t129[:, :Cout]), 'the register-staged 128x128 kernel differs from the 128x128 kernel'
+    if ldb > Cout:
+        assert torch.isnan(t129[:, Cout:]).all(), 'wrote outside the logical columns'
+    for _ in range(3):
+        assert torch.equal(run(129)[:, :Cout], t129[:, :Cout])
     if ldb > Cout:
         assert torch.isnan(pp[:, Cout:]).all(), 'wrote outside the logical columns'
     scale = max(1.0, ref.abs().max().item())
