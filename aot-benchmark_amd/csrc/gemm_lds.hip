@@ -1653,7 +1653,7 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
   const int srow = tid >> 2, sh = tid & 3;
   const int c0 = 4 * (sh >> 1) + (sh & 1);                       // its first 16-byte chunk of the row's 128 bytes; the second is c0 + 2
   const unsigned a_wr = (unsigned)(srow * 64 + ((sh ^ ((srow >> 2) & 3)) << 4));
-  const int bcc = tid / BN, bcol = tid % BN;
+  const int bcc = wave / (BN / 64), bcol = (wave % (BN / 64)) * 64 + lane;       // (the chunk column is wave-uniform)
   const unsigned b_wr = (unsigned)(A_BYTES + bcc * B_PIECE + bcol * 16);            // + pl * 4 pieces
   int is_i = 0, is_kt = 0;
   int a_off = 0, a_iy0 = 0, a_ix0 = 0;
@@ -2368,16 +2368,17 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     AOT_LAUNCH_CHECK();
   }
   const int nwide = cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  // Round 5 (profiles/r05_x6r.txt, every conv / linear of the frame at batch 1 and 3): the register-staged 64x64 kernel (tile 65) is
-  // the default of the family -- faster than the LDS-DMA 64x64 kernel on all but two shapes and than the 128x128 kernel on every 1x1
-  // layer; the 128x128 tile keeps the KxK layers that fill the chip with it (>= 200 tiles, rounds >= 70 % full: the 3x3 convolutions
-  // of the decoder at the 4x map), whose activation rows it re-reads half as often across the filter taps.
+  // Round 5 (profiles/r05_x6r.txt, r05_x6r128.txt: every conv / linear of the frame at batch 1 and 3): the register-staged 64x64
+  // kernel (tile 65) is the default of the family -- faster than the LDS-DMA 64x64 kernel on all but two shapes and than the 128x128
+  // kernels on every 1x1 layer; the 128x128 tile (its register-staged form, tile 129) keeps the KxK layers that fill the chip with it
+  // (>= 200 tiles, rounds >= 70 % full: the 3x3 convolutions of the decoder at the 4x map), whose activation rows it re-reads half as
+  // often across the filter taps.  The LDS-DMA kernels (tiles 64 / 128 / 256) stay in the library: tile 1 = the round-4 rule.
   const int rounds = (nwide + 255) / 256;
   const bool wide = tile == 128 || (tile == 0 && p.KH * p.KW > 1 && p.Cout >= 128 && nwide >= 200 &&
                                     (rounds == 1 || 10 * nwide >= 7 * 256 * rounds)) ||
                     // tile 1 = the round-4 rule (A/B runs: AOT_X6_TILE=1): 128x128 wherever it fills the chip, else the LDS-DMA 64x64 kernel
                     (tile == 1 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
-  if (tile == 0 && !wide) return launch_gemm_x6(p, w6, cout_pad, 65, s, terms, ksplit, scratch);
+  if (tile == 0) return launch_gemm_x6(p, w6, cout_pad, wide ? 129 : 65, s, terms, ksplit, scratch);
   if (wide) {
     const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
     if (is1x1)
