@@ -56,6 +56,7 @@ _SIGS = {
     'aot_idbank_f32': [_P] * 5 + [_I] * 13 + [_P, _P] + [_I] * 3 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
+    'aot_frame_tail_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
     'aot_copy_rows_f32': [_P, _P, _I, _L, _I, _L, _L, _I, _I, _P, _I, _P],
     # training-side stages (csrc/train_ops.hip)
@@ -684,6 +685,17 @@ def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corne
     _chk(load().aot_logits_finalize_f32(_dev(logits), _opt(out4), _opt(out), G, IH, IW, C, logits.stride(0), OH, OW,
                                         obj_total, int(align_corners), stream if stream is not None else stream_ptr()),
          'aot_logits_finalize_f32')
+
+
+def frame_tail(logits, out4, label_out, label_in, IH, IW, C, obj_total, align_corners, stream=None):
+    """logits [IH*IW, ld] (one object group) -> label_out [1,1,OH,OW] (argmax of the softmax of the resized, masked logits), label_in
+    [1,1,LH,LW] | None (nearest resize of label_out: the memory update's mask), out4 [1,C,IH,IW] | None: aot_frame_tail_f32."""
+    OH, OW = label_out.shape[-2:]
+    LH, LW = label_in.shape[-2:] if label_in is not None else (0, 0)
+    _chk(load().aot_frame_tail_f32(_dev(logits), _opt(out4), _dev(label_out), _opt(label_in), IH, IW, C, logits.stride(0), OH, OW,
+                                   LH, LW, obj_total, int(align_corners), stream if stream is not None else stream_ptr()),
+         'aot_frame_tail_f32')
+    return label_out, label_in
 
 
 def add(a, b, out, stream=None):

@@ -591,6 +591,115 @@ extern "C" int aot_logits_finalize_f32(const float* logits, float* out4, float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Frame tail in ONE launch (one object group, one augmentation): what aot_logits_finalize_f32 -> aot_fuse_probs_f32 ->
+// aot_label_resize_f32 compute in three, without the output-size logits ever touching memory (11 planes of 480 x 854 floats
+// written and read again per frame).  Role by thread index: [0, OH*OW): the label of an output pixel -- bilinear resize of the
+// masked stride-4 logits (the arithmetic of logits_resize_kernel), softmax, first maximum (the arithmetic of fuse_probs_kernel);
+// [OH*OW, + LH*LW): a pixel of the label map fed back to the memory update, the nearest-neighbour pick of label_resize_kernel --
+// recomputed from the logits of its source pixel, which gives the SAME value (one deterministic function of the pixel);
+// then IH*IW*C threads for the planar stride-4 copy (pred_id_logits).  Bit-identical to the three-launch path.
+// Replaces aot_engine.py:367-378 + evaluator.py:332-352,375-381 for the common case.
+// ---------------------------------------------------------------------------------------------
+template <int MAXC>
+__device__ __forceinline__ float tail_label_at(const float* __restrict__ in, int oy, int ox, int IH, int IW, int C, int ldi, int OH,
+                                               int OW, int on, int align, float sh, float sw, int vec) {
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bilinear_coord(oy, IH, OH, sh, align, y0, y1, wy0, wy1);
+  bilinear_coord(ox, IW, OW, sw, align, x0, x1, wx0, wx1);
+  const float* pa = in + ((long)y0 * IW + x0) * ldi;
+  const float* pb = in + ((long)y0 * IW + x1) * ldi;
+  const float* pc = in + ((long)y1 * IW + x0) * ldi;
+  const float* pd = in + ((long)y1 * IW + x1) * ldi;
+  float v[MAXC];
+  float m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < MAXC / 4; ++q) {
+    if (4 * q < C) {
+      float ca[4], cb[4], cq[4], cd[4];
+      if (vec) {
+        const float4 ta = reinterpret_cast<const float4*>(pa)[q], tb = reinterpret_cast<const float4*>(pb)[q];
+        const float4 tc = reinterpret_cast<const float4*>(pc)[q], td = reinterpret_cast<const float4*>(pd)[q];
+        ca[0] = ta.x; ca[1] = ta.y; ca[2] = ta.z; ca[3] = ta.w;
+        cb[0] = tb.x; cb[1] = tb.y; cb[2] = tb.z; cb[3] = tb.w;
+        cq[0] = tc.x; cq[1] = tc.y; cq[2] = tc.z; cq[3] = tc.w;
+        cd[0] = td.x; cd[1] = td.y; cd[2] = td.z; cd[3] = td.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = min(4 * q + e, C - 1);
+          ca[e] = pa[c]; cb[e] = pb[c]; cq[e] = pc[c]; cd[e] = pd[c];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        if (c < C) {
+          const bool off = c > on;
+          const float a = off ? -1e10f : ca[e], b = off ? -1e10f : cb[e], cc = off ? -1e10f : cq[e], d = off ? -1e10f : cd[e];
+          v[c] = wy0 * (wx0 * a + wx1 * b) + wy1 * (wx0 * cc + wx1 * d);        // logits_resize_kernel
+          m = fmaxf(m, v[c]);
+        }
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < C) { v[c] = expf(v[c] - m); s += v[c]; }                            // fuse_probs_kernel, A = 1
+  int best = 0;
+  float bv = -1.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < C) {
+      // one augmentation: the mean over augmentations is (0 + pr) / 1.0f = pr exactly
+      const float pr = v[c] / s;
+      if (pr > bv) { bv = pr; best = c; }
+    }
+  return (float)best;
+}
+
+template <int MAXC>
+__global__ void __launch_bounds__(256) frame_tail_kernel(const float* __restrict__ in, float* __restrict__ out4,
+                                                         float* __restrict__ label_out, float* __restrict__ label_in, int IH, int IW,
+                                                         int C, int ldi, int OH, int OW, int LH, int LW, int obj_total, int align,
+                                                         float sh, float sw, int vec) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_out = (long)OH * OW, n_in = label_in ? (long)LH * LW : 0, n4 = out4 ? (long)IH * IW * C : 0;
+  const int on = group_obj_num(0, C, obj_total);
+  if (idx < n_out) {
+    const int oy = (int)(idx / OW), ox = (int)(idx - (long)oy * OW);
+    label_out[idx] = tail_label_at<MAXC>(in, oy, ox, IH, IW, C, ldi, OH, OW, on, align, sh, sw, vec);
+  } else if (idx < n_out + n_in) {
+    const long i = idx - n_out;
+    const int y = (int)(i / LW), x = (int)(i - (long)y * LW);
+    // torch upsample_nearest2d ("nearest", legacy), as label_resize_kernel: src = min(floor(dst * (float)in / out), in - 1)
+    const float rh = (float)OH / (float)LH, rw = (float)OW / (float)LW;
+    const int sy = min((int)floorf(y * rh), OH - 1), sx = min((int)floorf(x * rw), OW - 1);
+    label_in[i] = tail_label_at<MAXC>(in, sy, sx, IH, IW, C, ldi, OH, OW, on, align, sh, sw, vec);
+  } else if (idx < n_out + n_in + n4) {
+    const long i = idx - n_out - n_in;
+    const long HW = (long)IH * IW;
+    const int c = (int)(i / HW);
+    const int p = (int)(i - (long)c * HW);
+    out4[i] = (c > on) ? -1e10f : in[(long)p * ldi + c];                         // logits_planar_kernel
+  }
+}
+
+extern "C" int aot_frame_tail_f32(const float* logits, float* out4, float* label_out, float* label_in, int IH, int IW, int C, int ldi,
+                                  int OH, int OW, int LH, int LW, int obj_total, int align_corners, void* stream) {
+  if (!logits || !label_out || IH <= 0 || IW <= 0 || C <= 1 || ldi < C || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+  if (label_in && (LH <= 0 || LW <= 0)) return AOT_ERR_BADARG;
+  if (C > 16) return AOT_ERR_UNSUPPORTED;
+  const int vec = (int)((ldi & 3) == 0 && ((uintptr_t)logits & 15) == 0 && ldi >= ((C + 3) & ~3));
+  const long total = (long)OH * OW + (label_in ? (long)LH * LW : 0) + (out4 ? (long)IH * IW * C : 0);
+  hipLaunchKernelGGL(frame_tail_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, out4, label_out, label_in,
+                     IH, IW, C, ldi, OH, OW, LH, LW, obj_total, align_corners, bilinear_scale(IH, OH, align_corners),
+                     bilinear_scale(IW, OW, align_corners), vec);
+  AOT_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Identity bank: one workgroup per output token; the KxK label patch is staged in LDS, then every
 // thread (= channel quad) walks the taps, gathering coalesced rows of the [label, ky, kx, C] table.
 // ---------------------------------------------------------------------------------------------

@@ -541,6 +541,8 @@ class AOTEngine(nn.Module):
         if self.pos_emb is None:
             self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(x16, h, w)).contiguous(
                 memory_format=torch.channels_last)).contiguous()
+            if hasattr(self.AOT.LSTT, 'prepare_pos'):     # AOT: the position term of the merged Q|K|V product, once per clip
+                self.AOT.LSTT.prepare_pos(self.pos_emb, aot_hip.stream_ptr())
         id_emb = self.assign_identity(mask)
         self.curr_id_embs = id_emb
         stream = aot_hip.stream_ptr()
@@ -625,6 +627,13 @@ class AOTEngine(nn.Module):
     def decode_current_logits(self, output_size=None):
         """Single-cohort form of the reference call (aot_engine.py:356-380)."""
         return _decode(self, [self], output_size)
+
+    @_in_table
+    def decode_current_labels(self, output_size):
+        """Extension (round 5): the evaluator's next two steps folded into the decode -- returns (label [1,1,OH,OW], label resized to
+        the input size [1,1,H,W]): argmax of the softmax of decode_current_logits(output_size) (evaluator.py:332-352 with one
+        augmentation) and its nearest resize (:375-381), bit-identical to those calls, without the output-size logits in memory."""
+        return _decode(self, [self], output_size, labels=True)
 
     def update_long_term_memory(self, new_long_term_memories):
         """Reference signature (aot_engine.py:291-305): list over layers of [K, V] ([N,1,C]), lane 0; appended."""
@@ -715,12 +724,28 @@ def _finalize(owner, cohorts, logits, h4, w4, output_size, stream):
     return out4, out
 
 
-def _decode(owner, cohorts, output_size):
+def _finalize_labels(owner, cohort, logits, h4, w4, output_size, stream):
+    """The frame tail of ONE object group in one launch (aot_frame_tail_f32): planar stride-4 logits, the label map at the output
+    size and its nearest resize to the input size (the memory update's mask) -- the output-size logits are never written.
+    Returns (out4, (label_out, label_in))."""
+    nc = logits.shape[1]
+    dev = logits.device
+    out4 = torch.empty(1, nc, h4, w4, dtype=torch.float32, device=dev)
+    lab = torch.empty(1, 1, output_size[0], output_size[1], dtype=torch.float32, device=dev)
+    lin = torch.empty(1, 1, int(cohort.input_size_2d[0]), int(cohort.input_size_2d[1]), dtype=torch.float32, device=dev)
+    aot_hip.frame_tail(logits, out4, lab, lin, h4, w4, nc, cohort._group_objects(), owner.align_corners, stream=stream)
+    return out4, (lab, lin)
+
+
+def _decode(owner, cohorts, output_size, labels=False):
     """decode_current_logits of one or several cohorts (aot_engine.py:356-380, 618-628): decoder, id masking, resize and
-    group aggregation.  One cohort in graph mode: a single replay."""
+    group aggregation.  One cohort in graph mode: a single replay.  labels = True (decode_current_labels): returns
+    (label at the output size, label at the input size) instead of the output-size logits -- for one object group the whole tail is
+    ONE kernel inside the same replay, otherwise the logits path followed by aot_hip.fuse_probs / label_resize."""
     first = cohorts[0]
     if output_size is not None:
         output_size = (int(output_size[0]), int(output_size[1]))
+    fused = labels and len(cohorts) == 1 and first.lanes == 1 and output_size is not None
 
     def launch():
         stream = aot_hip.stream_ptr()
@@ -740,6 +765,8 @@ def _decode(owner, cohorts, output_size):
                 buf[r:r + lg.shape[0], :lg.shape[1]].copy_(lg)
                 r += lg.shape[0]
             logits = buf[:, :parts[0].shape[1]]
+        if fused:
+            return _finalize_labels(owner, first, logits, h4, w4, output_size, stream)
         osz = output_size
         if osz is None and sum(c.lanes for c in cohorts) > 1:
             # several object groups, no output size: the reference aggregates the groups' stride-4 logits themselves
@@ -748,7 +775,7 @@ def _decode(owner, cohorts, output_size):
         return _finalize(owner, cohorts, logits, h4, w4, osz, stream)
 
     if len(cohorts) == 1 and first.use_graph:
-        key = ptr_key('decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
+        key = ptr_key('decode_labels' if fused else 'decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
                       first._group_objects(), aot_hip.gemm_table())
         out4, out = first._gx().run(key, launch)
     else:
@@ -757,6 +784,11 @@ def _decode(owner, cohorts, output_size):
     for c in cohorts:
         c.pred_id_logits = out4[g:g + c.lanes]
         g += c.lanes
+    if labels and not fused:
+        if out is None:
+            _die('decode_current_labels needs an output size')
+        lab = aot_hip.fuse_probs(out, [False], want_aug_labels=False)[0]
+        return lab, aot_hip.label_resize(lab, int(first.input_size_2d[0]), int(first.input_size_2d[1]))
     if out is not None:
         return out
     return out4
@@ -903,6 +935,12 @@ class AOTInferEngine(nn.Module):
     @_in_table
     def decode_current_logits(self, output_size=None):
         return _decode(self, self._cohorts, output_size)
+
+    @_in_table
+    def decode_current_labels(self, output_size):
+        """(label at the output size, label at the input size): see AOTEngine.decode_current_labels; several object groups take the
+        logits path + aot_hip.fuse_probs / label_resize."""
+        return _decode(self, self._cohorts, output_size, labels=True)
 
     @_in_table
     def update_memory(self, curr_mask, skip_long_term_update=False):

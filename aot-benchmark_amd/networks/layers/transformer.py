@@ -67,6 +67,9 @@ class LongShortTermTransformerBlock(nn.Module):
         p['sa_qk_w'] = attach_wt(torch.cat([wq, wk], 1).contiguous())   # [256, 512]: one GEMM for Q and K of (x1 + pos)
         p['sa_qk_b'] = torch.cat([bq, bk]).contiguous()
         p['sa_v_w'], p['sa_v_b'] = linear_t(sa.linear_V)
+        # Q, K and V of the self-attention as ONE product on the normed input (round 5): (x1 + pos) Wq = x1 Wq + pos Wq, and pos is
+        # fixed for a clip, so pos [Wq | Wk] + bias is computed once per clip (prepare_pos) and rides as the shared residual map
+        p['sa_qkv_w'] = attach_wt(torch.cat([wq, wk, p['sa_v_w'][:, :wq.shape[1]]], 1).contiguous())   # [256, 768]
         p['sa_o_w'], p['sa_o_b'] = linear_t(sa.projection)
         p['q_w'], p['q_b'] = linear_t(self.linear_Q)
         p['v_w'], p['v_b'] = linear_t(self.linear_V)
@@ -85,8 +88,18 @@ class LongShortTermTransformerBlock(nn.Module):
         self._p = p
         return p
 
+    def prepare_pos(self, pos, stream=None):
+        """[pos Wq + bq | pos Wk + bk | bv] for a clip's position embedding pos [N, C]: the residual map of the merged Q|K|V product.
+        Launched from the host once per clip (never inside a graph capture)."""
+        p = self.pack()
+        N, C = pos.shape
+        out = torch.empty(N, 3 * C, dtype=torch.float32, device=pos.device)
+        aot_hip.linear(pos, p['sa_qk_w'], p['sa_qk_b'], out[:, :2 * C], stream=stream)
+        out[:, 2 * C:] = p['sa_v_b']
+        return out
+
     # ---- reference transformer.py:312-362 -----------------------------------------------------
-    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
+    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, pos_qkv=None):
         """x [B*N, C(ld)] token-major (B lanes).  x6 = the bank's pre-split copy (planes, rows per lane) for the bf16x6 attention
         kernel, when the engine keeps one.  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
         (T_dev: device int holding T, for launches replayed from a graph while the bank grows);
@@ -108,12 +121,18 @@ class LongShortTermTransformerBlock(nn.Module):
 
         # self-attention
         x1 = ws.get('x1', (M, C), dev)
-        x1p = ws.get('x1p', (M, C), dev)
-        aot_hip.layernorm(x, *p['norm1'], x1, add=pos, out2=x1p, add_rows=N, stream=stream)
-        qk = ws.get('sa_qk', (M, 2 * C), dev)
-        aot_hip.linear(x1p, p['sa_qk_w'], p['sa_qk_b'], qk, stream=stream)
-        sv = ws.get('sa_v', (M, C), dev)
-        aot_hip.linear(x1, p['sa_v_w'], p['sa_v_b'], sv, stream=stream)
+        if pos_qkv is not None:       # one product for Q, K and V (pos_qkv = prepare_pos(pos): see pack())
+            aot_hip.layernorm(x, *p['norm1'], x1, stream=stream)
+            qkv = ws.get('sa_qkv', (M, 3 * C), dev)
+            aot_hip.linear(x1, p['sa_qkv_w'], None, qkv, res=pos_qkv, res_rows=N, stream=stream)
+            qk, sv = qkv[:, :2 * C], qkv[:, 2 * C:]
+        else:
+            x1p = ws.get('x1p', (M, C), dev)
+            aot_hip.layernorm(x, *p['norm1'], x1, add=pos, out2=x1p, add_rows=N, stream=stream)
+            qk = ws.get('sa_qk', (M, 2 * C), dev)
+            aot_hip.linear(x1p, p['sa_qk_w'], p['sa_qk_b'], qk, stream=stream)
+            sv = ws.get('sa_v', (M, C), dev)
+            aot_hip.linear(x1, p['sa_v_w'], p['sa_v_b'], sv, stream=stream)
         so = ws.get('sa_o', (M, C), dev)
         sx6 = None
         if x6 is not None and self.self_attn.hidden_dim == 32:
@@ -227,11 +246,12 @@ class LongShortTermTransformer(nn.Module):
         aot_hip.copy_rows(x0, out_cat, N, B=B, src_brows=0, dst_brows=N, stream=stream)    # the same image feature for every lane
         x = out_cat[:, :C]
         mems = []
+        pq = getattr(pos, '_aot_pos_qkv', None) if pos is not None else None      # prepare_pos(): the merged Q|K|V product's residual maps
         for i, layer in enumerate(self.layers):
             x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
                                       short_mems[i] if short_mems is not None else None,
                                       id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
-                                      keep=keep, x6=x6[i] if x6 is not None else None)
+                                      keep=keep, x6=x6[i] if x6 is not None else None, pos_qkv=pq[i] if pq is not None else None)
             mems.append((ck, cv, fv))
             is_last = i == L - 1
             norm = None
@@ -246,6 +266,12 @@ class LongShortTermTransformer(nn.Module):
             else:
                 d.copy_(x)
         return out_cat, mems
+
+    def prepare_pos(self, pos, stream=None):
+        """Once per clip, from the host: every layer's [pos Wq + bq | pos Wk + bk | bv], kept on the position tensor itself (the
+        engine passes the same tensor every frame; the maps go when it goes)."""
+        pos._aot_pos_qkv = [layer.prepare_pos(pos, stream) for layer in self.layers]
+        return pos
 
     def update_values(self, mems, id_sums, ws, stream, dst=None):
         """Memory update of every layer once the frame's mask is known (aot_engine.py:307-338): V <- linear_V(V + id_emb)

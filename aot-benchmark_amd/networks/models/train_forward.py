@@ -38,7 +38,9 @@ def _fold_bn(weight, bn):
         w._aot_wkey = (weight.data_ptr(), tuple(weight.shape), 'folded')      # names the weight inside train_ops.weight_cache()
         return w, shift
     # inside a weight_cache() scope (one optimiser step) the folded weight is ONE graph node shared by every frame that uses it
-    return T._cached((weight.data_ptr(), id(bn), 'fold'), make)
+    # (the grad mode is part of the key: a fold first formed under torch.no_grad() has no grad_fn, and handing it to a later
+    #  grad-enabled use would silently leave the conv weight without a gradient -- ADVICE r4)
+    return T._cached((weight.data_ptr(), id(bn), 'fold', torch.is_grad_enabled()), make)
 
 
 def _drop_path(x, p, training, B):

@@ -17,7 +17,14 @@ and `p.data` / `p.grad` are views into them, so that
     step), the EMA one launch (aot_ema_update_f32);
   * tensors that received no gradient on ANY rank are skipped by the optimiser exactly as torch.optim.AdamW skips
     `p.grad is None` (DDP's find_unused_parameters = True semantics, trainer.py:72): the hooks record which tensors were touched
-    and one small MAX all-reduce agrees on the set.
+    and one small MAX all-reduce agrees on the set (distributed runs only: its result comes back to the host, ONE small
+    synchronisation per step in front of the optimiser launches; a single process never waits);
+  * every rank issues the SAME sequence of collectives whatever it touched (round 5): bucket i goes out only after
+    buckets 0 .. i-1 -- from the hooks while backward runs when its turn has come, otherwise in average() -- and the touched-set
+    all-reduce comes last, after every bucket.  (Issuing a bucket as soon as ITS members had fired let two ranks that used
+    different tensors order their collectives differently: mismatched sizes on the wire.)
+  * construction broadcasts rank 0's parameters (what DistributedDataParallel does, trainer.py:59-74): replicas start identical
+    whatever seed each rank built its model with.
 
 The collective layer is torch.distributed (`nccl` = RCCL on the GPU box, `gloo` in the CPU tests); the optimiser kernels need
 the device (no CPU fallback: `step()` raises on CPU tensors, `average()` alone is backend-agnostic).
@@ -56,6 +63,9 @@ class FlatTrainState:
             view.copy_(p.data)
             p.data = view
             g['grad_view'] = self.flat_g[o:o + p.numel()].view_as(p)
+        if self.distributed() and dist.get_world_size(group) > 1:
+            # rank 0's values everywhere (DistributedDataParallel's constructor does the same): one broadcast of the flat buffer
+            dist.broadcast(self.flat_p, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self.shadow = self.flat_p.clone() if ema else None
         self.ema_decay, self.ema_updates = ema_decay, 0
         # buckets: contiguous ranges of the gradient buffer, cut at tensor boundaries
@@ -64,7 +74,8 @@ class FlatTrainState:
         for i, g in enumerate(self.groups):
             members.append(i)
             if self.offsets[i + 1] - start >= cap or i == len(self.groups) - 1:
-                self.buckets.append({'range': (start, self.offsets[i + 1]), 'members': members, 'pending': 0, 'work': None})
+                self.buckets.append({'range': (start, self.offsets[i + 1]), 'members': members, 'pending': 0, 'work': None,
+                                     'ready': False})
                 start, members = self.offsets[i + 1], []
         self._bucket_of = {}
         for b in self.buckets:
@@ -75,6 +86,7 @@ class FlatTrainState:
         self._touched_dev = torch.zeros(len(self.groups), dtype=torch.int32, device=dev)
         self._touch_work = None
         self.launch_order = []                 # bucket indices in the order their all-reduce was issued (tests read it)
+        self._next_bucket = 0
         self.launched_in_backward = 0
         self._in_backward = False
         self._hooks = [g['param'].register_post_accumulate_grad_hook(self._ready) for g in self.groups]
@@ -110,7 +122,8 @@ class FlatTrainState:
         for g in self.groups:
             g['param'].grad = g['grad_view']
         for b in self.buckets:
-            b['pending'], b['work'] = len(b['members']), None
+            b['pending'], b['work'], b['ready'] = len(b['members']), None, False
+        self._next_bucket = 0                  # buckets go out strictly in index order: the same order on every rank
         self._touched.zero_()
         self._touch_work = None
         self.launch_order, self.launched_in_backward, self._in_backward = [], 0, True
@@ -124,7 +137,12 @@ class FlatTrainState:
         b = self._bucket_of[i]
         b['pending'] -= 1
         if b['pending'] == 0:
-            self._launch(b)
+            b['ready'] = True
+            # rank-independent order: a complete bucket waits for its predecessors (a rank that never touches a tensor of bucket
+            # j < i issues j in average(), and i after it -- exactly what a rank that touched everything does)
+            while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket]['ready']:
+                self._launch(self.buckets[self._next_bucket])
+                self._next_bucket += 1
 
     def _launch(self, b):
         if b['work'] is not None or not self.distributed():
@@ -142,11 +160,11 @@ class FlatTrainState:
         self._in_backward = False
         world = self.world()
         if self.distributed():
+            for b in self.buckets[self._next_bucket:]:           # what the hooks could not issue, in index order
+                self._launch(b)
+            self._next_bucket = len(self.buckets)
             self._touched_dev.copy_(self._touched)
-            self._touch_work = dist.all_reduce(self._touched_dev, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-            for b in self.buckets:
-                if b['work'] is None:
-                    self._launch(b)
+            self._touch_work = dist.all_reduce(self._touched_dev, op=dist.ReduceOp.MAX, group=self.group, async_op=True)   # always last
             for b in self.buckets:
                 b['work'].wait()
             if world > 1:
@@ -205,6 +223,22 @@ class FlatTrainState:
             out[g['name']] = {'step': g['step'], 'exp_avg': self.exp_avg[o:o + p.numel()].view_as(p),
                               'exp_avg_sq': self.exp_avg_sq[o:o + p.numel()].view_as(p)}
         return out
+
+    def load_named_state(self, state, ema_updates=None):
+        """Resume: the inverse of named_state() -- {name: {'step', 'exp_avg', 'exp_avg_sq'}} in the per-tensor layout of a
+        torch.optim.AdamW checkpoint (the reference resumes its optimiser and ema.num_updates, trainer.py:170-215); tensors are
+        copied into the flat moment buffers, names this state does not hold are ignored, missing names keep zero moments."""
+        for g, o in zip(self.groups, self.offsets):
+            ent = state.get(g['name'])
+            if ent is None:
+                continue
+            p = g['param']
+            g['step'] = int(ent['step'])
+            self.exp_avg[o:o + p.numel()].view_as(p).copy_(torch.as_tensor(ent['exp_avg']).to(self.exp_avg.device))
+            self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(torch.as_tensor(ent['exp_avg_sq']).to(self.exp_avg_sq.device))
+        if ema_updates is not None:
+            self.ema_updates = int(ema_updates)
+        return self
 
     def shadow_of(self, p):
         i = self._index[id(p)]

@@ -144,11 +144,16 @@ def one_frame(engine, img, feedback=None):
     of a chaotic clip only): label [1,1,H,W] -> the label map to memorise."""
     import aot_hip
     engine.match_propogate_one_frame(img)
+    if feedback is None:
+        # decode -> softmax -> mean over the (single) augmentation -> argmax -> nearest-resized label feedback
+        # (aot_engine.py:356-380, evaluator.py:332-352,394-408): one replay, the tail as ONE kernel (aot_frame_tail_f32),
+        # bit-identical to decode_current_logits + aot_hip.fuse_probs + aot_hip.label_resize
+        label, fb = engine.decode_current_labels(OUT_SIZE)
+        engine.update_memory(fb)
+        return label
     logit = engine.decode_current_logits(OUT_SIZE)
-    # softmax -> mean over the (single) augmentation -> argmax, then the nearest-resized label feedback
-    # (evaluator.py:332-352,394-408) as the two device kernels of csrc/prepost.hip
     label, aug_labels, _ = aot_hip.fuse_probs(logit, [False])
-    fb = aug_labels[0] if feedback is None else feedback(label)
+    fb = feedback(label)
     engine.update_memory(aot_hip.label_resize(fb, engine.input_size_2d[0], engine.input_size_2d[1]))
     return label
 
@@ -368,7 +373,7 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
     return {'J': round(J, 6), 'F': round(Fm, 6), 'J&F': round((J + Fm) / 2, 6), 'frames': len(js),
             'pixels_differing': diff, 'pixels_outside_near_ties': outside, 'of_pixels': int(gold.size),
             'gemm_table': gemm_table, 'mfma': mfma, 'launch': 'hipGraph replay' if graph else 'host launches',
-            'labels': 'aot_hip.fuse_probs',
+            'labels': 'engine.decode_current_labels (aot_frame_tail_f32: resize + softmax + argmax + nearest feedback in the decode replay)',
             'encode_ahead_frames': ahead,
             'feedback': 'own labels',
             'clip': 'tests/golden/%s.npz (free-running, masks of the real reference; near-tie = top-2 logit gap < 2e-4 in the '

@@ -301,6 +301,16 @@ int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int B, 
 int aot_logits_finalize_f32(const float* logits, float* out4, float* out, int G, int IH, int IW, int C,
                             int ldi, int OH, int OW, int obj_total, int align_corners, void* stream);
 
+/* The frame tail for ONE object group and ONE augmentation in one launch (round 5): from the decoder's stride-4 logits
+ * [IH*IW, ldi] straight to (a) label_out [OH*OW] = argmax of the softmax of the bilinearly resized, id-masked logits (what
+ * aot_logits_finalize_f32 + aot_fuse_probs_f32 give: same arithmetic in the same order, bit-identical labels), (b) label_in
+ * [LH*LW] (may be NULL) = that label map resized to the engine's input size by nearest neighbour (aot_label_resize_f32), the
+ * mask the memory update reads, and (c) out4 [C, IH, IW] (may be NULL) = the planar masked stride-4 logits (pred_id_logits).  The
+ * output-size logits (C planes of OH x OW floats) are never written.
+ * Replaces aot_engine.py:367-378, evaluator.py:332-352 (softmax -> mean over one augmentation -> argmax) and :375-381. */
+int aot_frame_tail_f32(const float* logits, float* out4, float* label_out, float* label_in, int IH, int IW, int C, int ldi,
+                       int OH, int OW, int LH, int LW, int obj_total, int align_corners, void* stream);
+
 /* out = a + b over n floats (n % 4 == 0) -- V + id_emb in fuse_key_value_id (transformer.py:364-367). */
 int aot_add_f32(const float* a, const float* b, float* out, long n, void* stream);
 

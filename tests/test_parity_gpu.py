@@ -303,6 +303,35 @@ def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, ac
         assert torch.equal(run(256)[:, :Cout], pp[:, :Cout])
 
 
+@pytest.mark.parametrize('IH,IW,OH,OW,LH,LW,C,objs,align', [(121, 213, 480, 854, 481, 849, 11, 10, True), (121, 213, 480, 854, 481, 849, 11, 3, False),
+                                                             (33, 33, 129, 129, 131, 127, 11, 10, True), (17, 23, 64, 90, 65, 89, 4, 3, True)])
+def test_frame_tail_bit_identical(hip, IH, IW, OH, OW, LH, LW, C, objs, align):
+    """aot_frame_tail_f32 (resize + id masking + softmax + argmax + nearest feedback + planar copy in one launch) against the three
+    launches it replaces (aot_logits_finalize_f32 -> aot_fuse_probs_f32 -> aot_label_resize_f32): every output BIT-IDENTICAL, also
+    on logits quantised so coarsely that exact ties are everywhere (first maximum wins on both sides)."""
+    g = torch.Generator().manual_seed(IH * 7 + C)
+    ld = (C + 3) // 4 * 4
+    for quant in (0.0, 0.5):
+        raw = torch.randn(IH * IW, ld, generator=g) * 3
+        if quant:
+            raw = torch.round(raw / quant) * quant
+        lg = _dev(raw)[:, :C]
+        out4 = torch.empty(1, C, IH, IW, device='cuda')
+        out = torch.empty(1, C, OH, OW, device='cuda')
+        hip.logits_finalize(lg, out4, out, IH, IW, C, OH, OW, objs, align)
+        lab = hip.fuse_probs(out, [False], want_aug_labels=False)[0]
+        lin = hip.label_resize(lab, LH, LW)
+        o4 = torch.full_like(out4, float('nan'))
+        l2 = torch.full((1, 1, OH, OW), -1.0, device='cuda')
+        i2 = torch.full((1, 1, LH, LW), -1.0, device='cuda')
+        hip.frame_tail(lg, o4, l2, i2, IH, IW, C, objs, align)
+        assert torch.equal(o4, out4) and torch.equal(l2, lab) and torch.equal(i2, lin)
+        assert int(lab.max()) <= objs
+        l3 = torch.full((1, 1, OH, OW), -1.0, device='cuda')
+        hip.frame_tail(lg, None, l3, None, IH, IW, C, objs, align)          # the optional outputs left out
+        assert torch.equal(l3, lab)
+
+
 def test_linear_strided_views(hip):
     """column slices of wider buffers as A, C and residual (how the LSTT avoids concat/split copies)."""
     g = torch.Generator().manual_seed(5)
@@ -1059,7 +1088,9 @@ _FULL = ['c2_r50_aotl_70', 'c3b_r50_deaotl_70', 'c3_swinb_deaotl_480_70']
 # (throughput table, hipGraph replay, aot_hip.fuse_probs labels, encoder look-ahead 3), one clip at a time (latency table, the same
 # otherwise: `single_stream`), plus the eager / torch-label forms -- for ALL three whole-clip goldens.
 _X6_TF_CELLS = [('throughput', True, 'fuse_probs'), ('latency', True, 'fuse_probs'), ('latency', False, 'torch')]
-_X6_FR_CELLS = [('throughput', True, 'fuse_probs', 3), ('latency', True, 'fuse_probs', 3), ('throughput', True, 'fuse_probs', 1),
+# label path 'tail' = engine.decode_current_labels (aot_frame_tail_f32: resize + softmax + argmax + nearest feedback in one kernel of
+# the decode replay) -- what bench.py's one_frame() calls since round 5
+_X6_FR_CELLS = [('throughput', True, 'tail', 3), ('latency', True, 'tail', 3), ('throughput', True, 'fuse_probs', 1),
                 ('latency', False, 'torch', 1)]
 
 
@@ -1128,13 +1159,17 @@ def test_free_running_masks_equal_reference(hip, case, table, graph, labels, ahe
             if ahead > 1 and (t - 1) % ahead == 0:
                 eng.encode_ahead(list(frames[t:t + ahead]))
             eng.match_propogate_one_frame(frames[t])
-            logit = eng.decode_current_logits(out_size)
-            lab = label_fn(logit)
+            if labels == 'tail':
+                lab, fb = eng.decode_current_labels(out_size)
+            else:
+                logit = eng.decode_current_logits(out_size)
+                lab = label_fn(logit)
+                fb = F.interpolate(lab, size=eng.input_size_2d, mode='nearest')
             bad = lab[0, 0].cpu().numpy().astype(np.uint8) != g['masks'][t - 1]
             tie = unpack_gapmask(g, t, bad.shape)
             diffs.append(int(bad.sum()))
             hard += int((bad & ~tie).sum())
-            eng.update_memory(F.interpolate(lab, size=eng.input_size_2d, mode='nearest'))
+            eng.update_memory(fb)
     _record_parity(case, 'free_running/%s%s/%s/%s%s' % ('bf16x6/' if mfma == 'bf16x6' else '', table, 'graph' if graph else 'eager', labels,
                                                          '/ahead%d' % ahead if ahead > 1 else ''),
                    {'frames': len(diffs), 'pixels_differing_per_frame': diffs, 'pixels_differing': int(sum(diffs)),

@@ -467,6 +467,89 @@ def _flat_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_folded_weight_cache_respects_grad_mode():
+    """inside a weight_cache() scope the folded conv weight is cached per step -- a fold first formed under
+    torch.no_grad() (the aux decodes when their weight is 0) must not be what a later grad-enabled use gets."""
+    from networks.layers import train_ops as T
+    from networks.models.train_forward import _fold_bn
+
+    class BN:          # FrozenBatchNorm2d's constants
+        weight, bias = torch.ones(4), torch.zeros(4)
+        running_mean, running_var, epsilon = torch.zeros(4), torch.ones(4), 1e-5
+    w = torch.nn.Parameter(torch.randn(4, 3, 1, 1))
+    with T.weight_cache():
+        with torch.no_grad():
+            a, _ = _fold_bn(w, BN)
+        b, _ = _fold_bn(w, BN)
+        c, _ = _fold_bn(w, BN)
+    assert not a.requires_grad and b.requires_grad and b is c
+    b.sum().backward()
+    assert w.grad is not None and float(w.grad.abs().sum()) > 0
+
+
+def _flat_order_worker(rank, world, port, q):
+    """the one-sided tensor ALONE in a middle bucket; rank 0 never touches it, rank 1 does.  Both ranks must
+    issue the same collective sequence (bucket sizes differ, so a different order is a wire-level mismatch), replicas must start
+    from rank 0's values although every rank seeds its own, and the optimiser state must survive a named_state round trip."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from utils.flat_state import FlatTrainState
+    torch.manual_seed(100 + rank)                              # different initial weights per rank: the constructor must fix that
+    head = torch.nn.Linear(32, 8)
+    trunk = torch.nn.Linear(16, 32)
+    one_sided = torch.nn.Parameter(torch.ones(600))            # registered BETWEEN trunk and head: a bucket of its own in the middle
+    groups = [{'params': [p], 'name': 'trunk.' + k} for k, p in trunk.named_parameters()]
+    groups += [{'params': [one_sided], 'name': 'one_sided'}]
+    groups += [{'params': [p], 'name': 'head.' + k} for k, p in head.named_parameters()]
+    st = FlatTrainState(groups, bucket_mb=256 * 4 / 2 ** 20, group=None)       # 256 elements per bucket
+    w0 = [p.detach().clone() for p in list(trunk.parameters()) + list(head.parameters())]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [w.numpy().tolist() for w in w0])
+    same_start = gathered[0] == gathered[1]
+    mid = [i for i, b in enumerate(st.buckets) if b['members'] == [st._index[id(one_sided)]]]
+    x = torch.randn(world, 4, 16, generator=torch.Generator().manual_seed(7))
+    st.zero_grad()
+    out = head(torch.relu(trunk(x[rank])))
+    loss = out.pow(2).mean() + (one_sided.sum() * 0.01 if rank == 1 else 0.0)
+    loss.backward()
+    in_bwd = list(st.launch_order)
+    st.average()
+    named = st.named_state()
+    st2_moments = {k: {'step': 3, 'exp_avg': v['exp_avg'] + 1.0, 'exp_avg_sq': v['exp_avg_sq'] + 2.0} for k, v in named.items()}
+    st.load_named_state(st2_moments, ema_updates=5)
+    back = st.named_state()
+    round_trip = all(back[k]['step'] == 3 and torch.equal(back[k]['exp_avg'], st2_moments[k]['exp_avg']) and
+                     torch.equal(back[k]['exp_avg_sq'], st2_moments[k]['exp_avg_sq']) for k in named) and st.ema_updates == 5
+    q.put({'rank': rank, 'same_start': same_start, 'mid': mid, 'nbuckets': len(st.buckets), 'in_bwd': in_bwd,
+           'order': list(st.launch_order), 'one_sided': one_sided.grad.numpy().copy(), 'round_trip': round_trip})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_train_state_rank_independent_collective_order_gloo_world2():
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flat_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0['same_start'] and r1['same_start'], 'the constructor did not broadcast rank 0 parameters'
+    assert len(r0['mid']) == 1 and 0 < r0['mid'][0] < r0['nbuckets'] - 1, 'the one-sided tensor is not alone in a middle bucket: %s' % r0
+    assert r0['order'] == r1['order'] == list(range(r0['nbuckets'])), 'ranks issued different collective sequences: %s / %s' % (r0['order'], r1['order'])
+    m = r0['mid'][0]
+    # rank 0 never completes the middle bucket in backward: it (and everything behind it) waits for average(); rank 1 runs through
+    assert r0['in_bwd'] == list(range(m)) and r1['in_bwd'] == list(range(r1['nbuckets']))
+    assert np.allclose(r0['one_sided'], 0.005) and np.allclose(r1['one_sided'], 0.005)      # the average of (0, 0.01)
+    assert r0['round_trip'] and r1['round_trip']
+
+
 def test_flat_train_state_overlaps_and_averages_gloo_world2():
     """utils/flat_state.py over gloo, world 2 (trainer.py:59-74's DistributedDataParallel): parameters and gradients are views of
     the flat buffers; a bucket's all-reduce is issued from the post-accumulate-grad hooks WHILE backward runs, first the bucket of
