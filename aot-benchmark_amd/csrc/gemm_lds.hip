@@ -808,12 +808,6 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 //   * the ACTIVATION tile arrives as fp32 exactly as in the lean kernel (im2col through the buffer descriptor) and is split in
 //     registers right before use: 4 VALU per element + 3 v_perm per pair;
 //   * three ring stages of 20.6 KB (two workgroups per CU); a k-step is 12 MFMAs of 32 cycles instead of 16 of 64.
-#ifndef AOT_X6_ILV
-#define AOT_X6_ILV 0        // development switch: reads and DMA pieces interleaved with the MFMAs (pre-split member)
-#endif
-#ifndef AOT_X6_EARLY
-#define AOT_X6_EARLY 0      // development switch: DMA of step ss+3 issued in step ss (64x64 bf16x6 / bf16 kernels)
-#endif
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -881,15 +875,6 @@ __device__ __forceinline__ bf16x8 round8(const f32x4& x0, const f32x4& x1) {
 // NT = 6: the fp32-equivalent six-term product (inference, mfma = 'bf16x6').  NT = 1: ONE product of operands rounded to bf16 --
 // the training path's `precision = 'bf16'` (train_ops.matmul_precision): weight plane from aot_pack_bf16_f32 (round to nearest
 // even), activations rounded in registers; 2 MFMAs per k-step instead of 12, one weight plane through the ring instead of three.
-// (PS, interleaved form) fragment read I of a k-step: 0..5 = the A planes (plane I / 2, sub-step I % 2), 6..11 = the weight planes
-template <int I, int ST, int APL, int PIECE>
-__device__ __forceinline__ void x6p_read(bf16x8 (&pa)[3][2], bf16x8 (&rb)[3][2], const unsigned (&paddr)[2], unsigned baddr) {
-  if constexpr (I < 6) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pa[I / 2][I % 2]) : "v"(paddr[I % 2]), "n"(ST + (I / 2) * APL));
-  } else {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[(I - 6) / 2][(I - 6) % 2]) : "v"(baddr), "n"(ST + (4 * ((I - 6) / 2) + 2 * ((I - 6) % 2)) * PIECE));
-  }
-}
 // SK (with NT = 1, 1x1 only): split-K for the weight gradients of the training path -- item = (tile, k-slice), the partial tile goes
 // raw to its fp32 slab of `scratch` [ksplit][M][Cout] and splitk_reduce_kernel sums the slabs in order (+ bias / residual / act).
 // PS (with NT = 6): the activations arrive ALREADY SPLIT -- p.in is three bf16 planes [3][B*H*W][lda] (element stride lda, k in
@@ -1187,68 +1172,28 @@ __global__ void __launch_bounds__(256, 2) gemm_x6_kernel(const ConvParams p, con
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  // EARLY (AOT_X6_EARLY): the slot of step ss is dead once its fragments are in registers, i.e. DURING step ss -- the DMA of step
-  // ss+3 goes there right away instead of one step later: two steps of DMA in flight on the same three slots (counted waits).
-  constexpr bool EARLY = AOT_X6_EARLY != 0;
   issue(I0{});
   issue(I1{});
-  if (EARLY) issue(I2{});
-  __builtin_amdgcn_s_waitcnt(waitcnt_imm(EARLY ? 2 * LPW : LPW, 15));          // step 0 has landed
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(LPW, 15));          // step 0 has landed
   __builtin_amdgcn_s_barrier();
   fetch(I0{}, I0{});
   // step ss (ring stage U % 3, register set U % 2; the loop is unrolled by six): on entry the fragments of step ss are being
   // read into set U % 2, the DMA of step ss+1 is in flight
   auto step = [&](auto U) __attribute__((always_inline)) -> void {
-    constexpr int u = decltype(U)::value, set = u & 1, nslot = (u + 1) % 3, islot = EARLY ? u % 3 : (u + 2) % 3;
-    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished;
-    // EARLY: the pieces of step ss+2 may stay in flight)
+    constexpr int u = decltype(U)::value, set = u & 1, nslot = (u + 1) % 3, islot = (u + 2) % 3;
+    // step ss+1 has landed, and this wave's fragment reads of step ss (plus the stores of a tile the previous step finished)
     if (stores_pending) {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm((EARLY ? LPW : 0) + NSTORE, 0));
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(NSTORE, 0));
       stores_pending = 0;
     } else {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm(EARLY ? LPW : 0, 0));
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
     }
     __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage of step ss-1 (= of step ss+2) is free
     landed(std::integral_constant<int, set>{});
     if (c_kt == nk - 1) epi_loads();     // last k-step of the tile: its residual and bias, now -- BEFORE this step's DMA pieces, so
                                          // that the epilogue's counted wait (all but the youngest LPW) covers them
-    if (AOT_X6_ILV && PS) {
-      // interleaved form (as the fp32 lean kernel): one fragment read of step ss+1 behind every MFMA of step ss, one DMA piece of the
-      // step being issued behind every other -- the matrix pipe does not wait for the issue of 12 reads + 6 pieces up front
-      if (is_kt == 0) setup_item(is_i);
-      if (!IS1X1) s_tap = ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * AEL;
-      unsigned char* st = lds + islot * STAGE_BYTES;
-      int voff = a_off[0];
-      if (!IS1X1) {
-        const int iy = a_iy0[0] + tap_ky * p.dil, ix = a_ix0[0] + tap_kx * p.dil;
-        const bool in = a_ok[0] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        voff = in ? a_off[0] + s_tap : (int)OOB;
-      }
-      static_for<12>([&](auto II) __attribute__((always_inline)) {
-        constexpr int i = decltype(II)::value, sx = i / 6, t = i % 6;
-        constexpr int ai = t == 0 ? 1 : t == 1 ? 0 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0;
-        constexpr int bi = t == 0 ? 1 : t == 1 ? 2 : t == 2 ? 0 : t == 3 ? 1 : t == 4 ? 0 : 0;
-        acc[sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[set][ai][sx], rb[set][bi][sx], acc[sx], 0, 0, 0);
-        x6p_read<i, nslot * STAGE_BYTES, A_PLANE, B_PIECE>(pa[set ^ 1], rb[set ^ 1], paddr, baddr);
-        if (i % 2 == 0) {
-          constexpr int j = i / 2;
-          if (j < 3) dma16(rsrc_a, st + j * A_PLANE + wave * 1024, voff, (IS1X1 ? s_k : 0) + j * a_plane_bytes);
-          else dma16(rsrc_b, st + OPA_BYTES + ((j - 3) * 4 + wave) * B_PIECE, (int)b_off, s_kb + (j - 3) * plane_bytes);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      s_k += BK * AEL;
-      s_kb += 4 * wq.cout_pad * 16;
-      if (!IS1X1) {
-        tap_c += BK;
-        if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
-      }
-      if (++is_kt == nk) { is_kt = 0; ++is_i; }
-    } else {
     fetch(std::integral_constant<int, set ^ 1>{}, std::integral_constant<int, nslot>{});      // fragments of step ss+1
     issue(std::integral_constant<int, islot>{});                                             // DMA of step ss+2
-    }
-    if (!(AOT_X6_ILV && PS))
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (PS) {        // the planes as they came: same six products, same order

@@ -20,6 +20,8 @@ MI355X-first design -- same results as the reference, different machinery:
 """
 import functools
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -541,7 +543,7 @@ class AOTEngine(nn.Module):
         if self.pos_emb is None:
             self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(x16, h, w)).contiguous(
                 memory_format=torch.channels_last)).contiguous()
-            if hasattr(self.AOT.LSTT, 'prepare_pos'):     # AOT: the position term of the merged Q|K|V product, once per clip
+            if hasattr(self.AOT.LSTT, 'prepare_pos') and not os.environ.get('AOT_NO_QKV_MERGE'):     # AOT: the position term of the merged Q|K|V product, once per clip (env: A/B runs)
                 self.AOT.LSTT.prepare_pos(self.pos_emb, aot_hip.stream_ptr())
         id_emb = self.assign_identity(mask)
         self.curr_id_embs = id_emb

@@ -144,7 +144,7 @@ def one_frame(engine, img, feedback=None):
     of a chaotic clip only): label [1,1,H,W] -> the label map to memorise."""
     import aot_hip
     engine.match_propogate_one_frame(img)
-    if feedback is None:
+    if feedback is None and not os.environ.get('AOT_NO_TAIL'):
         # decode -> softmax -> mean over the (single) augmentation -> argmax -> nearest-resized label feedback
         # (aot_engine.py:356-380, evaluator.py:332-352,394-408): one replay, the tail as ONE kernel (aot_frame_tail_f32),
         # bit-identical to decode_current_logits + aot_hip.fuse_probs + aot_hip.label_resize
@@ -153,7 +153,7 @@ def one_frame(engine, img, feedback=None):
         return label
     logit = engine.decode_current_logits(OUT_SIZE)
     label, aug_labels, _ = aot_hip.fuse_probs(logit, [False])
-    fb = feedback(label)
+    fb = aug_labels[0] if feedback is None else feedback(label)
     engine.update_memory(aot_hip.label_resize(fb, engine.input_size_2d[0], engine.input_size_2d[1]))
     return label
 

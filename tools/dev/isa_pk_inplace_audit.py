@@ -9,6 +9,13 @@ ISA-level bisect (tools/dev/isa_bisect.py: with every packed op of the merge rep
 crossed v_pk_add_f32, the failure is back; with only those two replaced it is gone).
 
     python tools/dev/isa_pk_inplace_audit.py file.s [...]         exit status 1 if any such instruction exists
+    python tools/dev/isa_pk_inplace_audit.py --strict file.s [...] ANY in-place packed fp32 instruction (destination pair == a source
+                                                                  pair), crossed or not, is an error
+
+--strict (round 5): what triggers the wrong low half is not established below the instruction form (profiles/r04_hazard.txt section 5,
+profiles/r05_erratum_pk_inplace.md), so every source that does not write packed fp32 arithmetic BY HAND is built without the SLP
+vectoriser and must contain no in-place packed fp32 instruction at all; attention.hip (explicit v_pk_fma / v_pk_mul / v_pk_add, never
+with op_sel on the overwritten operand) is held to the crossed-halves rule.
 """
 import re
 import sys
@@ -17,7 +24,7 @@ PK = re.compile(r'^\s*(v_pk_\w+)\s+v\[(\d+):(\d+)\],\s*(.*)$')
 SRC = re.compile(r'v\[(\d+):(\d+)\]')
 
 
-def audit(path):
+def audit(path, strict=False):
     out, kern = [], None
     for ln in open(path, errors='replace'):
         s = ln.split(';')[0].rstrip()
@@ -48,16 +55,21 @@ def audit(path):
             h = hi[pos] if pos < len(hi) else 1
             if l == 1 or h == 0:                           # low result reads the high half and / or high result reads the low half
                 out.append((path, kern, s.strip()))
+            elif strict and op.endswith('_f32'):           # in place at all
+                out.append((path, kern, s.strip()))
     return out
 
 
 def main():
+    args = sys.argv[1:]
+    strict = '--strict' in args
     bad = []
-    for p in sys.argv[1:]:
-        bad += audit(p)
-    for path, kern, txt in bad:
+    for p in args:
+        if p != '--strict':
+            bad += audit(p, strict)
+    for path, kern, txt in bad[:200]:
         print('%s: %s: %s' % (path, kern, txt))
-    print('%d in-place packed instructions with crossed halves' % len(bad))
+    print('%d in-place packed instructions %s' % (len(bad), '(strict: any in-place packed fp32)' if strict else 'with crossed halves'))
     return 1 if bad else 0
 
 
