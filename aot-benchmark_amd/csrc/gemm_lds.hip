@@ -2125,7 +2125,8 @@ __global__ void __launch_bounds__(512, 2) gemm_x6pp_kernel(const ConvParams p, c
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));             // the all-out-of-bounds DMAs past the end still target this LDS
 }
 
-// sum of the k-slices in slice order + epilogue; one thread per 4 output channels
+// sum of the k-slices in slice order + epilogue; one thread per 4 output channels (16-byte loads and stores where the rows allow it:
+// Cout % 4 == 0 makes every slab row 16-byte aligned)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch) {
   const int nq = (p.Cout + 3) >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2135,13 +2136,28 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
   const float* src = scratch + (long)m * p.Cout + n0;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   const int cnt = min(4, p.Cout - n0);
-  for (int s = 0; s < ksplit; ++s)
-    for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
+  const bool vec = (p.Cout & 3) == 0 && ((uintptr_t)scratch & 15) == 0;
+  if (vec) {
+    for (int s = 0; s < ksplit; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (long)s * slab);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+  } else {
+    for (int s = 0; s < ksplit; ++s)
+      for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
+  }
   const long rrow = p.res_rows ? m % p.res_rows : m;
+  float o[4];
   for (int c = 0; c < cnt; ++c) {
     float t = v[c] + (p.bias ? p.bias[n0 + c] : 0.f);
     if (p.res) t += p.res[rrow * p.ldr + n0 + c];
-    p.out[(long)m * p.ldc + n0 + c] = apply_act(t, p.act);
+    o[c] = apply_act(t, p.act);
+  }
+  float* dst = p.out + (long)m * p.ldc + n0;
+  if (vec && (p.ldc & 3) == 0 && ((uintptr_t)p.out & 15) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (int c = 0; c < cnt; ++c) dst[c] = o[c];
   }
 }
 

@@ -45,11 +45,27 @@ class FPNSegmentationHead(nn.Module):
                           nsplit=32, B=B, add=add, add_rows=add_rows, stream=stream)
         return out
 
-    def run(self, x_in, f16, f8, f4, ws, stream, B=1):
+    def adapters(self, f16, f8, f4, ws, stream, B=1):
+        """The three adapter convolutions (fpn.py:36-37,45-46,52-53) of B stacked frames: they read the encoder's shortcut maps only,
+        so the engine runs them WITH the encoder (batched over the look-ahead frames, round 5) instead of once per frame inside the
+        decode stage.  Returns (ad16 [B*n16, hd], ad8 [B*n8, hd], ad4 [B*n4, hd/2]) in per-stream scratch."""
+        p = self.pack()
+        hd = self.hidden
+        (s16, h16, w16), (s8, h8, w8), (s4, h4, w4) = f16, f8, f4
+        dev = s16.device
+        ad16 = ws.get('enc_ad16', (B * h16 * w16, hd), dev)
+        aot_hip.conv2d(s16, *p['adapter_16x'], ad16, h16, w16, s16.shape[1], h16, w16, hd, B=B, stream=stream)
+        ad8 = ws.get('enc_ad8', (B * h8 * w8, hd), dev)
+        aot_hip.conv2d(s8, *p['adapter_8x'], ad8, h8, w8, s8.shape[1], h8, w8, hd, B=B, stream=stream)
+        ad4 = ws.get('enc_ad4', (B * h4 * w4, hd // 2), dev)
+        aot_hip.conv2d(s4, *p['adapter_4x'], ad4, h4, w4, s4.shape[1], h4, w4, hd // 2, B=B, stream=stream)
+        return ad16, ad8, ad4
+
+    def run(self, x_in, f16, f8, f4, ws, stream, B=1, ads=None):
         """x_in [B*N16, in_dim] (concatenated decoder input, or the last LSTT output) of B lanes (object groups of ONE
         frame), f16/f8/f4 = (feat, h, w) shortcuts at strides 16/8/4 shared by the lanes: the three adapter convs run
-        once and are added to every lane (GN-apply epilogue at 16x, bilinear epilogue at 8x / 4x).
-        Returns logits [B*h4*w4, out_dim] (row stride out_dim padded to 4)."""
+        once and are added to every lane (GN-apply epilogue at 16x, bilinear epilogue at 8x / 4x); ads = (ad16, ad8, ad4) of THIS
+        frame when adapters() has already formed them.  Returns logits [B*h4*w4, out_dim] (row stride out_dim padded to 4)."""
         p = self.pack()
         dev = x_in.device
         hd = self.hidden
@@ -57,8 +73,11 @@ class FPNSegmentationHead(nn.Module):
             raise aot_hip.AotHipError('decoder expects %d input channels, got %d' % (self.in_dim, x_in.shape[1]))
         (s16, h16, w16), (s8, h8, w8), (s4, h4, w4) = f16, f8, f4
         n16, n8, n4 = h16 * w16, h8 * w8, h4 * w4
-        ad16 = ws.get('dec_ad16', (n16, hd), dev)
-        aot_hip.conv2d(s16, *p['adapter_16x'], ad16, h16, w16, s16.shape[1], h16, w16, hd, stream=stream)
+        if ads is not None:
+            ad16 = ads[0]
+        else:
+            ad16 = ws.get('dec_ad16', (n16, hd), dev)
+            aot_hip.conv2d(s16, *p['adapter_16x'], ad16, h16, w16, s16.shape[1], h16, w16, hd, stream=stream)
         a = ws.get('dec_a16', (B * n16, hd), dev)
         aot_hip.linear(x_in, *p['conv_in'], a, stream=stream)
         b = ws.get('dec_b16', (B * n16, hd), dev)
@@ -66,16 +85,22 @@ class FPNSegmentationHead(nn.Module):
         aot_hip.conv2d(b, *p['conv_16x'], a, h16, w16, hd, h16, w16, hd, 3, 3, 1, 1, 1, B=B, stream=stream)
         self._gn_relu(a, a, 'conv_16x', B, ws, stream)
         # 8x: adapter(shortcut) + bilinear(a)
-        ad8 = ws.get('dec_ad8', (n8, hd), dev)
-        aot_hip.conv2d(s8, *p['adapter_8x'], ad8, h8, w8, s8.shape[1], h8, w8, hd, stream=stream)
+        if ads is not None:
+            ad8 = ads[1]
+        else:
+            ad8 = ws.get('dec_ad8', (n8, hd), dev)
+            aot_hip.conv2d(s8, *p['adapter_8x'], ad8, h8, w8, s8.shape[1], h8, w8, hd, stream=stream)
         c = ws.get('dec_a8', (B * n8, hd), dev)
         aot_hip.bilinear(a, c, h16, w16, h8, w8, hd, self.align_corners, add=ad8, B=B, add_shared=True, stream=stream)
         d = ws.get('dec_b8', (B * n8, hd // 2), dev)
         aot_hip.conv2d(c, *p['conv_8x'], d, h8, w8, hd, h8, w8, hd // 2, 3, 3, 1, 1, 1, B=B, stream=stream)
         self._gn_relu(d, d, 'conv_8x', B, ws, stream)
         # 4x
-        ad4 = ws.get('dec_ad4', (n4, hd // 2), dev)
-        aot_hip.conv2d(s4, *p['adapter_4x'], ad4, h4, w4, s4.shape[1], h4, w4, hd // 2, stream=stream)
+        if ads is not None:
+            ad4 = ads[2]
+        else:
+            ad4 = ws.get('dec_ad4', (n4, hd // 2), dev)
+            aot_hip.conv2d(s4, *p['adapter_4x'], ad4, h4, w4, s4.shape[1], h4, w4, hd // 2, stream=stream)
         e = ws.get('dec_a4', (B * n4, hd // 2), dev)
         aot_hip.bilinear(d, e, h8, w8, h4, w4, hd // 2, self.align_corners, add=ad4, B=B, add_shared=True, stream=stream)
         f = ws.get('dec_b4', (B * n4, hd // 2), dev)

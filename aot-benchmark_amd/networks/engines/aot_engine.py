@@ -460,6 +460,8 @@ class AOTEngine(nn.Module):
 
     def _stage(self, name, t):
         """Copies a caller-owned input into a buffer with a stable address (one per name and shape), fp32."""
+        if getattr(t, '_aot_stable', False) and t.dtype == torch.float32 and t.is_contiguous():
+            return t         # the output of one of this engine's own replays (decode_current_labels): its address does not change
         key = (name, tuple(t.shape))
         buf = self._static.get(key)
         if buf is None:
@@ -495,7 +497,8 @@ class AOTEngine(nn.Module):
         for b, img in enumerate(imgs):
             # the entry holds the image: its storage cannot be freed and re-used for another frame of the same shape while the
             # features wait, so (address, shape, version) identifies the frame for as long as the entry lives
-            self._ahead[_img_key(img)] = (img, [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats])
+            self._ahead[_img_key(img)] = (img, feats.frame(b) if hasattr(feats, 'frame') else
+                                          [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats])
 
     def _take_ahead(self, img):
         """Features of a frame encoded by encode_ahead(), if `img` is the same memory, unmodified since."""
@@ -623,6 +626,9 @@ class AOTEngine(nn.Module):
             # AOT with MODEL_DECODER_INTERMEDIATE_LSTT = False: the decoder takes the last LSTT output only (aot.py:86-92),
             # the last column block of the concatenated buffer
             x_in = x_in[:, -dec.in_dim:]
+        ads = getattr(self._feats, 'ads', None)
+        if ads is not None:
+            return dec.run(x_in, f16, f8, f4, self.AOT.ws, aot_hip.stream_ptr(), B=self.lanes, ads=ads)
         return dec.run(x_in, f16, f8, f4, self.AOT.ws, aot_hip.stream_ptr(), B=self.lanes)
 
     @_in_table
@@ -736,6 +742,7 @@ def _finalize_labels(owner, cohort, logits, h4, w4, output_size, stream):
     lab = torch.empty(1, 1, output_size[0], output_size[1], dtype=torch.float32, device=dev)
     lin = torch.empty(1, 1, int(cohort.input_size_2d[0]), int(cohort.input_size_2d[1]), dtype=torch.float32, device=dev)
     aot_hip.frame_tail(logits, out4, lab, lin, h4, w4, nc, cohort._group_objects(), owner.align_corners, stream=stream)
+    lin._aot_stable = cohort.use_graph         # (a replayed stage rewrites the SAME tensor every frame: update_memory reads it where it lies)
     return out4, (lab, lin)
 
 
@@ -777,7 +784,8 @@ def _decode(owner, cohorts, output_size, labels=False):
         return _finalize(owner, cohorts, logits, h4, w4, osz, stream)
 
     if len(cohorts) == 1 and first.use_graph:
-        key = ptr_key('decode_labels' if fused else 'decode', first._dec_in, [f[0] for f in first._feats], output_size, first.lanes,
+        key = ptr_key('decode_labels' if fused else 'decode', first._dec_in, [f[0] for f in first._feats],
+                      list(getattr(first._feats, 'ads', None) or ()), output_size, first.lanes,
                       first._group_objects(), aot_hip.gemm_table())
         out4, out = first._gx().run(key, launch)
     else:

@@ -36,6 +36,19 @@ def to_tokens(t):
     return t
 
 
+class Feats(list):
+    """[(f4,h,w), (f8,h,w), (f16,h,w), (proj16,h,w)] of encode_tokens, plus `.ads` = the decoder's adapter maps (ad16, ad8, ad4) of the
+    same frames when the decoder has adapters (None otherwise): a list to every caller of the reference surface."""
+    ads = None
+
+    def frame(self, b):
+        """The b-th frame of a batch as a Feats of its own (row slices)."""
+        out = Feats([(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in self])
+        if self.ads is not None:
+            out.ads = tuple(a[b * h * w:(b + 1) * h * w] for a, (_, h, w) in zip(self.ads, (self[2], self[1], self[0])))
+        return out
+
+
 def as_map(tok, h, w):
     """token-major [h*w, C] (row stride ld) -> [1,C,h,w] view (channels-last strides)."""
     ld = tok.stride(0)
@@ -150,7 +163,11 @@ class AOT(nn.Module):
         else:
             out = out_cat[:, :emb]
         aot_hip.conv2d(x, *p['proj'], out, h, w, x.shape[1], h, w, emb, B=B, stream=stream)
-        return [f4, f8, f16, (out, h, w)]
+        feats = Feats([f4, f8, f16, (out, h, w)])
+        if hasattr(self.decoder, 'adapters'):
+            # the decoder's adapter convolutions read these maps only: formed here, for all B frames in one launch each
+            feats.ads = self.decoder.adapters(f16, f8, f4, self.ws, stream, B=B)
+        return feats
 
     def id_emb_from_mask(self, mask, size_2d, stream=None, lanes=1, group0=None, fuse=None, want_out=True):
         """Fused one_hot_mask + patch_wise_id_bank (aot.py:76-79, utils/image.py:69-74): label map [1,1,H,W]
