@@ -260,7 +260,7 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
         if w6 is None:
             w6 = pack_bf16x6(w)
         ks = x6_ksplit(B * OH * OW, Cout, KH * KW * Cin) if X6_TILE == 0 else 1
-        if ks > 1:
+        if ks != 1:
             return conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, res=res, act=act, B=B,
                               res_rows=res_rows, ksplit=ks, stream=stream)
         _chk(load().aot_conv2d_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH,
@@ -287,10 +287,14 @@ def x6_ksplit(M, Cout, K):
     one clip at a time -- get the largest split that keeps (tiles x slices) within one dispatch round of 256 workgroups with at least
     eight k-steps per slice (profiles/r05_x6pp.txt: l3.c2 3x3 at three lanes 60.6 -> 46.5 us, at one lane 48.6 -> 29.2; dec c8 at one
     lane 49.5 -> 39.5)."""
+    nk = K // 32
     if K < 2304:
+        # K = 1024 on the stride-16 map one lane at a time (the LSTT's linear2: 108 tiles of 64x64, 32 k-steps): two slices on the
+        # 64x64 direct-weight kernel (negative = that kernel), 20.0 -> 17.4 us (profiles/r05_x6rd_splitk.txt)
+        if K >= 1024 and nk % 2 == 0 and -(-M // 64) * -(-Cout // 64) <= 128 and 2 * M * Cout <= X6K_SCRATCH_FLOATS:
+            return -2
         return 1
     nwide = -(-M // 128) * -(-Cout // 128)
-    nk = K // 32
     for ks in (9, 8, 6, 4, 3, 2):
         if nwide * ks <= 256 and nk % ks == 0 and nk // ks >= 8 and ks * M * Cout <= X6K_SCRATCH_FLOATS:
             return ks
@@ -306,11 +310,11 @@ def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, p
     if w6 is None:
         w6 = pack_bf16x6(w)
     scratch = None
-    if ksplit > 1:
+    if abs(ksplit) > 1:       # (ksplit < 0: |ksplit| slices on the 64x64 register-staged kernel instead of the 128x128 phase-shifted one)
         if _x6k_ws is None:
             from networks.layers.workspace import Workspace
             _x6k_ws = Workspace()
-        need = ksplit * B * OH * OW * Cout
+        need = abs(ksplit) * B * OH * OW * Cout
         scratch = _x6k_ws.get('x6k', (max(need, X6K_SCRATCH_FLOATS),), x.device)
     _chk(load().aot_conv2d_bf16x6k_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), B, H, W, Cin, OH, OW, Cout,
                                        KH, KW, stride, pad, dil, x.stride(0), out.stride(0), res.stride(0) if res is not None else 0,

@@ -708,7 +708,7 @@ extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_p
                                      float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
                                      int tile, void* stream) {
-  if (!in || !w6 || !out || (tile != 0 && tile != 1 && tile != 64 && tile != 65 && tile != 128 && tile != 129 && tile != 256)) return AOT_ERR_BADARG;
+  if (!in || !w6 || !out || (tile != 0 && tile != 1 && tile != 64 && tile != 65 && tile != 66 && tile != 128 && tile != 129 && tile != 256)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
@@ -728,18 +728,21 @@ extern "C" int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_
                                       float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                                       int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
                                       int ksplit, float* scratch, long scratch_floats, void* stream) {
-  if (!in || !w6 || !out || ksplit < 1 || ksplit > 64) return AOT_ERR_BADARG;
+  // ksplit < 0: |ksplit| slices on the 64x64 register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>)
+  const int ks = ksplit < 0 ? -ksplit : ksplit;
+  if (!in || !w6 || !out || ks < 1 || ks > 64 || ksplit == -1) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
   if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
-  if (ksplit > 1 && (!scratch || (long)ksplit * B * OH * OW * Cout > scratch_floats)) return AOT_ERR_BADARG;
+  if (ks > 1 && (!scratch || (long)ks * B * OH * OW * Cout > scratch_floats)) return AOT_ERR_BADARG;
   ConvParams p;
   p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
+  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch);     // 64x64 form
   return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch);
 }
 

@@ -1777,6 +1777,285 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
   }
 }
 
+// The 64x64 form with the WEIGHT fragments taken straight from global memory ("x6rd", round 5).  SQ counters of gemm_x6r_kernel<., 2, 1>
+// (profiles/r05_x6_gemm_pmc.txt): the LDS is as busy as the matrix pipe -- per k-step a workgroup writes 24 KB (ds_write_b128 moves
+// ~79 bytes per clock) and reads 48 KB -- and half of both is the weight tile, which needs no transposition at all: the packed planes
+// (aot_pack_bf16x6_f32) ARE the fragments (lane = column, 16 bytes = the eight k of a lane-half and sub-step), one 512-byte run per lane
+// half.  So every wave loads its six weight fragments of the NEXT step into a second register set (buffer_load_dwordx4 x 6; the two
+// row waves of a column fetch the same lines, the second one from the CU's L1) and only the activation planes go through the LDS:
+// 12 KB written + 24 KB read per step, two buffers of 12 KB.  Same products in the same order: bit-identical to the other 64x64 forms.
+// SK: split-K over the grid (item = (tile, k-slice); raw partial tiles to fp32 slabs [ksplit][M][Cout], summed in slice order by
+// splitk_reduce_kernel): the long-K 3x3 layers on the stride-16 map have 108-316 tiles of 72 k-steps each -- too few workgroups,
+// too long a chain.
+template <bool IS1X1, bool SK>
+__global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
+  constexpr int WM = 2, NBW = 1;
+  constexpr int NT = 128 * WM;                            // threads: WM x 2 waves
+  constexpr int BM = 32 * WM, BN = 64 * NBW;
+  constexpr int A_PLANE = BM * 64;                        // bytes: BM rows x four 16-byte chunks (32 bf16)
+  constexpr int A_BYTES = 3 * A_PLANE;
+  constexpr int BUF = A_BYTES;                            // 12 KB: the activation planes only
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(NT == 4 * BM, "one A fragment per thread and k-step");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int nk = SK ? (p.K / BK) / ksplit : p.K / BK;            // k-steps per item (host guarantees divisibility)
+  const int nitems = nbm * nbn * (SK ? ksplit : 1);
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
+  const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+  const int q8 = nitems >> 3, r8 = nitems & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int mine = li < chunk_n ? (chunk_n - li + nwg_x - 1) / nwg_x : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  auto item_of = [&](int i) __attribute__((always_inline)) {
+    const int it = chunk0 + li + i * nwg_x;
+    Item r;
+    r.bn = it % nbn;
+    if (SK) {            // item = ((bm * ksplit) + slice) * nbn + bn: the slices of a tile are neighbours
+      const int t = it / nbn;
+      r.kt0 = (t % ksplit) * nk;
+      r.bm = t / ksplit;
+    } else {
+      r.bm = it / nbn;
+      r.kt0 = 0;
+    }
+    return r;
+  };
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32 * NBW;
+  const int hw_out = p.OH * p.OW;
+  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wq.w6), 0, 3 * plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_out =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_res =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? (int)((long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_bias =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+  const bool has_res = !SK && p.res != nullptr, has_bias = !SK && p.bias != nullptr;      // (split-K: the reduce pass adds them)
+
+  // ---- staging side: thread = (row tid >> 2 of the tile, fragment slot sh = 2 s + h); weight chunk (cc = tid / BN, column tid % BN) ----
+  const int srow = tid >> 2, sh = tid & 3;
+  const int c0 = 4 * (sh >> 1) + (sh & 1);                       // its first 16-byte chunk of the row's 128 bytes; the second is c0 + 2
+  const unsigned a_wr = (unsigned)(srow * 64 + ((sh ^ ((srow >> 2) & 3)) << 4));
+  int is_i = 0, is_kt = 0;
+  int a_off = 0, a_iy0 = 0, a_ix0 = 0;
+  bool a_ok = false;
+  int s_k = 0;
+  // weight side: its own walk over the items, ONE step ahead of the MFMAs (the activations are two steps ahead: one in registers,
+  // one in LDS); lane (column wn + l31, half) fetches chunk column cc = 2 s + half of plane pl: + (pl planes, 2 s chunk columns) scalar
+  int ib_i = 0, ib_kt = 0, s_kb = 0;
+  unsigned b_off = 0;
+  int tap_c = 0, tap_ky = 0, tap_kx = 0;
+  u32x4v sa[2];                                                  // the staged step: 8 fp32 activations
+  bf16x8 fb[2][3][2];                                            // [register set][plane][sub-step]: this step's and the next step's weights
+  auto setup_item = [&](int i) __attribute__((always_inline)) {
+    const bool live = i < mine;
+    const Item it = item_of(live ? i : 0);
+    const int m = it.bm * BM + srow;
+    a_ok = live && m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int b = mm / hw_out, pix = mm - b * hw_out;
+    const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    a_iy0 = oy * p.stride - p.pad;
+    a_ix0 = ox * p.stride - p.pad;
+    a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + 4 * c0) * 4;
+    if (IS1X1 && !a_ok) a_off = (int)OOB;
+    s_k = SK ? it.kt0 * BK * 4 : 0;
+    if (!IS1X1) {
+      if (SK) {            // the slice's first k-step names its filter tap
+        const int k0 = it.kt0 * BK, tap = k0 / p.Cin;
+        tap_c = k0 - tap * p.Cin;
+        tap_ky = tap / p.KW;
+        tap_kx = tap - tap_ky * p.KW;
+      } else {
+        tap_c = 0; tap_ky = 0; tap_kx = 0;
+      }
+    }
+  };
+  auto gload = [&]() __attribute__((always_inline)) {            // global -> registers, the next step not yet staged
+    if (is_kt == 0) setup_item(is_i);
+    int voff = a_off;
+    if (!IS1X1) {
+      const int iy = a_iy0 + tap_ky * p.dil, ix = a_ix0 + tap_kx * p.dil;
+      const bool in = a_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      voff = in ? a_off + ((tap_ky * p.dil * p.W + tap_kx * p.dil) * p.lda + tap_c) * 4 : (int)OOB;
+    }
+    sa[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, IS1X1 ? s_k : 0, 0);
+    sa[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff + 32, IS1X1 ? s_k : 0, 0);
+    s_k += BK * 4;
+    if (!IS1X1) {
+      tap_c += BK;
+      if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; } }
+    }
+    if (++is_kt == nk) { is_kt = 0; ++is_i; }
+  };
+  auto gload_b = [&](auto SET) __attribute__((always_inline)) {       // the weight fragments of the next step -> register set SET
+    constexpr int q = decltype(SET)::value;
+    if (ib_kt == 0) {
+      const bool live = ib_i < mine;
+      const Item it = item_of(live ? ib_i : 0);
+      b_off = live ? (unsigned)((half * wq.cout_pad + it.bn * BN + wn + l31) * 16) : OOB;
+      s_kb = SK ? it.kt0 * 4 * wq.cout_pad * 16 : 0;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        fb[q][pl][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_off,
+                                                                                         s_kb + pl * plane_bytes + 2 * s * wq.cout_pad * 16, 0));
+    s_kb += 4 * wq.cout_pad * 16;
+    if (++ib_kt == nk) { ib_kt = 0; ++ib_i; }
+  };
+  auto stage_write = [&](auto BUFI) __attribute__((always_inline)) {   // registers -> split -> LDS buffer BUFI
+    unsigned char* st = lds + decltype(BUFI)::value * BUF;
+    bf16x8 pl3[3];
+    split3(__builtin_bit_cast(f32x4, sa[0]), __builtin_bit_cast(f32x4, sa[1]), pl3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(st + pl * A_PLANE + a_wr) = pl3[pl];
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  const int frow = wm + l31;
+  unsigned a_rd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) a_rd[s] = (unsigned)(frow * 64 + (((2 * s + half) ^ ((frow >> 2) & 3)) << 4));
+  f32x16 acc[2][NBW];          // [sub-step][column block]
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.f;
+  int c_i = 0, c_kt = 0;
+  float rv[NBW][16], bv[NBW];
+  auto epi_loads = [&]() __attribute__((always_inline)) {        // residual and bias of the tile, under its last k-step
+    const Item it = item_of(c_i);
+    const int m0 = it.bm * BM;
+    const int rr0 = p.res_rows ? m0 % p.res_rows : m0;            // (scalar: once per tile)
+    const bool wrap1 = p.res_rows >= BM;                          // a shared map at least a tile tall: at most one wrap
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+      if (has_bias) bv[nb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_bias, col_ok ? n * 4 : (int)OOB, 0, 0));
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = wm + mfma32_row(r, half);
+          int rr = rr0 + dm;
+          if (p.res_rows) {
+            if (wrap1) rr = rr >= p.res_rows ? rr - p.res_rows : rr;
+            else rr %= p.res_rows;
+          }
+          rv[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rsrc_res, (col_ok && m0 + dm < p.M) ? (rr * p.ldr + n) * 4 : (int)OOB, 0, 0));
+        }
+      }
+    }
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const Item it = item_of(c_i);
+    const int mlane = it.bm * BM + wm + 4 * half;
+    const int rows_left = p.M - mlane, ldc4 = p.ldc * 4;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = it.bn * BN + wn + 32 * nb + l31;
+      const bool col_ok = n < p.Cout;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][nb][r] += acc[1][nb][r]; acc[1][nb][r] = 0.f; }
+      if (SK) {          // the raw partial tile -> the slice's slab [M][Cout]
+        const __amdgpu_buffer_rsrc_t rsrc_slab = __builtin_amdgcn_make_buffer_rsrc(
+            scratch + (long)(it.kt0 / nk) * p.M * p.Cout, 0, (int)((long)p.M * p.Cout * 4), 0x00020000);
+        const int vbase_s = col_ok ? (mlane * p.Cout + n) * 4 : (int)OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float v = acc[0][nb][r];       // (a float of its own: __builtin_bit_cast applied to the vector ELEMENT expression
+                                               //  made hipcc store zeros for every element but the first -- seen in the ISA)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_slab,
+                                                c < rows_left ? vbase_s : (int)OOB, c * p.Cout * 4, 0);
+          acc[0][nb][r] = 0.f;
+        }
+        continue;
+      }
+      const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      if (has_bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] += bv[nb];
+      }
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] += rv[nb][r];
+      }
+      with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
+        constexpr int act = decltype(ACT)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[0][nb][r], act)), rsrc_out,
+                                                c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
+          acc[0][nb][r] = 0.f;
+        }
+      });
+    }
+  };
+  auto wg_barrier = [&]() __attribute__((always_inline)) {       // LDS writes of this wave done, then everybody's
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto step = [&](auto BUFI) __attribute__((always_inline)) -> void {
+    constexpr int bi = decltype(BUFI)::value;
+    const unsigned char* st = lds + bi * BUF;
+    bf16x8 fa[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fa[pl][s] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + a_rd[s]);
+    if (c_kt == nk - 1 && (has_res | has_bias)) epi_loads();
+    // smallest terms first per accumulator; sub-steps and column blocks alternate (consecutive MFMAs are independent).  The staging
+    // of the NEXT step (split + LDS writes) and the global loads of the one after sit between the two halves of the MFMA chain.
+#define AOT_X6R_TERM(PA, PB)                                                                                  \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)             \
+      acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][s], fb[bi][PB][s], acc[s][nb], 0, 0, 0);
+    AOT_X6R_TERM(1, 1)
+    AOT_X6R_TERM(0, 2)
+    AOT_X6R_TERM(2, 0)
+    stage_write(std::integral_constant<int, bi ^ 1>{});          // the step after this one: registers -> the other buffer
+    gload();                                                     // the step after that: global -> registers
+    gload_b(std::integral_constant<int, bi ^ 1>{});              // the next step's weight fragments -> the other register set
+    AOT_X6R_TERM(0, 1)
+    AOT_X6R_TERM(1, 0)
+    AOT_X6R_TERM(0, 0)
+#undef AOT_X6R_TERM
+    if (++c_kt == nk) {
+      epilogue();
+      c_kt = 0;
+      ++c_i;
+    }
+    wg_barrier();
+  };
+  gload();
+  stage_write(std::integral_constant<int, 0>{});
+  gload();
+  gload_b(std::integral_constant<int, 0>{});
+  wg_barrier();
+#pragma unroll 1
+  for (int ss = 0; ss < total; ss += 2) {
+    step(std::integral_constant<int, 0>{});
+    if (ss + 1 < total) step(std::integral_constant<int, 1>{});
+  }
+}
+
 // ---- the 128x128 tile in two PHASE-SHIFTED wave groups ("ping-pong"; round 5) ------------------------------------------------
 // gemm_x6w_kernel's eight waves all walk the same sequence inside a k-step -- weight fragments, split, MFMAs -- so the matrix pipe
 // idles while every wave reads and splits, and the vector pipe idles while every wave multiplies: the steady state of that kernel
@@ -2276,6 +2555,25 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
   AOT_LAUNCH_CHECK();
 }
 
+// split-K over the grid on the 64x64 register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>)
+int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch) {
+  if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if (ksplit < 2 || (p.K / BK) % ksplit != 0 || !scratch || (long)p.M * p.Cout * 4 >= 0x7fffffffL) return AOT_ERR_BADARG;
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64) * ksplit;
+  const int grid = nit < 1024 ? nit : 1024;                  // (the split-K form needs 118 registers: four workgroups per CU)
+  if (p.KH == 1 && p.KW == 1 && p.pad == 0)
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch);
+  else
+    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch);
+  const long n = (long)p.M * ((p.Cout + 3) >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+  AOT_LAUNCH_CHECK();
+}
+
 int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms, int ksplit, float* scratch) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
@@ -2291,6 +2589,19 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
       hipLaunchKernelGGL((gemm_x6r_kernel<true, 2, 1>), dim3(gr), dim3(256), 0, s, p, wr);
     else
       hipLaunchKernelGGL((gemm_x6r_kernel<false, 2, 1>), dim3(gr), dim3(256), 0, s, p, wr);
+    AOT_LAUNCH_CHECK();
+  }
+  if (tile == 66) {             // the register-staged 64x64 form with the weight fragments straight from global memory
+    if (terms != 6 || ksplit != 1) return AOT_ERR_BADARG;
+    X6Weight wr;
+    wr.w6 = w6;
+    wr.cout_pad = cout_pad;
+    const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+    const int gr = nit < 768 ? nit : 768;
+    if (p.KH == 1 && p.KW == 1 && p.pad == 0)
+      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wr, 1, nullptr);
+    else
+      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wr, 1, nullptr);
     AOT_LAUNCH_CHECK();
   }
   if (tile == 129) {            // the register-staged 128x128 form: eight waves, one workgroup per CU
@@ -2335,11 +2646,12 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
   // (>= 200 tiles, rounds >= 70 % full: the 3x3 convolutions of the decoder at the 4x map), whose activation rows it re-reads half as
   // often across the filter taps.  The LDS-DMA kernels (tiles 64 / 128 / 256) stay in the library: tile 1 = the round-4 rule.
   const int rounds = (nwide + 255) / 256;
-  const bool wide = tile == 128 || (tile == 0 && p.KH * p.KW > 1 && p.Cout >= 128 && nwide >= 200 &&
-                                    (rounds == 1 || 10 * nwide >= 7 * 256 * rounds)) ||
+  // (with the weight fragments straight from global memory -- tile 66, profiles/r05_x6rd.txt -- the 64x64 form also beats the 128x128
+  //  one on the 4x map at three lanes, 139.7 vs 146.0 us; the 128x128 tile keeps the KxK layers that fill ONE dispatch round with it)
+  const bool wide = tile == 128 || (tile == 0 && p.KH * p.KW > 1 && p.Cout >= 128 && nwide >= 200 && rounds == 1) ||
                     // tile 1 = the round-4 rule (A/B runs: AOT_X6_TILE=1): 128x128 wherever it fills the chip, else the LDS-DMA 64x64 kernel
                     (tile == 1 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
-  if (tile == 0) return launch_gemm_x6(p, w6, cout_pad, wide ? 129 : 65, s, terms, ksplit, scratch);
+  if (tile == 0) return launch_gemm_x6(p, w6, cout_pad, wide ? 129 : 66, s, terms, ksplit, scratch);
   if (wide) {
     const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
     if (is1x1)

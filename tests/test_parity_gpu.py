@@ -181,7 +181,7 @@ def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, re
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-@pytest.mark.parametrize('tile', [64, 65, 128, 129, 256])
+@pytest.mark.parametrize('tile', [64, 65, 66, 128, 129, 256])
 def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
     the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
@@ -273,6 +273,13 @@ def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, ac
         assert torch.isnan(t65[:, Cout:]).all(), 'wrote outside the logical columns'
     for _ in range(3):
         assert torch.equal(run(65)[:, :Cout], t65[:, :Cout])
+    # ... its form with the weight fragments straight from global memory (tile = 66)
+    t66 = run(66)
+    assert torch.equal(t64[:, :Cout], t66[:, :Cout]), 'the direct-weight register-staged kernel differs from the 64x64 kernel'
+    if ldb > Cout:
+        assert torch.isnan(t66[:, Cout:]).all(), 'wrote outside the logical columns'
+    for _ in range(3):
+        assert torch.equal(run(66)[:, :Cout], t66[:, :Cout])
     # ... and its 128x128 form (tile = 129) against the LDS-DMA 128x128 kernel
     t129 = run(129)
     assert torch.equal(wide[:, :Cout], t129[:, :Cout]), 'the register-staged 128x128 kernel differs from the 128x128 kernel'
@@ -296,6 +303,17 @@ def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, ac
         else:
             assert float((out[:, :Cout] - pp[:, :Cout]).abs().max()) <= 1e-5 * scale, 'split-K %d differs from the unsplit result' % ks
             _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'split-K %d' % ks)
+        if ldb > Cout:
+            assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+    # split-K on the 64x64 register-staged kernel with direct weight fragments (ksplit < 0 selects it)
+    for ks in (2, 3, 4, 8):
+        if nk % ks:
+            continue
+        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+        hip.conv2d_x6k(xt, wk, bd, out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
+                       ksplit=-ks)
+        assert float((out[:, :Cout] - pp[:, :Cout]).abs().max()) <= 1e-5 * scale, '64x64 split-K %d differs from the unsplit result' % ks
+        _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, '64x64 split-K %d' % ks)
         if ldb > Cout:
             assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
     # repeats are bit-identical (no order-dependent state between the phase-shifted groups)

@@ -14,12 +14,13 @@ g = torch.Generator(device='cuda').manual_seed(1)
 q = torch.randn(N, C, device='cuda', generator=g) * 2.0
 k = torch.randn(MMAX * N, C, device='cuda', generator=g); v = torch.randn(MMAX * N, C, device='cuda', generator=g)
 out, out6 = torch.empty(N, C, device='cuda'), torch.empty(N, C, device='cuda')
-part = torch.empty(4 * N * (C + 2 * H), device='cuda')
+part = torch.empty(12 * N * (C + 2 * H), device='cuda')
 bank = aot_hip.x6_bank(1, MMAX * N, C, 'cuda')
 for slot in range(MMAX):                                     # frame by frame, as the engine appends
     aot_hip.attention_pack_x6(k[slot * N:(slot + 1) * N], v[slot * N:(slot + 1) * N], bank, N, slot=slot)
 torch.cuda.synchronize()
 SWEEP = len(sys.argv) > 2 and sys.argv[2] == 'sweep'
+SWEEP2 = len(sys.argv) > 2 and sys.argv[2] == 'sweep2'       # round 5: wider grid splits of the x6 kernel (three waves per SIMD)
 QUICK = len(sys.argv) > 2 and sys.argv[2] == 'quick'       # A/B of kernel variants: two bank sizes, planned split, no extras
 
 
@@ -39,10 +40,10 @@ def ref64(T):
     return (torch.softmax(qh @ kh, -1) @ vh).permute(1, 0, 2).reshape(N, C)
 
 
-for M in ((4, 14) if QUICK else (1, 2, 4, 8, 14)):
+for M in ((4, 14) if QUICK else (2, 4, 7, 10, 14) if SWEEP2 else (1, 2, 4, 8, 14)):
     T = M * N if M != 2 else 2 * N - 13            # (one ragged length: partial last tile)
     ref = ref64(T)
-    for ns in ((1, 2, 3, 4) if SWEEP else (attn_splits(N, H, T, wg_waves=4),)):
+    for ns in ((1, 2, 3, 4) if SWEEP else (1, 2, 3, 4, 5, 6, 7, 9, 12) if SWEEP2 else (attn_splits(N, H, T, wg_waves=4),)):
         if ns > max(1, (T // 32) // 16):
             continue
         pt = part if ns > 1 else None
@@ -54,7 +55,7 @@ for M in ((4, 14) if QUICK else (1, 2, 4, 8, 14)):
         e32, e6 = float((out.double() - ref).abs().max()), float((out6.double() - ref).abs().max())
         print('M=%2d T=%5d ns=%d  fp32 %7.1f us (%5.1f TF)  x6 %7.1f us (%5.1f TF-eq)  x%.2f   max err vs fp64: fp32 %.2e  x6 %.2e  (x6 run-to-run %.1e)'
               % (M, T, ns, t32, 4.0 * N * T * C / t32 * 1e-6, t6, 4.0 * N * T * C / t6 * 1e-6, t32 / t6, e32, e6, rep), flush=True)
-if QUICK:
+if QUICK or SWEEP2:
     sys.exit(0)
 # pack cost, two lanes, device-side slot
 us = timed(lambda: aot_hip.attention_pack_x6(k[:N], v[:N], bank, N, slot=3))

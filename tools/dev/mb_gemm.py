@@ -56,14 +56,14 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
             else:
                 def run():
                     aot_hip.conv2d_x6p(aot_hip.split3(x), w6n, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
-        elif str(c).startswith('x6z') and len(c) > 3:      # x6zN = the phase-shifted 128x128 kernel with split-K N
-            ks = int(c[3:])
-            if Cin % 32 or (KK // 32) % ks: row.append('      -      -'); continue
+        elif (str(c).startswith('x6z') or str(c).startswith('x6k')) and len(c) > 3:      # x6zN = the phase-shifted 128x128 kernel with split-K N; x6kN = the 64x64 direct-weight kernel with split-K N
+            ks = int(c[3:]) * (-1 if c.startswith('x6k') else 1)
+            if Cin % 32 or (KK // 32) % abs(ks): row.append('      -      -'); continue
             aot_hip.pack_bf16x6(w)
             def run():
                 aot_hip.conv2d_x6k(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH, ksplit=ks)
         elif str(c).startswith('x6'):      # x6 = tile by shape, x6n = 64x64 forced, x6w = 128x128 forced, x6z = 128x128 phase-shifted
-            aot_hip.X6_TILE = {'x6': 0, 'x6o': 1, 'x6n': 64, 'x6r': 65, 'x6w': 128, 'x6s': 129, 'x6z': 256}[c]
+            aot_hip.X6_TILE = {'x6': 0, 'x6o': 1, 'x6n': 64, 'x6r': 65, 'x6d': 66, 'x6w': 128, 'x6s': 129, 'x6z': 256}[c]
             def run():        # (layers that do not qualify fall back to the fp32 dispatch inside conv2d, as in the engine)
                 with aot_hip.use_gemm_table('throughput', 'bf16x6'):
                     aot_hip.conv2d(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
