@@ -26,6 +26,7 @@
 // Numerics: v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fmaf chain; results differ from an fp32 reference by
 // summation order only.
 #include "conv_params.h"
+#include <cstdlib>
 #include <type_traits>
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -2651,7 +2652,11 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
   const bool wide = tile == 128 || (tile == 0 && p.KH * p.KW > 1 && p.Cout >= 128 && nwide >= 200 && rounds == 1) ||
                     // tile 1 = the round-4 rule (A/B runs: AOT_X6_TILE=1): 128x128 wherever it fills the chip, else the LDS-DMA 64x64 kernel
                     (tile == 1 && p.Cout >= 128 && nwide >= 150 && (rounds == 1 || 10 * nwide >= 7 * 256 * rounds));
-  if (tile == 0) return launch_gemm_x6(p, w6, cout_pad, wide ? 129 : 66, s, terms, ksplit, scratch);
+  if (tile == 0) {
+    // (development switch for A/B runs in one process tree: AOT_X6_DEF64=65 makes the both-operands-staged kernel the 64x64 default)
+    static const int def64 = [] { const char* e = getenv("AOT_X6_DEF64"); return (e && atoi(e) == 65) ? 65 : 66; }();
+    return launch_gemm_x6(p, w6, cout_pad, wide ? 129 : def64, s, terms, ksplit, scratch);
+  }
   if (wide) {
     const int grid = nwide < 256 ? nwide : 256;               // one 8-wave workgroup per CU
     if (is1x1)

@@ -46,7 +46,8 @@ BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 (same guide)
 
 
 X6_WHAT = ('conv / linear layers with >= %d tiles of 64x64 on aot_conv2d_bf16x6_f32 (three truncated bf16 planes per operand, six of the '
-           'nine partial products, fp32 accumulation); long-term and self-attention on aot_attn_x6_f32 (aot_gated_attn_x6_f32 for DeAOT) '
+           'nine partial products, fp32 accumulation; register-staged tile kernels gemm_x6rd / gemm_x6r, split-K through '
+           'aot_conv2d_bf16x6k_f32 for the long-K layers of under-filled maps); long-term and self-attention on aot_attn_x6_f32 (aot_gated_attn_x6_f32 for DeAOT) '
            'over the memory bank kept pre-split by aot_attn_pack_x6_f32; everything else as in the fp32 family')
 
 
