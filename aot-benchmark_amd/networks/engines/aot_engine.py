@@ -544,10 +544,23 @@ class AOTEngine(nn.Module):
         if self.input_size_2d is None:
             self.update_size(img.size()[2:] if img is not None else mask.size()[2:], (h, w))
         if self.pos_emb is None:
-            self.pos_emb = to_tokens(self.AOT.get_pos_emb(as_map(x16, h, w)).contiguous(
+            pos = to_tokens(self.AOT.get_pos_emb(as_map(x16, h, w)).contiguous(
                 memory_format=torch.channels_last)).contiguous()
+            # (kept at ONE address per geometry for the engine's lifetime -- like everything a replayed stage reads: a tensor of its
+            #  own per clip would give every clip new graph keys and a new round of captures)
+            key = ('pos_emb', tuple(pos.shape))
+            buf = self._static.get(key)
+            if buf is None:
+                buf = self._static[key] = torch.empty_like(pos)
+            buf.copy_(pos)
+            self.pos_emb = buf
             if hasattr(self.AOT.LSTT, 'prepare_pos') and not os.environ.get('AOT_NO_QKV_MERGE'):     # AOT: the position term of the merged Q|K|V product, once per clip (env: A/B runs)
-                self.AOT.LSTT.prepare_pos(self.pos_emb, aot_hip.stream_ptr())
+                key = ('pos_qkv', tuple(pos.shape))
+                outs = self._static.get(key)
+                if outs is None:
+                    outs = self._static[key] = [torch.empty(pos.shape[0], 3 * pos.shape[1], dtype=torch.float32, device=pos.device)
+                                                for _ in self.AOT.LSTT.layers]
+                self.AOT.LSTT.prepare_pos(self.pos_emb, aot_hip.stream_ptr(), outs)
         id_emb = self.assign_identity(mask)
         self.curr_id_embs = id_emb
         stream = aot_hip.stream_ptr()

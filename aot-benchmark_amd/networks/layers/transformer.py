@@ -88,12 +88,13 @@ class LongShortTermTransformerBlock(nn.Module):
         self._p = p
         return p
 
-    def prepare_pos(self, pos, stream=None):
+    def prepare_pos(self, pos, stream=None, out=None):
         """[pos Wq + bq | pos Wk + bk | bv] for a clip's position embedding pos [N, C]: the residual map of the merged Q|K|V product.
-        Launched from the host once per clip (never inside a graph capture)."""
+        Launched from the host once per clip (never inside a graph capture); out: the caller's [N, 3C] buffer (stable address)."""
         p = self.pack()
         N, C = pos.shape
-        out = torch.empty(N, 3 * C, dtype=torch.float32, device=pos.device)
+        if out is None:
+            out = torch.empty(N, 3 * C, dtype=torch.float32, device=pos.device)
         aot_hip.linear(pos, p['sa_qk_w'], p['sa_qk_b'], out[:, :2 * C], stream=stream)
         out[:, 2 * C:] = p['sa_v_b']
         return out
@@ -267,10 +268,10 @@ class LongShortTermTransformer(nn.Module):
                 d.copy_(x)
         return out_cat, mems
 
-    def prepare_pos(self, pos, stream=None):
+    def prepare_pos(self, pos, stream=None, outs=None):
         """Once per clip, from the host: every layer's [pos Wq + bq | pos Wk + bk | bv], kept on the position tensor itself (the
-        engine passes the same tensor every frame; the maps go when it goes)."""
-        pos._aot_pos_qkv = [layer.prepare_pos(pos, stream) for layer in self.layers]
+        engine passes the same tensor every frame; the maps go when it goes).  outs: per-layer [N, 3C] buffers of the caller."""
+        pos._aot_pos_qkv = [layer.prepare_pos(pos, stream, outs[i] if outs is not None else None) for i, layer in enumerate(self.layers)]
         return pos
 
     def update_values(self, mems, id_sums, ws, stream, dst=None):
