@@ -65,8 +65,13 @@ int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const 
  * the dropped terms are <= 3 * 2^-24 of the product, one fp32 rounding.  aot_pack_bf16x6_f32 splits a weight w [K, ldb]
  * (K % 32 == 0; the layout aot_conv2d_nhwc_f32 takes) once into w6 = three bf16 planes in the kernel's tile order,
  * 3 * K * cout_pad * 2 bytes, cout_pad = Cout rounded up to 64.  aot_conv2d_bf16x6_f32 is aot_conv2d_nhwc_f32 on that weight
- * (same arguments and epilogue; needs Cin % 32 == 0; activations are split on the fly; tile = 0: the 128x128 eight-wave
- * kernel where the layer has >= 128 output channels and >= 192 such tiles, else the 64x64 one; 64 / 128 force one).  An engine opts in
+ * (same arguments and epilogue; needs Cin % 32 == 0; activations are split on the fly).  `tile` selects the member: 0 = by shape
+ * (round 5: the register-staged 64x64 kernel with the weight fragments straight from global memory, 66, everywhere except KxK layers
+ * with >= 128 output channels whose 128x128 tiles fill exactly one dispatch round -- those take the register-staged 128x128 form,
+ * 129); 64 / 128 = the LDS-DMA tile kernels of rounds 3-4; 65 = register-staged 64x64 with both operands through LDS; 256 = the
+ * phase-shifted 128x128 LDS-DMA form; 1 = the round-4 rule (64 / 128 by shape).  All members form the same six products in the same
+ * order per accumulator: same-tile members are bit-identical, 64- and 128-wide members differ by nothing either (the accumulation
+ * order over k does not depend on the tile).  An engine opts in
  * (build_engine(..., mfma='bf16x6'); bench.py times this arithmetic by default since round 4), and results are reported under their own dtype string.
  * Replaces the same reference code as aot_conv2d_nhwc_f32. */
 int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
@@ -78,7 +83,8 @@ int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const f
  * ALUs work at the same time; bit-identical to tile = 128.  aot_conv2d_bf16x6k_f32 is that form with split-K over the grid for
  * layers whose 128x128 tiles alone do not fill the chip (the stride-16 maps): (K / 32) % ksplit == 0, every k-slice writes its raw
  * partial tile to a slab of `scratch` ([ksplit][M][Cout] floats, scratch_floats = its size), one more launch sums the slabs in
- * slice order and applies bias / residual / activation.  ksplit = 1: no scratch needed.
+ * slice order and applies bias / residual / activation.  ksplit = 1: no scratch needed.  ksplit < -1: |ksplit| slices on the 64x64
+ * register-staged kernel with direct weight fragments instead (gemm_x6rd_kernel<., true>; the K = 1024 linear of the LSTT at one lane).
  * Replaces the same reference code as aot_conv2d_nhwc_f32. */
 int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
