@@ -37,6 +37,8 @@ _SIGS = {
     'aot_groupnorm_stats_f32': [_P] * 4 + [_I] * 5 + [_F, _I, _P],
     'aot_groupnorm_apply_f32': [_P] * 6 + [_I] * 9 + [_P],
     'aot_gn_act_dwconv5_f32': [_P] * 6 + [_I] * 8 + [_P],
+    'aot_linear_gn_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P, _L, _P],
+    'aot_gn_act_dwconv5p_f32': [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_F, _P],
     'aot_attn_f32': [_P] * 5 + [_I, _L, _I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
     'aot_attn_pack_x6_f32': [_P] * 3 + [_I, _L, _I, _L, _I, _I, _L, _P, _I, _P],
@@ -689,6 +691,36 @@ def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corne
     _chk(load().aot_logits_finalize_f32(_dev(logits), _opt(out4), _opt(out), G, IH, IW, C, logits.stride(0), OH, OW,
                                         obj_total, int(align_corners), stream if stream is not None else stream_ptr()),
          'aot_logits_finalize_f32')
+
+
+def x6_gn_fusable(M, K, Cout, B=1):
+    """True where linear_gn_x6 + gn_act_dwconv5_part may replace linear + groupnorm_stats + gn_act_dwconv5: a bf16x6 scope with the
+    kernel choice left open, one lane, 32-channel groups on a layer the family takes anyway."""
+    stack = _scopes.stack
+    return bool(stack and stack[-1][1] and X6_TILE == 0 and B == 1 and K % 32 == 0 and Cout % 32 == 0 and
+                -(-M // 64) * -(-Cout // 64) >= X6_MIN_TILES)
+
+
+def linear_gn_x6(x, w, bias, out, part, res=None, act=ACT_NONE, res_rows=0, stream=None):
+    """out[M, N] = act(x @ w + bias (+ res)) on the bf16x6 family, and the GroupNorm partial sums of out (32-channel groups) into
+    `part` [2 * ceil(M / 64) * N / 32 * 2] floats from the same tile end (aot_linear_gn_bf16x6_f32).  Returns P, the partial rows."""
+    M, K = x.shape
+    N = out.shape[1]
+    w6 = getattr(w, '_aot_w6', None)
+    if w6 is None:
+        w6 = pack_bf16x6(w)
+    _chk(load().aot_linear_gn_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), M, K, N, x.stride(0),
+                                         out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, _dev(part), part.numel(),
+                                         stream if stream is not None else stream_ptr()), 'aot_linear_gn_bf16x6_f32')
+    return 2 * (-(-M // 64))
+
+
+def gn_act_dwconv5_part(x, gamma, beta, w, out, groups, part, P, H, W, act=ACT_GELU, eps=1e-5, stream=None):
+    """gn_act_dwconv5 with the statistics taken from the producing GEMM's partial sums (linear_gn_x6; one lane)."""
+    _chk(load().aot_gn_act_dwconv5p_f32(_dev(x), _dev(part), P, _dev(gamma), _dev(beta), _dev(w), _dev(out), H, W, x.shape[1], groups,
+                                        x.stride(0), out.stride(0), act, eps, stream if stream is not None else stream_ptr()),
+         'aot_gn_act_dwconv5p_f32')
+    return out
 
 
 def frame_tail(logits, out4, label_out, label_in, IH, IW, C, obj_total, align_corners, stream=None):

@@ -30,6 +30,8 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
 int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit = 1, float* scratch = nullptr);
 // split-K over the grid on the 64x64 register-staged kernel with the weight fragments straight from global memory
 int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch);
+// a linear layer on the same kernel whose tile end also writes GroupNorm partial sums: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats
+int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part);
 // activations pre-split into three bf16 planes (p.in reinterpreted: [3][B*H*W][lda] bf16), weight packed in natural k order
 // out_planes != nullptr: the result is written as three bf16 planes [3][M][ldp] instead of fp32 (p.out unused)
 int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s, void* out_planes = nullptr, int ldp = 0);

@@ -746,6 +746,24 @@ extern "C" int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_
   return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch);
 }
 
+// out = act(x W + bias (+ res)) on the bf16x6 family AND the GroupNorm partial sums of `out` (32-channel groups) from the same tile
+// end: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats (sum, sum of squares per 32-row block and group; gn_part_floats = its size)
+extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                                        int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, float* gn_part,
+                                        long gn_part_floats, void* stream) {
+  if (!in || !w6 || !out || !gn_part || M <= 0 || K <= 0 || Cout <= 0) return AOT_ERR_BADARG;
+  if ((lda & 3) || lda < K || ldc < Cout || (K % 32) || (Cout % 32)) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if (gn_part_floats < 2L * ((M + 63) / 64) * (Cout / 32) * 2) return AOT_ERR_BADARG;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
+  p.B = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = M; p.K = K; p.act = act;
+  return launch_gemm_x6rd_gn(p, w6, cout_pad, (hipStream_t)stream, gn_part);
+}
+
 extern "C" int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
                                    int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                                    int dil, int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, void* stream) {

@@ -1788,8 +1788,14 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 // SK: split-K over the grid (item = (tile, k-slice); raw partial tiles to fp32 slabs [ksplit][M][Cout], summed in slice order by
 // splitk_reduce_kernel): the long-K 3x3 layers on the stride-16 map have 108-316 tiles of 72 k-steps each -- too few workgroups,
 // too long a chain.
-template <bool IS1X1, bool SK>
+// GN (not with SK; `scratch` then carries the partial-sum buffer): the tile end also writes the GroupNorm partial sums of its output --
+// every wave owns a 32-row x 32-column block, i.e. 32 rows of ONE 32-channel group: (sum, sum of squares) of the block's valid
+// elements (fp32, the stored values themselves) -> gn_part[(2 * tile row + wave row) * (Cout / 32) + column block][2].  The consumer
+// (gn_act_dwconv5_kernel<true>) adds the partials of a group in index order in double: the statistics pass over the whole map and its
+// launch are gone (linear1 -> GN -> GELU -> dw5x5 of the LSTT's feed-forward, transformer.py:355-362 / basic.py:15-35).
+template <bool IS1X1, bool SK, bool GN = false>
 __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
+  static_assert(!(SK && GN), "GroupNorm partials come from the unsplit form");
   constexpr int WM = 2, NBW = 1;
   constexpr int NT = 128 * WM;                            // threads: WM x 2 waves
   constexpr int BM = 32 * WM, BN = 64 * NBW;
@@ -1997,16 +2003,27 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][nb][r] += rv[nb][r];
       }
+      float ps = 0.f, pq = 0.f;
       with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
         constexpr int act = decltype(ACT)::value;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = (r & 3) + 8 * (r >> 2);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[0][nb][r], act)), rsrc_out,
-                                                c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
+          const float v = apply_act(acc[0][nb][r], act);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
+          if (GN && c < rows_left && col_ok) { ps += v; pq += v * v; }
           acc[0][nb][r] = 0.f;
         }
       });
+      if (GN) {          // the wave's 32 x 32 block = 32 rows of one group: fixed butterfly over the 64 lanes, lane 0 writes
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ps += __shfl_xor(ps, off); pq += __shfl_xor(pq, off); }
+        if (lane == 0) {
+          float* dst = scratch + ((long)(it.bm * 2 + (wave >> 1)) * (p.Cout >> 5) + ((it.bn * BN + wn + 32 * nb) >> 5)) * 2;
+          dst[0] = ps;
+          dst[1] = pq;
+        }
+      }
     }
   };
   auto wg_barrier = [&]() __attribute__((always_inline)) {       // LDS writes of this wave done, then everybody's
@@ -2553,6 +2570,20 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
     hipLaunchKernelGGL((gemm_x6pp_kernel<true, false>), dim3(grid), dim3(512), 0, s, p, wq, 1, nullptr);
   else
     hipLaunchKernelGGL((gemm_x6pp_kernel<false, false>), dim3(grid), dim3(512), 0, s, p, wq, 1, nullptr);
+  AOT_LAUNCH_CHECK();
+}
+
+// linear layer on the 64x64 direct-weight kernel whose tile end also writes GroupNorm partial sums (gemm_x6rd_kernel<true, false, true>)
+int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part) {
+  if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if (!gn_part || (p.Cout & 31) || !(p.KH == 1 && p.KW == 1 && p.pad == 0)) return AOT_ERR_BADARG;
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nit < 768 ? nit : 768;
+  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part);
   AOT_LAUNCH_CHECK();
 }
 

@@ -210,17 +210,49 @@ extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, cons
 // (basic.py:15-35) after the statistics pass, i.e. gn -> GELU -> conv in one launch.  A workgroup owns an 8x8 output
 // tile of one (lane, group): the 12x12 input halo is normalised and activated ONCE per element on its way into LDS (the
 // conv zero-pads AFTER the activation), then every thread (pixel, 8 channels) walks the 25 taps out of LDS.
+// PART (round 5): the statistics arrive as the PARTIAL sums the producing GEMM's tile end wrote (aot_linear_gn_bf16x6_f32:
+// part[P][G][2] floats, one (sum, sum of squares) per 32-row block and group; one lane): every workgroup adds its group's P partials
+// in double -- thread t takes partials t, t + 256, ... in index order, then a fixed tree over the 256 threads: the same bits in every
+// workgroup and every run -- and forms (mean, rstd) exactly as gn_stats_kernel does.  The statistics launch and its pass over the map
+// are gone.
+template <bool PART>
 __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ w, float* __restrict__ out, int H,
-                                                             int W, int C, int G, int ldx, int ldo, int act, int tiles_x) {
+                                                             int W, int C, int G, int ldx, int ldo, int act, int tiles_x,
+                                                             const float* __restrict__ part, int P, float eps) {
   constexpr int TH = 8, TW = 8, R = 2, IH = TH + 2 * R, IW = TW + 2 * R, CB = 32;
   __shared__ __attribute__((aligned(16))) float tile[IH * IW][CB + 4];    // +4: rows 36 floats apart (bank spread)
   __shared__ __attribute__((aligned(16))) float wk[25][CB];
   const int g = blockIdx.y, bl = blockIdx.z;
   const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
   const int t = threadIdx.x;
-  const float mean = (float)stats[((long)bl * G + g) * 2], rstd = (float)stats[((long)bl * G + g) * 2 + 1];
+  float mean, rstd;
+  if (PART) {
+    __shared__ double red[2][256];
+    double ps = 0.0, pq = 0.0;
+    for (int i = t; i < P; i += 256) {
+      ps += (double)part[((long)i * G + g) * 2];
+      pq += (double)part[((long)i * G + g) * 2 + 1];
+    }
+    red[0][t] = ps;
+    red[1][t] = pq;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) { red[0][t] += red[0][t + off]; red[1][t] += red[1][t + off]; }
+      __syncthreads();
+    }
+    const double cnt = (double)H * W * CB;
+    const double m = red[0][0] / cnt;
+    double var = red[1][0] / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    mean = (float)stats[((long)bl * G + g) * 2];
+    rstd = (float)stats[((long)bl * G + g) * 2 + 1];
+  }
   const float* xb = x + (long)bl * H * W * ldx + g * CB;
   const int c4 = t & 7;                          // channel quad of the group
   const float4 ga = *reinterpret_cast<const float4*>(gamma + g * CB + c4 * 4);
@@ -272,8 +304,21 @@ extern "C" int aot_gn_act_dwconv5_f32(const float* x, const double* stats, const
     return AOT_ERR_BADARG;
   if (C != G * 32 || B > 65535 || G > 65535) return AOT_ERR_UNSUPPORTED;
   const int tx = cdiv(W, 8), ty = cdiv(H, 8);
-  hipLaunchKernelGGL(gn_act_dwconv5_kernel, dim3(tx * ty, G, B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, w,
-                     out, H, W, C, G, ldx, ldo, act, tx);
+  hipLaunchKernelGGL(gn_act_dwconv5_kernel<false>, dim3(tx * ty, G, B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, w,
+                     out, H, W, C, G, ldx, ldo, act, tx, (const float*)nullptr, 0, 0.f);
+  AOT_LAUNCH_CHECK();
+}
+
+// the same with the statistics taken from the producing GEMM's partial sums (one lane): part [P][G][2] floats
+extern "C" int aot_gn_act_dwconv5p_f32(const float* x, const float* part, int P, const float* gamma, const float* beta,
+                                       const float* w, float* out, int H, int W, int C, int G, int ldx, int ldo, int act,
+                                       float eps, void* stream) {
+  if (!x || !part || P <= 0 || !gamma || !beta || !w || !out || H <= 0 || W <= 0 || C <= 0 || G <= 0 || (ldx & 3) || (ldo & 3))
+    return AOT_ERR_BADARG;
+  if (C != G * 32 || G > 65535) return AOT_ERR_UNSUPPORTED;
+  const int tx = cdiv(W, 8), ty = cdiv(H, 8);
+  hipLaunchKernelGGL(gn_act_dwconv5_kernel<true>, dim3(tx * ty, G, 1), dim3(256), 0, (hipStream_t)stream, x, (const double*)nullptr,
+                     gamma, beta, w, out, H, W, C, G, ldx, ldo, act, tx, part, P, eps);
   AOT_LAUNCH_CHECK();
 }
 

@@ -11,6 +11,8 @@ Per-layer launch sequence of the AOT block (N = h*w):
   (both write halves of one [B*N, 512] buffer) -> one K=512 GEMM = proj_lt + proj_st (+residual)
   LN3 -> linear1 GEMM -> GroupNorm statistics -> [GN-apply + GELU + 5x5 depthwise conv] -> linear2 GEMM (+residual)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -171,8 +173,18 @@ class LongShortTermTransformerBlock(nn.Module):
         aot_hip.layernorm(xb, *p['norm3'], x3, stream=stream)
         F1 = self.dim_ff
         f = ws.get('ffn_a', (M, F1), dev)
-        aot_hip.linear(x3, p['w1'], p['b1'], f, stream=stream)
         g = ws.get('ffn_b', (M, F1), dev)
+        if F1 == 32 * 32 and aot_hip.x6_gn_fusable(M, C, F1, B) and not os.environ.get('AOT_NO_GN_FUSE'):
+            # bf16x6, one lane: linear1's tile end writes the GroupNorm partial sums, the fused GN + GELU + dw5x5 kernel adds them up
+            # in its prologue -- no statistics launch, no extra pass over the [M, 1024] map
+            part = ws.get('ffn_gnpart', (2 * ((M + 63) // 64) * 32 * 2,), dev)
+            P = aot_hip.linear_gn_x6(x3, p['w1'], p['b1'], f, part, stream=stream)
+            aot_hip.gn_act_dwconv5_part(f, *p['gn'], p['dw'], g, 32, part, P, h, w, act=aot_hip.ACT_GELU, eps=self.activation.gn.eps,
+                                        stream=stream)
+            out = ws.get('layer_out_%d' % id(self), (M, C), dev)
+            aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
+            return out, qc, x2, fused_v
+        aot_hip.linear(x3, p['w1'], p['b1'], f, stream=stream)
         if F1 == 32 * 32:
             aot_hip.gn_act_dwconv5(f, *p['gn'], p['dw'], g, 32, aot_hip.gn_buffers(ws, dev, B, 32, 8), h, w,
                                    act=aot_hip.ACT_GELU, nsplit=8, B=B, stream=stream)

@@ -165,6 +165,19 @@ int aot_gn_act_dwconv5_f32(const float* x, const double* stats, const float* gam
                            const float* w, float* out, int B, int H, int W, int C, int G, int ldx, int ldo,
                            int act, void* stream);
 
+/* The statistics pass folded into the producing GEMM (round 5): aot_linear_gn_bf16x6_f32 is a linear layer of the bf16x6 family
+ * (out = act(x W + bias (+ res)), x [M, lda], w6 from aot_pack_bf16x6_f32, Cout % 32 == 0) whose tile end ALSO writes the GroupNorm
+ * partial sums of `out` for 32-channel groups: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats = (sum, sum of squares) of every
+ * 32-row x 32-column block (gn_part_floats = the buffer's size).  aot_gn_act_dwconv5p_f32 is aot_gn_act_dwconv5_f32 (one lane) that
+ * takes those P = 2 * ceil(M / 64) partial rows instead of finished statistics: every workgroup adds its group's partials in index
+ * order in double and forms (mean, rstd) as aot_groupnorm_stats_f32 does -- deterministic, no statistics launch, no extra pass over
+ * the map.  Replaces linear1 + GNActDWConv2d of the LSTT's feed-forward (networks/layers/transformer.py:355-362, basic.py:15-35). */
+int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                             int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, float* gn_part,
+                             long gn_part_floats, void* stream);
+int aot_gn_act_dwconv5p_f32(const float* x, const float* part, int P, const float* gamma, const float* beta, const float* w,
+                            float* out, int H, int W, int C, int G, int ldx, int ldo, int act, float eps, void* stream);
+
 /* Multi-head softmax attention over a key/value bank, flash style (no S materialised):
  *   out[n, h*d:(h+1)*d] = softmax_t( (q[n,h]/scale_div) . k[t,h] ) @ v[t,h]          (d == 32)
  * B independent lanes (object groups of one frame, or clips): lane b owns query rows [b*Nq, (b+1)*Nq) of q / out

@@ -350,6 +350,49 @@ def test_frame_tail_bit_identical(hip, IH, IW, OH, OW, LH, LW, C, objs, align):
         assert torch.equal(l3, lab)
 
 
+@pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
+def test_gn_partials_from_gemm_tile_end(hip, h, w):
+    """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
+    GEMM's tile end, added up in the consumer's prologue -- against the three-launch path (linear, statistics pass, fused GN + GELU +
+    dw5x5): the linear output bit-identical, the partials' totals equal to a double-precision sum of that output to 1e-6 of its
+    scale, the final map within 2e-5 of its scale; repeats bit-identical."""
+    g = torch.Generator().manual_seed(h * 100 + w)
+    M, K, N = h * w, 256, 1024
+    x = _dev(torch.randn(M, K, generator=g))
+    wk = hip.attach_wt(_dev(torch.randn(K, N, generator=g) / K ** 0.5), K)
+    b = _dev(torch.randn(N, generator=g))
+    gamma, beta = _dev(torch.randn(N, generator=g)), _dev(torch.randn(N, generator=g))
+    dw = _dev(torch.randn(25, N, generator=g) / 5)
+    ws = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace()
+    with hip.use_gemm_table('throughput', 'bf16x6'):
+        assert hip.x6_gn_fusable(M, K, N) == (-(-M // 64) * (N // 64) >= hip.X6_MIN_TILES)
+        f0 = torch.empty(M, N, device='cuda')
+        hip.linear(x, wk, b, f0)
+        want = torch.empty(M, N, device='cuda')
+        hip.gn_act_dwconv5(f0, gamma, beta, dw, want, 32, hip.gn_buffers(ws, x.device, 1, 32, 8), h, w, act=hip.ACT_GELU, nsplit=8)
+        f1 = torch.full((M, N), float('nan'), device='cuda')
+        part = torch.full((2 * ((M + 63) // 64) * 32 * 2,), float('nan'), device='cuda')
+        P = hip.linear_gn_x6(x, wk, b, f1, part)
+        got = torch.empty(M, N, device='cuda')
+        hip.gn_act_dwconv5_part(f1, gamma, beta, dw, got, 32, part, P, h, w, act=hip.ACT_GELU)
+    assert torch.equal(f0, f1), 'the tile end with partial sums changed the linear output'
+    pp = part.view(P, 32, 2).double()
+    assert not torch.isnan(pp).any()
+    fd = f0.double().view(M, 32, 32)
+    scale = float(fd.abs().sum())
+    assert abs(float(pp[:, :, 0].sum() - fd.sum())) <= 1e-6 * scale
+    assert float((pp[:, :, 0].sum(0) - fd.sum((0, 2))).abs().max()) <= 1e-6 * scale
+    assert float((pp[:, :, 1].sum(0) - (fd * fd).sum((0, 2))).abs().max()) <= 1e-6 * float((fd * fd).sum())
+    s = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= 2e-5 * s, float((got - want).abs().max())
+    again = torch.empty(M, N, device='cuda')
+    with hip.use_gemm_table('throughput', 'bf16x6'):
+        part2 = torch.empty_like(part)
+        hip.linear_gn_x6(x, wk, b, f1, part2)
+        hip.gn_act_dwconv5_part(f1, gamma, beta, dw, again, 32, part2, P, h, w, act=hip.ACT_GELU)
+    assert torch.equal(part, part2) and torch.equal(again, got)
+
+
 def test_linear_strided_views(hip):
     """column slices of wider buffers as A, C and residual (how the LSTT avoids concat/split copies)."""
     g = torch.Generator().manual_seed(5)
