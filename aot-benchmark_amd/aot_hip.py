@@ -24,6 +24,7 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
+    'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_split3_bf16_f32': [_P, _P, _L, _I, _I, _I, _L, _P],
     'aot_pack_bf16x6n_f32': [_P, _P, _I, _I, _I, _I, _P],
@@ -249,6 +250,9 @@ def pack_bf16x6_all():
     for w in list(_gemm_weights or ()):
         if w.is_cuda and w.dim() == 2 and w.shape[0] % 32 == 0 and getattr(w, '_aot_w6', None) is None:
             pack_bf16x6(w)
+        taps = getattr(w, '_aot_c4_taps', 0)
+        if w.is_cuda and taps and getattr(w, '_aot_w6c4', None) is None:
+            pack_bf16x6_c4(w, taps)
 
 
 def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE,
@@ -278,6 +282,34 @@ def conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0
                                     (stack[-1][0] if stack else -1) if cfg == -1 else cfg,
                                     stream if stream is not None else stream_ptr()), 'aot_conv2d_nhwc_f32')
     return out
+
+
+def pack_bf16x6_c4(w, taps):
+    """The bf16x6 planes of a four-channel KxK weight w [taps * 4, ld] for aot_conv2d_c4_bf16x6_f32: rows zero-padded to eight taps per
+    k-step, then aot_pack_bf16x6_f32; kept on the tensor (`_aot_w6c4`).  Not inside a graph capture (pack_bf16x6_all() covers it)."""
+    w6 = getattr(w, '_aot_w6c4', None)
+    if w6 is not None:
+        return w6
+    if torch.cuda.is_current_stream_capturing():
+        raise AotHipError('a four-channel weight reached the bf16x6 path unpacked inside a graph capture: call aot_hip.pack_bf16x6_all() first')
+    kp = -(-taps // 8) * 32
+    wp = torch.zeros(kp, w.shape[1], dtype=torch.float32, device=w.device)
+    wp[:taps * 4] = w[:taps * 4]
+    w._aot_w6c4 = pack_bf16x6(wp)
+    return w._aot_w6c4
+
+
+def conv2d_c4(x, w, bias, out, H, W, OH, OW, Cout, KH, KW, stride, pad, dil=1, act=ACT_NONE, B=1, stream=None):
+    """KxK convolution of B four-channel NHWC images [B*H*W, 4] (the ResNet stem).  In a bf16x6 scope with the kernel choice left
+    open: aot_conv2d_c4_bf16x6_f32 (one chunk = one filter tap); otherwise the fp32 dispatch of conv2d."""
+    stack = _scopes.stack
+    if stack and stack[-1][1] and X6_TILE == 0 and Cout > 32 and x.stride(0) == 4 and not os.environ.get('AOT_NO_C4'):
+        w6 = pack_bf16x6_c4(w, KH * KW)
+        _chk(load().aot_conv2d_c4_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _dev(out), B, H, W, OH, OW, Cout, KH, KW,
+                                             stride, pad, dil, out.stride(0), act, stream if stream is not None else stream_ptr()),
+             'aot_conv2d_c4_bf16x6_f32')
+        return out
+    return conv2d(x, w, bias, out, H, W, 4, OH, OW, Cout, KH, KW, stride, pad, dil, act=act, B=B, stream=stream)
 
 
 _x6k_ws = None

@@ -32,6 +32,8 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
 int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch);
 // a linear layer on the same kernel whose tile end also writes GroupNorm partial sums: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats
 int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part);
+// a KxK convolution on four input channels (Cin = lda = 4: the ResNet stem) on the same kernel; w6: K rounded up to 8 taps per k-step
+int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);
 // activations pre-split into three bf16 planes (p.in reinterpreted: [3][B*H*W][lda] bf16), weight packed in natural k order
 // out_planes != nullptr: the result is written as three bf16 planes [3][M][ldp] instead of fp32 (p.out unused)
 int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s, void* out_planes = nullptr, int ldp = 0);

@@ -764,6 +764,24 @@ extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cou
   return launch_gemm_x6rd_gn(p, w6, cout_pad, (hipStream_t)stream, gn_part);
 }
 
+// KxK convolution of B four-channel NHWC images (the ResNet stem: the image padded to r, g, b, 0) in the bf16x6 family: one 16-byte chunk
+// of an im2col row = one filter tap, eight taps per k-step; w6 = aot_pack_bf16x6_f32 of the weight [Kp, ldb] with rows k = 4 * tap +
+// channel and Kp = ceil(KH * KW / 8) * 32 (zero rows past KH * KW * 4)
+extern "C" int aot_conv2d_c4_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, float* out, int B, int H, int W,
+                                        int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int ldc, int act,
+                                        void* stream) {
+  if (!in || !w6 || !out || B <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || ldc < Cout)
+    return AOT_ERR_BADARG;
+  if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = 4; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.lda = 4; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = 0; p.res_rows = 0;
+  p.M = B * OH * OW; p.K = KH * KW * 4; p.act = act;
+  return launch_gemm_x6rd_c4(p, w6, cout_pad, (hipStream_t)stream);
+}
+
 extern "C" int aot_conv2d_bf16_f32(const float* in, const void* wq, int cout_pad, const float* bias, const float* res, float* out,
                                    int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                                    int dil, int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, void* stream) {

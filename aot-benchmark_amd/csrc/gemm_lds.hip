@@ -1793,9 +1793,14 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 // elements (fp32, the stored values themselves) -> gn_part[(2 * tile row + wave row) * (Cout / 32) + column block][2].  The consumer
 // (gn_act_dwconv5_kernel<true>) adds the partials of a group in index order in double: the statistics pass over the whole map and its
 // launch are gone (linear1 -> GN -> GELU -> dw5x5 of the LSTT's feed-forward, transformer.py:355-362 / basic.py:15-35).
-template <bool IS1X1, bool SK, bool GN = false>
+// C4 (the ResNet stem, 7x7 stride 2 on the image padded to FOUR channels): Cin = 4 makes one 16-byte chunk of the A row exactly one
+// filter tap (r, g, b, 0 of one input pixel), so a k-step is eight taps instead of 32 channels of one tap: the thread's two chunks are
+// two taps with a bounds check each; K = KH * KW * 4 rounded up to 32 (the weight rows past it are zero: aot_pack_bf16x6_f32 of the
+// zero-padded matrix).  The last big layer that was still on the fp32 matrix cores in bf16x6 engines.
+template <bool IS1X1, bool SK, bool GN = false, bool C4 = false>
 __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
   static_assert(!(SK && GN), "GroupNorm partials come from the unsplit form");
+  static_assert(!C4 || (!IS1X1 && !SK && !GN), "the four-channel form: a KxK layer, unsplit");
   constexpr int WM = 2, NBW = 1;
   constexpr int NT = 128 * WM;                            // threads: WM x 2 waves
   constexpr int BM = 32 * WM, BN = 64 * NBW;
@@ -1810,7 +1815,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int nbn = (p.Cout + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int nk = SK ? (p.K / BK) / ksplit : p.K / BK;            // k-steps per item (host guarantees divisibility)
+  const int nk = C4 ? (p.KH * p.KW + 7) / 8 : SK ? (p.K / BK) / ksplit : p.K / BK;      // k-steps per item (host guarantees divisibility)
   const int nitems = nbm * nbn * (SK ? ksplit : 1);
   const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // XCD-aware item order, as in gemm_lds_kernel
   const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
@@ -1836,7 +1841,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   };
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32 * NBW;
   const int hw_out = p.OH * p.OW;
-  const int plane_bytes = (p.K / 8) * wq.cout_pad * 16;
+  const int plane_bytes = (C4 ? nk * 4 : p.K / 8) * wq.cout_pad * 16;
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((long)p.B * p.H * p.W * p.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
@@ -1874,7 +1879,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
     const int oy = pix / p.OW, ox = pix - oy * p.OW;
     a_iy0 = oy * p.stride - p.pad;
     a_ix0 = ox * p.stride - p.pad;
-    a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + 4 * c0) * 4;
+    a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + (C4 ? 0 : 4 * c0)) * 4;
     if (IS1X1 && !a_ok) a_off = (int)OOB;
     s_k = SK ? it.kt0 * BK * 4 : 0;
     if (!IS1X1) {
@@ -1890,6 +1895,18 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   };
   auto gload = [&]() __attribute__((always_inline)) {            // global -> registers, the next step not yet staged
     if (is_kt == 0) setup_item(is_i);
+    if (C4) {            // chunk = tap: taps 8 is_kt + c0 and + 2 of the filter, each inside the image or not
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int tap = 8 * is_kt + c0 + 2 * j;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int iy = a_iy0 + ky * p.dil, ix = a_ix0 + kx * p.dil;
+        const bool in = a_ok & (tap < p.KH * p.KW) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        sa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, in ? a_off + ((ky * p.dil * p.W + kx * p.dil) * p.lda) * 4 : (int)OOB, 0, 0);
+      }
+      if (++is_kt == nk) { is_kt = 0; ++is_i; }
+      return;
+    }
     int voff = a_off;
     if (!IS1X1) {
       const int iy = a_iy0 + tap_ky * p.dil, ix = a_ix0 + tap_kx * p.dil;
@@ -2584,6 +2601,24 @@ int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipSt
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
   hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part);
+  AOT_LAUNCH_CHECK();
+}
+
+// a KxK convolution on FOUR input channels (the ResNet stem) on the 64x64 direct-weight kernel: w6 = the planes of the weight
+// [ceil(KH * KW / 8) * 32, ld] (rows k = 4 * tap + channel, zero rows past KH * KW * 4)
+int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s) {
+  if (!w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15) || ((uintptr_t)p.in & 15)) return AOT_ERR_UNSUPPORTED;
+  if (p.Cin != 4 || p.lda != 4 || p.KH * p.KW <= 1) return AOT_ERR_UNSUPPORTED;
+  const int nk = (p.KH * p.KW + 7) / 8;
+  if ((long)p.B * p.H * p.W * 16 >= 0x7fffffffL || (long)p.M * p.ldc * 4 >= 0x7fffffffL || 3L * nk * 4 * cout_pad * 16 >= 0x7fffffffL ||
+      (p.res && (long)(p.res_rows ? p.res_rows : p.M) * p.ldr * 4 >= 0x7fffffffL))
+    return AOT_ERR_UNSUPPORTED;
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nit < 768 ? nit : 768;
+  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
   AOT_LAUNCH_CHECK();
 }
 

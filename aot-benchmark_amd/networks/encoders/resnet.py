@@ -113,12 +113,13 @@ class ResNet(nn.Module):
         dev = img.device
         if self._stem is None:
             self._stem = fold_conv_bn(self.conv1, self.bn1, pad_cin=4)
+            self._stem[0]._aot_c4_taps = 49          # (bf16x6 engines: its four-channel planes are packed by pack_bf16x6_all; fold_conv_bn registered it)
         x4 = ws.get('img_nhwc4', (B * H * W, 4), dev)
         H1, W1 = _osz(H, 7, 2, 3), _osz(W, 7, 2, 3)
         for b in range(B):
             aot_hip.nchw_to_nhwc(img[b:b + 1], x4[b * H * W:(b + 1) * H * W], 3, H, W, 4, stream=stream)
         s1 = ws.get('stem', (B * H1 * W1, 64), dev)
-        aot_hip.conv2d(x4, *self._stem, s1, H, W, 4, H1, W1, 64, 7, 7, 2, 3, 1, act=aot_hip.ACT_RELU, B=B, stream=stream)
+        aot_hip.conv2d_c4(x4, *self._stem, s1, H, W, H1, W1, 64, 7, 7, 2, 3, 1, act=aot_hip.ACT_RELU, B=B, stream=stream)
         H2, W2 = _osz(H1, 3, 2, 1), _osz(W1, 3, 2, 1)
         x = ws.get('pool', (B * H2 * W2, 64), dev)
         for b in range(B):

@@ -90,6 +90,12 @@ int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const 
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                            int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
                            void* stream);
+/* The ResNet stem in the same family (round 5): a KxK convolution of B NHWC images with FOUR channels (the image padded to r, g, b, 0 by
+ * aot_nchw_to_nhwc_f32): one 16-byte chunk of an im2col row is one filter tap, a k-step is eight taps.  w6 = aot_pack_bf16x6_f32 of the
+ * weight [Kp, ldb] with rows k = 4 * tap + channel, Kp = ceil(KH * KW / 8) * 32, zero rows past KH * KW * 4.  in [B*H*W, 4], out
+ * [B*OH*OW, ldc].  Replaces conv1 + bn1 + relu of networks/encoders/resnet.py:140-143. */
+int aot_conv2d_c4_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, float* out, int B, int H, int W,
+                             int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int ldc, int act, void* stream);
 
 /* The member of the same family that takes its activations ALREADY SPLIT (experimental in round 4: called by tests and
  * tools/dev/mb_gemm.py only, no engine stage hands over split activations yet).  aot_split3_bf16_f32: x [M, ldx] fp32 -> three

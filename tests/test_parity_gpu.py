@@ -393,6 +393,42 @@ def test_gn_partials_from_gemm_tile_end(hip, h, w):
     assert torch.equal(part, part2) and torch.equal(again, got)
 
 
+@pytest.mark.parametrize('H,W,B,K,s,p', [(481, 849, 1, 7, 2, 3), (129, 161, 3, 7, 2, 3), (65, 67, 2, 3, 2, 1), (40, 33, 1, 5, 1, 2)])
+def test_conv2d_c4_bf16x6_stem(hip, H, W, B, K, s, p):
+    """aot_conv2d_c4_bf16x6_f32 (round 5): the ResNet stem -- a KxK convolution of four-channel NHWC images, one 16-byte chunk of an
+    im2col row = one filter tap -- in the bf16x6 family: the family's tolerance against fp64 (2e-5 of the output scale) and never
+    further from it than 4x the fp32 kernel's own error + 1e-6; nothing written outside the logical columns; repeats bit-identical."""
+    g = torch.Generator().manual_seed(H + 7 * K)
+    Cout = 64
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(Cout, 3, K, K, generator=g) / (3 * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), s, p)).float()
+    OH, OW = ref.shape[2:]
+    wk = torch.zeros(K * K * 4, Cout)
+    wk.view(K * K, 4, Cout)[:, :3] = w.permute(2, 3, 1, 0).reshape(K * K, 3, Cout)
+    wk = _dev(wk)
+    x4 = torch.zeros(B * H * W, 4)
+    x4[:, :3] = x.permute(0, 2, 3, 1).reshape(B * H * W, 3)
+    x4 = _dev(x4)
+    outs = {}
+    for mode in ('f32', 'bf16x6'):
+        out = torch.full((B * OH * OW, Cout + 4), float('nan'), device='cuda')
+        with hip.use_gemm_table('throughput', mode):
+            hip.conv2d_c4(x4, wk, _dev(b), out[:, :Cout], H, W, OH, OW, Cout, K, K, s, p, 1, act=hip.ACT_RELU, B=B)
+        assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+        outs[mode] = out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    scale = max(1.0, ref.abs().max().item())
+    e32 = (outs['f32'].double() - ref.double()).abs().max().item()
+    e6 = _close(outs['bf16x6'], ref, 2e-5 * scale, 'four-channel bf16x6 conv')
+    assert not torch.equal(outs['f32'], outs['bf16x6']), 'the bf16x6 stem did not run'
+    assert e6 <= 4 * e32 + 1e-6 * scale, 'bf16x6 error %g vs fp32-kernel error %g' % (e6, e32)
+    again = torch.empty(B * OH * OW, Cout, device='cuda')
+    with hip.use_gemm_table('throughput', 'bf16x6'):
+        hip.conv2d_c4(x4, wk, _dev(b), again, H, W, OH, OW, Cout, K, K, s, p, 1, act=hip.ACT_RELU, B=B)
+    assert torch.equal(again.cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), outs['bf16x6'])
+
+
 def test_linear_strided_views(hip):
     """column slices of wider buffers as A, C and residual (how the LSTT avoids concat/split copies)."""
     g = torch.Generator().manual_seed(5)
