@@ -674,3 +674,32 @@ def test_no_inplace_crossed_packed_ops(tmp_path):
     assert r.returncode == 1 and r.stdout.count('v_pk_') == 1 and 'v_pk_add_f32 v[0:1]' in r.stdout
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dev', 'isa_pk_inplace_audit.py'), '--strict', str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and r.stdout.count('v_pk_') == 2 and 'v_pk_mul_f32 v[2:3], v[2:3]' in r.stdout
+
+
+def test_bf16x6_split_k_rule_and_feature_slices():
+    """Host logic of round 5, no device needed: aot_hip.x6_ksplit -- which layers of the 480p frame go to a split-K kernel, and to which
+    (positive = slices on the phase-shifted 128x128 kernel, negative = on the 64x64 direct-weight kernel) -- and the per-frame slices of
+    a batch of encoder features incl. the decoder's adapter maps (networks.models.aot.Feats)."""
+    import torch
+    import aot_hip
+    from networks.models.aot import Feats
+    ks = aot_hip.x6_ksplit
+    assert ks(3 * 1674, 256, 2304) == 3          # l3.c2 3x3 at three lanes: 80 tiles of 128x128 -> 240 workgroups
+    assert ks(1674, 256, 2304) == 9              # ... at one lane: 28 tiles -> 252
+    assert ks(6527, 128, 2304) == 4              # dec c8 at one lane: 51 tiles -> 204
+    assert ks(3 * 6527, 128, 2304) == 1          # ... at three lanes: 153 tiles fill the chip alone
+    assert ks(1674, 256, 1024) == -2             # the LSTT's linear2 at one lane: two slices on the 64x64 kernel
+    assert ks(3 * 1674, 256, 1024) == 1 and ks(1674, 256, 256) == 1 and ks(25773, 128, 1152) == 1
+    for m, c, k in ((5022, 256, 2304), (1674, 256, 2304), (6527, 128, 2304), (1674, 256, 1024)):
+        n = abs(ks(m, c, k))
+        assert (k // 32) % n == 0 and n * m * c <= aot_hip.X6K_SCRATCH_FLOATS
+    B = 3
+    dims = [(8, 6, 5), (16, 4, 3), (32, 2, 2)]     # (channels, h, w) of f4, f8, f16
+    maps = [(torch.arange(B * h * w * c, dtype=torch.float32).view(B * h * w, c), h, w) for c, h, w in dims]
+    f = Feats(maps + [(torch.zeros(B * 2 * 2, 7), 2, 2)])
+    f.ads = (torch.arange(B * 4 * 9.).view(B * 4, 9), torch.arange(B * 12 * 9.).view(B * 12, 9), torch.arange(B * 30 * 5.).view(B * 30, 5))
+    one = f.frame(1)
+    assert isinstance(one, list) and len(one) == 4 and [t.shape[0] for t, _, _ in one] == [30, 12, 4, 4]
+    assert torch.equal(one[0][0], maps[0][0][30:60]) and torch.equal(one[2][0], maps[2][0][4:8])
+    assert torch.equal(one.ads[0], f.ads[0][4:8]) and torch.equal(one.ads[1], f.ads[1][12:24]) and torch.equal(one.ads[2], f.ads[2][30:60])
+    assert Feats(maps).frame(0).ads is None
