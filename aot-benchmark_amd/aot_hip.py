@@ -605,9 +605,9 @@ def gated_attention_x6(q, bank, gate, out, T, scale_div, part=None, nsplit=1, T_
     _chk(lib.aot_gated_attn_x6_f32(_dev(q), _dev(kp), _dev(vp), _opt(gate), _dev(out), _opt(part), B, cap, nq, T, _opt(T_dev),
                                    q.shape[1], dv, q.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0),
                                    scale_div, nsplit, s), 'aot_gated_attn_x6_f32')
-    if nsplit > 1:
+    if abs(nsplit) > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), _opt(gate), _dev(out), q.shape[0], dv // 256, dv,
-                                    gate.stride(0) if gate is not None else 0, out.stride(0), nsplit, s), 'aot_attn_merge_f32')
+                                    gate.stride(0) if gate is not None else 0, out.stride(0), abs(nsplit), s), 'aot_attn_merge_f32')
     return out
 
 

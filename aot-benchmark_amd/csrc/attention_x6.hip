@@ -545,6 +545,266 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide_coop_kernel(const GatedX6
   }
 }
 
+
+// ---- round 6: the 64-query form ---------------------------------------------------------------------------------------------------
+// What bounds the 32-query kernel above is the bank's way INTO the CU, not the matrix pipe: per key tile a workgroup pulls
+// 32 x 1152 x 6 B = 221 KB for 4 x 108 MFMAs = 3456 cycles per SIMD -- 64 B per clock and CU, which is the L2's whole rate
+// (34.5 TB/s over 256 CUs; MI355X_MICROARCH.md) -- and it is measured at a third of that (profiles/r03z_attn_pmc.txt: matrix pipe
+// 27 %, waves parked on V 38 %).  Here a workgroup owns TWO query tiles: every V fragment a wave fetches feeds the MFMAs of both
+// (the A operand stays in its registers; only the B operand P changes), so the same bytes buy twice the matrix work -- 32 B per
+// clock and CU at the full MFMA rate.  Wave w still contracts channels [32 w, 32 w + 32) of q . k, now for both tiles (24 MFMAs;
+// the partial score tiles meet in LDS in wave order, as 16-byte accesses), and owns value blocks [8 w, 8 w + 8) for both:
+// 2 x 8 x 16 = 256 accumulator registers (the whole AGPR half of the unified file) + <= 256 VGPRs, one wave per SIMD.  A V block
+// now covers 24 MFMAs = 768 cycles, so NVB = 3 sets (two blocks ahead) hide what five sets hid before.
+// Block order: the grid is ONE dimension and XCD-major -- block id -> XCD id % 8 (the dispatcher's round robin), and the
+// (lane, key range, query pair) triples are dealt so that each XCD gets a CONTIGUOUS run of them in key-range-major order: an
+// XCD's L2 then streams one or two key ranges instead of all of them (the 32-query kernel's order made every XCD pull the whole
+// bank: 1.3-1.4x the algorithmic bytes on the fabric side in bf16x6 form, 9x in the fp32 twin).
+// The score tile of the 64-query kernel must NOT live in accumulator registers: its 256 AGPRs are the 2 x 8 output blocks, and hipcc
+// selects the AGPR form for every MFMA of a kernel that uses AGPRs at all (16 more would spill the output blocks around each score
+// chain: 486 dwords of scratch in the first build).  The hardware takes a VGPR destination just as well, so the 24 score MFMAs of a
+// key tile are written by hand with "v" constraints.  Hazards the compiler no longer sees (LLVM's gfx940 table, confirmed on the
+// hardware in round 4, profiles/r04_mfma_hazard_probe.txt): dependent MFMAs on one accumulator issue back to back; a VALU / LDS
+// store reading the result needs 12 wait states after the last MFMA of the chain -> mfma_vgpr_settle() (16 states, once per chain);
+// the A / B operands come from loads or loop-invariant registers (s_waitcnt is placed from the register operands as for any asm).
+__device__ __forceinline__ void mfma_bf16_v(const bf16x8& a, const bf16x8& b, f32x16& acc) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_bf16_v0(const bf16x8& a, const bf16x8& b, f32x16& acc) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+template <bool FIRST>
+__device__ __forceinline__ void mfma6_vgpr(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& acc) {
+  if (FIRST) mfma_bf16_v0(a[1], b[1], acc); else mfma_bf16_v(a[1], b[1], acc);
+  mfma_bf16_v(a[0], b[2], acc);
+  mfma_bf16_v(a[2], b[0], acc);
+  mfma_bf16_v(a[0], b[1], acc);
+  mfma_bf16_v(a[1], b[0], acc);
+  mfma_bf16_v(a[0], b[0], acc);
+}
+__device__ __forceinline__ void mfma_vgpr_settle(f32x16& acc) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc)); }
+
+#ifndef AOT_GX6_NVB
+#define AOT_GX6_NVB 3
+#endif
+template <int NVB>
+__global__ void __launch_bounds__(256, 1) attn_x6_wide64_kernel(const GatedX6Params p) {
+  constexpr int NDV = 8, PS = 20;       // PS: floats per lane of a partial score tile in LDS (16 + 4 of padding: conflict-free b128)
+  const int ntq = (p.Nq + 63) >> 6;
+  int split, b, qt;
+  {
+    const int total = p.B * p.nsplit * ntq, per = (total + 7) >> 3;
+#ifdef AOT_GX6_LINEAR      // development A/B: dispatch order = (lane, query pair, key range), ranges fastest, as the 32-query kernel
+    const int lin = blockIdx.x;
+    if (lin >= total) return;
+    const int pair = ((lin / p.nsplit) / ntq * p.nsplit + lin % p.nsplit) * ntq + (lin / p.nsplit) % ntq;
+    (void)per;
+#else
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd * per + slot;
+    if (slot >= per || pair >= total) return;
+#endif
+    qt = pair % ntq;
+    const int bs = pair / ntq;
+    split = bs % p.nsplit;
+    b = bs / p.nsplit;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int t0 = min(T, split * tps * 32);
+  const int t1 = min(T, t0 + tps * 32);
+  const long qrow0 = (long)b * p.Nq;
+  const long cap_tiles = p.cap_rows >> 5;
+  __shared__ float part[2][2][4][64 * PS];     // [buffer][query tile][wave][lane][score register]
+
+  bf16x8 qp[2][2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qrow = min(qt * 64 + t * 32 + j, p.Nq - 1);
+    const float* src = p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
+                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
+      split3(x, qp[t][c]);
+    }
+  }
+  const unsigned short* kbase = p.kp + ((long)b * cap_tiles * 4 + wave) * 3072 + lane * 8;
+  const unsigned short* vbase = p.vp + ((long)b * cap_tiles * 32 + wave * NDV) * 3072 + lane * 8;
+
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  f32x16 o[2][NDV];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][d][r] = 0.f;
+
+  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
+    const unsigned short* src = kbase + min((long)(kt >> 5), cap_tiles - 1) * (4 * 3072);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto load_v = [&](bf16x8 (&vf)[2][3], int kt, int d) {
+    const unsigned short* src = vbase + min((long)(kt >> 5), cap_tiles - 1) * (32 * 3072) + d * 3072;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
+  };
+  auto qk_part = [&](const bf16x8 (&kf)[2][3], int buf) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 sc;
+      mfma6_vgpr<true>(kf[0], qp[t][0], sc);
+      mfma6_vgpr<false>(kf[1], qp[t][1], sc);
+      mfma_vgpr_settle(sc);
+      float4* dst = reinterpret_cast<float4*>(&part[buf][t][wave][lane * PS]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dst[g] = make_float4(sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]);
+    }
+  };
+
+  bf16x8 ka[2][3], vb[NVB][2][3];
+  if (t0 < t1) {
+    load_k(ka, t0);
+    qk_part(ka, 0);
+    load_k(ka, t0 + 32);
+  }
+  __syncthreads();
+  int it = 0;
+  auto step = [&](int kt) {
+    const int buf = it & 1;
+#pragma unroll
+    for (int d = 0; d < NVB - 1; ++d) load_v(vb[d], kt, d);
+    bf16x8 pp[2][2][3];
+    float alpha[2];
+    bool moved = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      __builtin_amdgcn_sched_barrier(0);      // one query tile at a time: hipcc otherwise hoists both tiles' 32 LDS reads (128 registers)
+      float sc[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {      // fixed wave order: every wave of the workgroup gets the same bits
+        const float4 a0 = *reinterpret_cast<const float4*>(&part[buf][t][0][lane * PS + 4 * g]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&part[buf][t][1][lane * PS + 4 * g]);
+        const float4 a2 = *reinterpret_cast<const float4*>(&part[buf][t][2][lane * PS + 4 * g]);
+        const float4 a3 = *reinterpret_cast<const float4*>(&part[buf][t][3][lane * PS + 4 * g]);
+        sc[4 * g] = ((a0.x + a1.x) + a2.x) + a3.x;
+        sc[4 * g + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
+        sc[4 * g + 2] = ((a0.z + a1.z) + a2.z) + a3.z;
+        sc[4 * g + 3] = ((a0.w + a1.w) + a2.w) + a3.w;
+      }
+      if (kt + 32 > t1) {      // the range's last, partial tile (wave-uniform; ONE loop body: a second, masked copy of the step
+#pragma unroll                // made hipcc spill half the accumulators at the join)
+        for (int r = 0; r < 16; ++r)
+          if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
+      }
+      const float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
+                            max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
+      const float mnew = fmaxf(m[t], fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+      alpha[t] = __builtin_amdgcn_exp2f(m[t] - mnew);
+      moved = moved || (mnew > m[t]);
+      m[t] = mnew;
+      l[t] *= alpha[t];
+      float pf[16], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -mnew));
+        ps += pf[r];
+      }
+      l[t] += ps;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float x8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
+        split3(x8, pp[t][c]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of everything above but the LDS buffer
+    load_k(ka, kt + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (__any(moved)) {              // (rare after the first tiles of a range)
+      // explicit AGPR reads / writes, as in attn_fwd_wide_coop_kernel (attention.hip): as plain C++ the rescale makes hipcc move the
+      // accumulators through VGPRs around the branch on every key tile -- with 256 of them, 429 dwords of scratch
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            float a0, a1;
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a0), "=v"(a1) : "a"(o[t][d][r]), "a"(o[t][d][r + 1]));
+            a0 *= alpha[t];
+            a1 *= alpha[t];
+            float w0, w1;
+            asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(w0), "=a"(w1) : "v"(a0), "v"(a1));
+            o[t][d][r] = w0;
+            o[t][d][r + 1] = w1;
+          }
+    }
+#pragma unroll
+    for (int d = 0; d < NDV; ++d) {
+      if (d + NVB - 1 < NDV) load_v(vb[(d + NVB - 1) % NVB], kt, d + NVB - 1);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        mfma6(vb[d % NVB][c], pp[0][c], o[0][d]);
+        mfma6(vb[d % NVB][c], pp[1][c], o[1][d]);
+      }
+    }
+    ++it;
+    __syncthreads();
+  };
+  for (int kt = t0; kt < t1; kt += 32) step(kt);
+
+  const long prow = (long)p.B * p.Nq;
+  const int cbase = wave * 32 * NDV + 4 * hi;
+  constexpr int CV = 32 * NDV * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float lt = l[t] + __shfl_xor(l[t], 32);
+    const int ql = qt * 64 + t * 32 + j;
+    if (ql >= p.Nq) continue;
+    const long qi = qrow0 + ql;
+    if (p.nsplit == 1) {
+      const float inv = 1.f / lt;
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v4 = make_float4(o[t][d][4 * g] * inv, o[t][d][4 * g + 1] * inv, o[t][d][4 * g + 2] * inv, o[t][d][4 * g + 3] * inv);
+          const int c = cbase + d * 32 + 8 * g;
+          if (p.gate) {
+            const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
+            v4.x *= u.x; v4.y *= u.y; v4.z *= u.z; v4.w *= u.w;
+          }
+          *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = v4;
+        }
+    } else {
+      float* dst = p.part + ((long)split * prow + qi) * CV;
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
+              make_float4(o[t][d][4 * g], o[t][d][4 * g + 1], o[t][d][4 * g + 2], o[t][d][4 * g + 3]);
+      if (hi == 0) {
+        float* ml = p.part + (long)p.nsplit * prow * CV + (((long)split * prow + qi) * 4 + wave) * 2;
+        ml[0] = m[t];
+        ml[1] = lt;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ===== C ABI ==============================================================================================================
@@ -595,11 +855,18 @@ extern "C" int aot_gated_attn_x6_f32(const float* q, const void* kp, const void*
   if ((ldq & 3) || (ldo & 3) || (gate && (ldg & 3)) || ((uintptr_t)q & 15) || ((uintptr_t)out & 15) || ((uintptr_t)kp & 15) ||
       ((uintptr_t)vp & 15))
     return AOT_ERR_BADARG;
+  const bool q32 = nsplit < 0;      // development A/B only (tools/dev/mb_gated_x6.py): the 32-query kernel of rounds 3-5
+  if (q32) nsplit = -nsplit;
   if (nsplit < 1 || (nsplit > 1 && !part)) return AOT_ERR_BADARG;
   GatedX6Params p;
   p.q = q; p.kp = (const unsigned short*)kp; p.vp = (const unsigned short*)vp; p.out = out; p.part = part; p.T_dev = T_dev;
   p.gate = (nsplit == 1) ? gate : nullptr;     // with splits the gate is applied by aot_attn_merge_f32
   p.Nq = Nq; p.T = T; p.ldq = ldq; p.ldg = ldg; p.ldo = ldo; p.nsplit = nsplit; p.B = B; p.cap_rows = cap_rows; p.scale_div = scale_div;
-  hipLaunchKernelGGL(attn_x6_wide_coop_kernel, dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+  if (q32) {
+    hipLaunchKernelGGL(attn_x6_wide_coop_kernel, dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    const int total = B * nsplit * cdiv(Nq, 64);
+    hipLaunchKernelGGL((attn_x6_wide64_kernel<AOT_GX6_NVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
+  }
   AOT_LAUNCH_CHECK();
 }

@@ -54,6 +54,15 @@ def gated_splits(nq, t, slots=512):
     return max(1, min(slots // max(qt, 1), tiles // 4, 16))
 
 
+def gated_splits_x6(nq, lanes, t, max_splits=16):
+    """Grid-level key split of the bf16x6 gated kernel (attn_x6_wide64_kernel, round 6): one 4-wave workgroup per (lane, 64 queries,
+    key range), one resident per CU.  Same rule as gated_splits(): the largest split whose grid fits one dispatch round of 256
+    workgroups, at least four key tiles per range (27 query pairs at 480p -> 9 ranges, 243 workgroups)."""
+    qt = lanes * ((nq + 63) // 64)
+    tiles = (t + 31) // 32
+    return max(1, min(256 // max(qt, 1), tiles // 4, max_splits))
+
+
 def _planned_len(t, nq, kv_brows):
     """Bank length a launch is PLANNED for: beyond the first memorised frame the launch geometry (the grid-level key split)
     follows the bank's CAPACITY (kv_brows: rows between lanes = rows of the pre-allocated bank), not its length of the
@@ -224,7 +233,7 @@ class GatedPropagation(nn.Module):
         t_plan = _planned_len(t, nq, kv_brows)
         use_x6 = x6 is not None and out.shape[1] == 1024 and q.shape[1] == 128
         if use_x6:
-            ns = gated_splits(nq * B, t_plan, slots=256)
+            ns = gated_splits_x6(nq, B, t_plan)
         else:
             ns = gated_splits(nq * B, t_plan) if out.shape[1] == 1024 else attn_splits(nq * B, out.shape[1] // 256, t_plan, occ=1, c0=1.0)
         part = None
