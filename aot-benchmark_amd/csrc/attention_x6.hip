@@ -587,6 +587,9 @@ __device__ __forceinline__ void mfma_vgpr_settle(f32x16& acc) { asm volatile("s_
 #ifndef AOT_GX6_NVB
 #define AOT_GX6_NVB 3
 #endif
+#ifndef AOT_GX6_PNVB
+#define AOT_GX6_PNVB 4
+#endif
 template <int NVB>
 __global__ void __launch_bounds__(256, 1) attn_x6_wide64_kernel(const GatedX6Params p) {
   constexpr int NDV = 8, PS = 20;       // PS: floats per lane of a partial score tile in LDS (16 + 4 of padding: conflict-free b128)
@@ -805,6 +808,290 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64_kernel(const GatedX6Par
   }
 }
 
+
+// ---- round 6, second form: the 64-query kernel as a SOFTWARE PIPELINE -------------------------------------------------------------
+// Measured (profiles/r06_gated64_first.txt): attn_x6_wide64_kernel takes ~13 000 cycles per key tile for 6912 cycles of MFMA even
+// when 27 workgroups have the chip to themselves -- the bound is the wave's own instruction stream, not the bank's way in: one wave
+// per SIMD issues in order, so the ~700 vector instructions of the two softmaxes + P splits (every wave repeats them) run with the
+// matrix pipe idle, and hipcc sinks the V fetches to a few MFMAs before their use.  This form removes both:
+//   * the softmax of key tile i + 1 runs INSIDE the value products of tile i.  The four waves share it: wave w sums the partial
+//     score tiles of query tile w >> 1 and the running maximum (both waves of a pair compute the same bits), exponentiates and
+//     splits only the eight score registers of sub-step w & 1, and publishes its three P planes (3 x 16 B per lane) and the rescale
+//     factor through LDS; after the tile's barrier every wave reads the 12 plane fragments of both query tiles straight into MFMA
+//     B operands.  ~130 vector instructions per wave and tile instead of ~700;
+//   * no branch inside a tile: out-of-range rows are masked by select on every tile (a range's last tile and the look-ahead tiles
+//     past it alike), so the whole tile is ONE scheduling region, cut by sched_barrier() into eight value blocks; each block's
+//     V fetch (three blocks ahead, four rotating register sets, across the tile boundary) and its share of the softmax / of the
+//     next-but-one tile's score MFMAs are pinned to it.
+// Row sums: wave (t, c) keeps the sum of ITS eight registers; the four (sub-step, lane half) pieces of a query meet once, at the end.
+template <int NVB>
+__global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Params p) {
+  static_assert(8 % NVB == 0, "the rotating V sets must divide the eight value blocks of a tile");
+  constexpr int NDV = 8, PS = 20;
+  const int ntq = (p.Nq + 63) >> 6;
+  int split, b, qt;
+  {
+    const int total = p.B * p.nsplit * ntq, per = (total + 7) >> 3;
+#ifdef AOT_GX6_LINEAR      // development A/B: dispatch order = (lane, query pair, key range), ranges fastest, as the 32-query kernel
+    const int lin = blockIdx.x;
+    if (lin >= total) return;
+    const int pair = ((lin / p.nsplit) / ntq * p.nsplit + lin % p.nsplit) * ntq + (lin / p.nsplit) % ntq;
+    (void)per;
+#else
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd * per + slot;
+    if (slot >= per || pair >= total) return;
+#endif
+    qt = pair % ntq;
+    const int bs = pair / ntq;
+    split = bs % p.nsplit;
+    b = bs / p.nsplit;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+  const int st = wave >> 1, sc_half = wave & 1;     // softmax role: query tile, sub-step
+  const int T = p.T_dev ? *p.T_dev : p.T;
+  const int ntile = (T + 31) >> 5;
+  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
+  const int t0 = min(T, split * tps * 32);
+  const int t1 = min(T, t0 + tps * 32);
+  const long qrow0 = (long)b * p.Nq;
+  const long cap_tiles = p.cap_rows >> 5;
+  __shared__ float part[2][2][4][64 * PS];        // [buffer][query tile][wave][lane][score register (+ pad)]
+  __shared__ u32x4 pbuf[2][2][2][3][64];           // [buffer][query tile][sub-step][plane][lane]: P^T as bf16 B-operand fragments
+  __shared__ float abuf[2][2][64];                 // [buffer][query tile][lane]: factor the accumulators take before that tile
+  __shared__ float lbuf[2][2][64], mbuf[2][64];    // end of the range: row-sum pieces [query tile][sub-step][lane], maxima
+
+  // Q^T planes of this wave's 32 channels, both query tiles: 12 fragments of 16 B per lane, parked in LDS (they are needed for 24 of
+  // a tile's 216 MFMAs; as registers they would cost the fourth V set)
+  __shared__ u32x4 qbuf[4][2][2][3][64];           // [wave][query tile][sub-step][plane][lane]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qrow = min(qt * 64 + t * 32 + j, p.Nq - 1);
+    const float* src = p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
+                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
+      bf16x8 q3[3];
+      split3(x, q3);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) qbuf[wave][t][c][pl][lane] = __builtin_bit_cast(u32x4, q3[pl]);
+    }
+  }
+  // bank fetches through buffer descriptors: ONE per-lane offset register (lane * 16), the (tile, block) part a scalar, the 1 KB
+  // chunk an immediate -- as 64-bit global addresses hipcc kept a dozen VGPR pairs alive for them.  The descriptors are based at
+  // the range's first tile of this wave's blocks (64-bit pointer arithmetic), so their 32-bit offsets see the range only
+  // (< 4 GB: checked by the entry point); tiles are clamped to the bank's capacity, never to the descriptor's size.
+  const long tile0 = t0 >> 5, tile_last = cap_tiles - 1 - tile0;      // (relative) last tile that exists
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(p.kp) + (((long)b * cap_tiles + tile0) * 4 + wave) * 3072, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(p.vp) + (((long)b * cap_tiles + tile0) * 32 + wave * NDV) * 3072, 0, 0xffffffff, 0x00020000);
+  const int lane_off = lane * 16;
+
+  float m = -INFINITY, l = 0.f;       // of query tile st, over the registers of sub-step sc_half
+  f32x16 o[2][NDV];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][d][r] = 0.f;
+
+  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {      // kt: key offset from t0
+    const int so = (int)min((long)(kt >> 5), tile_last) * (4 * 6144);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        kf[c][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, lane_off + (pl * 2 + c) * 1024, so, 0));
+  };
+  auto load_v = [&](bf16x8 (&vf)[2][3], int kt, int d) {
+    const int so = ((int)min((long)(kt >> 5), tile_last) * 32 + d) * 6144;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        vf[c][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, lane_off + (pl * 2 + c) * 1024, so, 0));
+  };
+  // partial score tile (this wave's 32 channels) of query tile t for the keys in kf -> LDS
+  auto qk_part = [&](const bf16x8 (&kf)[2][3], int buf, int t) {
+    bf16x8 qf[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) qf[c][pl] = __builtin_bit_cast(bf16x8, qbuf[wave][t][c][pl][lane]);
+    f32x16 sc;
+    mfma6_vgpr<true>(kf[0], qf[0], sc);
+    mfma6_vgpr<false>(kf[1], qf[1], sc);
+    mfma_vgpr_settle(sc);
+    float4* dst = reinterpret_cast<float4*>(&part[buf][t][wave][lane * PS]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[g] = make_float4(sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]);
+  };
+  // this wave's share of the softmax of the tile starting at key kt (scores in part[buf]) -> pbuf[buf], abuf[buf]; in three pieces
+  // so that the caller can spread them over value blocks
+  float sm_sc[16], sm_p[8];
+  auto softmax_a = [&](int buf, int kt) {      // sum of the four partial tiles, mask, maximum
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {      // fixed wave order: both waves of the pair get the same bits
+      const float4 a0 = *reinterpret_cast<const float4*>(&part[buf][st][0][lane * PS + 4 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&part[buf][st][1][lane * PS + 4 * g]);
+      const float4 a2 = *reinterpret_cast<const float4*>(&part[buf][st][2][lane * PS + 4 * g]);
+      const float4 a3 = *reinterpret_cast<const float4*>(&part[buf][st][3][lane * PS + 4 * g]);
+      sm_sc[4 * g] = ((a0.x + a1.x) + a2.x) + a3.x;
+      sm_sc[4 * g + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
+      sm_sc[4 * g + 2] = ((a0.z + a1.z) + a2.z) + a3.z;
+      sm_sc[4 * g + 3] = ((a0.w + a1.w) + a2.w) + a3.w;
+    }
+    const int rem = t1 - kt - 4 * hi;      // rows r of this lane with mfma32_row(r, 0) >= rem are past the range (rem <= 0: all)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (mfma32_row(r, 0) >= rem) sm_sc[r] = -INFINITY;
+  };
+  auto softmax_b = [&](int buf) {      // new maximum, rescale factor, the eight weights of this wave's sub-step, their sum
+    const float x = max3f(max3f(max3f(sm_sc[0], sm_sc[1], sm_sc[2]), max3f(sm_sc[3], sm_sc[4], sm_sc[5]), max3f(sm_sc[6], sm_sc[7], sm_sc[8])),
+                          max3f(sm_sc[9], sm_sc[10], sm_sc[11]), max3f(sm_sc[12], sm_sc[13], max3f(sm_sc[14], sm_sc[15], sm_sc[15])));
+    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
+    const float alpha = (m == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m - mnew);      // (m = -inf: nothing accumulated yet)
+    m = mnew;
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float sv = sc_half ? sm_sc[8 + i] : sm_sc[i];
+      sm_p[i] = (mnew == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, AOT_LOG2E, -mnew));
+      ps += sm_p[i];
+    }
+    l = l * alpha + ps;
+    abuf[buf][st][lane] = alpha;      // (both waves of the pair store the same value)
+  };
+  auto softmax_c = [&](int buf) {      // the three bf16 planes of the eight weights -> LDS
+    bf16x8 pl3[3];
+    split3(sm_p, pl3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) pbuf[buf][st][sc_half][pl][lane] = __builtin_bit_cast(u32x4, pl3[pl]);
+  };
+
+  bf16x8 ka[2][3], vb[NVB][2][3];
+  const int nt = (t1 - t0 + 31) >> 5;       // key tiles of this range
+  if (nt <= 0) {                            // empty range (more splits than tiles): an all-zero partial with m = -inf
+    // falls through to the epilogue with o = 0, l = 0, m = -inf
+  }
+  // prologue: scores of tile 0 -> softmax of tile 0 -> scores of tile 1; V of the first NVB - 1 blocks on their way
+  load_k(ka, 0);
+#pragma unroll
+  for (int d = 0; d < NVB - 1; ++d) load_v(vb[d], 0, d);
+  qk_part(ka, 0, 0);
+  qk_part(ka, 0, 1);
+  load_k(ka, 32);
+  __syncthreads();
+  softmax_a(0, t0);
+  softmax_b(0);
+  softmax_c(0);
+  qk_part(ka, 1, 0);
+  qk_part(ka, 1, 1);
+  __syncthreads();
+
+  for (int i = 0; i < nt; ++i) {
+    const int kt = t0 + 32 * i, buf = i & 1;
+    // P of this tile (both query tiles) and the factors its accumulators take first
+    bf16x8 pp[2][2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pp[t][c][pl] = __builtin_bit_cast(bf16x8, pbuf[buf][t][c][pl][lane]);
+    const float al0 = abuf[buf][0][lane], al1 = abuf[buf][1][lane];
+    if (__any(al0 != 1.f || al1 != 1.f)) {      // (rare after the first tiles of a range)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            float a0, a1;
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a0), "=v"(a1) : "a"(o[t][d][r]), "a"(o[t][d][r + 1]));
+            a0 *= t ? al1 : al0;
+            a1 *= t ? al1 : al0;
+            float w0, w1;
+            asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(w0), "=a"(w1) : "v"(a0), "v"(a1));
+            o[t][d][r] = w0;
+            o[t][d][r + 1] = w1;
+          }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < NDV; ++d) {
+      // the block NVB - 1 ahead: of this tile, or of the next one (clamped past the bank's end: fetched, never used)
+      {
+        const int dn = d + NVB - 1;
+        if (dn < NDV) load_v(vb[dn % NVB], 32 * i, dn);
+        else load_v(vb[dn % NVB], 32 * i + 32, dn - NDV);
+      }
+      // this block's share of the look-ahead work
+      if (d == 1) softmax_a(buf ^ 1, kt + 32);
+      if (d == 2) softmax_b(buf ^ 1);
+      if (d == 3) { softmax_c(buf ^ 1); load_k(ka, 32 * i + 64); }
+      if (d == 5) qk_part(ka, buf, 0);            // scores of tile i + 2 into the buffer tile i's softmax has finished with
+      if (d == 6) qk_part(ka, buf, 1);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        mfma6(vb[d % NVB][c], pp[0][c], o[0][d]);
+        mfma6(vb[d % NVB][c], pp[1][c], o[1][d]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- end of the range: the four row-sum pieces and the maximum of each query tile meet ----
+  lbuf[st][sc_half][lane] = l;
+  mbuf[st][lane] = m;
+  __syncthreads();
+  const long prow = (long)p.B * p.Nq;
+  const int cbase = wave * 32 * NDV + 4 * hi;
+  constexpr int CV = 32 * NDV * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float lh = lbuf[t][0][lane] + lbuf[t][1][lane];
+    const float lt = lh + __shfl_xor(lh, 32);
+    const float mt = mbuf[t][lane];
+    const int ql = qt * 64 + t * 32 + j;
+    if (ql >= p.Nq) continue;
+    const long qi = qrow0 + ql;
+    if (p.nsplit == 1) {
+      const float inv = 1.f / lt;
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v4 = make_float4(o[t][d][4 * g] * inv, o[t][d][4 * g + 1] * inv, o[t][d][4 * g + 2] * inv, o[t][d][4 * g + 3] * inv);
+          const int c = cbase + d * 32 + 8 * g;
+          if (p.gate) {
+            const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
+            v4.x *= u.x; v4.y *= u.y; v4.z *= u.z; v4.w *= u.w;
+          }
+          *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = v4;
+        }
+    } else {
+      float* dst = p.part + ((long)split * prow + qi) * CV;
+#pragma unroll
+      for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
+              make_float4(o[t][d][4 * g], o[t][d][4 * g + 1], o[t][d][4 * g + 2], o[t][d][4 * g + 3]);
+      if (hi == 0) {
+        float* ml = p.part + (long)p.nsplit * prow * CV + (((long)split * prow + qi) * 4 + wave) * 2;
+        ml[0] = mt;
+        ml[1] = lt;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ===== C ABI ==============================================================================================================
@@ -865,8 +1152,14 @@ extern "C" int aot_gated_attn_x6_f32(const float* q, const void* kp, const void*
   if (q32) {
     hipLaunchKernelGGL(attn_x6_wide_coop_kernel, dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
   } else {
+    // the kernel addresses a key range through 32-bit buffer offsets (196 608 B of V planes per key tile)
+    if (((cap_rows >> 5) / nsplit + 2) * 196608L > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
     const int total = B * nsplit * cdiv(Nq, 64);
+#ifdef AOT_GX6_NOPIPE
     hipLaunchKernelGGL((attn_x6_wide64_kernel<AOT_GX6_NVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
+#else
+    hipLaunchKernelGGL((attn_x6_wide64p_kernel<AOT_GX6_PNVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
+#endif
   }
   AOT_LAUNCH_CHECK();
 }
