@@ -348,6 +348,10 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
     run.ahead = ahead
     run.restart()
     js, fs, diff, outside = [], [], 0, 0
+    # the reference's own fp64 run of the same frames (tests/golden/make_fp64_ties.py): where do this run's flips sit on it?
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fp64_ties
+    f64, on64 = fp64_ties.load_fp64_ties(name), {}
     refs = torch.from_numpy(gold.astype('int64')).to(device)
     npix = gold.shape[1] * gold.shape[2]
     on_device = True         # the metric's reductions and dilations run where the masks are; host fallback if the device refuses
@@ -369,10 +373,16 @@ def jf_vs_reference(device, graph=False, gemm_table='latency', ahead=1, mfma='f3
         nbad = int(bad.sum())
         if nbad:
             outside += int((bad & ~tie_of(t)).sum())
+            if f64 is not None:
+                fp64_ties.add_counts(on64, fp64_ties.classify_flips(f64, t, label.cpu().numpy(), gold[t - 1]))
         diff += nbad
     J, Fm = sum(js) / len(js), sum(fs) / len(fs)
     return {'J': round(J, 6), 'F': round(Fm, 6), 'J&F': round((J + Fm) / 2, 6), 'frames': len(js),
             'pixels_differing': diff, 'pixels_outside_near_ties': outside, 'of_pixels': int(gold.size),
+            # of the differing pixels: on how many does the REFERENCE's own argmax differ between its fp32 and fp64 runs (and this
+            # engine carries the fp64 id), how many of the others have an fp64 top-2 gap below 5e-5 / 1e-4 / 2e-4 (smallest bin)
+            'flips_on_the_fp64_reference': None if f64 is None else (on64 or {'flips': 0}),
+            'reference_fp32_vs_fp64_flips': None if f64 is None else int(f64['stats'][:, 2].sum()),
             'gemm_table': gemm_table, 'mfma': mfma, 'launch': 'hipGraph replay' if graph else 'host launches',
             'labels': 'engine.decode_current_labels (aot_frame_tail_f32: resize + softmax + argmax + nearest feedback in the decode replay)',
             'encode_ahead_frames': ahead,

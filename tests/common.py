@@ -75,6 +75,9 @@ def unpack_gapmask(g, t, shape):
     return bits.reshape(shape).astype(bool)
 
 
+from fp64_ties import FP64_GAP_BINS, add_counts, classify_flips, load_fp64_ties  # noqa: E402,F401  (pure numpy; bench.py's J&F leg uses it too)
+
+
 def check_masks(pred, g, t, what):
     """argmax mask ids must equal the reference's except on the reference's own near-tie pixels."""
     ref = g['masks'][t - 1]

@@ -355,3 +355,45 @@ def test_oracle_memory_schedule_options_match_reference(case):
         assert int((bad & ~ties[t - 1]).sum()) == 0
     e0 = eng.aot_engines[0]
     assert e0.long_term_memories[0][0].shape[0] // e0.enc_hw == int(g[case + '.bank_frames']) == 3
+
+
+@pytest.mark.parametrize('case', ['c2_r50_aotl_70', 'c3b_r50_deaotl_70', 'c3_swinb_deaotl_480_70'])
+def test_fp64_reference_fixture_is_consistent(case):
+    """tests/golden/<case>_fp64.npz (the REAL reference in double over the whole-clip golden, make_fp64_ties.py): one record per
+    propagated frame; the pixels where the reference's fp32 and fp64 argmax disagree carry the OTHER id in fp64; and the noise level
+    the GPU parity tests lean on is what the fixture says -- on the ResNet clips every such pixel lies inside the fp32 run's own 2e-4
+    near-tie mask, on the Swin-B clip a quarter of them do not (the reference's fp32 run is that far from its fp64 run there)."""
+    from common import load_case, unpack_gapmask
+    from fp64_ties import classify_flips, load_fp64_ties
+    c, g = load_case(case)
+    f64 = load_fp64_ties(case)
+    assert f64 is not None
+    T = c['frames'] - 1
+    assert f64['stats'].shape == (T, 5) and f64['free_diff'].shape == (T,)
+    own, outside = 0, 0
+    for t in range(1, T + 1):
+        idx, gap, diff = f64['idx_%d' % t], f64['gap_%d' % t], f64['diff_%d' % t]
+        assert len(idx) == len(gap) == len(f64['top1_%d' % t]) == len(f64['top2_%d' % t])
+        assert (gap >= 0).all() and (gap < 2e-4).all() and (np.diff(idx) > 0).all()
+        ref = g['masks'][t - 1].reshape(-1)
+        tie = unpack_gapmask(g, t, g['masks'][t - 1].shape).reshape(-1)
+        own += len(diff)
+        outside += int((~tie[diff]).sum())
+        # where the stored fp64 id is known (gap64 < 2e-4) it differs from the fp32 id on exactly those pixels
+        pos = {int(i): n for n, i in enumerate(idx)}
+        for px in diff:
+            if int(px) in pos:
+                assert f64['top1_%d' % t][pos[int(px)]] != ref[px]
+        # a mask equal to the reference's has no flips; one that takes the fp64 id on the reference's own flips sides with fp64
+        assert classify_flips(f64, t, ref, ref)['flips'] == 0
+        if len(diff):
+            alt = ref.copy()
+            for px in diff:
+                alt[px] = f64['top1_%d' % t][pos[int(px)]] if int(px) in pos else (ref[px] + 1) % 11
+            cl = classify_flips(f64, t, alt, ref)
+            assert cl['flips'] == cl['ref_undecided'] == cl['sides_with_fp64'] == len(diff)
+    assert own == int(f64['stats'][:, 2].sum()) and outside == int(f64['stats'][:, 4].sum())
+    if 'swinb' in case:
+        assert own > 400 and outside > 100
+    else:
+        assert 20 <= own <= 60 and outside == 0
