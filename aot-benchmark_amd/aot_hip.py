@@ -26,9 +26,6 @@ _SIGS = {
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
     'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
-    'aot_split3_bf16_f32': [_P, _P, _L, _I, _I, _I, _L, _P],
-    'aot_pack_bf16x6n_f32': [_P, _P, _I, _I, _I, _I, _P],
-    'aot_conv2d_bf16x6p_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 17 + [_P, _I, _P],
     'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
     'aot_dwconv2d_nhwc_f32': [_P] * 4 + [_I] * 12 + [_P],
     'aot_maxpool3x3s2_nhwc_f32': [_P, _P] + [_I] * 5 + [_P],
@@ -107,7 +104,7 @@ GEMM_TABLES = {'latency': -1, 'throughput': -2}
 # fp32-equivalent six-term bf16 split (aot_conv2d_bf16x6_f32; include/aot_hip.h) wherever a layer qualifies.  An engine attribute
 # too (build_engine(..., mfma=)), carried by the same scope.
 MFMA_MODES = ('f32', 'bf16x6')
-X6_TILE = int(os.environ.get('AOT_X6_TILE', '0'))   # 0: kernel of the bf16x6 family chosen by shape; 64 / 65 / 128 / 256 force one (tests, tuning); 1: the round-4 rule
+X6_TILE = int(os.environ.get('AOT_X6_TILE', '0'))   # 0: kernel of the bf16x6 family chosen by shape; 66 / 129 force one (tests, tuning)
 X6K_SCRATCH_FLOATS = 8 << 20   # floats of the per-stream split-K scratch (32 MB: every stride-16 layer of a 480p frame at three lanes fits)
 X6_MIN_TILES = 16            # 64x64 output tiles below which a layer stays on the fp32 kernels (their split-K / small-tile forms)
 
@@ -357,40 +354,6 @@ def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, p
     return out
 
 
-def split3(x, C=None):
-    """x [M, ld] fp32 -> its three truncated-bf16 planes, int16 [3, M, ldp] (ldp = C rounded up to 8; aot_split3_bf16_f32): the input
-    format of conv2d_x6p.  Experimental (round 4): what a producing kernel's tile end will write."""
-    M = x.shape[0]
-    C = x.shape[1] if C is None else C
-    ldp = (C + 7) // 8 * 8
-    planes = torch.empty(3, M, ldp, dtype=torch.int16, device=x.device)
-    _chk(load().aot_split3_bf16_f32(_dev(x), _dev(planes), M, C, x.stride(0), ldp, M * ldp, stream_ptr()), 'aot_split3_bf16_f32')
-    return planes
-
-
-def pack_bf16x6n(w):
-    """Weight w [K, ld] -> three bf16 planes with k in natural order (aot_pack_bf16x6n_f32): int16 [3, K/32, 4, cout_pad, 8]."""
-    K, ld = w.shape
-    if K % 32:
-        raise AotHipError('bf16x6 weights need K % 32 == 0')
-    cout_pad = (ld + 63) // 64 * 64
-    w6 = torch.empty(3, K // 32, 4, cout_pad, 8, dtype=torch.int16, device=w.device)
-    _chk(load().aot_pack_bf16x6n_f32(_dev(w), _dev(w6), K, ld, w.stride(0), cout_pad, stream_ptr()), 'aot_pack_bf16x6n_f32')
-    return w6
-
-
-def conv2d_x6p(planes, w6n, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dil=1, res=None, act=ACT_NONE, B=1,
-               res_rows=0, stream=None, out_planes=None):
-    """The bf16x6 convolution / linear layer on PRE-SPLIT activations (planes from split3: [3, B*H*W, lda]); same epilogue as conv2d.
-    out_planes (int16 [3, B*OH*OW, ldp]): the result as planes instead of fp32 (`out` may be None)."""
-    _chk(load().aot_conv2d_bf16x6p_f32(_dev(planes), _dev(w6n), w6n.shape[3], _opt(bias), _opt(res), _opt(out), B, H, W, Cin, OH, OW, Cout,
-                                       KH, KW, stride, pad, dil, planes.stride(1), out.stride(0) if out is not None else 0,
-                                       res.stride(0) if res is not None else 0, res_rows, act, _opt(out_planes),
-                                       out_planes.stride(1) if out_planes is not None else 0,
-                                       stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6p_f32')
-    return out_planes if out_planes is not None else out
-
-
 def pack_bf16(w_kn, stream=None):
     """w [K, N] fp32 (K % 32 == 0, unit column stride) -> one bf16 plane in the tile order of the matrix-core kernels, rounded to
     nearest even (aot_pack_bf16_f32): int16 [K/32, 4, cout_pad, 8]."""
@@ -605,9 +568,9 @@ def gated_attention_x6(q, bank, gate, out, T, scale_div, part=None, nsplit=1, T_
     _chk(lib.aot_gated_attn_x6_f32(_dev(q), _dev(kp), _dev(vp), _opt(gate), _dev(out), _opt(part), B, cap, nq, T, _opt(T_dev),
                                    q.shape[1], dv, q.stride(0), gate.stride(0) if gate is not None else 0, out.stride(0),
                                    scale_div, nsplit, s), 'aot_gated_attn_x6_f32')
-    if abs(nsplit) > 1:
+    if nsplit > 1:
         _chk(lib.aot_attn_merge_f32(_dev(part), _opt(gate), _dev(out), q.shape[0], dv // 256, dv,
-                                    gate.stride(0) if gate is not None else 0, out.stride(0), abs(nsplit), s), 'aot_attn_merge_f32')
+                                    gate.stride(0) if gate is not None else 0, out.stride(0), nsplit, s), 'aot_attn_merge_f32')
     return out
 
 

@@ -503,8 +503,21 @@ template <int NDV>
 __global__ void __launch_bounds__(256, 2) attn_fwd_wide_coop_kernel(const AttnParams p) {
   constexpr int NVB = 2;       // rotating V register sets
   const int ntq = (p.Nq + 31) >> 5;
-  const int split = blockIdx.x, bz = blockIdx.y;
-  const int b = bz / ntq, qt = bz - b * ntq;
+  // XCD-major block order (round 6, as attn_x6_wide64p_kernel): block id -> XCD id % 8, and each XCD takes a contiguous run of the
+  // (lane, key range, query tile) triples in key-range-major order, so that its L2 streams one or two key ranges.  With the key
+  // range in blockIdx.x every XCD pulled the whole bank: 621.6 MB of fabric traffic per launch, 9x the algorithmic bytes
+  // (profiles/r04_gated_attn_traffic.json).
+  int split, b, qt;
+  {
+    const int total = p.B * p.nsplit * ntq, per = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = xcd * per + slot;
+    if (slot >= per || pair >= total) return;
+    qt = pair % ntq;
+    const int bs = pair / ntq;
+    split = bs % p.nsplit;
+    b = bs / p.nsplit;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
   const int ch = wave;
   const int T = p.T_dev ? *p.T_dev : p.T;
@@ -744,7 +757,7 @@ extern "C" int aot_gated_attn_f32(const float* q, const float* k, const float* v
   p.gate = (nsplit == 1) ? gate : nullptr;   // with splits the gate is applied by aot_attn_merge_f32
   p.ldg = ldg;
   if (nch == 4)     // dv = 1024 (every DeAOT config): the four chunk waves share one score tile
-    hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_wide_coop_kernel<8>), dim3(8 * cdiv((long)B * nsplit * cdiv(Nq, 32), 8)), dim3(256), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((attn_fwd_wide_pipe_kernel<128, 8>), dim3(nch, nsplit, B * cdiv(Nq, 32)), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();

@@ -128,11 +128,7 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
   }
   // K: lane = key row j of the tile; V: lane = value channel j; chunk (plane, c) of either = 64 lanes x 16 bytes
   const unsigned short* kvbase = p.kv + ((long)b * cap_tiles * p.H + h) * 6144 + lane * 8;
-#ifdef AOT_X6_PROBE_SAMETILE      // timing probe only (wrong results): every key tile reads the bank's first tile -> all fetches hit L1
-  const long tile_stride = 0;
-#else
   const long tile_stride = (long)p.H * 6144;
-#endif
 
   float m = -INFINITY, l = 0.f;
   f32x16 o;
@@ -364,9 +360,10 @@ static int launch_pack(bool tr, const float* x, unsigned short* planes, int B, l
 }
 
 // ---- gated-propagation form (DeAOT, attention.py:672-707) in the bf16x6 family: the twin of attn_fwd_wide_coop_kernel<8> ----------
-// One 4-wave workgroup owns 32 queries; wave w contracts channels [32 w, 32 w + 32) of q . k (12 MFMAs, partial score tiles meet in
-// LDS in wave order) and owns value chunk w = eight 32-channel blocks of the 1024-wide [V | ID_V] (96 MFMAs per key tile against
-// 128 fp32 MFMAs of twice the length).  K planes [lane][tile][4 blocks][3072], V planes [lane][tile][32 blocks][3072].
+// One 128-wide query / key head, a value 1024 wide = [V | ID_V], the gate fused.  K planes [lane][tile][4 blocks][3072], V planes
+// [lane][tile][32 blocks][3072] (aot_attn_pack_x6_part_f32).  Rounds 3-5 ran one 4-wave workgroup per 32 queries, every wave
+// repeating the softmax: 0.23-0.32 of the bf16x6 roof.  Round 6 (below): 64 queries per workgroup, the softmax shared and
+// software-pipelined -- 0.43 at a 14-frame bank, 0.39-0.41 over a clip's launch mix (profiles/r06_gated64_*.txt).
 struct GatedX6Params {
   const float* q;
   const unsigned short* kp;
@@ -380,187 +377,7 @@ struct GatedX6Params {
   float scale_div;
 };
 
-__global__ void __launch_bounds__(256, 1) attn_x6_wide_coop_kernel(const GatedX6Params p) {
-  constexpr int NDV = 8;
-  const int ntq = (p.Nq + 31) >> 5;
-  const int split = blockIdx.x, bz = blockIdx.y;
-  const int b = bz / ntq, qt = bz - b * ntq;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
-  const int T = p.T_dev ? *p.T_dev : p.T;
-  const int ntile = (T + 31) >> 5;
-  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = min(T, split * tps * 32);
-  const int t1 = min(T, t0 + tps * 32);
-  const int qrow = min(qt * 32 + j, p.Nq - 1);
-  const long qrow0 = (long)b * p.Nq;
-  const long cap_tiles = p.cap_rows >> 5;
-  __shared__ float part[2][4][16][64];     // [buffer][wave][score register][lane]
-
-  bf16x8 qp[2][3];
-  {
-    const float* src = p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 8;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
-      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
-                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
-      split3(x, qp[c]);
-    }
-  }
-  const unsigned short* kbase = p.kp + ((long)b * cap_tiles * 4 + wave) * 3072 + lane * 8;
-  const unsigned short* vbase = p.vp + ((long)b * cap_tiles * 32 + wave * NDV) * 3072 + lane * 8;
-
-  float m = -INFINITY, l = 0.f;
-  f32x16 o[NDV];
-#pragma unroll
-  for (int d = 0; d < NDV; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-
-  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
-    const unsigned short* src = kbase + min((long)(kt >> 5), cap_tiles - 1) * (4 * 3072);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
-  };
-  auto load_v = [&](bf16x8 (&vf)[2][3], int kt, int d) {
-    const unsigned short* src = vbase + min((long)(kt >> 5), cap_tiles - 1) * (32 * 3072) + d * 3072;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
-  };
-  auto qk_part = [&](const bf16x8 (&kf)[2][3], int buf) {
-    f32x16 sc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-    mfma6(kf[0], qp[0], sc);
-    mfma6(kf[1], qp[1], sc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[buf][wave][r][lane] = sc[r];
-  };
-
-  // rotating V register sets: a block's fetch is issued NVB - 1 = 4 blocks ahead of its MFMAs (one wave per SIMD: nothing else hides
-  // the latency; 2 / 3 / 4 / 5 / 6 sets measured: 891 / 841 / 713 / 673 / 718 us at a bank of 14 frames, profiles/r03r_gated_x6_nvb.txt)
-  constexpr int NVB = 5;
-  bf16x8 ka[2][3], vb[NVB][2][3];
-  if (t0 < t1) {
-    load_k(ka, t0);
-    qk_part(ka, 0);
-    load_k(ka, t0 + 32);
-  }
-  __syncthreads();
-  int it = 0;
-  auto step = [&](int kt, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
-    const int buf = it & 1;
-#pragma unroll
-    for (int d = 0; d < NVB - 1; ++d) load_v(vb[d], kt, d);
-    f32x16 sc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)      // fixed wave order: every wave of the workgroup gets the same bits
-      sc[r] = ((part[buf][0][r][lane] + part[buf][1][r][lane]) + part[buf][2][r][lane]) + part[buf][3][r][lane];
-    qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of the softmax below
-    if (TAIL) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
-    }
-    const float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
-                          max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
-    const float mnew = fmaxf(m, fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    const bool moved = mnew > m;
-    m = mnew;
-    l *= alpha;
-    float pf[16], ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -m));
-      ps += pf[r];
-    }
-    l += ps;
-    load_k(ka, kt + 64);
-    if (__any(moved)) {              // (rare after the first tiles of a range)
-#pragma unroll
-      for (int d = 0; d < NDV; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-    bf16x8 pp[2][3];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float x8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
-      split3(x8, pp[c]);
-    }
-#pragma unroll
-    for (int d = 0; d < NDV; ++d) {
-      if (d + NVB - 1 < NDV) load_v(vb[(d + NVB - 1) % NVB], kt, d + NVB - 1);
-      mfma6(vb[d % NVB][0], pp[0], o[d]);
-      mfma6(vb[d % NVB][1], pp[1], o[d]);
-    }
-    ++it;
-    __syncthreads();
-  };
-  int kt = t0;
-  for (; kt + 32 < t1; kt += 32) step(kt, std::false_type{});
-  if (kt < t1) step(kt, std::true_type{});
-
-  l += __shfl_xor(l, 32);
-  if (qt * 32 + j >= p.Nq) return;
-  const long qi = qrow0 + qt * 32 + j;
-  const long prow = (long)p.B * p.Nq;
-  const int cbase = wave * 32 * NDV + 4 * hi;
-  constexpr int CV = 32 * NDV * 4;
-  if (p.nsplit == 1) {
-    const float inv = 1.f / l;
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 t = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        const int c = cbase + d * 32 + 8 * g;
-        if (p.gate) {
-          const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
-          t.x *= u.x; t.y *= u.y; t.z *= u.z; t.w *= u.w;
-        }
-        *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = t;
-      }
-  } else {
-    float* dst = p.part + ((long)split * prow + qi) * CV;
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
-            make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
-    if (hi == 0) {
-      float* ml = p.part + (long)p.nsplit * prow * CV + (((long)split * prow + qi) * 4 + wave) * 2;
-      ml[0] = m;
-      ml[1] = l;
-    }
-  }
-}
-
-
-// ---- round 6: the 64-query form ---------------------------------------------------------------------------------------------------
-// What bounds the 32-query kernel above is the bank's way INTO the CU, not the matrix pipe: per key tile a workgroup pulls
-// 32 x 1152 x 6 B = 221 KB for 4 x 108 MFMAs = 3456 cycles per SIMD -- 64 B per clock and CU, which is the L2's whole rate
-// (34.5 TB/s over 256 CUs; MI355X_MICROARCH.md) -- and it is measured at a third of that (profiles/r03z_attn_pmc.txt: matrix pipe
-// 27 %, waves parked on V 38 %).  Here a workgroup owns TWO query tiles: every V fragment a wave fetches feeds the MFMAs of both
-// (the A operand stays in its registers; only the B operand P changes), so the same bytes buy twice the matrix work -- 32 B per
-// clock and CU at the full MFMA rate.  Wave w still contracts channels [32 w, 32 w + 32) of q . k, now for both tiles (24 MFMAs;
-// the partial score tiles meet in LDS in wave order, as 16-byte accesses), and owns value blocks [8 w, 8 w + 8) for both:
-// 2 x 8 x 16 = 256 accumulator registers (the whole AGPR half of the unified file) + <= 256 VGPRs, one wave per SIMD.  A V block
-// now covers 24 MFMAs = 768 cycles, so NVB = 3 sets (two blocks ahead) hide what five sets hid before.
-// Block order: the grid is ONE dimension and XCD-major -- block id -> XCD id % 8 (the dispatcher's round robin), and the
-// (lane, key range, query pair) triples are dealt so that each XCD gets a CONTIGUOUS run of them in key-range-major order: an
-// XCD's L2 then streams one or two key ranges instead of all of them (the 32-query kernel's order made every XCD pull the whole
-// bank: 1.3-1.4x the algorithmic bytes on the fabric side in bf16x6 form, 9x in the fp32 twin).
-// The score tile of the 64-query kernel must NOT live in accumulator registers: its 256 AGPRs are the 2 x 8 output blocks, and hipcc
+// The score tile of the kernel must NOT live in accumulator registers: its 256 AGPRs are the 2 x 8 output blocks, and hipcc
 // selects the AGPR form for every MFMA of a kernel that uses AGPRs at all (16 more would spill the output blocks around each score
 // chain: 486 dwords of scratch in the first build).  The hardware takes a VGPR destination just as well, so the 24 score MFMAs of a
 // key tile are written by hand with "v" constraints.  Hazards the compiler no longer sees (LLVM's gfx940 table, confirmed on the
@@ -584,236 +401,15 @@ __device__ __forceinline__ void mfma6_vgpr(const bf16x8 (&a)[3], const bf16x8 (&
 }
 __device__ __forceinline__ void mfma_vgpr_settle(f32x16& acc) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc)); }
 
-#ifndef AOT_GX6_NVB
-#define AOT_GX6_NVB 3
-#endif
-#ifndef AOT_GX6_PNVB
-#define AOT_GX6_PNVB 4
-#endif
-template <int NVB>
-__global__ void __launch_bounds__(256, 1) attn_x6_wide64_kernel(const GatedX6Params p) {
-  constexpr int NDV = 8, PS = 20;       // PS: floats per lane of a partial score tile in LDS (16 + 4 of padding: conflict-free b128)
-  const int ntq = (p.Nq + 63) >> 6;
-  int split, b, qt;
-  {
-    const int total = p.B * p.nsplit * ntq, per = (total + 7) >> 3;
-#ifdef AOT_GX6_LINEAR      // development A/B: dispatch order = (lane, query pair, key range), ranges fastest, as the 32-query kernel
-    const int lin = blockIdx.x;
-    if (lin >= total) return;
-    const int pair = ((lin / p.nsplit) / ntq * p.nsplit + lin % p.nsplit) * ntq + (lin / p.nsplit) % ntq;
-    (void)per;
-#else
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pair = xcd * per + slot;
-    if (slot >= per || pair >= total) return;
-#endif
-    qt = pair % ntq;
-    const int bs = pair / ntq;
-    split = bs % p.nsplit;
-    b = bs / p.nsplit;
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
-  const int T = p.T_dev ? *p.T_dev : p.T;
-  const int ntile = (T + 31) >> 5;
-  const int tps = (ntile + p.nsplit - 1) / p.nsplit;
-  const int t0 = min(T, split * tps * 32);
-  const int t1 = min(T, t0 + tps * 32);
-  const long qrow0 = (long)b * p.Nq;
-  const long cap_tiles = p.cap_rows >> 5;
-  __shared__ float part[2][2][4][64 * PS];     // [buffer][query tile][wave][lane][score register]
-
-  bf16x8 qp[2][2][3];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int qrow = min(qt * 64 + t * 32 + j, p.Nq - 1);
-    const float* src = p.q + (qrow0 + qrow) * p.ldq + wave * 32 + hi * 8;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float4 u0 = *reinterpret_cast<const float4*>(src + 16 * c), u1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
-      float x[8] = {u0.x / p.scale_div, u0.y / p.scale_div, u0.z / p.scale_div, u0.w / p.scale_div,
-                    u1.x / p.scale_div, u1.y / p.scale_div, u1.z / p.scale_div, u1.w / p.scale_div};
-      split3(x, qp[t][c]);
-    }
-  }
-  const unsigned short* kbase = p.kp + ((long)b * cap_tiles * 4 + wave) * 3072 + lane * 8;
-  const unsigned short* vbase = p.vp + ((long)b * cap_tiles * 32 + wave * NDV) * 3072 + lane * 8;
-
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-  f32x16 o[2][NDV];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][d][r] = 0.f;
-
-  auto load_k = [&](bf16x8 (&kf)[2][3], int kt) {
-    const unsigned short* src = kbase + min((long)(kt >> 5), cap_tiles - 1) * (4 * 3072);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) kf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
-  };
-  auto load_v = [&](bf16x8 (&vf)[2][3], int kt, int d) {
-    const unsigned short* src = vbase + min((long)(kt >> 5), cap_tiles - 1) * (32 * 3072) + d * 3072;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) vf[c][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + (pl * 2 + c) * 512));
-  };
-  auto qk_part = [&](const bf16x8 (&kf)[2][3], int buf) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x16 sc;
-      mfma6_vgpr<true>(kf[0], qp[t][0], sc);
-      mfma6_vgpr<false>(kf[1], qp[t][1], sc);
-      mfma_vgpr_settle(sc);
-      float4* dst = reinterpret_cast<float4*>(&part[buf][t][wave][lane * PS]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) dst[g] = make_float4(sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]);
-    }
-  };
-
-  bf16x8 ka[2][3], vb[NVB][2][3];
-  if (t0 < t1) {
-    load_k(ka, t0);
-    qk_part(ka, 0);
-    load_k(ka, t0 + 32);
-  }
-  __syncthreads();
-  int it = 0;
-  auto step = [&](int kt) {
-    const int buf = it & 1;
-#pragma unroll
-    for (int d = 0; d < NVB - 1; ++d) load_v(vb[d], kt, d);
-    bf16x8 pp[2][2][3];
-    float alpha[2];
-    bool moved = false;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      __builtin_amdgcn_sched_barrier(0);      // one query tile at a time: hipcc otherwise hoists both tiles' 32 LDS reads (128 registers)
-      float sc[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {      // fixed wave order: every wave of the workgroup gets the same bits
-        const float4 a0 = *reinterpret_cast<const float4*>(&part[buf][t][0][lane * PS + 4 * g]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&part[buf][t][1][lane * PS + 4 * g]);
-        const float4 a2 = *reinterpret_cast<const float4*>(&part[buf][t][2][lane * PS + 4 * g]);
-        const float4 a3 = *reinterpret_cast<const float4*>(&part[buf][t][3][lane * PS + 4 * g]);
-        sc[4 * g] = ((a0.x + a1.x) + a2.x) + a3.x;
-        sc[4 * g + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
-        sc[4 * g + 2] = ((a0.z + a1.z) + a2.z) + a3.z;
-        sc[4 * g + 3] = ((a0.w + a1.w) + a2.w) + a3.w;
-      }
-      if (kt + 32 > t1) {      // the range's last, partial tile (wave-uniform; ONE loop body: a second, masked copy of the step
-#pragma unroll                // made hipcc spill half the accumulators at the join)
-        for (int r = 0; r < 16; ++r)
-          if (kt + mfma32_row(r, hi) >= t1) sc[r] = -INFINITY;
-      }
-      const float x = max3f(max3f(max3f(sc[0], sc[1], sc[2]), max3f(sc[3], sc[4], sc[5]), max3f(sc[6], sc[7], sc[8])),
-                            max3f(sc[9], sc[10], sc[11]), max3f(sc[12], sc[13], max3f(sc[14], sc[15], sc[15])));
-      const float mnew = fmaxf(m[t], fmaxf(x, __shfl_xor(x, 32)) * AOT_LOG2E);
-      alpha[t] = __builtin_amdgcn_exp2f(m[t] - mnew);
-      moved = moved || (mnew > m[t]);
-      m[t] = mnew;
-      l[t] *= alpha[t];
-      float pf[16], ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -mnew));
-        ps += pf[r];
-      }
-      l[t] += ps;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float x8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
-        split3(x8, pp[t][c]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    qk_part(ka, buf ^ 1);            // next tile's partial scores: independent of everything above but the LDS buffer
-    load_k(ka, kt + 64);
-    __builtin_amdgcn_sched_barrier(0);
-    if (__any(moved)) {              // (rare after the first tiles of a range)
-      // explicit AGPR reads / writes, as in attn_fwd_wide_coop_kernel (attention.hip): as plain C++ the rescale makes hipcc move the
-      // accumulators through VGPRs around the branch on every key tile -- with 256 of them, 429 dwords of scratch
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int d = 0; d < NDV; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            float a0, a1;
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a0), "=v"(a1) : "a"(o[t][d][r]), "a"(o[t][d][r + 1]));
-            a0 *= alpha[t];
-            a1 *= alpha[t];
-            float w0, w1;
-            asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3" : "=a"(w0), "=a"(w1) : "v"(a0), "v"(a1));
-            o[t][d][r] = w0;
-            o[t][d][r + 1] = w1;
-          }
-    }
-#pragma unroll
-    for (int d = 0; d < NDV; ++d) {
-      if (d + NVB - 1 < NDV) load_v(vb[(d + NVB - 1) % NVB], kt, d + NVB - 1);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        mfma6(vb[d % NVB][c], pp[0][c], o[0][d]);
-        mfma6(vb[d % NVB][c], pp[1][c], o[1][d]);
-      }
-    }
-    ++it;
-    __syncthreads();
-  };
-  for (int kt = t0; kt < t1; kt += 32) step(kt);
-
-  const long prow = (long)p.B * p.Nq;
-  const int cbase = wave * 32 * NDV + 4 * hi;
-  constexpr int CV = 32 * NDV * 4;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const float lt = l[t] + __shfl_xor(l[t], 32);
-    const int ql = qt * 64 + t * 32 + j;
-    if (ql >= p.Nq) continue;
-    const long qi = qrow0 + ql;
-    if (p.nsplit == 1) {
-      const float inv = 1.f / lt;
-#pragma unroll
-      for (int d = 0; d < NDV; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 v4 = make_float4(o[t][d][4 * g] * inv, o[t][d][4 * g + 1] * inv, o[t][d][4 * g + 2] * inv, o[t][d][4 * g + 3] * inv);
-          const int c = cbase + d * 32 + 8 * g;
-          if (p.gate) {
-            const float4 u = *reinterpret_cast<const float4*>(p.gate + qi * p.ldg + c);
-            v4.x *= u.x; v4.y *= u.y; v4.z *= u.z; v4.w *= u.w;
-          }
-          *reinterpret_cast<float4*>(p.out + qi * p.ldo + c) = v4;
-        }
-    } else {
-      float* dst = p.part + ((long)split * prow + qi) * CV;
-#pragma unroll
-      for (int d = 0; d < NDV; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(dst + cbase + d * 32 + 8 * g) =
-              make_float4(o[t][d][4 * g], o[t][d][4 * g + 1], o[t][d][4 * g + 2], o[t][d][4 * g + 3]);
-      if (hi == 0) {
-        float* ml = p.part + (long)p.nsplit * prow * CV + (((long)split * prow + qi) * 4 + wave) * 2;
-        ml[0] = m[t];
-        ml[1] = lt;
-      }
-    }
-  }
-}
-
-
-// ---- round 6, second form: the 64-query kernel as a SOFTWARE PIPELINE -------------------------------------------------------------
-// Measured (profiles/r06_gated64_first.txt): attn_x6_wide64_kernel takes ~13 000 cycles per key tile for 6912 cycles of MFMA even
-// when 27 workgroups have the chip to themselves -- the bound is the wave's own instruction stream, not the bank's way in: one wave
-// per SIMD issues in order, so the ~700 vector instructions of the two softmaxes + P splits (every wave repeats them) run with the
-// matrix pipe idle, and hipcc sinks the V fetches to a few MFMAs before their use.  This form removes both:
+// ---- the kernel: 64 queries per workgroup, software-pipelined ---------------------------------------------------------------------
+// A workgroup of four waves (one per SIMD, 256 VGPRs + 256 AGPRs each) owns TWO 32-query tiles and a key range.  Wave w contracts
+// channels [32 w, 32 w + 32) of q . k for both tiles (24 MFMAs per key tile; the partial score tiles meet in LDS in wave order) and
+// owns value blocks [8 w, 8 w + 8) for both: every V fragment it fetches feeds the MFMAs of both tiles (the A operand stays in its
+// registers, only the B operand P changes) -- 221 KB per key tile buy 4 x 216 MFMAs instead of 4 x 108.
+// What the first builds of this shape taught (profiles/r06_gated64_first.txt, r06_gated64_pipelined.txt): with each wave doing its own
+// two softmaxes + P splits before the value products a key tile took ~13 000 cycles for 6912 cycles of MFMA even with 27 workgroups
+// alone on the chip -- one wave per SIMD issues in order, so ~700 vector instructions ran with the matrix pipe idle, and hipcc sank
+// the V fetches to a few MFMAs before their use.  Hence:
 //   * the softmax of key tile i + 1 runs INSIDE the value products of tile i.  The four waves share it: wave w sums the partial
 //     score tiles of query tile w >> 1 and the running maximum (both waves of a pair compute the same bits), exponentiates and
 //     splits only the eight score registers of sub-step w & 1, and publishes its three P planes (3 x 16 B per lane) and the rescale
@@ -822,8 +418,15 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64_kernel(const GatedX6Par
 //   * no branch inside a tile: out-of-range rows are masked by select on every tile (a range's last tile and the look-ahead tiles
 //     past it alike), so the whole tile is ONE scheduling region, cut by sched_barrier() into eight value blocks; each block's
 //     V fetch (three blocks ahead, four rotating register sets, across the tile boundary) and its share of the softmax / of the
-//     next-but-one tile's score MFMAs are pinned to it.
+//     next-but-one tile's score MFMAs are pinned to it;
+//   * Q planes parked in LDS, bank fetches through buffer descriptors (one per-lane offset register): no spill in the loop.
 // Row sums: wave (t, c) keeps the sum of ITS eight registers; the four (sub-step, lane half) pieces of a query meet once, at the end.
+// Block order: the grid is ONE dimension and XCD-major -- block id -> XCD id % 8 (the dispatcher's round robin), and the (lane,
+// key range, query pair) triples are dealt so that each XCD gets a CONTIGUOUS run of them in key-range-major order: an XCD's L2
+// streams one or two key ranges instead of all of them (R50-DeAOTL 422 against 412 fps with the ranges-fastest order).
+// Counters at a 14-frame bank (profiles/r06_gated64_pmc.txt): matrix pipe 56 % busy on the SIMDs that have a wave, waves parked on
+// memory 13 %; 25 B per clock and CU arrive from the L2 -- the rate every streaming kernel of this library sees.
+constexpr int AOT_GX6_NVB = 4;      // rotating V register sets (2 and 4 measured equal once nothing spills)
 template <int NVB>
 __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Params p) {
   static_assert(8 % NVB == 0, "the rotating V sets must divide the eight value blocks of a tile");
@@ -832,16 +435,9 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Pa
   int split, b, qt;
   {
     const int total = p.B * p.nsplit * ntq, per = (total + 7) >> 3;
-#ifdef AOT_GX6_LINEAR      // development A/B: dispatch order = (lane, query pair, key range), ranges fastest, as the 32-query kernel
-    const int lin = blockIdx.x;
-    if (lin >= total) return;
-    const int pair = ((lin / p.nsplit) / ntq * p.nsplit + lin % p.nsplit) * ntq + (lin / p.nsplit) % ntq;
-    (void)per;
-#else
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = xcd * per + slot;
     if (slot >= per || pair >= total) return;
-#endif
     qt = pair % ntq;
     const int bs = pair / ntq;
     split = bs % p.nsplit;
@@ -1138,28 +734,17 @@ extern "C" int aot_gated_attn_x6_f32(const float* q, const void* kp, const void*
                                      float scale_div, int nsplit, void* stream) {
   if (dqk != 128 || dv != 1024) return AOT_ERR_UNSUPPORTED;
   if (!q || !kp || !vp || !out || Nq <= 0 || T <= 0 || B <= 0 || cap_rows < T || (cap_rows & 31)) return AOT_ERR_BADARG;
-  if ((long)B * cdiv(Nq, 32) > 65535) return AOT_ERR_UNSUPPORTED;
   if ((ldq & 3) || (ldo & 3) || (gate && (ldg & 3)) || ((uintptr_t)q & 15) || ((uintptr_t)out & 15) || ((uintptr_t)kp & 15) ||
       ((uintptr_t)vp & 15))
     return AOT_ERR_BADARG;
-  const bool q32 = nsplit < 0;      // development A/B only (tools/dev/mb_gated_x6.py): the 32-query kernel of rounds 3-5
-  if (q32) nsplit = -nsplit;
   if (nsplit < 1 || (nsplit > 1 && !part)) return AOT_ERR_BADARG;
+  // the kernel addresses a key range through 32-bit buffer offsets (196 608 B of V planes per key tile)
+  if (((cap_rows >> 5) / nsplit + 2) * 196608L > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   GatedX6Params p;
   p.q = q; p.kp = (const unsigned short*)kp; p.vp = (const unsigned short*)vp; p.out = out; p.part = part; p.T_dev = T_dev;
   p.gate = (nsplit == 1) ? gate : nullptr;     // with splits the gate is applied by aot_attn_merge_f32
   p.Nq = Nq; p.T = T; p.ldq = ldq; p.ldg = ldg; p.ldo = ldo; p.nsplit = nsplit; p.B = B; p.cap_rows = cap_rows; p.scale_div = scale_div;
-  if (q32) {
-    hipLaunchKernelGGL(attn_x6_wide_coop_kernel, dim3(nsplit, B * cdiv(Nq, 32)), dim3(256), 0, (hipStream_t)stream, p);
-  } else {
-    // the kernel addresses a key range through 32-bit buffer offsets (196 608 B of V planes per key tile)
-    if (((cap_rows >> 5) / nsplit + 2) * 196608L > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
-    const int total = B * nsplit * cdiv(Nq, 64);
-#ifdef AOT_GX6_NOPIPE
-    hipLaunchKernelGGL((attn_x6_wide64_kernel<AOT_GX6_NVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
-#else
-    hipLaunchKernelGGL((attn_x6_wide64p_kernel<AOT_GX6_PNVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
-#endif
-  }
+  const int total = B * nsplit * cdiv(Nq, 64);
+  hipLaunchKernelGGL((attn_x6_wide64p_kernel<AOT_GX6_NVB>), dim3(8 * cdiv(total, 8)), dim3(256), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

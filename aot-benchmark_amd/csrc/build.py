@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'attention.hip', 'attention_x6.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip', 'train_ops.hip', 'train_bwd.hip']
+SOURCES = ['gemm_conv.hip', 'gemm_lds.hip', 'gemm_x6.hip', 'attention.hip', 'attention_x6.hip', 'attn_topk.hip', 'local_attn.hip', 'local_gated.hip', 'swin.hip', 'norm_act.hip', 'prepost.hip', 'train_ops.hip', 'train_bwd.hip']
 LIB = os.path.join(HERE, 'libaot_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 # Per-file additions.  -fno-slp-vectorize: hipcc's SLP vectoriser pairs scalar fp32 arithmetic into packed (VOP3P) instructions and,
@@ -36,7 +36,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + ['common.h', 'conv_params.h', 'build.py', os.path.join('..', '..', 'include', 'aot_hip.h')]
+    deps = SOURCES + ['common.h', 'conv_params.h', 'gemm_tile.h', 'build.py', os.path.join('..', '..', 'include', 'aot_hip.h')]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 

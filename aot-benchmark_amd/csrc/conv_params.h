@@ -24,16 +24,13 @@ bool gemm_lean_eligible(const ConvParams& p);
 // bf16 x 6 variant of the lean 64x64 kernel (gemm_lds.hip): w6 = the weight pre-split into three bf16 planes, layout
 // [3][K/32][4][cout_pad][8] (aot_pack_bf16x6_f32)
 bool gemm_x6_eligible(const ConvParams& p);
-// tile: 0 = chosen by shape, 64 / 128 = forced (the 128x128 eight-wave form / the 64x64 form)
+// tile: 0 = chosen by shape, 66 / 129 = forced (the 64x64 direct-weight form / the register-staged 128x128 form); terms 1 = plain bf16
 int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms = 6, int ksplit = 1, float* scratch = nullptr);
-// tile 256 = the phase-shifted 128x128 form (gemm_x6pp_kernel); with ksplit > 1 split-K over the grid (slabs in scratch)
-int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit = 1, float* scratch = nullptr);
+// the phase-shifted 128x128 form (gemm_x6pp_kernel) with split-K over the grid (ksplit >= 2, slabs in scratch)
+int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch);
 // split-K over the grid on the 64x64 register-staged kernel with the weight fragments straight from global memory
 int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch);
 // a linear layer on the same kernel whose tile end also writes GroupNorm partial sums: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats
 int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part);
 // a KxK convolution on four input channels (Cin = lda = 4: the ResNet stem) on the same kernel; w6: K rounded up to 8 taps per k-step
 int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);
-// activations pre-split into three bf16 planes (p.in reinterpreted: [3][B*H*W][lda] bf16), weight packed in natural k order
-// out_planes != nullptr: the result is written as three bf16 planes [3][M][ldp] instead of fp32 (p.out unused)
-int launch_gemm_x6_presplit(const ConvParams& p, const void* w6n, int cout_pad, hipStream_t s, void* out_planes = nullptr, int ldp = 0);

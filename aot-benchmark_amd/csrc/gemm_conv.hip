@@ -565,13 +565,10 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
   }
 }
 
-// ---- bf16 x 6 family (gemm_lds.hip: gemm_x6_kernel) ----------------------------------------------------------------------
+// ---- bf16 x 6 family (gemm_lds.hip: gemm_x6rd_kernel and friends) --------------------------------------------------------------
 // weight [K, ldb] fp32 -> three truncated-bf16 planes in the kernel's tile order, w6[plane][K/32][cc][cout_pad][8]:
 // element e of chunk cc = 2 s + h of k-block kb is k = 32 kb + 16 s + 4 h + (e & 3) + 8 (e >> 2); columns >= Cout are zero.
 // One thread per (kb, cc, n): reads 8 weights, writes three 16-byte chunks.
-// NATURAL: chunk cc holds k = 32 kb + 8 cc + e instead (the order of the member that takes pre-split activations, whose A planes
-// keep their channels in memory order).
-template <bool NATURAL>
 __global__ void __launch_bounds__(256) pack_x6_kernel(const float* __restrict__ w, unsigned* __restrict__ w6, int K, int Cout,
                                                        int ldb, int cout_pad) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -580,10 +577,10 @@ __global__ void __launch_bounds__(256) pack_x6_kernel(const float* __restrict__ 
   const int n = (int)(idx % cout_pad);
   const int cc = (int)((idx / cout_pad) & 3);
   const int kb = (int)(idx / ((long)cout_pad * 4));
-  const int k0 = NATURAL ? 32 * kb + 8 * cc : 32 * kb + 16 * (cc >> 1) + 4 * (cc & 1);
+  const int k0 = 32 * kb + 16 * (cc >> 1) + 4 * (cc & 1);
   float x[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = n < Cout ? w[(long)(k0 + (NATURAL ? e : (e & 3) + 8 * (e >> 2))) * ldb + n] : 0.f;
+  for (int e = 0; e < 8; ++e) x[e] = n < Cout ? w[(long)(k0 + (e & 3) + 8 * (e >> 2)) * ldb + n] : 0.f;
   const long plane = (long)(K / 8) * cout_pad * 4;      // dwords per plane
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
@@ -637,78 +634,16 @@ extern "C" int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, in
   if (!w || !w6 || K <= 0 || (K % 32) || Cout <= 0 || ldb < Cout || cout_pad < Cout || (cout_pad % 64) || ((uintptr_t)w6 & 15))
     return AOT_ERR_BADARG;
   const long total = (long)(K / 32) * 4 * cout_pad;
-  hipLaunchKernelGGL(pack_x6_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)w6, K, Cout, ldb,
+  hipLaunchKernelGGL(pack_x6_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)w6, K, Cout, ldb,
                      cout_pad);
   AOT_LAUNCH_CHECK();
-}
-
-extern "C" int aot_pack_bf16x6n_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream) {
-  if (!w || !w6 || K <= 0 || (K % 32) || Cout <= 0 || ldb < Cout || cout_pad < Cout || (cout_pad % 64) || ((uintptr_t)w6 & 15))
-    return AOT_ERR_BADARG;
-  const long total = (long)(K / 32) * 4 * cout_pad;
-  hipLaunchKernelGGL(pack_x6_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)w6, K, Cout, ldb,
-                     cout_pad);
-  AOT_LAUNCH_CHECK();
-}
-
-// x [M, ldx] fp32 -> three truncated-bf16 planes [3][M][ldp] (plane stride `pstride` elements), channels in memory order: one
-// thread per eight channels of a row (32 bytes in, 16 bytes out per plane; both sides coalesced).  x = plane 0 + plane 1 + plane 2
-// exactly.  Channels C .. ldp-1 (padding) are written as zeros.
-__global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, long M, int C, int ldx,
-                                                      int ldp, long pstride) {
-  const int cpr = ldp >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * cpr) return;
-  const long m = idx / cpr;
-  const int c0 = (int)(idx - m * cpr) * 8;
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? x[m * ldx + c0 + e] : 0.f;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    unsigned o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned a = __float_as_uint(v[2 * e]) & 0xffff0000u, b = __float_as_uint(v[2 * e + 1]) & 0xffff0000u;
-      o[e] = (a >> 16) | b;
-      v[2 * e] -= __uint_as_float(a);
-      v[2 * e + 1] -= __uint_as_float(b);
-    }
-    *reinterpret_cast<uint4*>(planes + pl * pstride + m * ldp + c0) = make_uint4(o[0], o[1], o[2], o[3]);
-  }
-}
-
-extern "C" int aot_split3_bf16_f32(const float* x, void* planes, long M, int C, int ldx, int ldp, long pstride, void* stream) {
-  if (!x || !planes || M <= 0 || C <= 0 || ldx < C || ldp < C || (ldp & 7) || pstride < M * ldp || (pstride & 7) || ((uintptr_t)planes & 15))
-    return AOT_ERR_BADARG;
-  hipLaunchKernelGGL(split3_kernel, dim3(cdiv(M * (ldp >> 3), 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, M, C, ldx,
-                     ldp, pstride);
-  AOT_LAUNCH_CHECK();
-}
-
-extern "C" int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, int cout_pad, const float* bias, const float* res,
-                                      float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
-                                      void* out_planes, int ldp, void* stream) {
-  if (!in_planes || !w6n || (!out && !out_planes)) return AOT_ERR_BADARG;
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
-  if ((lda & 7) || lda < Cin || (!out_planes && ldc < Cout)) return AOT_ERR_BADARG;
-  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
-  if ((long)B * OH * OW > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
-  ConvParams p;
-  p.in = reinterpret_cast<const float*>(in_planes); p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
-  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
-  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
-  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  return launch_gemm_x6_presplit(p, w6n, cout_pad, (hipStream_t)stream, out_planes, ldp);
 }
 
 extern "C" int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
                                      float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                                      int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
                                      int tile, void* stream) {
-  if (!in || !w6 || !out || (tile != 0 && tile != 1 && tile != 64 && tile != 65 && tile != 66 && tile != 128 && tile != 129 && tile != 256)) return AOT_ERR_BADARG;
+  if (!in || !w6 || !out || (tile != 0 && tile != 66 && tile != 129)) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
@@ -730,7 +665,7 @@ extern "C" int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_
                                       int ksplit, float* scratch, long scratch_floats, void* stream) {
   // ksplit < 0: |ksplit| slices on the 64x64 register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>)
   const int ks = ksplit < 0 ? -ksplit : ksplit;
-  if (!in || !w6 || !out || ks < 1 || ks > 64 || ksplit == -1) return AOT_ERR_BADARG;
+  if (!in || !w6 || !out || ks < 2 || ks > 64) return AOT_ERR_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;

@@ -22,9 +22,6 @@
 // peak and would waste 3/4 of a dense tile).
 #include "common.h"
 
-#ifndef ABLATE
-#define ABLATE 0   // tuning only: 1 no rel tables, 2 no q.k / p.v LDS math, 3 no staging traffic, 4 no exp
-#endif
 
 struct LocalParams {
   const float* q;
@@ -129,7 +126,7 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
       const int pos = f >> 3, c4 = f & 7;
       const int kx = x0 - R + pos;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ABLATE != 3 && f < NF4 && kx >= 0 && kx < p.w)
+      if (f < NF4 && kx >= 0 && kx < p.w)
         t = *reinterpret_cast<const float4*>(base + ((long)ky * p.w + kx) * ld + hd * D + c4 * 4);
       stage[i] = t;
     }
@@ -171,14 +168,12 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
       const float* bk = p.relk_b + ((long)hd * WS + dy) * 16;
 #pragma unroll
       for (int dx = 0; dx < WS; ++dx) s[dx] = bk[dx];
-      if (ABLATE != 1)
 #pragma unroll
       for (int c = 0; c < D; ++c) dpp_axpy15(s, tk[c], qs[c]);
     }
 #pragma unroll
     for (int dx = 0; dx < WS; ++dx) {
       float dot = 0.f;
-      if (ABLATE != 2)
 #pragma unroll
       for (int c4 = 0; c4 < D / 4; ++c4) {
         const float4 kk = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LDS_LD + c4 * 4]);
@@ -201,7 +196,7 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
     m = mnew;
 #pragma unroll
     for (int dx = 0; dx < WS; ++dx) {
-      s[dx] = (ABLATE == 4) ? s[dx] - mnew : expf(s[dx] - mnew);  // exp(-inf) = 0 for masked slots
+      s[dx] = expf(s[dx] - mnew);  // exp(-inf) = 0 for masked slots
       l += s[dx];
     }
 
@@ -222,7 +217,6 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
 #pragma unroll
     for (int dx = 0; dx < WS; ++dx) {
       const float pw = s[dx];
-      if (ABLATE != 2)
 #pragma unroll
       for (int c4 = 0; c4 < D / 4; ++c4) {
         const float4 vv = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LDS_LD + c4 * 4]);
@@ -233,7 +227,6 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
       }
     }
     {
-      if (ABLATE != 1)
 #pragma unroll
       for (int c = 0; c < D; c += 2) dpp_dot15x2(o[c], o[c + 1], tv[c], tv[c + 1], s);
     }
@@ -275,9 +268,6 @@ __global__ void __launch_bounds__(NWV * 64) local_attn_d32_kernel(const LocalPar
   }
 }
 
-#ifndef NWAVE
-#define NWAVE 8
-#endif
 
 extern "C" int aot_local_attn_f32(const float* q, const float* k, const float* v, const float* relk_t,
                                   const float* relk_b, const float* relv_t, float* out, int B, long kv_brows, int h,
@@ -292,6 +282,6 @@ extern "C" int aot_local_attn_f32(const float* q, const float* k, const float* v
   p.q = q; p.k = k; p.v = v; p.relk_t = relk_t; p.relk_b = relk_b; p.relv_t = relv_t; p.out = out;
   p.h = h; p.w = w; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale_div = scale_div;
   p.kv_brows = kv_brows;
-  hipLaunchKernelGGL((local_attn_d32_kernel<7, NWAVE>), dim3(cdiv(w, 64), h, B * H), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL((local_attn_d32_kernel<7, 8>), dim3(cdiv(w, 64), h, B * H), dim3(8 * 64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }

@@ -60,7 +60,8 @@ def gated_splits_x6(nq, lanes, t, max_splits=16):
     workgroups, at least four key tiles per range (27 query pairs at 480p -> 9 ranges, 243 workgroups)."""
     qt = lanes * ((nq + 63) // 64)
     tiles = (t + 31) // 32
-    return max(1, min(256 // max(qt, 1), tiles // 4, max_splits))
+    ns = max(1, min(256 // max(qt, 1), tiles // 4, max_splits))
+    return max(ns, -(-tiles // 10900))      # the kernel addresses a key range through 32-bit offsets: < 10 922 key tiles per range
 
 
 def _planned_len(t, nq, kv_brows):

@@ -271,16 +271,64 @@ def attention_roofline(engine, clip, device):
             byts = 8.0 * (T * kw.get('B', 1) + q.shape[0]) * H * 32
         recs.append((e0, e1, flop, byts))
         return r
+    # ... and around every conv / linear call (the GEMM family: aot_hip.conv2d -- which aot_hip.linear and the fp32 fall-back of the
+    # stem go through --, the four-channel stem entry and the GroupNorm-partials linear): 2 * M * K * N FLOP each
+    grecs, depth = [], [0]
+    greal = {n: getattr(aot_hip, n) for n in ('conv2d', 'conv2d_c4', 'linear_gn_x6')}
+
+    def gemm_timed(fname, flop_of):
+        fn = greal[fname]
+
+        def run(*a, **kw):
+            if depth[0]:                     # conv2d reached from conv2d_c4's fall-back: already inside a timed call
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            depth[0] += 1
+            e0.record(torch.cuda.current_stream())
+            try:
+                r = fn(*a, **kw)
+            finally:
+                depth[0] -= 1
+            e1.record(torch.cuda.current_stream())
+            grecs.append((e0, e1, flop_of(*a, **kw)))
+            return r
+        return run
+
+    def conv_flop(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, *a, **kw):
+        return 2.0 * kw.get('B', 1) * OH * OW * KH * KW * Cin * Cout
+
+    def c4_flop(x, w, bias, out, H, W, OH, OW, Cout, KH, KW, *a, **kw):
+        return 2.0 * kw.get('B', 1) * OH * OW * KH * KW * 3 * Cout       # (the fourth input channel is padding)
+
+    def lgn_flop(x, w, bias, out, *a, **kw):
+        return 2.0 * x.shape[0] * x.shape[1] * out.shape[1]
     frames, mask, objs = clip
     engine.restart_engine()
     engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
     setattr(aot_hip, name, timed)
+    for fname, fl in (('conv2d', conv_flop), ('conv2d_c4', c4_flop), ('linear_gn_x6', lgn_flop)):
+        setattr(aot_hip, fname, gemm_timed(fname, fl))
     try:
         for t in range(1, len(frames)):
             one_frame(engine, frames[t])
     finally:
         setattr(aot_hip, name, real)
+        for fname, fn in greal.items():
+            setattr(aot_hip, fname, fn)
     torch.cuda.synchronize(device)
+    gms = sum(a.elapsed_time(b) for a, b, _ in grecs)
+    gflop = sum(f for _, _, f in grecs)
+    gtf = gflop / max(gms, 1e-9) / 1e9
+    gemm = {'bound': 'mfma', 'achieved': round(gtf, 2), 'unit': 'TFLOP/s (fp32-equivalent)' if x6 else 'TFLOP/s',
+            'peak': round(BF16_MFMA_PEAK_TF / 6.0, 1) if x6 else FP32_MFMA_PEAK_TF,
+            'frac': round(gtf * 6.0 / BF16_MFMA_PEAK_TF if x6 else gtf / FP32_MFMA_PEAK_TF, 4),
+            'kernel': ('gemm_x6rd_kernel and the other members of the bf16x6 conv / linear family' if x6 else
+                       'gemm_lean_kernel and the other members of the fp32 conv / linear family'),
+            'what': 'every conv / linear launch of the propagated frames of one clip, one clip at a time, no encoder look-ahead, host '
+                    'launches: HIP events around each call (a call = the GEMM kernel plus, for the split-K forms, its reduce launch)',
+            'launches': len(grecs), 'launches_per_frame': round(len(grecs) / max(1, len(frames) - 1), 1),
+            'us_per_frame': round(gms * 1e3 / max(1, len(frames) - 1), 1), 'gflop_per_frame': round(gflop / 1e9 / max(1, len(frames) - 1), 2),
+            'traffic': None}
     ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
     flop = sum(f for _, _, f, _ in recs)
     n = len(recs)
@@ -289,7 +337,7 @@ def attention_roofline(engine, clip, device):
     # record of that run and `traffic_source` names it -- it is NOT measured in this run
     traffic = src = None
     tp = None
-    for rnd in ('r04', 'r03z', 'r03'):        # the newest committed record of the kernel as built
+    for rnd in ('r06', 'r04', 'r03z', 'r03'):        # the newest committed record of the kernel as built
         cand = os.path.join('profiles', '%s_%sattn_%straffic.json' % (rnd, 'gated_' if deaot else '', 'x6_' if x6 else ''))
         if os.path.exists(os.path.join(ROOT, cand)):
             tp = cand
@@ -306,15 +354,15 @@ def attention_roofline(engine, clip, device):
                 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs; the kernel issues 6 bf16 MFMA products per product)',
                 'frac': round(tf * 6.0 / BF16_MFMA_PEAK_TF, 4), 'bf16_mfma_tflops_issued': round(6.0 * tf, 1),
                 'peak_bf16_dense': BF16_MFMA_PEAK_TF, 'traffic': traffic, 'traffic_source': src,
-                'kernel': 'attn_x6_wide_coop_kernel' if deaot else 'attn_x6_d32_kernel', 'launches': n,
+                'kernel': 'attn_x6_wide64p_kernel' if deaot else 'attn_x6_d32_kernel', 'launches': n,
                 'avg_launch_us': round(ms * 1e3 / n, 2), 'gflop_per_launch': round(flop / n / 1e9, 3),
-                'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n)}
+                'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n), 'gemm': gemm}
     return {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TF,
             'unit': 'TFLOP/s', 'frac': round(tf / FP32_MFMA_PEAK_TF, 4), 'traffic': traffic,
             'traffic_source': src,
             'kernel': 'attn_fwd_wide_coop_kernel<8>' if deaot else 'attn_fwd_d32_pipe_kernel', 'launches': n,
             'avg_launch_us': round(ms * 1e3 / n, 2), 'gflop_per_launch': round(flop / n / 1e9, 3),
-            'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n)}
+            'algorithmic_bytes_per_launch': round(sum(b for _, _, _, b in recs) / n), 'gemm': gemm}
 
 
 # golden clips of the real reference, whole 70-frame clips (tests/golden/make_golden.py): model -> (fixture, synthetic clip id).
@@ -708,6 +756,32 @@ def main(argv=None):
             single = {'fps': round(f1 / e1, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in sruns],
                       'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead}
             del one
+            # ... and STRICTLY ONLINE, timed the reference's way (evaluator.py:325-330, 444-446, 486-498): one clip, no encoder
+            # look-ahead (every frame is encoded when it arrives), a device event just before match_propogate_one_frame and one
+            # just after update_memory, All-Frame FPS = propagated frames / sum of the per-frame event times over the whole clip;
+            # the reference frame is outside, as there
+            onl = StreamClip(new_engine('latency'), streams[0], clips[0])
+            onl.ahead = 1
+            oruns = []
+            for r in range(R + 1):               # the first pass captures the graphs (untimed)
+                onl.restart()
+                evs = []
+                for t in range(1, CLIP_FRAMES):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(streams[0])
+                    onl.step()
+                    e1.record(streams[0])
+                    evs.append((e0, e1))
+                torch.cuda.synchronize(device)
+                if r:
+                    oruns.append(sum(a.elapsed_time(b) for a, b in evs) * 1e-3)
+            oruns.sort()
+            single['online'] = {'fps': round((CLIP_FRAMES - 1) / oruns[(len(oruns) - 1) // 2], 2),
+                                'repeat_fps': [round((CLIP_FRAMES - 1) / e, 2) for e in oruns], 'frames': CLIP_FRAMES - 1,
+                                'encode_ahead_frames': 1, 'gemm_table': 'latency',
+                                'timing': 'device events around each propagated frame (match -> decode -> memory update), summed '
+                                          'over the whole clip: the All-Frame FPS of evaluator.py:325-330,444-446,486-498'}
+            del onl
 
         phase('single-stream leg')
         whole = None
@@ -817,7 +891,7 @@ def main(argv=None):
                        'timed_M_mean': round(float(stats[:, 3].sum()) / total_frames, 2),
                        'repeats': R, 'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _ in runs],
                        'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
-                       'single_stream': single, 'whole_clip': whole,
+                       'single_stream': single, 'single_stream_online': (single or {}).get('online'), 'whole_clip': whole,
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': table,

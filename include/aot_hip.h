@@ -66,25 +66,23 @@ int aot_conv2d_nhwc_f32(const float* in, const float* w, const float* wt, const 
  * (K % 32 == 0; the layout aot_conv2d_nhwc_f32 takes) once into w6 = three bf16 planes in the kernel's tile order,
  * 3 * K * cout_pad * 2 bytes, cout_pad = Cout rounded up to 64.  aot_conv2d_bf16x6_f32 is aot_conv2d_nhwc_f32 on that weight
  * (same arguments and epilogue; needs Cin % 32 == 0; activations are split on the fly).  `tile` selects the member: 0 = by shape
- * (round 5: the register-staged 64x64 kernel with the weight fragments straight from global memory, 66, everywhere except KxK layers
- * with >= 128 output channels whose 128x128 tiles fill exactly one dispatch round -- those take the register-staged 128x128 form,
- * 129); 64 / 128 = the LDS-DMA tile kernels of rounds 3-4; 65 = register-staged 64x64 with both operands through LDS; 256 = the
- * phase-shifted 128x128 LDS-DMA form; 1 = the round-4 rule (64 / 128 by shape).  All members form the same six products in the same
- * order per accumulator: same-tile members are bit-identical, 64- and 128-wide members differ by nothing either (the accumulation
- * order over k does not depend on the tile).  An engine opts in
+ * (the register-staged 64x64 kernel with the weight fragments straight from global memory, 66, everywhere except KxK layers with
+ * >= 128 output channels whose 128x128 tiles fill exactly one dispatch round -- those take the register-staged 128x128 form, 129);
+ * 66 / 129 force one (tests, tuning).  Both form the same six products in the same order per accumulator and accumulate over k in
+ * the same order: bit-identical results.  (The LDS-DMA members of rounds 3-5 -- tiles 64 / 128 / 65 / 1 and the form on pre-split
+ * activation planes -- were superseded in round 5 and removed from the library in round 6.)  An engine opts in
  * (build_engine(..., mfma='bf16x6'); bench.py times this arithmetic by default since round 4), and results are reported under their own dtype string.
  * Replaces the same reference code as aot_conv2d_nhwc_f32. */
 int aot_pack_bf16x6_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
 int aot_conv2d_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                           int lda, int ldc, int ldr, int res_rows, int act, int tile, void* stream);
-/* tile = 256 selects the PHASE-SHIFTED form of the 128x128 tile (gemm_x6pp_kernel, round 5): the two waves that share a SIMD
- * alternate between a load phase (fragment reads, activation split, DMA issue) and an MFMA phase, so the matrix pipe and the vector
- * ALUs work at the same time; bit-identical to tile = 128.  aot_conv2d_bf16x6k_f32 is that form with split-K over the grid for
- * layers whose 128x128 tiles alone do not fill the chip (the stride-16 maps): (K / 32) % ksplit == 0, every k-slice writes its raw
+/* Split-K forms of the same product for layers whose tiles alone do not fill the chip (the stride-16 maps): (K / 32) % |ksplit| == 0,
+ * every k-slice writes its raw
  * partial tile to a slab of `scratch` ([ksplit][M][Cout] floats, scratch_floats = its size), one more launch sums the slabs in
- * slice order and applies bias / residual / activation.  ksplit = 1: no scratch needed.  ksplit < -1: |ksplit| slices on the 64x64
- * register-staged kernel with direct weight fragments instead (gemm_x6rd_kernel<., true>; the K = 1024 linear of the LSTT at one lane).
+ * slice order and applies bias / residual / activation.  ksplit > 1: the 128x128 LDS-DMA tile whose two waves per SIMD alternate
+ * between a load phase and an MFMA phase (gemm_x6pp_kernel<., true>; the K = 2304 layers); ksplit < -1: |ksplit| slices on the 64x64
+ * register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>; the K = 1024 linear of the LSTT at one lane).
  * Replaces the same reference code as aot_conv2d_nhwc_f32. */
 int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
@@ -96,22 +94,6 @@ int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const 
  * [B*OH*OW, ldc].  Replaces conv1 + bn1 + relu of networks/encoders/resnet.py:140-143. */
 int aot_conv2d_c4_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, float* out, int B, int H, int W,
                              int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int ldc, int act, void* stream);
-
-/* The member of the same family that takes its activations ALREADY SPLIT (experimental in round 4: called by tests and
- * tools/dev/mb_gemm.py only, no engine stage hands over split activations yet).  aot_split3_bf16_f32: x [M, ldx] fp32 -> three
- * truncated-bf16 planes [3][M][ldp] (plane stride pstride elements; ldp % 8 == 0; channels in memory order; x = the sum of its
- * planes exactly) -- what a producing kernel's tile end will write.  aot_pack_bf16x6n_f32: the weight planes with k in natural
- * order inside a 32-block (same sizes as aot_pack_bf16x6_f32).  aot_conv2d_bf16x6p_f32: same arguments and epilogue as
- * aot_conv2d_bf16x6_f32 with `in_planes` = the three planes of the B NHWC maps ([3][B*H*W][lda] bf16, lda % 8 == 0, plane stride =
- * B*H*W*lda) -- the A fragments go from LDS into the matrix cores without touching the vector ALUs, where the split of the fp32
- * form is 7.3 of its 10.7 VALU instructions per MFMA (profiles/r04_x6_gemm_pmc.txt); results equal up to the position of a k inside
- * its MFMA (64x64 tile).  out_planes != NULL: the tile end writes the result as three bf16 planes [3][B*OH*OW][ldp] (ldp % 8 == 0,
- * ldp >= Cout) INSTEAD of fp32 (`out` may be NULL) -- the producer side of a conv -> conv chain. */
-int aot_split3_bf16_f32(const float* x, void* planes, long M, int C, int ldx, int ldp, long pstride, void* stream);
-int aot_pack_bf16x6n_f32(const float* w, void* w6, int K, int Cout, int ldb, int cout_pad, void* stream);
-int aot_conv2d_bf16x6p_f32(const void* in_planes, const void* w6n, int cout_pad, const float* bias, const float* res, float* out,
-                           int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                           int lda, int ldc, int ldr, int res_rows, int act, void* out_planes, int ldp, void* stream);
 
 /* Plain bf16 form of the same operation for the TRAINING path (`--amp` of the reference's trainer, trainer.py:123-125,460-487 --
  * there fp16 autocast + GradScaler; BASELINE config 5: bf16): both operands rounded to bf16 (round to nearest even), ONE

@@ -130,58 +130,7 @@ X6_CASES = [
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-def test_conv2d_bf16x6_presplit_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
-    """The member of the bf16x6 family that takes PRE-SPLIT activations (aot_split3_bf16_f32 + aot_pack_bf16x6n_f32 +
-    aot_conv2d_bf16x6p_f32): the planes sum to the fp32 activations exactly; the result is the 64x64 on-the-fly kernel's up to the
-    position of a k inside its MFMA (the planes keep the channels in memory order, the on-the-fly split does not): within 1e-5 of
-    the output scale of it, and within the family's own tolerance of the fp64 result -- every case of the family's own test."""
-    g = torch.Generator().manual_seed(H * 131 + Cout + B)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
-    b = torch.randn(Cout, generator=g)
-    OH, OW = (H + 2 * p - d * (K - 1) - 1) // s + 1, (W + 2 * p - d * (K - 1) - 1) // s + 1
-    r = torch.randn(1, Cout, OH, OW, generator=g) if res else None
-    ldb = (Cout + 3) // 4 * 4
-    wk = torch.zeros(K * K * Cin, ldb)
-    wk[:, :Cout] = w.permute(2, 3, 1, 0).reshape(K * K * Cin, Cout)
-    wk = hip.attach_wt(_dev(wk), Cin)
-    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
-    rt = _dev(r[0].permute(1, 2, 0).reshape(OH * OW, Cout)) if res else None
-    planes = hip.split3(xt)
-    back = (planes.to(torch.int32) << 16).view(torch.float32).double().sum(0)
-    assert planes.shape == (3, B * H * W, Cin) and torch.equal(back, xt.double()), 'the activation planes do not sum to the fp32 values'
-    w6n = hip.pack_bf16x6n(wk)
-    want = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-    w6 = hip.pack_bf16x6(wk)
-    bd = _dev(b)
-    rc = hip.load().aot_conv2d_bf16x6_f32(xt.data_ptr(), w6.data_ptr(), w6.shape[3], bd.data_ptr(), rt.data_ptr() if res else None,
-                                          want.data_ptr(), B, H, W, Cin, OH, OW, Cout, K, K, s, p, d, xt.stride(0), want.stride(0),
-                                          rt.stride(0) if res else 0, OH * OW if res else 0, act, 64, hip.stream_ptr())
-    assert rc == 0
-    got = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-    hip.conv2d_x6p(planes, w6n, bd, got, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0)
-    ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
-    if res:
-        ref = ref + r.double()
-    ref = {0: ref, 1: F.relu(ref), 3: F.gelu(ref), 4: F.silu(ref)}[act].float()
-    scale = max(1.0, ref.abs().max().item())
-    gotc = got[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2)
-    _close(gotc, ref, 2e-5 * scale, 'pre-split bf16x6 conv')
-    assert float((got[:, :Cout] - want[:, :Cout]).abs().max()) <= 1e-5 * scale, 'pre-split member differs from the on-the-fly split'
-    if ldb > Cout:
-        assert torch.isnan(got[:, Cout:]).all(), 'wrote outside the logical columns'
-    if Cout % 8 == 0:
-        # the producer side: the tile end writes the result AS PLANES -- bit for bit the split of the fp32 result above
-        ldp = Cout + 8                                    # (a padded row: the padding must stay untouched)
-        op = torch.full((3, B * OH * OW, ldp), 0x7fc1, dtype=torch.int16, device='cuda')
-        hip.conv2d_x6p(planes, w6n, bd, None, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
-                       out_planes=op)
-        assert torch.equal(op[:, :, :Cout], hip.split3(got[:, :Cout].contiguous())), 'plane output differs from the split of the fp32 output'
-        assert bool((op[:, :, Cout:] == 0x7fc1).all()), 'wrote into the row padding of the planes'
-
-
-@pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-@pytest.mark.parametrize('tile', [64, 65, 66, 128, 129, 256])
+@pytest.mark.parametrize('tile', [66, 129])
 def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, tile):
     """The bf16x6 family (aot_pack_bf16x6_f32 + aot_conv2d_bf16x6_f32): fp32-equivalent arithmetic on the bf16 matrix cores --
     the same cases and the SAME tolerance as the fp32 lean kernel (2e-5 relative to the output scale), and additionally
@@ -214,7 +163,7 @@ def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, til
     outs = {}
     for mode in ('f32', 'bf16x6'):
         out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-        hip.X6_TILE = tile                  # the tile forms of the family: 64x64 (four waves), 128x128 (eight waves), 256 = 128x128 phase-shifted
+        hip.X6_TILE = tile                  # the tile forms of the family: 66 = 64x64 direct-weight, 129 = register-staged 128x128
         try:
             with hip.use_gemm_table('throughput', mode):
                 hip.conv2d(xt, wk, _dev(b), out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B,
@@ -234,10 +183,12 @@ def test_conv2d_bf16x6_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B, til
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,K,s,p,d,act,res,B', X6_CASES)
-def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
-    """gemm_x6pp_kernel (tile = 256; aot_conv2d_bf16x6k_f32): the two waves of a SIMD in opposite load / MFMA phases.  Same tile, same
-    six products in the same order per accumulator as the 128x128 kernel: BIT-IDENTICAL to it; with split-K over the grid (partial
-    slabs summed in slice order by a second launch) within the family's tolerance of fp64 and 1e-5 of the scale from the unsplit result."""
+def test_conv2d_bf16x6_members_and_split_k(hip, H, W, Cin, Cout, K, s, p, d, act, res, B):
+    """The members of the bf16x6 conv / linear family against each other: the 64x64 direct-weight kernel (tile 66, the default) and the
+    register-staged 128x128 kernel (tile 129) form the same six products in the same order per accumulator and accumulate over k in
+    the same order -- BIT-IDENTICAL; repeats are bit-identical; the split-K forms (aot_conv2d_bf16x6k_f32: ksplit > 1 = the phase-
+    shifted 128x128 kernel gemm_x6pp_kernel<., true>, ksplit < 0 = gemm_x6rd_kernel<., true>; partial slabs summed in slice order by a
+    second launch) are within the family's tolerance of fp64 and 1e-5 of the scale from the unsplit result."""
     g = torch.Generator().manual_seed(H * 131 + Cout + B)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
@@ -264,61 +215,37 @@ def test_conv2d_bf16x6_phase_shifted_kernel(hip, H, W, Cin, Cout, K, s, p, d, ac
                                               rt.stride(0) if res else 0, OH * OW if res else 0, act, tile, hip.stream_ptr())
         assert rc == 0
         return out
-    wide, pp = run(128), run(256)
-    assert torch.equal(wide[:, :Cout], pp[:, :Cout]), 'the phase-shifted kernel differs from the 128x128 kernel'
-    # the register-staged 64x64 member (tile = 65): same k mapping and product order as the LDS-DMA 64x64 kernel
-    t64, t65 = run(64), run(65)
-    assert torch.equal(t64[:, :Cout], t65[:, :Cout]), 'the register-staged kernel differs from the 64x64 kernel'
-    if ldb > Cout:
-        assert torch.isnan(t65[:, Cout:]).all(), 'wrote outside the logical columns'
-    for _ in range(3):
-        assert torch.equal(run(65)[:, :Cout], t65[:, :Cout])
-    # ... its form with the weight fragments straight from global memory (tile = 66)
-    t66 = run(66)
-    assert torch.equal(t64[:, :Cout], t66[:, :Cout]), 'the direct-weight register-staged kernel differs from the 64x64 kernel'
-    if ldb > Cout:
-        assert torch.isnan(t66[:, Cout:]).all(), 'wrote outside the logical columns'
-    for _ in range(3):
-        assert torch.equal(run(66)[:, :Cout], t66[:, :Cout])
-    # ... and its 128x128 form (tile = 129) against the LDS-DMA 128x128 kernel
-    t129 = run(129)
-    assert torch.equal(wide[:, :Cout], t129[:, :Cout]), 'the register-staged 128x128 kernel differs from the 128x128 kernel'
-    if ldb > Cout:
-        assert torch.isnan(t129[:, Cout:]).all(), 'wrote outside the logical columns'
-    for _ in range(3):
-        assert torch.equal(run(129)[:, :Cout], t129[:, :Cout])
-    if ldb > Cout:
-        assert torch.isnan(pp[:, Cout:]).all(), 'wrote outside the logical columns'
+    t66, t129 = run(66), run(129)
+    assert torch.equal(t66[:, :Cout], t129[:, :Cout]), 'the register-staged 128x128 kernel differs from the 64x64 direct-weight kernel'
+    for t, ref_t in ((66, t66), (129, t129)):
+        if ldb > Cout:
+            assert torch.isnan(ref_t[:, Cout:]).all(), 'wrote outside the logical columns'
+        for _ in range(3):
+            assert torch.equal(run(t)[:, :Cout], ref_t[:, :Cout])
+    assert torch.equal(run(0)[:, :Cout], t66[:, :Cout])          # chosen by shape: one of the two
     scale = max(1.0, ref.abs().max().item())
-    _close(pp[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'phase-shifted bf16x6 conv')
+    _close(t66[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'bf16x6 conv')
+    for member in (64, 128, 65, 1, 256):                         # the members removed in round 6 are refused, not silently replaced
+        out = torch.empty(B * OH * OW, ldb, device='cuda')
+        rc = hip.load().aot_conv2d_bf16x6_f32(xt.data_ptr(), w6.data_ptr(), w6.shape[3], bd.data_ptr(), None, out.data_ptr(), B, H, W, Cin,
+                                              OH, OW, Cout, K, K, s, p, d, xt.stride(0), out.stride(0), 0, 0, act, member, hip.stream_ptr())
+        assert rc != 0
     nk = K * K * Cin // 32
-    for ks in (1, 2, 3, 4, 8):
-        if nk % ks:
-            continue
-        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-        hip.conv2d_x6k(xt, wk, bd, out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
-                       ksplit=ks)
-        if ks == 1:
-            assert torch.equal(out[:, :Cout], pp[:, :Cout])
-        else:
-            assert float((out[:, :Cout] - pp[:, :Cout]).abs().max()) <= 1e-5 * scale, 'split-K %d differs from the unsplit result' % ks
-            _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, 'split-K %d' % ks)
-        if ldb > Cout:
-            assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
-    # split-K on the 64x64 register-staged kernel with direct weight fragments (ksplit < 0 selects it)
-    for ks in (2, 3, 4, 8):
-        if nk % ks:
-            continue
-        out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
-        hip.conv2d_x6k(xt, wk, bd, out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
-                       ksplit=-ks)
-        assert float((out[:, :Cout] - pp[:, :Cout]).abs().max()) <= 1e-5 * scale, '64x64 split-K %d differs from the unsplit result' % ks
-        _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, '64x64 split-K %d' % ks)
-        if ldb > Cout:
-            assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
-    # repeats are bit-identical (no order-dependent state between the phase-shifted groups)
-    for _ in range(3):
-        assert torch.equal(run(256)[:, :Cout], pp[:, :Cout])
+    for sign, what in ((1, 'phase-shifted 128x128'), (-1, '64x64 direct-weight')):
+        for ks in (2, 3, 4, 8):
+            if nk % ks:
+                continue
+            out = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+            hip.conv2d_x6k(xt, wk, bd, out, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
+                           ksplit=sign * ks)
+            assert float((out[:, :Cout] - t66[:, :Cout]).abs().max()) <= 1e-5 * scale, '%s split-K %d differs from the unsplit result' % (what, ks)
+            _close(out[:, :Cout].cpu().view(B, OH, OW, Cout).permute(0, 3, 1, 2), ref, 2e-5 * scale, '%s split-K %d' % (what, ks))
+            if ldb > Cout:
+                assert torch.isnan(out[:, Cout:]).all(), 'wrote outside the logical columns'
+            again = torch.full((B * OH * OW, ldb), float('nan'), device='cuda')
+            hip.conv2d_x6k(xt, wk, bd, again, H, W, Cin, OH, OW, Cout, K, K, s, p, d, res=rt, act=act, B=B, res_rows=OH * OW if res else 0,
+                           ksplit=sign * ks)
+            assert torch.equal(again[:, :Cout], out[:, :Cout])      # no order-dependent state between the phase-shifted groups
 
 
 @pytest.mark.parametrize('IH,IW,OH,OW,LH,LW,C,objs,align', [(121, 213, 480, 854, 481, 849, 11, 10, True), (121, 213, 480, 854, 481, 849, 11, 3, False),

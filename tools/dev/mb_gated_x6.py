@@ -1,6 +1,6 @@
 """bf16x6 gated (DeAOT) attention (aot_gated_attn_x6_f32 on packed K / V banks) against an fp64 reference: error and launch time
-(kernel + merge) at several bank sizes and grid-level key splits (N = 1674 queries, value 1024 wide).  Round 6: the 64-query
-kernel (nsplit > 0) beside the 32-query kernel of rounds 3-5 (nsplit < 0, development A/B only).
+(kernel + merge) at several bank sizes and grid-level key splits (N = 1674 queries, value 1024 wide), beside the fp32 kernel.
+(profiles/r06_gated64_first.txt / r06_gated64_pipelined.txt were taken with the 32-query kernel of rounds 3-5 in the second column.)
     python tools/dev/mb_gated_x6.py [path/to/libaot_hip.so] [quick] [N]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,19 +38,19 @@ for M in ((1, 4, 14) if QUICK else (1, 2, 4, 8, 14)):
     T = M * N if M != 2 else 2 * N - 13
     ref = (torch.softmax((q.double() / 128 ** 0.5) @ k[:T].double().t(), -1) @ v[:T].double()) * u.double()
     tiles = (T + 31) // 32
-    pick64, pick32 = gated_splits_x6(N, 1, T), gated_splits(N, T, slots=256)
+    pick64, pick32 = gated_splits_x6(N, 1, T), gated_splits(N, T)
     for ns in sorted({1, 2, 4, 6, 8, 9, 12, 16, pick64, pick32}):
         if ns > max(1, tiles // 4):
             continue
         pt = part if ns > 1 else None
         new = lambda: aot_hip.gated_attention_x6(q, bank, u, out6, T, 128 ** 0.5, part=pt, nsplit=ns)
-        old = lambda: aot_hip.gated_attention_x6(q, bank, u, out5, T, 128 ** 0.5, part=pt, nsplit=-ns)
+        old = lambda: aot_hip.gated_attention(q, k, v, u, out5, T, 128 ** 0.5, part=pt, nsplit=ns)
         t6, t5 = timed(new), timed(old)
         first = out6.clone(); new(); torch.cuda.synchronize()
         rep = float((first - out6).abs().max())
         e6, e5 = float((out6.double() - ref).abs().max()), float((out5.double() - ref).abs().max())
         gf = 2.0 * N * T * 1152
-        print('M=%2d T=%5d ns=%2d%s%s q64 %7.1f us (%5.1f TF-eq, %.3f of 416.7)  q32 %7.1f us (%5.1f TF-eq)  x%.2f   max err vs fp64: q64 %.2e  q32 %.2e  (q64 run-to-run %.1e)'
+        print('M=%2d T=%5d ns=%2d%s%s q64 %7.1f us (%5.1f TF-eq, %.3f of 416.7)  fp32 %7.1f us (%5.1f TF)  x%.2f   max err vs fp64: q64 %.2e  fp32 %.2e  (q64 run-to-run %.1e)'
               % (M, T, ns, '*' if ns == pick64 else ' ', '+' if ns == pick32 else ' ', t6, gf / t6 * 1e-6, gf / t6 * 1e-6 / 416.7, t5, gf / t5 * 1e-6,
                  t5 / t6, e6, e5, rep), flush=True)
 print('pack of one frame: K %.1f us, V %.1f us' % (timed(lambda: aot_hip.gated_pack_x6(k[:N], None, bank, N, slot=3)),

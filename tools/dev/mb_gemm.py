@@ -1,5 +1,7 @@
 """Per-shape microbenchmark of the implicit-GEMM conv for every conv/linear of the R50-AOTL 480p frame.
-usage: python tools/dev/mb_gemm.py [cfgs e.g. -1,0,1,2,x6] [lib] [only] [batch]      (x6 = the bf16x6 family, auto dispatch)"""
+usage: python tools/dev/mb_gemm.py [cfgs e.g. -1,0,1,2,x6] [lib] [only] [batch]      (x6 = the bf16x6 family by shape, x6d / x6s = one member,
+x6zN / x6kN = split-K N on the phase-shifted 128x128 / the 64x64 direct-weight kernel; the members x6n / x6w / x6r / x6o / x6p of rounds 3-5
+are gone from the library)"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
@@ -39,31 +41,14 @@ for (name, H, W, Cin, Cout, K, s, cnt) in S:
     row = []
     ref_out = None
     for c in cfgs:
-        if c == 'x6pp':                  # planes in, planes out (the tile end writes the three planes): a link of a conv -> conv chain
-            if Cin % 32 or Cout % 8: row.append('      -      -'); continue
-            w6n = aot_hip.pack_bf16x6n(w)
-            planes = aot_hip.split3(x)
-            oplanes = torch.empty(3, M, Cout, dtype=torch.int16, device='cuda')
-            def run():
-                aot_hip.conv2d_x6p(planes, w6n, b, None, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH, out_planes=oplanes)
-        elif c in ('x6p', 'x6ps'):         # x6p = the 64x64 kernel on PRE-SPLIT activations (planes made outside the timed loop); x6ps = split pass + kernel
-            if Cin % 32: row.append('      -      -'); continue
-            w6n = aot_hip.pack_bf16x6n(w)
-            planes = aot_hip.split3(x)
-            if c == 'x6p':
-                def run():
-                    aot_hip.conv2d_x6p(planes, w6n, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
-            else:
-                def run():
-                    aot_hip.conv2d_x6p(aot_hip.split3(x), w6n, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)
-        elif (str(c).startswith('x6z') or str(c).startswith('x6k')) and len(c) > 3:      # x6zN = the phase-shifted 128x128 kernel with split-K N; x6kN = the 64x64 direct-weight kernel with split-K N
+        if (str(c).startswith('x6z') or str(c).startswith('x6k')) and len(c) > 3:      # x6zN = the phase-shifted 128x128 kernel with split-K N; x6kN = the 64x64 direct-weight kernel with split-K N
             ks = int(c[3:]) * (-1 if c.startswith('x6k') else 1)
             if Cin % 32 or (KK // 32) % abs(ks): row.append('      -      -'); continue
             aot_hip.pack_bf16x6(w)
             def run():
                 aot_hip.conv2d_x6k(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH, ksplit=ks)
-        elif str(c).startswith('x6'):      # x6 = tile by shape, x6n = 64x64 forced, x6w = 128x128 forced, x6z = 128x128 phase-shifted
-            aot_hip.X6_TILE = {'x6': 0, 'x6o': 1, 'x6n': 64, 'x6r': 65, 'x6d': 66, 'x6w': 128, 'x6s': 129, 'x6z': 256}[c]
+        elif str(c).startswith('x6'):      # x6 = tile by shape, x6d = the 64x64 direct-weight kernel forced, x6s = the register-staged 128x128 kernel forced
+            aot_hip.X6_TILE = {'x6': 0, 'x6d': 66, 'x6s': 129}[c]
             def run():        # (layers that do not qualify fall back to the fp32 dispatch inside conv2d, as in the engine)
                 with aot_hip.use_gemm_table('throughput', 'bf16x6'):
                     aot_hip.conv2d(x, w, b, out, H, W, Cin, OH, OW, Cout, K, K, s, p, 1, act=1, B=BATCH)

@@ -2,14 +2,14 @@
 frame and one long-term attention over the bank, M = 1 + (t-1)//5 memorised frames), on the default stream, for
 rocprofv3 --pmc passes (PMC collection hangs on bench.py's per-clip HIP streams).
     python tools/dev/pmc_attn_mix.py [aot|aotx6|gated|gatedx6|m14]      aot: R50-AOTL (attn_fwd_d32_pipe_kernel; aotx6: attn_x6_d32_kernel), gated: R50-DeAOTL
-    (attn_fwd_wide_coop_kernel<8>), m14: three launches of each kernel -- fp32 and bf16x6 forms -- at M = 14 (SQ counter passes)
+    (attn_fwd_wide_coop_kernel<8>; gatedx6: attn_x6_wide64p_kernel), m14: three launches of each kernel -- fp32 and bf16x6 forms -- at M = 14 (SQ counter passes)
 AOT_HIP_LIB selects a variant build of the library."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'aot-benchmark_amd'))
 import torch, aot_hip
 aot_hip.load()
-from networks.layers.attention import attn_splits, gated_splits, _planned_len
+from networks.layers.attention import attn_splits, gated_splits, gated_splits_x6, _planned_len
 mode = sys.argv[1] if len(sys.argv) > 1 else 'aot'
 N, C, H, E, CAP = 1674, 256, 8, 1024, 32
 q = torch.randn(N, C, device='cuda'); out = torch.empty(N, C, device='cuda')
@@ -35,7 +35,7 @@ def d32_x6(T, brows):
 
 
 def gated_x6(T, brows):
-    ns = gated_splits(N, _planned_len(T, N, brows), slots=256)
+    ns = gated_splits_x6(N, 1, _planned_len(T, N, brows))
     aot_hip.gated_attention_x6(gq, gbank, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
 
 
@@ -66,7 +66,7 @@ else:
         aot_hip.gated_pack_x6(gk[:N], gv[:N], gsbank, N)
 
         def fn(T, brows):
-            ns = gated_splits(N, _planned_len(T, N, brows), slots=256)
+            ns = gated_splits_x6(N, 1, _planned_len(T, N, brows))
             aot_hip.gated_attention_x6(gq, gsbank if brows == N else gbank, gu, go, T, 128 ** 0.5, part=gpart if ns > 1 else None, nsplit=ns)
     else:
         fn = d32 if mode == 'aot' else gated

@@ -1,5 +1,5 @@
-"""Three launches each of the bf16x6 gated attention kernels at a 14-frame bank (N = 1674), for rocprofv3 --pmc passes:
-the 64-query pipelined kernel (round 6, split rule of gated_splits_x6) and the 32-query kernel of rounds 3-5 (4 splits).
+"""Three launches of the bf16x6 gated attention kernel (attn_x6_wide64p_kernel) and of its fp32 twin at an M-frame bank (N = 1674), for
+rocprofv3 --pmc passes.  (profiles/r06_gated64_pmc.txt was taken while the 32-query kernel of rounds 3-5 still existed beside it.)
     python tools/dev/pmc_gated_x6.py [M]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,9 +14,9 @@ u = torch.randn(N, E, device='cuda'); out = torch.empty(N, E, device='cuda'); pa
 bank = aot_hip.x6_gated_bank(1, M * N, 128, E, 'cuda')
 aot_hip.gated_pack_x6(k, v, bank, M * N)
 T = M * N
-n64, n32 = gated_splits_x6(N, 1, T), gated_splits(N, T, slots=256)
+n64, n32 = gated_splits_x6(N, 1, T), gated_splits(N, T)
 for _ in range(3):
     aot_hip.gated_attention_x6(q, bank, u, out, T, 128 ** 0.5, part=part, nsplit=n64)
-    aot_hip.gated_attention_x6(q, bank, u, out, T, 128 ** 0.5, part=part, nsplit=-n32)
+    aot_hip.gated_attention(q, k, v, u, out, T, 128 ** 0.5, part=part, nsplit=n32)
 torch.cuda.synchronize()
 print('M', M, 'splits', n64, n32)
