@@ -617,8 +617,8 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 // splitk_reduce_kernel): the long-K 3x3 layers on the stride-16 map have 108-316 tiles of 72 k-steps each -- too few workgroups,
 // too long a chain.
 // GN (not with SK; `scratch` then carries the partial-sum buffer): the tile end also writes the GroupNorm partial sums of its output --
-// every wave owns a 32-row x 32-column block, i.e. 32 rows of ONE 32-channel group: (sum, sum of squares) of the block's valid
-// elements (fp32, the stored values themselves) -> gn_part[(2 * tile row + wave row) * (Cout / 32) + column block][2].  The consumer
+// every wave owns a 32-row x 32-column block, i.e. 32 rows of ONE 32-channel group: (sum, sum of squared deviations from the block's
+// own mean) of the block's valid elements (fp32, the stored values themselves) -> gn_part[(2 * tile row + wave row) * (Cout / 32) + column block][2].  The consumer
 // (gn_act_dwconv5_kernel<true>) adds the partials of a group in index order in double: the statistics pass over the whole map and its
 // launch are gone (linear1 -> GN -> GELU -> dw5x5 of the LSTT's feed-forward, transformer.py:355-362 / basic.py:15-35).
 // C4 (the ResNet stem, 7x7 stride 2 on the image padded to FOUR channels): Cin = 4 makes one 16-byte chunk of the A row exactly one
@@ -848,7 +848,8 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][nb][r] += rv[nb][r];
       }
-      float ps = 0.f, pq = 0.f;
+      float ps = 0.f;
+      float gv[16];
       with_act(p.act, [&](auto ACT) __attribute__((always_inline)) -> void {
         constexpr int act = decltype(ACT)::value;
 #pragma unroll
@@ -856,13 +857,30 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
           const int c = (r & 3) + 8 * (r >> 2);
           const float v = apply_act(acc[0][nb][r], act);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_out, c < rows_left ? vbase : (int)OOB, c * ldc4, 0);
-          if (GN && c < rows_left && col_ok) { ps += v; pq += v * v; }
+          if (GN) {
+            gv[r] = v;
+            if (c < rows_left && col_ok) ps += v;
+          }
           acc[0][nb][r] = 0.f;
         }
       });
-      if (GN) {          // the wave's 32 x 32 block = 32 rows of one group: fixed butterfly over the 64 lanes, lane 0 writes
+      // the wave's 32 x 32 block = 32 rows of one group (the column block lies inside Cout: a block past it -- Cout % 64 == 32 -- writes
+      // nothing).  Partial = (sum, sum of squared deviations from the BLOCK's own mean): the consumer combines the blocks
+      // with Chan's formula -- no E[x^2] - mean^2 cancellation when |mean| >> std.  Fixed butterflies over the 64 lanes.
+      if (GN && it.bn * BN + wn + 32 * nb < p.Cout) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { ps += __shfl_xor(ps, off); pq += __shfl_xor(pq, off); }
+        for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+        const int brows = min(32, max(0, p.M - (it.bm * BM + wm)));
+        const float mb = brows > 0 ? ps / (float)(brows * 32) : 0.f;
+        float pq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float dv = gv[r] - mb;
+          if (c < rows_left && col_ok) pq += dv * dv;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pq += __shfl_xor(pq, off);
         if (lane == 0) {
           float* dst = scratch + ((long)(it.bm * 2 + (wave >> 1)) * (p.Cout >> 5) + ((it.bn * BN + wn + 32 * nb) >> 5)) * 2;
           dst[0] = ps;

@@ -229,26 +229,40 @@ __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __rest
   const int t = threadIdx.x;
   float mean, rstd;
   if (PART) {
-    __shared__ double red[2][256];
-    double ps = 0.0, pq = 0.0;
-    for (int i = t; i < P; i += 256) {
-      ps += (double)part[((long)i * G + g) * 2];
-      pq += (double)part[((long)i * G + g) * 2 + 1];
-    }
-    red[0][t] = ps;
-    red[1][t] = pq;
+    // partial i = (sum, sum of squared deviations from its own mean) of rows [32 i, 32 i + 32) x this group's CB channels, written by
+    // the producing GEMM's tile end; combined with Chan's formula in double, in index order (fixed tree): first the grand mean, then
+    // M2 = sum_i [M2_i + n_i (mean_i - mean)^2]
+    __shared__ double red[256];
+    const long rows = (long)H * W;
+    double ps = 0.0;
+    for (int i = t; i < P; i += 256) ps += (double)part[((long)i * G + g) * 2];
+    red[t] = ps;
     __syncthreads();
 #pragma unroll
     for (int off = 128; off > 0; off >>= 1) {
-      if (t < off) { red[0][t] += red[0][t + off]; red[1][t] += red[1][t + off]; }
+      if (t < off) red[t] += red[t + off];
       __syncthreads();
     }
-    const double cnt = (double)H * W * CB;
-    const double m = red[0][0] / cnt;
-    double var = red[1][0] / cnt - m * m;
-    if (var < 0.0) var = 0.0;
+    const double cnt = (double)rows * CB;
+    const double m = red[0] / cnt;
+    __syncthreads();
+    double pq = 0.0;
+    for (int i = t; i < P; i += 256) {
+      const long nr = min(32L, max(0L, rows - 32L * i));
+      if (nr > 0) {
+        const double ni = (double)nr * CB, di = (double)part[((long)i * G + g) * 2] / ni - m;
+        pq += (double)part[((long)i * G + g) * 2 + 1] + ni * di * di;
+      }
+    }
+    red[t] = pq;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) red[t] += red[t + off];
+      __syncthreads();
+    }
     mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    rstd = (float)(1.0 / sqrt(red[0] / cnt + (double)eps));
   } else {
     mean = (float)stats[((long)bl * G + g) * 2];
     rstd = (float)stats[((long)bl * G + g) * 2 + 1];

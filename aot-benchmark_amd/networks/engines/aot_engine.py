@@ -553,6 +553,7 @@ class AOTEngine(nn.Module):
             if buf is None:
                 buf = self._static[key] = torch.empty_like(pos)
             buf.copy_(pos)
+            buf._aot_pos_qkv = None          # (the buffer outlives clips and weight reloads: maps of an earlier clip never leak into this one)
             self.pos_emb = buf
             if hasattr(self.AOT.LSTT, 'prepare_pos') and not os.environ.get('AOT_NO_QKV_MERGE'):     # AOT: the position term of the merged Q|K|V product, once per clip (env: A/B runs)
                 key = ('pos_qkv', tuple(pos.shape))
@@ -767,7 +768,8 @@ def _decode(owner, cohorts, output_size, labels=False):
     first = cohorts[0]
     if output_size is not None:
         output_size = (int(output_size[0]), int(output_size[1]))
-    fused = labels and len(cohorts) == 1 and first.lanes == 1 and output_size is not None
+    # (aot_frame_tail_f32 takes up to 16 classes: larger max_obj_num models go through logits + fuse_probs + label_resize)
+    fused = labels and len(cohorts) == 1 and first.lanes == 1 and output_size is not None and first.AOT.max_obj_num + 1 <= 16
 
     def launch():
         stream = aot_hip.stream_ptr()
@@ -799,7 +801,10 @@ def _decode(owner, cohorts, output_size, labels=False):
     if len(cohorts) == 1 and first.use_graph:
         key = ptr_key('decode_labels' if fused else 'decode', first._dec_in, [f[0] for f in first._feats],
                       list(getattr(first._feats, 'ads', None) or ()), output_size, first.lanes,
-                      first._group_objects(), aot_hip.gemm_table())
+                      first._group_objects(), aot_hip.gemm_table(),
+                      # the fused tail bakes the INPUT size into its launch (the nearest-resized feedback label): two input sizes can share
+                      # every feature-map shape -- a key names every integer argument (graphs.py)
+                      tuple(first.input_size_2d) if fused else None)
         out4, out = first._gx().run(key, launch)
     else:
         out4, out = launch()

@@ -739,9 +739,9 @@ def main(argv=None):
             elapsed, frames_done, msum = run_plan(lanes, passes, lambda pi, i: pi * S + i)
             assert frames_done == args.steps
             tm = reduce_max(torch.tensor([elapsed], dtype=torch.float64, device=device))
-            runs.append((float(tm.item()), frames_done, msum))
+            runs.append((float(tm.item()), frames_done, msum, elapsed))
             events.append('timed_run_%d' % r)
-        tmax, frames_done, msum = median_run(runs)
+        tmax, frames_done, msum, own_elapsed = median_run(runs)
         elapsed = tmax
         phase('warm-up + %d timed runs' % R)
         single = None
@@ -827,7 +827,7 @@ def main(argv=None):
                 print('[bench] %s leg failed: %s' % (other, x6['error']), file=sys.stderr, flush=True)
         phase('second-arithmetic leg (%s)' % other)
         peak = 0.0 if dry else torch.cuda.max_memory_allocated(device) / 2**30
-        stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum)], dtype=torch.float64,
+        stats = gather_stats(torch.tensor([elapsed, float(frames_done), peak, float(msum), own_elapsed], dtype=torch.float64,
                                           device=device), world)
 
         roof = None
@@ -889,10 +889,16 @@ def main(argv=None):
                                    % (MODEL, IN_SIZE[0], IN_SIZE[1]),
                        'frames_per_clip': CLIP_FRAMES, 'clips_per_gpu': nclips_rank, 'streams_per_gpu': S,
                        'timed_M_mean': round(float(stats[:, 3].sum()) / total_frames, 2),
-                       'repeats': R, 'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _ in runs],
+                       'repeats': R, 'repeat_fps': [None if dry else round(world * f / e, 2) for e, f, _, _ in runs],
                        'timed_windows': passes[0] if len(passes) == 1 else '%d passes x %s' % (len(passes), passes[0]),
                        'single_stream': single, 'single_stream_online': (single or {}).get('online'), 'whole_clip': whole,
                        'parallelism': 'clip-sharded dp%d x %d concurrent clips per GPU' % (joined, S),
+                       # how `value` is formed, rank by rank (the first N > 1 run on hardware must be readable from its own line):
+                       # value = sum(per_rank_frames) / max(per_rank_elapsed_s) of the median run; ranks_joined = the size of the process
+                       # group every collective of this run went through (= n_gpus)
+                       'ranks_joined': joined, 'per_rank_frames': [int(x) for x in stats[:, 1].tolist()],
+                       'per_rank_elapsed_s': [round(float(x), 6) for x in stats[:, 4].tolist()],
+                       'elapsed_max_s': round(tmax, 6),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': table,
                        'encode_ahead_frames': max(1, args.encode_ahead),

@@ -1014,6 +1014,39 @@ def _hip_engine(model_name, **kw):
     return cfg, model, eng, sd
 
 
+@pytest.mark.parametrize('mfma', ['f32', 'bf16x6'])
+def test_merged_qkv_product_matches_the_unmerged_one(hip, mfma, monkeypatch):
+    """The self-attention's Q, K and V as ONE product on the normed input with the position term as a per-clip residual map
+    (transformer.py::prepare_pos: (x1 + pos) Wq = x1 Wq + pos Wq) against the two separate products of the reference's order
+    (transformer.py:322-324), in exact-fp32 mode too: same frames, logits within 2e-5 -- and the switch is honoured per clip on the
+    SAME engine (the position buffer outlives clips: its maps are dropped when a clip starts)."""
+    c, g = load_case('c1c_aotb')                       # three LSTT layers on MobileNetV2, 129x193
+    _, _, eng, _ = _hip_engine(c['model'], mfma=mfma)
+    frames, mask, objs, out_size = case_clip(c, device='cuda', g=g)
+
+    def run():
+        eng.restart_engine()
+        outs = []
+        with torch.no_grad():
+            eng.add_reference_frame(frames[0], mask, objs, frame_step=0)
+            merged = getattr(eng.aot_engines[0].pos_emb, '_aot_pos_qkv', None) is not None
+            for t in range(1, len(frames)):
+                eng.match_propogate_one_frame(frames[t])
+                lg = eng.decode_current_logits(out_size)
+                outs.append(eng.aot_engines[0].pred_id_logits.clone())
+                eng.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=eng.input_size_2d, mode='nearest'))
+        return merged, outs
+    m1, a = run()
+    monkeypatch.setenv('AOT_NO_QKV_MERGE', '1')
+    m2, b = run()
+    monkeypatch.delenv('AOT_NO_QKV_MERGE')
+    m3, a2 = run()
+    assert m1 and not m2 and m3, 'the merged product must follow the switch clip by clip: %s' % ((m1, m2, m3),)
+    for x, y, z in zip(a, b, a2):
+        assert torch.equal(x, z)
+        assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize('case', ['c1_aott', 'c1b_aott_ragged', 'c1c_aotb', 'c2_r50_aotl', 'c2b_swinb_aotl', 'c2c_r101_aotl', 'c3a_deaott', 'c3b_r50_deaotl', 'c3c_swinb_deaotl', 'c3d_deaots'])
 def test_end_to_end_vs_reference_golden(hip, case):
     """BASELINE configs 1 and 2 through the engine API on the GPU vs the real reference's outputs

@@ -121,6 +121,12 @@ def test_bench_entry_point_world_8_dry_run():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and line['value'] is None
+    # how the N > 1 figure is formed is readable from the line itself: every rank joined the group the collectives ran in, each
+    # contributed --steps frames, and the time `value` divides by is the MAX over the ranks' own elapsed times of the median run
+    cfg = line['config']
+    assert cfg['ranks_joined'] == 8 and cfg['per_rank_frames'] == [line['steps']] * 8 and len(cfg['per_rank_elapsed_s']) == 8
+    assert abs(cfg['elapsed_max_s'] - max(cfg['per_rank_elapsed_s'])) < 1e-5
+    assert abs(line['ms_per_step'] - cfg['elapsed_max_s'] / line['steps'] * 1e3) < 2e-3
     assert line['cpu_baseline'] is None                                   # N = 1 only
     tr = line['config']['dry_trace']
     assert sorted(t['rank'] for t in tr) == list(range(8))
