@@ -281,8 +281,8 @@ def test_frame_tail_bit_identical(hip, IH, IW, OH, OW, LH, LW, C, objs, align):
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
     GEMM's tile end, added up in the consumer's prologue -- against the three-launch path (linear, statistics pass, fused GN + GELU +
-    dw5x5): the linear output bit-identical, the partials' totals equal to a double-precision sum of that output to 1e-6 of its
-    scale, the final map within 2e-5 of its scale; repeats bit-identical."""
+    dw5x5): the linear output bit-identical, the partials (sum, squared deviations about the block mean) equal to double-precision
+    sums of that output and combining (Chan) to the group statistics, the final map within 2e-5 of its scale; repeats bit-identical."""
     g = torch.Generator().manual_seed(h * 100 + w)
     M, K, N = h * w, 256, 1024
     x = _dev(torch.randn(M, K, generator=g))
@@ -309,7 +309,20 @@ def test_gn_partials_from_gemm_tile_end(hip, h, w):
     scale = float(fd.abs().sum())
     assert abs(float(pp[:, :, 0].sum() - fd.sum())) <= 1e-6 * scale
     assert float((pp[:, :, 0].sum(0) - fd.sum((0, 2))).abs().max()) <= 1e-6 * scale
-    assert float((pp[:, :, 1].sum(0) - (fd * fd).sum((0, 2))).abs().max()) <= 1e-6 * float((fd * fd).sum())
+    # second entry (round 6): the sum of squared deviations from the BLOCK's own mean (32 rows x 32 channels; the last block ragged);
+    # Chan's combination of the blocks gives each group's sum of squared deviations from its grand mean
+    for i in range(P):
+        rows = fd[32 * i:32 * i + 32]
+        if rows.shape[0]:
+            m2 = ((rows - rows.mean((0, 2), keepdim=True)) ** 2).sum((0, 2))
+            assert float((pp[i, :, 1] - m2).abs().max()) <= 1e-5 * max(1.0, float(m2.max())), i
+        else:
+            assert float(pp[i].abs().max()) == 0.0
+    nrow = torch.tensor([max(0, min(32, M - 32 * i)) * 32 for i in range(P)], dtype=torch.float64, device='cuda').view(P, 1)
+    gmean = pp[:, :, 0].sum(0) / (M * 32)
+    m2 = (pp[:, :, 1] + nrow * (pp[:, :, 0] / nrow.clamp(min=1) - gmean) ** 2 * (nrow > 0)).sum(0)
+    want_m2 = ((fd - fd.mean((0, 2), keepdim=True)) ** 2).sum((0, 2))
+    assert float((m2 - want_m2).abs().max()) <= 1e-6 * float(want_m2.max())
     s = max(1.0, float(want.abs().max()))
     assert float((got - want).abs().max()) <= 2e-5 * s, float((got - want).abs().max())
     again = torch.empty(M, N, device='cuda')
