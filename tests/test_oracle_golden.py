@@ -397,3 +397,26 @@ def test_fp64_reference_fixture_is_consistent(case):
         assert own > 400 and outside > 100
     else:
         assert 20 <= own <= 60 and outside == 0
+
+
+def test_demo_real_image_fixture_is_consistent():
+    """tests/golden/demo_1001 (make_demo_e2e.py: the REAL reference's Evaluator on six 1080p JPEG frames of its own demo sequence, 44
+    objects): the files decode to what the golden was made from, one mask + two near-tie maps per propagated frame, ids within 0..44,
+    the tighter tie map inside the wider one.  (The GPU test runs SequenceEvaluator against it; the oracle's replay of this clip --
+    five object groups at 577x1041 -- takes minutes on the host and is not part of the default CPU suite.)"""
+    import os
+    from PIL import Image
+    from common import GOLD
+    root = os.path.join(GOLD, 'demo_1001')
+    g = np.load(os.path.join(root, 'golden.npz'))
+    names = [str(n) for n in g['names']]
+    assert len(names) == 6 and g['masks'].shape == (5, 1080, 1920) and str(g['model']) == 'r50_aotl'
+    for n in names:
+        im = Image.open(os.path.join(root, n))
+        assert im.size == (1920, 1080) and im.mode == 'RGB'
+    lab = np.array(Image.open(os.path.join(root, names[0].replace('jpg', 'png'))))
+    assert lab.shape == (1080, 1920) and sorted(np.unique(lab).tolist()) == list(range(45))
+    assert int(g['masks'].max()) <= 44 and tuple(g['input_size']) == (577, 1041) and tuple(g['logit_shape']) == (1, 51, 1080, 1920)
+    n = 5 * 1080 * 1920
+    wide, tight = np.unpackbits(g['ties_1e3'])[:n].astype(bool), np.unpackbits(g['ties_2e4'])[:n].astype(bool)
+    assert not (tight & ~wide).any() and 0 < tight.sum() < wide.sum() < 0.02 * n

@@ -1618,6 +1618,49 @@ def test_sequence_evaluator_vs_oracle(hip, flip, ms, tmp_path):
     assert (got[1].cpu()[5:25, 100:140] == 3).all()
 
 
+def test_demo_real_images_vs_reference_golden(hip, tmp_path):
+    """Real images end to end (tools/demo.py:112-255 == evaluator.py:209-505; SURVEY 8f1 + 8f2 together): the first six 1080p JPEG
+    frames of the reference's datasets/Demo/images/1001_3iEIq5HBY1s with its 44-object first-frame mask -- decoded from the JPEG
+    bytes, bicubic restrict-size to 577x1041 on the device, five object groups as lanes of one engine, soft aggregation, labels back at
+    1080x1920, palette PNGs -- against the REAL reference's `Evaluator.evaluating` on the same files (tests/golden/make_demo_e2e.py).
+    Every differing pixel must be one of the reference's own near-ties (fused top-2 probabilities within 1e-3), and there must be few."""
+    from PIL import Image
+    from networks.managers.evaluator import SequenceEvaluator
+    from common import GOLD
+    from utils.image import davis_palette
+    root = os.path.join(GOLD, 'demo_1001')
+    g = np.load(os.path.join(root, 'golden.npz'))
+    names = [str(n) for n in g['names']]
+    cfg, model, sd = synth_model_state(str(g['model']), cfg_overrides=dict(TEST_FLIP=False, TEST_MULTISCALE=[1.0], TEST_MAX_SHORT_EDGE=None,
+                                                                           TEST_MAX_LONG_EDGE=800 * 1.3, TEST_LONG_TERM_MEM_GAP=int(g['gap'])))
+    model = model.cuda().eval()
+    frames = [torch.from_numpy(np.array(Image.open(os.path.join(root, n)).convert('RGB'))).cuda() for n in names]
+    label = torch.from_numpy(np.array(Image.open(os.path.join(root, names[0].replace('jpg', 'png'))))).cuda()
+    H, W = frames[0].shape[:2]
+    assert (H, W) == (1080, 1920) and int(label.max()) == 44
+    ev = SequenceEvaluator(cfg, model)
+    assert ev.augmentations(H, W) == [(int(g['input_size'][0]), int(g['input_size'][1]), False)]
+    got = ev.run(frames, {0: label}, {0: 44}, save_dir=str(tmp_path), names=[n[:-4] for n in names], obj_idx=list(range(45)))
+    assert len(got) == len(names) - 1 == g['masks'].shape[0]
+    assert sum(e.lanes for e in ev.engines[0].aot_engines) == 5            # 44 objects = five groups of <= 10
+    npx = H * W
+    ties = np.unpackbits(g['ties_1e3'])[:len(got) * npx].reshape(len(got), H, W).astype(bool)
+    tight = np.unpackbits(g['ties_2e4'])[:len(got) * npx].reshape(len(got), H, W).astype(bool)
+    rec = []
+    for t, m in enumerate(got):
+        m = m.cpu().numpy().astype(np.uint8)
+        bad = m != g['masks'][t]
+        hard = int((bad & ~ties[t]).sum())
+        rec.append({'differing': int(bad.sum()), 'of_them_within_2e-4': int((bad & tight[t]).sum()), 'near_ties_1e-3': int(ties[t].sum()),
+                    'outside_near_ties': hard})
+        assert hard == 0, 'frame %d: %d pixels differ outside the reference near-ties' % (t + 1, hard)
+        assert bad.sum() <= 0.05 * ties[t].sum() + 8, rec[-1]
+        png = Image.open(str(tmp_path / (names[t + 1][:-4] + '.png')))
+        assert png.mode == 'P' and png.getpalette() == davis_palette() and np.array_equal(np.array(png), m)
+    _record_parity('demo_1001_real_images', 'sequence_evaluator', {'frames': len(got), 'pixels': int(g['masks'].size), 'per_frame': rec,
+                                                                   'objects': 44, 'groups': 5, 'input_size': [int(x) for x in g['input_size']]})
+
+
 def test_torch_ops_match_direct_calls(hip):
     """torch.ops.aot_hip.* (aot_hip_ops.py) run the same kernels as the direct ctypes wrappers: bit-identical outputs."""
     import aot_hip_ops  # noqa: F401
