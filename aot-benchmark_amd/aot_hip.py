@@ -24,6 +24,7 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
+    'aot_conv2d_bf16x6k_gn_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _I, _P, _L, _P, _P, _F, _P],
     'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
@@ -37,6 +38,7 @@ _SIGS = {
     'aot_gn_act_dwconv5_f32': [_P] * 6 + [_I] * 8 + [_P],
     'aot_linear_gn_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P, _L, _P],
     'aot_gn_act_dwconv5p_f32': [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_F, _P],
+    'aot_layernorm_linear_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 8 + [_F, _P, _L, _P],
     'aot_attn_f32': [_P] * 5 + [_I, _L, _I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
     'aot_attn_pack_x6_f32': [_P] * 3 + [_I, _L, _I, _L, _I, _I, _L, _P, _I, _P],
@@ -55,6 +57,7 @@ _SIGS = {
     'aot_patch_merge_f32': [_P, _P] + [_I] * 4 + [_P],
     'aot_idbank_f32': [_P] * 5 + [_I] * 13 + [_P, _P] + [_I] * 3 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
+    'aot_gn_bilinear_nhwc_f32': [_P] * 6 + [_I] * 13 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_frame_tail_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
@@ -351,6 +354,47 @@ def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, p
                                        KH, KW, stride, pad, dil, x.stride(0), out.stride(0), res.stride(0) if res is not None else 0,
                                        res_rows, act, ksplit, _opt(scratch), scratch.numel() if scratch is not None else 0,
                                        stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6k_f32')
+    return out
+
+
+def conv2d_gn_stats(x, w, bias, out, H, W, Cin, OH, OW, Cout, groups, ws, KH=1, KW=1, stride=1, pad=0, dil=1, eps=1e-5, B=1, stream=None):
+    """out = conv(x) AND the GroupNorm statistics of out where the layer runs split-K in a bf16x6 scope (one lane): the reduce launch
+    forms them (aot_conv2d_bf16x6k_gn_f32) -- returns stats [G][2] doubles (mean, rstd) for aot_groupnorm_apply_f32; otherwise runs the
+    plain conv2d and returns None (the caller launches the statistics pass).  AOT_NO_GNR_FUSE: always the latter (A/B runs)."""
+    global _x6k_ws
+    stack = _scopes.stack
+    M = B * OH * OW
+    if B == 1 and stack and stack[-1][1] and X6_TILE == 0 and Cin % 32 == 0 and Cout > 32 and Cout % 4 == 0 and \
+            -(-M // 64) * -(-Cout // 64) >= X6_MIN_TILES and not os.environ.get('AOT_NO_GNR_FUSE'):
+        nq = Cout // 4
+        ks = x6_ksplit(M, Cout, KH * KW * Cin)
+        if ks != 1 and nq <= 64 and nq & (nq - 1) == 0 and nq % groups == 0 and (nq // groups) & (nq // groups - 1) == 0:
+            w6 = getattr(w, '_aot_w6', None)
+            if w6 is None:
+                w6 = pack_bf16x6(w)
+            if _x6k_ws is None:
+                from networks.layers.workspace import Workspace
+                _x6k_ws = Workspace()
+            scratch = _x6k_ws.get('x6k', (max(abs(ks) * M * Cout, X6K_SCRATCH_FLOATS),), x.device)
+            nwg = -(-M * nq // 256)
+            part = ws.get('gnr_part_%d_%d' % (nwg, groups), (nwg * groups * 2,), x.device, torch.float64)
+            stats = ws.get('gnr_stats_%d' % groups, (groups * 2,), x.device, torch.float64)
+            ticket = ws.get_zeroed('gnr_ticket', (1,), x.device, torch.int32)
+            _chk(load().aot_conv2d_bf16x6k_gn_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), None, _dev(out), 1, H, W, Cin, OH, OW, Cout,
+                                                  KH, KW, stride, pad, dil, x.stride(0), out.stride(0), 0, 0, ACT_NONE, ks, _dev(scratch),
+                                                  scratch.numel(), groups, _dev(part), part.numel(), _dev(stats), _dev(ticket), eps,
+                                                  stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6k_gn_f32')
+            return stats
+    conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, B=B, stream=stream)
+    return None
+
+
+def groupnorm_apply(x, stats, gamma, beta, out, groups, act=ACT_NONE, B=1, add=None, add_rows=0, stream=None):
+    """The apply half of groupnorm() on finished statistics (stats [B][G][2] doubles)."""
+    M = x.shape[0] // B
+    _chk(load().aot_groupnorm_apply_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(out), _opt(add), B, M, x.shape[1], groups,
+                                        x.stride(0), out.stride(0), add.stride(0) if add is not None else 0, add_rows, act,
+                                        stream if stream is not None else stream_ptr()), 'aot_groupnorm_apply_f32')
     return out
 
 
@@ -680,6 +724,17 @@ def bilinear(x, out, IH, IW, OH, OW, C, align_corners, add=None, B=1, add_shared
     return out
 
 
+def gn_bilinear(x, stats, gamma, beta, out, IH, IW, OH, OW, C, groups, align_corners, act=ACT_NONE, add=None, B=1, add_shared=False,
+                stream=None):
+    """out = bilinear(act(GroupNorm(x))) (+ add) with finished statistics (aot_gn_bilinear_nhwc_f32): groupnorm_apply + bilinear in
+    one launch, bit-identical to the pair."""
+    _chk(load().aot_gn_bilinear_nhwc_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _opt(add), _dev(out), B, IH, IW, OH, OW, C, groups,
+                                         x.stride(0), add.stride(0) if add is not None else 0, out.stride(0), int(align_corners),
+                                         int(bool(add_shared)), act, stream if stream is not None else stream_ptr()),
+         'aot_gn_bilinear_nhwc_f32')
+    return out
+
+
 def logits_finalize(logits, out4, out, IH, IW, C, OH, OW, obj_total, align_corners, G=1, stream=None):
     """logits [G*IH*IW, ld]: out4 [G, C, IH, IW] planar masked copy, out [C, OH, OW] (G = 1) or the soft aggregation of the
     G object groups [1 + G*(C-1), OH, OW]; obj_total = objects in the frame (group g holds ids g*(C-1)+1 ..)."""
@@ -708,6 +763,39 @@ def linear_gn_x6(x, w, bias, out, part, res=None, act=ACT_NONE, res_rows=0, stre
                                          out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, _dev(part), part.numel(),
                                          stream if stream is not None else stream_ptr()), 'aot_linear_gn_bf16x6_f32')
     return 2 * (-(-M // 64))
+
+
+def fold_layernorm(w, bias, gamma, beta):
+    """The affine half of LayerNorm folded into the linear layer behind it: (n * gamma + beta) W + b = n (diag(gamma) W) + (beta W + b)
+    for the row-normalised n.  w [K, N] packed k-major; returns (W' registered for the bf16x6 packer, b'); beta W in double."""
+    wf = _register_weight((gamma.detach().float()[:, None] * w).contiguous())
+    bf = beta.detach().double() @ w.double()
+    if bias is not None:
+        bf = bf + bias.double()
+    return wf, bf.float().contiguous()
+
+
+def x6_ln_fusable(M, K, Cout):
+    """True where layernorm_linear_x6 may replace layernorm + linear: a bf16x6 scope with the kernel choice left open, on a layer the
+    family takes anyway (AOT_NO_LN_FUSE: the two-launch form, for A/B runs)."""
+    stack = _scopes.stack
+    return bool(stack and stack[-1][1] and X6_TILE == 0 and K % 32 == 0 and K <= 2048 and Cout > 32 and
+                -(-M // 64) * -(-Cout // 64) >= X6_MIN_TILES and not os.environ.get('AOT_NO_LN_FUSE'))
+
+
+def layernorm_linear_x6(x, wf, bf, out, eps=1e-5, res=None, act=ACT_NONE, res_rows=0, gn_part=None, stream=None):
+    """out[M, N] = act(LayerNorm(x) @ w + b (+ res)) in one launch (aot_layernorm_linear_bf16x6_f32); (wf, bf) = fold_layernorm(w, b,
+    gamma, beta).  gn_part: also the GroupNorm partials of out, as linear_gn_x6 -- returns their row count P then, else out."""
+    M, K = x.shape
+    N = out.shape[1]
+    w6 = getattr(wf, '_aot_w6', None)
+    if w6 is None:
+        w6 = pack_bf16x6(wf)
+    _chk(load().aot_layernorm_linear_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bf), _opt(res), _dev(out), M, K, N, x.stride(0),
+                                                out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, eps,
+                                                _opt(gn_part), gn_part.numel() if gn_part is not None else 0,
+                                                stream if stream is not None else stream_ptr()), 'aot_layernorm_linear_bf16x6_f32')
+    return out if gn_part is None else 2 * (-(-M // 64))
 
 
 def gn_act_dwconv5_part(x, gamma, beta, w, out, groups, part, P, H, W, act=ACT_GELU, eps=1e-5, stream=None):

@@ -681,6 +681,34 @@ extern "C" int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_
   return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch);
 }
 
+// aot_conv2d_bf16x6k_f32 whose reduce launch also forms the GroupNorm statistics of the result (round 6: the ConvGN blocks of the FPN head
+// on the stride-16 / stride-8 maps, one lane): stats [G][2] doubles (mean, rstd) as aot_groupnorm_stats_f32 writes them; gn_part =
+// scratch of ceil(B*OH*OW * Cout/4 / 256) * G * 2 doubles (gn_part_doubles = its size), ticket = one zeroed word (left zero)
+extern "C" int aot_conv2d_bf16x6k_gn_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
+                                         float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                                         int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
+                                         int ksplit, float* scratch, long scratch_floats, int G, double* gn_part, long gn_part_doubles,
+                                         double* stats, unsigned* ticket, float eps, void* stream) {
+  const int ks = ksplit < 0 ? -ksplit : ksplit;
+  if (!in || !w6 || !out || ks < 2 || ks > 64 || !gn_part || !stats || !ticket || !(eps > 0.f)) return AOT_ERR_BADARG;
+  if (B != 1 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
+  if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if (!scratch || (long)ks * OH * OW * Cout > scratch_floats) return AOT_ERR_BADARG;
+  if (!splitk_reduce_gn_ok(Cout, G)) return AOT_ERR_UNSUPPORTED;
+  if (gn_part_doubles < (long)splitk_reduce_gn_workgroups(OH * OW, Cout) * G * 2) return AOT_ERR_BADARG;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
+  GnStatsOut gn;
+  gn.G = G; gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.eps = eps;
+  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &gn);
+  return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &gn);
+}
+
 // out = act(x W + bias (+ res)) on the bf16x6 family AND the GroupNorm partial sums of `out` (32-channel groups) from the same tile
 // end: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats (sum, sum of squares per 32-row block and group; gn_part_floats = its size)
 extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
@@ -697,6 +725,26 @@ extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cou
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = M; p.K = K; p.act = act;
   return launch_gemm_x6rd_gn(p, w6, cout_pad, (hipStream_t)stream, gn_part);
+}
+
+// out = act(LayerNorm(x) W + bias (+ res)) in ONE launch on the bf16x6 family (round 6; SURVEY 8b's aot_layernorm_linear, reference
+// transformer.py:321-323 norm1 -> linear_Q|K|V and :355-359 norm3 -> linear1): x [M, lda] un-normalised, w6 = aot_pack_bf16x6_f32 of
+// diag(gamma) W, bias = beta W + b -- both folded by the caller -- so the kernel normalises rows only ((x - mean) before the split, rstd
+// at the tile end); eps as nn.LayerNorm.  gn_part (optional): the GroupNorm partials of `out` as aot_linear_gn_bf16x6_f32 writes them.
+extern "C" int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
+                                               float* out, int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act,
+                                               float eps, float* gn_part, long gn_part_floats, void* stream) {
+  if (!in || !w6 || !out || M <= 0 || K <= 0 || Cout <= 0 || !(eps > 0.f)) return AOT_ERR_BADARG;
+  if ((lda & 3) || lda < K || ldc < Cout || (K % 32)) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if (gn_part && ((Cout % 32) || gn_part_floats < 2L * ((M + 63) / 64) * (Cout / 32) * 2)) return AOT_ERR_BADARG;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
+  p.B = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = M; p.K = K; p.act = act;
+  return launch_gemm_x6rd_ln(p, w6, cout_pad, (hipStream_t)stream, eps, gn_part);
 }
 
 // KxK convolution of B four-channel NHWC images (the ResNet stem: the image padded to r, g, b, 0) in the bf16x6 family: one 16-byte chunk

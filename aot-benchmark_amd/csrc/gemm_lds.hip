@@ -709,39 +709,113 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 }
 
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels (16-byte loads and stores where the rows allow it:
-// Cout % 4 == 0 makes every slab row 16-byte aligned)
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch) {
+// Cout % 4 == 0 makes every slab row 16-byte aligned).
+// GN (round 6): the launch ALSO forms the GroupNorm statistics of its output (one lane; the ConvGN blocks of the FPN head, whose
+// convolutions are split-K on the stride-16 / stride-8 maps: fpn.py:18-21 / basic.py:38-58 in the reference) -- every workgroup reduces
+// the (sum, sum of squares) of its 1024 outputs per group in double (lanes of a group are neighbours: butterflies, then the rows of the
+// wave, then the four waves in order), publishes G partial pairs and draws a ticket; the last workgroup to arrive adds the partials of
+// all workgroups in index order and writes (mean, rstd) exactly as gn_stats_kernel does.  Deterministic; no statistics launch and no
+// second pass over the map.  Needs Cout / 4 and Cout / (4 G) powers of two with Cout / 4 <= 64 (checked by the host).
+struct GnReduce {
+  double* part;        // [workgroups][G][2]
+  double* stats;       // [G][2] (mean, rstd)
+  unsigned* ticket;    // one word, zero between launches
+  int G;
+  float eps;
+};
+template <bool GN>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch, const GnReduce gn) {
   const int nq = (p.Cout + 3) >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)p.M * nq) return;
-  const int m = (int)(idx / nq), n0 = (int)(idx - (long)m * nq) * 4;
-  const long slab = (long)p.M * p.Cout;
-  const float* src = scratch + (long)m * p.Cout + n0;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  const int cnt = min(4, p.Cout - n0);
-  const bool vec = (p.Cout & 3) == 0 && ((uintptr_t)scratch & 15) == 0;
-  if (vec) {
-    for (int s = 0; s < ksplit; ++s) {
-      const float4 t = *reinterpret_cast<const float4*>(src + (long)s * slab);
-      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  const bool live = idx < (long)p.M * nq;
+  if (!GN && !live) return;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  if (live) {
+    const int m = (int)(idx / nq), n0 = (int)(idx - (long)m * nq) * 4;
+    const long slab = (long)p.M * p.Cout;
+    const float* src = scratch + (long)m * p.Cout + n0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    cnt = min(4, p.Cout - n0);
+    const bool vec = (p.Cout & 3) == 0 && ((uintptr_t)scratch & 15) == 0;
+    if (vec) {
+      for (int s = 0; s < ksplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (long)s * slab);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+    } else {
+      for (int s = 0; s < ksplit; ++s)
+        for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
     }
-  } else {
-    for (int s = 0; s < ksplit; ++s)
-      for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
+    const long rrow = p.res_rows ? m % p.res_rows : m;
+    for (int c = 0; c < cnt; ++c) {
+      float t = v[c] + (p.bias ? p.bias[n0 + c] : 0.f);
+      if (p.res) t += p.res[rrow * p.ldr + n0 + c];
+      o[c] = apply_act(t, p.act);
+    }
+    float* dst = p.out + (long)m * p.ldc + n0;
+    if (vec && (p.ldc & 3) == 0 && ((uintptr_t)p.out & 15) == 0) {
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (int c = 0; c < cnt; ++c) dst[c] = o[c];
+    }
   }
-  const long rrow = p.res_rows ? m % p.res_rows : m;
-  float o[4];
-  for (int c = 0; c < cnt; ++c) {
-    float t = v[c] + (p.bias ? p.bias[n0 + c] : 0.f);
-    if (p.res) t += p.res[rrow * p.ldr + n0 + c];
-    o[c] = apply_act(t, p.act);
+  if (!GN) return;
+  // ---- GroupNorm statistics of the stored values ----
+  __shared__ double red[4][64][2];
+  __shared__ int last_flag;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int G = gn.G, L = nq / G;                      // lanes per group (a power of two)
+  double s = 0.0, sq = 0.0;
+  if (live) {
+    s = ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
+    sq = ((double)o[0] * o[0] + (double)o[1] * o[1]) + ((double)o[2] * o[2] + (double)o[3] * o[3]);
   }
-  float* dst = p.out + (long)m * p.ldc + n0;
-  if (vec && (p.ldc & 3) == 0 && ((uintptr_t)p.out & 15) == 0) {
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-  } else {
-    for (int c = 0; c < cnt; ++c) dst[c] = o[c];
+  for (int off = 1; off < L; off <<= 1) { s += __shfl_xor(s, off); sq += __shfl_xor(sq, off); }        // the group's lanes
+  for (int off = nq; off < 64; off <<= 1) { s += __shfl_xor(s, off); sq += __shfl_xor(sq, off); }      // the wave's rows
+  if (lane < nq && (lane & (L - 1)) == 0) { red[wave][lane / L][0] = s; red[wave][lane / L][1] = sq; }
+  __syncthreads();
+  if (t < 64) {          // (one wave: its stores are one instruction, the wait below covers all of them)
+    if (t < G) {
+      const double ps = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
+      const double pq = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
+      double* dst = gn.part + ((long)blockIdx.x * G + t) * 2;
+      __hip_atomic_store(dst, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(gn.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = prev == gridDim.x - 1;
+    }
   }
+  __syncthreads();
+  if (!last_flag) return;
+  // the last workgroup: thread t adds the partials of workgroups t, t + 256, ... of every group, then the 256 threads meet in a fixed tree
+  const int nwg = (int)gridDim.x;
+  for (int g = 0; g < G; ++g) {
+    double ts = 0.0, tq = 0.0;
+    for (int w2 = t; w2 < nwg; w2 += 256) {
+      ts += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tq += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ts += __shfl_xor(ts, off); tq += __shfl_xor(tq, off); }
+    __syncthreads();          // (the previous round's readers are done with red)
+    if (lane == 0) { red[wave][0][0] = ts; red[wave][0][1] = tq; }
+    __syncthreads();
+    if (t == 0) {
+      const double as = (red[0][0][0] + red[1][0][0]) + (red[2][0][0] + red[3][0][0]);
+      const double aq = (red[0][0][1] + red[1][0][1]) + (red[2][0][1] + red[3][0][1]);
+      const double cnt_g = (double)p.M * (p.Cout / G);
+      const double mean = as / cnt_g;
+      double var = aq / cnt_g - mean * mean;
+      if (var < 0.0) var = 0.0;
+      gn.stats[g * 2] = mean;
+      gn.stats[g * 2 + 1] = 1.0 / sqrt(var + (double)gn.eps);
+    }
+  }
+  if (t == 0) __hip_atomic_store(gn.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call / replay
 }
 
 template <int BMB, int PFD>
@@ -757,7 +831,7 @@ int launch_variant(const ConvParams& p, bool is1x1, int ksplit, float* scratch, 
     hipLaunchKernelGGL((gemm_lds_kernel<BMB, false, PFD>), dim3(grid), dim3(256), 0, s, p, ksplit, scratch);
   if (ksplit > 1) {
     const long n = (long)p.M * ((p.Cout + 3) >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
   }
   AOT_LAUNCH_CHECK();
 }
@@ -775,7 +849,7 @@ int launch_lean(const ConvParams& p, bool is1x1, int ksplit, float* scratch, hip
     hipLaunchKernelGGL((gemm_lean_kernel<BMB, false>), dim3(grid), dim3(256), 0, s, p, ksplit, scratch);
   if (ksplit > 1) {
     const long n = (long)p.M * ((p.Cout + 3) >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
   }
   AOT_LAUNCH_CHECK();
 }
@@ -796,7 +870,21 @@ bool gemm_lean_eligible(const ConvParams& p) {
 
 void launch_splitk_reduce(const ConvParams& p, int ksplit, const float* scratch, hipStream_t s) {
   const long n = (long)p.M * ((p.Cout + 3) >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch);
+  hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
+}
+
+// ... and the GroupNorm statistics of the result from the same launch (splitk_reduce_kernel<true>); gn_part: workgroups x G x 2 doubles
+int splitk_reduce_gn_workgroups(int M, int Cout) { return (int)cdiv((long)M * (Cout >> 2), 256); }
+bool splitk_reduce_gn_ok(int Cout, int G) {
+  if (G <= 0 || (Cout & 3) || Cout % G) return false;
+  const int nq = Cout >> 2, L = nq / G;
+  return nq <= 64 && (nq & (nq - 1)) == 0 && nq % G == 0 && L >= 1 && (L & (L - 1)) == 0;
+}
+void launch_splitk_reduce_gn(const ConvParams& p, int ksplit, const float* scratch, int G, double* gn_part, double* stats, unsigned* ticket,
+                             float eps, hipStream_t s) {
+  GnReduce gn;
+  gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.G = G; gn.eps = eps;
+  hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(splitk_reduce_gn_workgroups(p.M, p.Cout)), dim3(256), 0, s, p, ksplit, scratch, gn);
 }
 
 int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s) {

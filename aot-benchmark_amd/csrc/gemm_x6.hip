@@ -625,10 +625,19 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 // filter tap (r, g, b, 0 of one input pixel), so a k-step is eight taps instead of 32 channels of one tap: the thread's two chunks are
 // two taps with a bounds check each; K = KH * KW * 4 rounded up to 32 (the weight rows past it are zero: aot_pack_bf16x6_f32 of the
 // zero-padded matrix).  The last big layer that was still on the fp32 matrix cores in bf16x6 engines.
-template <bool IS1X1, bool SK, bool GN = false, bool C4 = false>
-__global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch) {
+// LN (a linear layer, unsplit; round 6 -- the `aot_layernorm_linear` of SURVEY 8b, transformer.py:321-359): the A operand is the
+// LayerNorm of `in` over its K channels, never materialised.  gamma is folded into the weight and beta into the bias by the host
+// (W' = diag(gamma) W, b' = beta W + b), so the kernel owes (x - mean) * rstd per row: the row MEAN comes from a pass of the staging
+// threads over their own chunks of the tile's rows when an item starts (four threads per row, quad reduce; the lines are the ones the
+// k-loop then re-reads from L1 / L2), the deviations x - mean are what gets split into planes, their squares are summed on the way
+// (two-pass variance, no cancellation), and RSTD -- a per-row factor of the whole product -- scales the accumulator at the tile end
+// (through 64 floats of LDS, double-buffered by item parity: the staging side runs two steps ahead of the MFMAs).
+template <bool IS1X1, bool SK, bool GN = false, bool C4 = false, bool LN = false>
+__global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch,
+                                                           const float ln_eps) {
   static_assert(!(SK && GN), "GroupNorm partials come from the unsplit form");
   static_assert(!C4 || (!IS1X1 && !SK && !GN), "the four-channel form: a KxK layer, unsplit");
+  static_assert(!LN || (IS1X1 && !SK && !C4), "the LayerNorm prologue: a linear layer, unsplit");
   constexpr int WM = 2, NBW = 1;
   constexpr int NT = 128 * WM;                            // threads: WM x 2 waves
   constexpr int BM = 32 * WM, BN = 64 * NBW;
@@ -638,6 +647,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   constexpr unsigned OOB = 0x80000000u;
   static_assert(NT == 4 * BM, "one A fragment per thread and k-step");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  __shared__ __attribute__((aligned(16))) float ln_rstd[LN ? 2 * BM : 4];       // LN: 1 / sqrt(var + eps) of the tile's rows, by item parity
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -697,6 +707,8 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   int tap_c = 0, tap_ky = 0, tap_kx = 0;
   u32x4v sa[2];                                                  // the staged step: 8 fp32 activations
   bf16x8 fb[2][3][2];                                            // [register set][plane][sub-step]: this step's and the next step's weights
+  float ln_mu = 0.f, ln_q = 0.f;                                 // LN: the row mean of the item being staged; this thread's share of sum (x - mean)^2
+  int sw_kt = 0, sw_i = 0;                                       // LN: the staging side's own step / item counters
   auto setup_item = [&](int i) __attribute__((always_inline)) {
     const bool live = i < mine;
     const Item it = item_of(live ? i : 0);
@@ -710,6 +722,18 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
     a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + (C4 ? 0 : 4 * c0)) * 4;
     if (IS1X1 && !a_ok) a_off = (int)OOB;
     s_k = SK ? it.kt0 * BK * 4 : 0;
+    if (LN) {            // the row's mean: this thread's 2 x nk chunks, then the four threads of the row (rows past M read zeros)
+      float s = 0.f;
+#pragma unroll 8
+      for (int kt = 0; kt < nk; ++kt) {
+        const f32x4 t0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off, kt * BK * 4, 0));
+        const f32x4 t1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off + 32, kt * BK * 4, 0));
+        s += ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      ln_mu = s / (float)p.K;
+    }
     if (!IS1X1) {
       if (SK) {            // the slice's first k-step names its filter tap
         const int k0 = it.kt0 * BK, tap = k0 / p.Cin;
@@ -770,7 +794,27 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   auto stage_write = [&](auto BUFI) __attribute__((always_inline)) {   // registers -> split -> LDS buffer BUFI
     unsigned char* st = lds + decltype(BUFI)::value * BUF;
     bf16x8 pl3[3];
-    split3(__builtin_bit_cast(f32x4, sa[0]), __builtin_bit_cast(f32x4, sa[1]), pl3);
+    if (LN) {            // the deviations from the row mean are the operand; their squares add up to the row's variance
+      f32x4 d0 = __builtin_bit_cast(f32x4, sa[0]), d1 = __builtin_bit_cast(f32x4, sa[1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d0[e] -= ln_mu;
+        d1[e] -= ln_mu;
+        ln_q = fmaf(d0[e], d0[e], ln_q);
+        ln_q = fmaf(d1[e], d1[e], ln_q);
+      }
+      split3(d0, d1, pl3);
+      if (++sw_kt == nk) {            // the item's last step is staged: rstd of the row -> LDS (read by the tile end >= one barrier later)
+        float q = ln_q + __shfl_xor(ln_q, 1);
+        q += __shfl_xor(q, 2);
+        if (sh == 0) ln_rstd[(sw_i & 1) * BM + srow] = 1.f / sqrtf(q / (float)p.K + ln_eps);
+        ln_q = 0.f;
+        sw_kt = 0;
+        ++sw_i;
+      }
+    } else {
+      split3(__builtin_bit_cast(f32x4, sa[0]), __builtin_bit_cast(f32x4, sa[1]), pl3);
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(st + pl * A_PLANE + a_wr) = pl3[pl];
   };
@@ -840,6 +884,11 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
         continue;
       }
       const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
+      if (LN) {            // (x - mean) W' is in the accumulator: times the row's rstd
+        const float* rs = ln_rstd + (c_i & 1) * BM + wm + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] *= rs[(r & 3) + 8 * (r >> 2)];
+      }
       if (has_bias) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][nb][r] += bv[nb];
@@ -1292,7 +1341,7 @@ bool gemm_x6_eligible(const ConvParams& p) {
 
 // the phase-shifted 128x128 form with split-K over the grid (gemm_x6pp_kernel<., true>): slabs [ksplit][M][Cout] in `scratch`
 // (its unsplit form was no faster than the plain 128x128 kernel -- profiles/r05_x6pp.txt -- and is not built)
-int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch) {
+int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   if (ksplit < 2 || (p.K / BK) % ksplit != 0) return AOT_ERR_BADARG;
@@ -1307,7 +1356,8 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
     hipLaunchKernelGGL((gemm_x6pp_kernel<true, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
   else
     hipLaunchKernelGGL((gemm_x6pp_kernel<false, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
-  launch_splitk_reduce(p, ksplit, scratch, s);
+  if (gn) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+  else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1321,7 +1371,26 @@ int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, 0.f);
+  AOT_LAUNCH_CHECK();
+}
+
+// LayerNorm + linear layer in one launch (gemm_x6rd_kernel<true, false, GN, false, true>): `in` is the un-normalised [M, K] map, w6 the
+// planes of diag(gamma) W, bias = beta W + b (folded by the caller); gn_part != nullptr: the GroupNorm partials of the output as well
+int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, float* gn_part) {
+  if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  if (!(p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1) || !(eps > 0.f)) return AOT_ERR_BADARG;
+  if (gn_part && (p.Cout & 31)) return AOT_ERR_BADARG;
+  X6Weight wq;
+  wq.w6 = w6;
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int grid = nit < 768 ? nit : 768;
+  if (gn_part)
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, eps);
+  else
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, eps);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1339,12 +1408,12 @@ int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
   AOT_LAUNCH_CHECK();
 }
 
 // split-K over the grid on the 64x64 register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>)
-int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch) {
+int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   if (ksplit < 2 || (p.K / BK) % ksplit != 0 || !scratch || (long)p.M * p.Cout * 4 >= 0x7fffffffL) return AOT_ERR_BADARG;
@@ -1354,10 +1423,11 @@ int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, h
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64) * ksplit;
   const int grid = nit < 1024 ? nit : 1024;                  // (the split-K form needs 118 registers: four workgroups per CU)
   if (p.KH == 1 && p.KW == 1 && p.pad == 0)
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f);
   else
-    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch);
-  launch_splitk_reduce(p, ksplit, scratch, s);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f);
+  if (gn) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+  else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1403,9 +1473,9 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
     const int gr = nit < 768 ? nit : 768;
     if (is1x1)
-      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
     else
-      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
     AOT_LAUNCH_CHECK();
   }
   if (tile == 129) {            // the register-staged 128x128 form: eight waves, one workgroup per CU

@@ -483,10 +483,16 @@ static inline float bilinear_scale(int in_size, int out_size, int align) {
   return (float)in_size / (float)out_size;
 }
 
+// GN (round 6): the input is read THROUGH GroupNorm-apply + activation -- in = the un-normalised map of a ConvGN block, stats its
+// finished (mean, rstd) per lane and group: the four taps are normalised on the fly with gn_apply_kernel's own arithmetic (same
+// order, fp32), so the result is bit-identical to gn_apply -> bilinear while the normalised map is never written (the FPN head's
+// conv_16x / conv_8x outputs feed nothing but the next upsampling: fpn.py:40-44, 50-51 in the reference).
+template <bool GN>
 __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__ in, const float* __restrict__ add,
                                                        float* __restrict__ out, int IH, int IW, int OH, int OW, int C,
                                                        int ldi, int ldadd, int ldo, int align, float sh, float sw,
-                                                       int add_shared) {
+                                                       int add_shared, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int G, int act) {
   in += (long)blockIdx.y * IH * IW * ldi;       // lane of the batch; `add` is one map per lane, or one shared by all lanes
   out += (long)blockIdx.y * OH * OW * ldo;
   if (add && !add_shared) add += (long)blockIdx.y * OH * OW * ldadd;
@@ -500,10 +506,24 @@ __global__ void __launch_bounds__(256) bilinear_kernel(const float* __restrict__
   float wy0, wy1, wx0, wx1;
   bilinear_coord(oy, IH, OH, sh, align, y0, y1, wy0, wy1);
   bilinear_coord(ox, IW, OW, sw, align, x0, x1, wx0, wx1);
-  const float4 a = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x0) * ldi + c4 * 4);
-  const float4 b = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x1) * ldi + c4 * 4);
-  const float4 c = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x0) * ldi + c4 * 4);
-  const float4 d = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x1) * ldi + c4 * 4);
+  float4 a = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x0) * ldi + c4 * 4);
+  float4 b = *reinterpret_cast<const float4*>(in + ((long)y0 * IW + x1) * ldi + c4 * 4);
+  float4 c = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x0) * ldi + c4 * 4);
+  float4 d = *reinterpret_cast<const float4*>(in + ((long)y1 * IW + x1) * ldi + c4 * 4);
+  if (GN) {
+    const int g = (c4 * 4) / (C / G);
+    const double* st = stats + ((long)blockIdx.y * G + g) * 2;
+    const float mean = (float)st[0], rstd = (float)st[1];
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
+    auto norm = [&](float4& v) {
+      v.x = gn_act((v.x - mean) * rstd * ga.x + be.x, act);
+      v.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
+      v.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
+      v.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+    };
+    norm(a); norm(b); norm(c); norm(d);
+  }
   float4 o;
   o.x = wy0 * (wx0 * a.x + wx1 * b.x) + wy1 * (wx0 * c.x + wx1 * d.x);
   o.y = wy0 * (wx0 * a.y + wx1 * b.y) + wy1 * (wx0 * c.y + wx1 * d.y);
@@ -523,9 +543,25 @@ extern "C" int aot_bilinear_nhwc_f32(const float* in, const float* add, float* o
     return AOT_ERR_BADARG;
   if (add && (ldadd & 3)) return AOT_ERR_BADARG;
   const long total = (long)OH * OW * (C / 4);
-  hipLaunchKernelGGL(bilinear_kernel, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
+  hipLaunchKernelGGL(bilinear_kernel<false>, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
                      OW, C, ldi, ldadd, ldo, align_corners, bilinear_scale(IH, OH, align_corners),
-                     bilinear_scale(IW, OW, align_corners), add_shared);
+                     bilinear_scale(IW, OW, align_corners), add_shared, nullptr, nullptr, nullptr, 1, 0);
+  AOT_LAUNCH_CHECK();
+}
+
+// out = bilinear(act(GroupNorm(in))) (+ add): aot_groupnorm_apply_f32 + aot_bilinear_nhwc_f32 in one launch, bit-identical to the pair;
+// stats [B][G][2] doubles (mean, rstd) from aot_groupnorm_stats_f32 or aot_conv2d_bf16x6k_gn_f32
+extern "C" int aot_gn_bilinear_nhwc_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* add,
+                                        float* out, int B, int IH, int IW, int OH, int OW, int C, int G, int ldi, int ldadd, int ldo,
+                                        int align_corners, int add_shared, int act, void* stream) {
+  if (!in || !stats || !gamma || !beta || !out || B <= 0 || B > 65535 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 ||
+      (C & 3) || (ldi & 3) || (ldo & 3) || G <= 0 || C % G || ((C / G) & 3))
+    return AOT_ERR_BADARG;
+  if (add && (ldadd & 3)) return AOT_ERR_BADARG;
+  const long total = (long)OH * OW * (C / 4);
+  hipLaunchKernelGGL(bilinear_kernel<true>, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, add, out, IH, IW, OH,
+                     OW, C, ldi, ldadd, ldo, align_corners, bilinear_scale(IH, OH, align_corners),
+                     bilinear_scale(IW, OW, align_corners), add_shared, stats, gamma, beta, G, act);
   AOT_LAUNCH_CHECK();
 }
 

@@ -84,6 +84,10 @@ class LongShortTermTransformerBlock(nn.Module):
         p['dw'], _ = fold_dwconv_bn(self.activation.conv)
         for n in ('norm1', 'norm2', 'norm3'):
             p[n] = _ln_params(getattr(self, n))
+        # LayerNorm as the prologue of the GEMM behind it (round 6, aot_layernorm_linear_bf16x6_f32): the affine half folded into the
+        # weights -- norm1 -> merged Q|K|V (its residual map carries the biases), norm3 -> linear1
+        p['ln1_qkv'] = aot_hip.fold_layernorm(p['sa_qkv_w'], None, *p['norm1'])
+        p['ln3_w1'] = aot_hip.fold_layernorm(p['w1'], p['b1'], *p['norm3'])
         p['gn'] = (self.activation.gn.weight.detach().float().contiguous(),
                    self.activation.gn.bias.detach().float().contiguous())
         self.short_term_attn.pack()
@@ -125,9 +129,12 @@ class LongShortTermTransformerBlock(nn.Module):
         # self-attention
         x1 = ws.get('x1', (M, C), dev)
         if pos_qkv is not None:       # one product for Q, K and V (pos_qkv = prepare_pos(pos): see pack())
-            aot_hip.layernorm(x, *p['norm1'], x1, stream=stream)
             qkv = ws.get('sa_qkv', (M, 3 * C), dev)
-            aot_hip.linear(x1, p['sa_qkv_w'], None, qkv, res=pos_qkv, res_rows=N, stream=stream)
+            if aot_hip.x6_ln_fusable(M, C, 3 * C):      # ... with norm1 as its prologue: x1 is never written
+                aot_hip.layernorm_linear_x6(x, *p['ln1_qkv'], qkv, eps=self.norm1.eps, res=pos_qkv, res_rows=N, stream=stream)
+            else:
+                aot_hip.layernorm(x, *p['norm1'], x1, eps=self.norm1.eps, stream=stream)
+                aot_hip.linear(x1, p['sa_qkv_w'], None, qkv, res=pos_qkv, res_rows=N, stream=stream)
             qk, sv = qkv[:, :2 * C], qkv[:, 2 * C:]
         else:
             x1p = ws.get('x1p', (M, C), dev)
@@ -169,22 +176,31 @@ class LongShortTermTransformerBlock(nn.Module):
         aot_hip.linear(cat, p['lst_w'], p['lst_b'], xb, res=xa, stream=stream)
 
         # feed-forward: linear1 -> GN(32) statistics -> [GN-apply + GELU + dw5x5] -> linear2
-        x3 = ws.get('x3', (M, C), dev)
-        aot_hip.layernorm(xb, *p['norm3'], x3, stream=stream)
         F1 = self.dim_ff
         f = ws.get('ffn_a', (M, F1), dev)
         g = ws.get('ffn_b', (M, F1), dev)
-        if F1 == 32 * 32 and aot_hip.x6_gn_fusable(M, C, F1, B) and not os.environ.get('AOT_NO_GN_FUSE'):
+        gn_fuse = F1 == 32 * 32 and aot_hip.x6_gn_fusable(M, C, F1, B) and not os.environ.get('AOT_NO_GN_FUSE')
+        ln_fuse = aot_hip.x6_ln_fusable(M, C, F1)      # norm3 as linear1's prologue (round 6): x3 is never written
+        if not ln_fuse:
+            x3 = ws.get('x3', (M, C), dev)
+            aot_hip.layernorm(xb, *p['norm3'], x3, eps=self.norm3.eps, stream=stream)
+        if gn_fuse:
             # bf16x6, one lane: linear1's tile end writes the GroupNorm partial sums, the fused GN + GELU + dw5x5 kernel adds them up
             # in its prologue -- no statistics launch, no extra pass over the [M, 1024] map
             part = ws.get('ffn_gnpart', (2 * ((M + 63) // 64) * 32 * 2,), dev)
-            P = aot_hip.linear_gn_x6(x3, p['w1'], p['b1'], f, part, stream=stream)
+            if ln_fuse:
+                P = aot_hip.layernorm_linear_x6(xb, *p['ln3_w1'], f, eps=self.norm3.eps, gn_part=part, stream=stream)
+            else:
+                P = aot_hip.linear_gn_x6(x3, p['w1'], p['b1'], f, part, stream=stream)
             aot_hip.gn_act_dwconv5_part(f, *p['gn'], p['dw'], g, 32, part, P, h, w, act=aot_hip.ACT_GELU, eps=self.activation.gn.eps,
                                         stream=stream)
             out = ws.get('layer_out_%d' % id(self), (M, C), dev)
             aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
             return out, qc, x2, fused_v
-        aot_hip.linear(x3, p['w1'], p['b1'], f, stream=stream)
+        if ln_fuse:
+            aot_hip.layernorm_linear_x6(xb, *p['ln3_w1'], f, eps=self.norm3.eps, stream=stream)
+        else:
+            aot_hip.linear(x3, p['w1'], p['b1'], f, stream=stream)
         if F1 == 32 * 32:
             aot_hip.gn_act_dwconv5(f, *p['gn'], p['dw'], g, 32, aot_hip.gn_buffers(ws, dev, B, 32, 8), h, w,
                                    act=aot_hip.ACT_GELU, nsplit=8, B=B, stream=stream)

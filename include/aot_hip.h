@@ -88,6 +88,16 @@ int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const 
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                            int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
                            void* stream);
+/* The same with the GroupNorm statistics of the result out of the REDUCE launch (round 6; one lane, B == 1): every workgroup of the
+ * reduce adds (sum, sum of squares) of its outputs per group in double, the last one to arrive (device-scope ticket) adds the
+ * workgroups' partials in index order and writes stats [G][2] doubles = (mean, rstd) exactly as aot_groupnorm_stats_f32 -- no
+ * statistics launch, no second pass over the map.  Cout / 4 <= 64 and Cout / (4 G) powers of two (else AOT_ERR_UNSUPPORTED);
+ * gn_part = ceil(OH*OW * (Cout/4) / 256) * G * 2 doubles of scratch, ticket = one zeroed word (left zero).  Replaces conv + the
+ * statistics half of gn in the ConvGN blocks of the FPN head (networks/layers/basic.py:38-58, networks/decoders/fpn.py:18-21). */
+int aot_conv2d_bf16x6k_gn_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                              int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                              int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
+                              int G, double* gn_part, long gn_part_doubles, double* stats, unsigned* ticket, float eps, void* stream);
 /* The ResNet stem in the same family (round 5): a KxK convolution of B NHWC images with FOUR channels (the image padded to r, g, b, 0 by
  * aot_nchw_to_nhwc_f32): one 16-byte chunk of an im2col row is one filter tap, a k-step is eight taps.  w6 = aot_pack_bf16x6_f32 of the
  * weight [Kp, ldb] with rows k = 4 * tap + channel, Kp = ceil(KH * KW / 8) * 32, zero rows past KH * KW * 4.  in [B*H*W, 4], out
@@ -165,6 +175,18 @@ int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cout_pad, cons
                              long gn_part_floats, void* stream);
 int aot_gn_act_dwconv5p_f32(const float* x, const float* part, int P, const float* gamma, const float* beta, const float* w,
                             float* out, int H, int W, int C, int G, int ldx, int ldo, int act, float eps, void* stream);
+
+/* LayerNorm folded into the consuming GEMM (round 6; SURVEY 8b `aot_layernorm_linear`): out = act(LayerNorm(x) W + b (+ res)) in one
+ * launch of the bf16x6 family, the normalised map never materialised.  x [M, lda] un-normalised, K % 32 == 0; the CALLER folds the
+ * affine part once per model: w6 = aot_pack_bf16x6_f32 of diag(gamma) W and bias = beta W + b, so the kernel owes (x - mean) * rstd
+ * per row -- the mean from a pass of the staging threads over the tile's rows, x - mean split into the bf16 planes, the squared
+ * deviations summed on the way (two-pass variance), rstd applied to the accumulator at the tile end; eps as nn.LayerNorm (biased
+ * variance).  gn_part / gn_part_floats optional (NULL, 0): the GroupNorm partials of `out` exactly as aot_linear_gn_bf16x6_f32.
+ * Replaces norm1 -> linear_Q|K|V of the self-attention and norm3 -> linear1 of the LSTT block
+ * (networks/layers/transformer.py:321-323, 355-359 in the reference). */
+int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                                    int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, float eps,
+                                    float* gn_part, long gn_part_floats, void* stream);
 
 /* Multi-head softmax attention over a key/value bank, flash style (no S materialised):
  *   out[n, h*d:(h+1)*d] = softmax_t( (q[n,h]/scale_div) . k[t,h] ) @ v[t,h]          (d == 32)
@@ -298,6 +320,13 @@ int aot_idbank_f32(const float* mask, const float* table, const float* sumtab, c
 int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int B, int IH, int IW, int OH,
                           int OW, int C, int ldi, int ldadd, int ldo, int align_corners, int add_shared,
                           void* stream);
+/* aot_groupnorm_apply_f32 + aot_bilinear_nhwc_f32 in one launch (round 6): out = bilinear(act(GroupNorm(in))) (+ add), the four taps
+ * normalised on the fly with the apply kernel's own arithmetic -- bit-identical to the pair, the normalised map never written.  stats
+ * [B][G][2] doubles (mean, rstd); (C / G) % 4 == 0.  The FPN head's conv_16x / conv_8x blocks, whose GroupNorm output feeds only the next
+ * upsampling (networks/decoders/fpn.py:40-44, 50-51). */
+int aot_gn_bilinear_nhwc_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* add, float* out,
+                             int B, int IH, int IW, int OH, int OW, int C, int G, int ldi, int ldadd, int ldo, int align_corners,
+                             int add_shared, int act, void* stream);
 
 /* Logit finalisation for the G object groups (lanes) of a frame: logits [G*IH*IW, ldi] stride-4 NHWC.  Per group the
  * channels of unused identities (group g holds objects g*(C-1)+1 .. min((g+1)*(C-1), obj_total)) are set to -1e10, the

@@ -277,6 +277,125 @@ def test_frame_tail_bit_identical(hip, IH, IW, OH, OW, LH, LW, C, objs, align):
         assert torch.equal(l3, lab)
 
 
+@pytest.mark.parametrize('M,K,N,shift,lanes', [(1674, 256, 768, 0.0, 1), (1674, 256, 1024, 0.0, 1), (1590, 256, 1024, 40.0, 1),
+                                               (5022, 256, 768, 3.0, 3), (99, 512, 320, -7.0, 1), (70000, 128, 192, 0.5, 1)])
+def test_layernorm_linear_x6_vs_fp64(hip, M, K, N, shift, lanes):
+    """aot_layernorm_linear_bf16x6_f32 (round 6; SURVEY 8b's aot_layernorm_linear, reference transformer.py:321-323, 355-359): LayerNorm
+    as the prologue of the GEMM behind it, affine half folded into the weights -- against fp64 LayerNorm + linear (+ the shared
+    residual map of the merged Q|K|V product), held to the error of the two-launch path (aot_layernorm_f32 + the bf16x6 linear) against
+    the same fp64 result; rows with |mean| >> std (shift 40: no cancellation in the variance); M no multiple of 64; several items per
+    workgroup (M = 70000); the GroupNorm partials of the fused output equal to those of aot_linear_gn_bf16x6_f32 on the two-launch
+    operand up to the same tolerance; repeats bit-identical."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = _dev(torch.randn(M, K, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g)) + shift * torch.randn(M, 1, generator=g))
+    w = _dev(torch.randn(K, N, generator=g) / K ** 0.5)
+    b = _dev(torch.randn(N, generator=g))
+    gamma, beta = _dev(1 + 0.3 * torch.randn(K, generator=g)), _dev(0.2 * torch.randn(K, generator=g))
+    rows = M // lanes
+    res = _dev(torch.randn(rows, N, generator=g)) if lanes > 1 or N == 768 else None
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    n64 = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    want = (n64 * gamma.double() + beta.double()) @ w.double() + b.double()
+    if res is not None:
+        want = want + res.double().repeat(M // rows, 1)
+    wk = hip.attach_wt(w.clone(), K)
+    wf, bf = hip.fold_layernorm(w, b, gamma, beta)
+    assert float((bf.double() - (beta.double() @ w.double() + b.double())).abs().max()) < 1e-6
+    kw = dict(res=res, res_rows=rows if res is not None else 0)
+    with hip.use_gemm_table('throughput', 'bf16x6'):
+        assert hip.x6_ln_fusable(M, K, N) == (-(-M // 64) * -(-N // 64) >= hip.X6_MIN_TILES)
+        x1 = torch.empty(M, K, device='cuda')
+        hip.layernorm(x, gamma, beta, x1)
+        two = torch.empty(M, N, device='cuda')
+        hip.linear(x1, wk, b, two, **kw)
+        got = torch.full((M, N), float('nan'), device='cuda')
+        hip.layernorm_linear_x6(x, wf, bf, got, **kw)
+        again = torch.empty(M, N, device='cuda')
+        hip.layernorm_linear_x6(x, wf, bf, again, **kw)
+    assert not torch.isnan(got).any() and torch.equal(got, again)
+    s = float(want.abs().max())
+    e_two, e_got = float((two.double() - want).abs().max()), float((got.double() - want).abs().max())
+    assert e_got <= max(2.0 * e_two, 2e-6 * s), (e_got, e_two, s)
+    assert e_got <= 1e-5 * s
+    if N % 32 == 0 and res is None and lanes == 1:          # with the GroupNorm partials from the same tile end
+        P = 2 * ((M + 63) // 64)
+        part = torch.full((P * (N // 32) * 2,), float('nan'), device='cuda')
+        part2 = torch.full((P * (N // 32) * 2,), float('nan'), device='cuda')
+        gg = torch.full((M, N), float('nan'), device='cuda')
+        with hip.use_gemm_table('throughput', 'bf16x6'):
+            assert hip.layernorm_linear_x6(x, wf, bf, gg, gn_part=part) == P
+            hip.linear_gn_x6(x1, wk, b, two, part2)
+        assert torch.equal(gg, got)
+        pp, pq = part.view(P, N // 32, 2).double(), part2.view(P, N // 32, 2).double()
+        fd = gg.double().view(M, N // 32, 32)
+        assert float((pp[:, :, 0].sum(0) - fd.sum((0, 2))).abs().max()) <= 1e-6 * float(fd.abs().sum())
+        assert float((pp - pq).abs().max()) <= 1e-4 * float(pq.abs().max())
+
+
+@pytest.mark.parametrize('h,w,cin,cout,k', [(31, 54, 1024, 256, 1), (31, 54, 256, 256, 3), (61, 107, 256, 128, 3), (30, 53, 256, 256, 3)])
+def test_gn_statistics_from_splitk_reduce(hip, h, w, cin, cout, k):
+    """aot_conv2d_bf16x6k_gn_f32 (round 6): the ConvGN blocks of the FPN head on the stride-16 / stride-8 maps (fpn.py:18-21,
+    basic.py:38-58) -- the split-K reduce launch also forms the GroupNorm(8) statistics of its output.  Against conv2d + the
+    statistics launch: the convolution output bit-identical, (mean, rstd) equal to fp64 statistics of that output to 1e-11 and to
+    aot_groupnorm_stats_f32's, the ticket word back at zero, repeats bit-identical (the last-arriver adds in index order)."""
+    g = torch.Generator().manual_seed(h * w + cin + cout)
+    M, K = h * w, k * k * cin
+    x = _dev(torch.randn(M, cin, generator=g) + 0.5)
+    wk = hip.attach_wt(_dev(torch.randn(K, cout, generator=g) / K ** 0.5), cin)
+    b = _dev(torch.randn(cout, generator=g))
+    Workspace = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace
+    ws = Workspace()
+    kw = dict(KH=k, KW=k, pad=k // 2)
+    with hip.use_gemm_table('latency', 'bf16x6'):
+        assert hip.x6_ksplit(M, cout, K) != 1
+        ref = torch.empty(M, cout, device='cuda')
+        hip.conv2d(x, wk, b, ref, h, w, cin, h, w, cout, k, k, 1, k // 2, 1)
+        want = hip.groupnorm_stats(ref, 8, hip.gn_buffers(ws, x.device, 1, 8, 32), nsplit=32).clone()
+        out = torch.full((M, cout), float('nan'), device='cuda')
+        st = hip.conv2d_gn_stats(x, wk, b, out, h, w, cin, h, w, cout, 8, ws, **kw)
+        assert st is not None
+        got = st.clone()
+        out2 = torch.empty(M, cout, device='cuda')
+        again = hip.conv2d_gn_stats(x, wk, b, out2, h, w, cin, h, w, cout, 8, ws, **kw).clone()
+    assert torch.equal(out, ref) and torch.equal(out2, ref)
+    assert torch.equal(got, again)
+    assert int(ws.get('gnr_ticket', (1,), x.device, torch.int32).item()) == 0
+    rd = ref.double().view(M, 8, cout // 8)
+    mean = rd.mean((0, 2))
+    rstd = 1.0 / torch.sqrt(((rd - mean.view(1, 8, 1)) ** 2).mean((0, 2)) + 1e-5)
+    gs = got.view(8, 2)
+    assert float((gs[:, 0] - mean).abs().max()) <= 1e-11 * max(1.0, float(mean.abs().max()))
+    assert float((gs[:, 1] / rstd - 1).abs().max()) <= 1e-9
+    assert float((got - want).abs().max()) <= 1e-10 * float(want.abs().max())
+    with hip.use_gemm_table('latency', 'bf16x6'):      # the fallbacks: a layer that is not split, several lanes
+        assert hip.conv2d_gn_stats(x[:, :64].contiguous(), hip.attach_wt(_dev(torch.randn(64, cout, generator=g)), 64), b, out, 1, M, 64, 1, M,
+                                   cout, 8, ws) is None
+
+
+@pytest.mark.parametrize('B,ih,iw,oh,ow,C,align', [(1, 31, 54, 61, 107, 256, True), (3, 31, 54, 61, 107, 256, True), (1, 61, 107, 121, 213, 128, True),
+                                                  (2, 9, 11, 18, 22, 64, False)])
+def test_gn_bilinear_bit_identical_to_the_pair(hip, B, ih, iw, oh, ow, C, align):
+    """aot_gn_bilinear_nhwc_f32 (round 6): GroupNorm-apply + ReLU as the read side of the bilinear resize (+ shared adapter map) -- the
+    same fp32 arithmetic in the same order as aot_groupnorm_apply_f32 -> aot_bilinear_nhwc_f32: bit-identical, per lane."""
+    g = torch.Generator().manual_seed(B * 1000 + C + ih)
+    x = _dev(torch.randn(B * ih * iw, C, generator=g) * 2 + 0.3)
+    gamma, beta = _dev(torch.randn(C, generator=g)), _dev(torch.randn(C, generator=g))
+    add = _dev(torch.randn(oh * ow, C, generator=g))
+    ws = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace()
+    stats = hip.groupnorm_stats(x, 8, hip.gn_buffers(ws, x.device, B, 8, 32), B=B, nsplit=32)
+    y = torch.empty_like(x)
+    hip.groupnorm_apply(x, stats, gamma, beta, y, 8, act=hip.ACT_RELU, B=B)
+    want = torch.empty(B * oh * ow, C, device='cuda')
+    hip.bilinear(y, want, ih, iw, oh, ow, C, align, add=add, B=B, add_shared=True)
+    got = torch.full((B * oh * ow, C), float('nan'), device='cuda')
+    hip.gn_bilinear(x, stats, gamma, beta, got, ih, iw, oh, ow, C, 8, align, act=hip.ACT_RELU, add=add, B=B, add_shared=True)
+    assert torch.equal(got, want)
+    hip.gn_bilinear(x, stats, gamma, beta, got, ih, iw, oh, ow, C, 8, align, act=hip.ACT_RELU, B=B)
+    hip.bilinear(y, want, ih, iw, oh, ow, C, align, B=B)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
