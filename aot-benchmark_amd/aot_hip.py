@@ -58,6 +58,7 @@ _SIGS = {
     'aot_idbank_f32': [_P] * 5 + [_I] * 13 + [_P, _P] + [_I] * 3 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
     'aot_gn_bilinear_nhwc_f32': [_P] * 6 + [_I] * 13 + [_P],
+    'aot_gn_conv1x1_f32': [_P] * 7 + [_I] * 10 + [_P],
     'aot_logits_finalize_f32': [_P] * 3 + [_I] * 9 + [_P],
     'aot_frame_tail_f32': [_P] * 4 + [_I] * 10 + [_P],
     'aot_add_f32': [_P] * 3 + [_L, _P],
@@ -732,6 +733,16 @@ def gn_bilinear(x, stats, gamma, beta, out, IH, IW, OH, OW, C, groups, align_cor
                                          x.stride(0), add.stride(0) if add is not None else 0, out.stride(0), int(align_corners),
                                          int(bool(add_shared)), act, stream if stream is not None else stream_ptr()),
          'aot_gn_bilinear_nhwc_f32')
+    return out
+
+
+def gn_conv1x1(x, stats, gamma, beta, w, bias, out, groups, cout, gn_act=ACT_NONE, act=ACT_NONE, B=1, stream=None):
+    """out[:, :cout] = act(gn_act(GroupNorm(x)) @ w + bias) for cout <= 32 with finished statistics (aot_gn_conv1x1_f32): groupnorm_apply
+    + the 1x1 convolution in one launch, bit-identical to the pair (fp32 matrix cores, cfg 3)."""
+    M = x.shape[0] // B
+    _chk(load().aot_gn_conv1x1_f32(_dev(x), _dev(stats), _dev(gamma), _dev(beta), _dev(w), _opt(bias), _dev(out), B, M, x.shape[1], cout,
+                                   groups, x.stride(0), w.stride(0), out.stride(0), gn_act, act,
+                                   stream if stream is not None else stream_ptr()), 'aot_gn_conv1x1_f32')
     return out
 
 

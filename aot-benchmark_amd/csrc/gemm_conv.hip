@@ -19,9 +19,25 @@
 #include "conv_params.h"
 #include <cstdlib>
 
-template <int BM, int BN, int WM, int WN, int BK, bool IS1X1>
+// GNA (round 6, 1x1 only): the A operand is read THROUGH GroupNorm-apply + activation -- `in` is the un-normalised output of a ConvGN
+// block and gna its finished statistics (per lane of gna.rows rows and group: mean, rstd in double) and affine parameters: each loaded
+// float4 is normalised with gn_apply_kernel's own arithmetic, so the product equals gn_apply -> conv bit for bit while the normalised
+// map is never written (the FPN head's conv_4x block feeds nothing but conv_out: fpn.py:56-58 in the reference).
+struct GnApplyIn {
+  const double* stats;   // [lanes][G][2]
+  const float* gamma;
+  const float* beta;
+  int G, act, rows;      // rows per lane
+};
+__device__ __forceinline__ float gna_act(float v, int act) {      // (gn_act of norm_act.hip)
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+template <int BM, int BN, int WM, int WN, int BK, bool IS1X1, bool GNA = false>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
-conv_gemm_kernel(const ConvParams p) {
+conv_gemm_kernel(const ConvParams p, const GnApplyIn gna) {
+  static_assert(!GNA || IS1X1, "GroupNorm-apply on the A operand: a 1x1 layer");
   constexpr int NW_N = BN / WN;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -86,7 +102,19 @@ conv_gemm_kernel(const ConvParams p) {
       const int k = kt * BK + (f % KQ) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (IS1X1) {
-        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const float4*>(p.in + a_base[i] + (long)kt * BK);
+        if (a_ok[i] && k < p.K) {
+          v = *reinterpret_cast<const float4*>(p.in + a_base[i] + (long)kt * BK);
+          if (GNA) {
+            const int m = m0 + f / KQ;
+            const double* st = gna.stats + ((long)(m / gna.rows) * gna.G + k / (p.K / gna.G)) * 2;
+            const float mean = (float)st[0], rstd = (float)st[1];
+            const float4 ga = *reinterpret_cast<const float4*>(gna.gamma + k), be = *reinterpret_cast<const float4*>(gna.beta + k);
+            v.x = gna_act((v.x - mean) * rstd * ga.x + be.x, gna.act);
+            v.y = gna_act((v.y - mean) * rstd * ga.y + be.y, gna.act);
+            v.z = gna_act((v.z - mean) * rstd * ga.z + be.z, gna.act);
+            v.w = gna_act((v.w - mean) * rstd * ga.w + be.w, gna.act);
+          }
+        }
       } else {
         const int iy = a_iy0[i] + a_ky[i] * p.dil, ix = a_ix0[i] + a_kx[i] * p.dil;
         if (a_ok[i] && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
@@ -476,9 +504,9 @@ static int launch_cfg(const ConvParams& p, bool is1x1, hipStream_t s) {
   const int nb = cdiv(p.M, BM) * cdiv(p.Cout, BN);
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   if (is1x1)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, true>), dim3(nb), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, true>), dim3(nb), dim3(NT), 0, s, p, GnApplyIn{});
   else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, false>), dim3(nb), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, BK, false>), dim3(nb), dim3(NT), 0, s, p, GnApplyIn{});
   AOT_LAUNCH_CHECK();
 }
 
@@ -563,6 +591,31 @@ extern "C" int aot_conv2d_nhwc_f32(const float* in, const float* w, const float*
       }
     default: return AOT_ERR_BADARG;
   }
+}
+
+// out = act(conv1x1(gn_act(GroupNorm(in))) + bias) for Cout <= 32 (the FPN head's conv_out behind its conv_4x block): GroupNorm-apply
+// + activation folded into the A loads of the 128x32 register-staged kernel -- bit-identical to aot_groupnorm_apply_f32 followed by
+// aot_conv2d_nhwc_f32 (cfg 3).  in [B*M, lda] un-normalised, stats [B][G][2] doubles, w [K, ldb] k-major.
+extern "C" int aot_gn_conv1x1_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* w,
+                                  const float* bias, float* out, int B, int M, int K, int Cout, int G, int lda, int ldb, int ldc,
+                                  int gn_act, int act, void* stream) {
+  if (!in || !stats || !gamma || !beta || !w || !out || B <= 0 || M <= 0 || K <= 0 || Cout <= 0 || G <= 0) return AOT_ERR_BADARG;
+  if ((K & 3) || (lda & 3) || lda < K || ldc < Cout || (ldb & 3) || ldb < Cout || ((uintptr_t)w & 15) || ((uintptr_t)in & 15) ||
+      ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
+    return AOT_ERR_BADARG;
+  if (K % G || ((K / G) & 3)) return AOT_ERR_BADARG;
+  if (Cout > 32 || (long)B * M > 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  ConvParams p;
+  p.in = in; p.w = w; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out;
+  p.B = 1; p.H = 1; p.W = B * M; p.Cin = K; p.OH = 1; p.OW = B * M; p.Cout = Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.lda = lda; p.ldb = ldb; p.ldwt = 0; p.ldc = ldc; p.ldr = 0; p.res_rows = 0;
+  p.M = B * M; p.K = K; p.act = act;
+  GnApplyIn gna;
+  gna.stats = stats; gna.gamma = gamma; gna.beta = beta; gna.G = G; gna.act = gn_act; gna.rows = M;
+  const int nb = cdiv(p.M, 128) * cdiv(p.Cout, 32);
+  hipLaunchKernelGGL((conv_gemm_kernel<128, 32, 32, 32, 16, true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, p, gna);
+  AOT_LAUNCH_CHECK();
 }
 
 // ---- bf16 x 6 family (gemm_lds.hip: gemm_x6rd_kernel and friends) --------------------------------------------------------------

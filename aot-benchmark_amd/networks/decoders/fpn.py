@@ -132,8 +132,14 @@ class FPNSegmentationHead(nn.Module):
         self._gn_relu_up(d, e, 'conv_8x', B, ws, stream, h8, w8, h4, w4, ad4, stats=st)
         f = ws.get('dec_b4', (B * n4, hd // 2), dev)
         st = self._conv_gn(e, f, 'conv_4x', h4, w4, hd // 2, hd // 2, 3, B, ws, stream)
-        self._gn_relu(f, f, 'conv_4x', B, ws, stream, stats=st)
         ldo = (self.out_dim + 3) // 4 * 4
         out = ws.get('dec_logits', (B * n4, ldo), dev)
-        aot_hip.conv2d(f, *p['conv_out'], out, 1, B * n4, hd // 2, 1, B * n4, self.out_dim, stream=stream)
+        if self.out_dim <= 32 and not os.environ.get('AOT_NO_GN_UP'):
+            # conv_out reads relu(gn(conv_4x)) through its A loads (aot_gn_conv1x1_f32): the normalised 4x map is never written
+            if st is None:
+                st = aot_hip.groupnorm_stats(f, 8, aot_hip.gn_buffers(ws, dev, B, 8, 32), B=B, eps=self.conv_4x.gn.eps, nsplit=32, stream=stream)
+            aot_hip.gn_conv1x1(f, st, *p['conv_4x_gn'], *p['conv_out'], out, 8, self.out_dim, gn_act=aot_hip.ACT_RELU, B=B, stream=stream)
+        else:
+            self._gn_relu(f, f, 'conv_4x', B, ws, stream, stats=st)
+            aot_hip.conv2d(f, *p['conv_out'], out, 1, B * n4, hd // 2, 1, B * n4, self.out_dim, stream=stream)
         return out[:, :self.out_dim], h4, w4

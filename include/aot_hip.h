@@ -324,6 +324,12 @@ int aot_bilinear_nhwc_f32(const float* in, const float* add, float* out, int B, 
  * normalised on the fly with the apply kernel's own arithmetic -- bit-identical to the pair, the normalised map never written.  stats
  * [B][G][2] doubles (mean, rstd); (C / G) % 4 == 0.  The FPN head's conv_16x / conv_8x blocks, whose GroupNorm output feeds only the next
  * upsampling (networks/decoders/fpn.py:40-44, 50-51). */
+/* aot_groupnorm_apply_f32 + a 1x1 convolution with Cout <= 32 in one launch (round 6): out = act(gn_act(GroupNorm(in)) W + bias), the
+ * normalisation applied to the A operand as it is loaded -- bit-identical to the pair.  in [B*M, lda] (B lanes of M rows), stats
+ * [B][G][2] doubles, w [K, ldb] k-major as aot_conv2d_nhwc_f32 takes it.  The FPN head's conv_4x block -> conv_out
+ * (networks/decoders/fpn.py:56-58). */
+int aot_gn_conv1x1_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* w, const float* bias,
+                       float* out, int B, int M, int K, int Cout, int G, int lda, int ldb, int ldc, int gn_act, int act, void* stream);
 int aot_gn_bilinear_nhwc_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* add, float* out,
                              int B, int IH, int IW, int OH, int OW, int C, int G, int ldi, int ldadd, int ldo, int align_corners,
                              int add_shared, int act, void* stream);

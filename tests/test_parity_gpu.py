@@ -396,6 +396,30 @@ def test_gn_bilinear_bit_identical_to_the_pair(hip, B, ih, iw, oh, ow, C, align)
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize('B,M,K,cout', [(1, 121 * 213, 128, 11), (3, 1000, 128, 11), (2, 777, 64, 4), (1, 130, 256, 32)])
+def test_gn_conv1x1_bit_identical_to_the_pair(hip, B, M, K, cout):
+    """aot_gn_conv1x1_f32 (round 6): GroupNorm-apply + ReLU folded into the A loads of the Cout <= 32 convolution (conv_out behind the
+    FPN head's conv_4x block, fpn.py:56-58): bit-identical to aot_groupnorm_apply_f32 -> aot_conv2d_nhwc_f32, per lane."""
+    g = torch.Generator().manual_seed(B * 7 + M + K)
+    x = _dev(torch.randn(B * M, K, generator=g) * 1.5 - 0.2)
+    gamma, beta = _dev(torch.randn(K, generator=g)), _dev(torch.randn(K, generator=g))
+    ldb = (cout + 3) // 4 * 4
+    w = torch.zeros(K, ldb)
+    w[:, :cout] = torch.randn(K, cout, generator=g) / K ** 0.5
+    w, bias = hip.attach_wt(_dev(w), K), _dev(torch.randn(cout, generator=g))
+    ws = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace()
+    stats = hip.groupnorm_stats(x, 8, hip.gn_buffers(ws, x.device, B, 8, 32), B=B, nsplit=32)
+    y = torch.empty_like(x)
+    hip.groupnorm_apply(x, stats, gamma, beta, y, 8, act=hip.ACT_RELU, B=B)
+    want = torch.zeros(B * M, ldb, device='cuda')
+    for scope in (('latency', 'f32'), ('throughput', 'bf16x6')):      # what conv_out is dispatched to in either engine mode
+        with hip.use_gemm_table(*scope):
+            hip.conv2d(y, w, bias, want, 1, B * M, K, 1, B * M, cout)
+        got = torch.zeros(B * M, ldb, device='cuda')
+        hip.gn_conv1x1(x, stats, gamma, beta, w, bias, got, 8, cout, gn_act=hip.ACT_RELU, B=B)
+        assert torch.equal(got, want), scope
+
+
 @pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
