@@ -24,6 +24,7 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
+    'aot_linear_bf16x6k_ln_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 9 + [_P, _L, _P, _P, _P, _I, _F, _P],
     'aot_conv2d_bf16x6k_gn_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _I, _P, _L, _P, _P, _F, _P],
     'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
@@ -38,7 +39,7 @@ _SIGS = {
     'aot_gn_act_dwconv5_f32': [_P] * 6 + [_I] * 8 + [_P],
     'aot_linear_gn_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P, _L, _P],
     'aot_gn_act_dwconv5p_f32': [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_F, _P],
-    'aot_layernorm_linear_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 8 + [_F, _P, _L, _P],
+    'aot_layernorm_linear_bf16x6_f32': [_P, _P, _I, _P, _P, _P, _P] + [_I] * 8 + [_F, _P, _L, _P],
     'aot_attn_f32': [_P] * 5 + [_I, _L, _I, _I, _P] + [_I] * 6 + [_F, _I, _P],
     'aot_attn_merge_f32': [_P, _P, _P] + [_I] * 6 + [_P],
     'aot_attn_pack_x6_f32': [_P] * 3 + [_I, _L, _I, _L, _I, _I, _L, _P, _I, _P],
@@ -369,7 +370,7 @@ def conv2d_gn_stats(x, w, bias, out, H, W, Cin, OH, OW, Cout, groups, ws, KH=1, 
             -(-M // 64) * -(-Cout // 64) >= X6_MIN_TILES and not os.environ.get('AOT_NO_GNR_FUSE'):
         nq = Cout // 4
         ks = x6_ksplit(M, Cout, KH * KW * Cin)
-        if ks != 1 and nq <= 64 and nq & (nq - 1) == 0 and nq % groups == 0 and (nq // groups) & (nq // groups - 1) == 0:
+        if ks != 1 and nq <= 64 and nq & (nq - 1) == 0 and nq % groups == 0 and (nq // groups) & (nq // groups - 1) == 0 and 256 % groups == 0:
             w6 = getattr(w, '_aot_w6', None)
             if w6 is None:
                 w6 = pack_bf16x6(w)
@@ -388,6 +389,36 @@ def conv2d_gn_stats(x, w, bias, out, H, W, Cin, OH, OW, Cout, groups, ws, KH=1, 
             return stats
     conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, B=B, stream=stream)
     return None
+
+
+def linear_ln_out(x, w, bias, out, gamma, beta, ln_out, eps=1e-5, res=None, res_rows=0, stream=None):
+    """out = x @ w + bias (+ res) and ln_out = LayerNorm(out) * gamma + beta.  Where the layer runs split-K in a bf16x6 scope with 256
+    output channels, the reduce launch writes both (aot_linear_bf16x6k_ln_f32; bit-identical to the separate LayerNorm launch);
+    otherwise linear() + layernorm().  AOT_NO_LNO_FUSE: always the latter (A/B runs)."""
+    global _x6k_ws
+    M, K = x.shape
+    N = out.shape[1]
+    stack = _scopes.stack
+    st = stream if stream is not None else stream_ptr()
+    if stack and stack[-1][1] and X6_TILE == 0 and N == 256 and K % 32 == 0 and -(-M // 64) * 4 >= X6_MIN_TILES and \
+            ln_out.stride(0) % 4 == 0 and ln_out.data_ptr() % 16 == 0 and not os.environ.get('AOT_NO_LNO_FUSE'):
+        ks = x6_ksplit(M, N, K)
+        if ks != 1:
+            w6 = getattr(w, '_aot_w6', None)
+            if w6 is None:
+                w6 = pack_bf16x6(w)
+            if _x6k_ws is None:
+                from networks.layers.workspace import Workspace
+                _x6k_ws = Workspace()
+            scratch = _x6k_ws.get('x6k', (max(abs(ks) * M * N, X6K_SCRATCH_FLOATS),), x.device)
+            _chk(load().aot_linear_bf16x6k_ln_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), _opt(res), _dev(out), M, K, N, x.stride(0),
+                                                  out.stride(0), res.stride(0) if res is not None else 0, res_rows, ACT_NONE, ks,
+                                                  _dev(scratch), scratch.numel(), _dev(gamma), _dev(beta), _dev(ln_out), ln_out.stride(0),
+                                                  eps, st), 'aot_linear_bf16x6k_ln_f32')
+            return out
+    linear(x, w, bias, out, res=res, res_rows=res_rows, stream=st)
+    layernorm(out, gamma, beta, ln_out, eps=eps, stream=st)
+    return out
 
 
 def groupnorm_apply(x, stats, gamma, beta, out, groups, act=ACT_NONE, B=1, add=None, add_rows=0, stream=None):
@@ -778,8 +809,10 @@ def linear_gn_x6(x, w, bias, out, part, res=None, act=ACT_NONE, res_rows=0, stre
 
 def fold_layernorm(w, bias, gamma, beta):
     """The affine half of LayerNorm folded into the linear layer behind it: (n * gamma + beta) W + b = n (diag(gamma) W) + (beta W + b)
-    for the row-normalised n.  w [K, N] packed k-major; returns (W' registered for the bf16x6 packer, b'); beta W in double."""
+    for the row-normalised n.  w [K, N] packed k-major; returns (W' registered for the bf16x6 packer, b'); beta W in double.  W' carries
+    its column sums (`_aot_colsum`, summed in double): the kernel's mean correction, (x - mean) W' = (x - c) W' - (mean - c) colsum."""
     wf = _register_weight((gamma.detach().float()[:, None] * w).contiguous())
+    wf._aot_colsum = wf.double().sum(0).float().contiguous()
     bf = beta.detach().double() @ w.double()
     if bias is not None:
         bf = bf + bias.double()
@@ -802,7 +835,7 @@ def layernorm_linear_x6(x, wf, bf, out, eps=1e-5, res=None, act=ACT_NONE, res_ro
     w6 = getattr(wf, '_aot_w6', None)
     if w6 is None:
         w6 = pack_bf16x6(wf)
-    _chk(load().aot_layernorm_linear_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bf), _opt(res), _dev(out), M, K, N, x.stride(0),
+    _chk(load().aot_layernorm_linear_bf16x6_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bf), _dev(wf._aot_colsum), _opt(res), _dev(out), M, K, N, x.stride(0),
                                                 out.stride(0), res.stride(0) if res is not None else 0, res_rows, act, eps,
                                                 _opt(gn_part), gn_part.numel() if gn_part is not None else 0,
                                                 stream if stream is not None else stream_ptr()), 'aot_layernorm_linear_bf16x6_f32')

@@ -29,12 +29,17 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
 // the phase-shifted 128x128 form (gemm_x6pp_kernel) with split-K over the grid (ksplit >= 2, slabs in scratch)
 // gn != nullptr (both split-K forms): the reduce launch also forms the GroupNorm statistics of the result (one lane): gn->part =
 // splitk_reduce_gn_workgroups(M, Cout) x G x 2 doubles of scratch, gn->stats [G][2] (mean, rstd), gn->ticket one zeroed word
+// (G == 0: instead, LayerNorm(result) over the Cout == 256 channels as a second output map -- ln_gamma / ln_beta / ln_out / ld_ln / eps)
 struct GnStatsOut {
   int G;
   double* part;
   double* stats;
   unsigned* ticket;
   float eps;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float* ln_out;
+  int ld_ln;
 };
 int splitk_reduce_gn_workgroups(int M, int Cout);
 bool splitk_reduce_gn_ok(int Cout, int G);
@@ -45,6 +50,6 @@ int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, h
 int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part);
 // LayerNorm over the K channels of `in` + the linear layer in one launch (gamma / beta folded into w6 / bias by the caller); gn_part
 // optional (the GroupNorm partials of the output as launch_gemm_x6rd_gn writes them)
-int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, float* gn_part);
+int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, const float* colsum, float* gn_part);
 // a KxK convolution on four input channels (Cin = lda = 4: the ResNet stem) on the same kernel; w6: K rounded up to 8 taps per k-step
 int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);

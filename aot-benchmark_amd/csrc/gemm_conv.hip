@@ -756,8 +756,32 @@ extern "C" int aot_conv2d_bf16x6k_gn_f32(const float* in, const void* w6, int co
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  GnStatsOut gn;
+  GnStatsOut gn{};
   gn.G = G; gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.eps = eps;
+  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &gn);
+  return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &gn);
+}
+
+// aot_conv2d_bf16x6k_f32 as a linear layer with Cout == 256 whose reduce launch also writes LayerNorm(out) to ln_out [M, ld_ln] (round 6:
+// linear2 + residual of an LSTT block followed by the stack's output norm) -- bit-identical to aot_layernorm_f32 on the stored result
+extern "C" int aot_linear_bf16x6k_ln_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
+                                         int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, int ksplit,
+                                         float* scratch, long scratch_floats, const float* ln_gamma, const float* ln_beta, float* ln_out,
+                                         int ld_ln, float eps, void* stream) {
+  const int ks = ksplit < 0 ? -ksplit : ksplit;
+  if (!in || !w6 || !out || ks < 2 || ks > 64 || !ln_gamma || !ln_beta || !ln_out || !(eps > 0.f)) return AOT_ERR_BADARG;
+  if (M <= 0 || K <= 0 || (lda & 3) || lda < K || ldc < Cout || (ld_ln & 3) || ld_ln < Cout) return AOT_ERR_BADARG;
+  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  if (!scratch || (long)ks * M * Cout > scratch_floats) return AOT_ERR_BADARG;
+  if (Cout != 256 || ((uintptr_t)ln_out & 15) || ((uintptr_t)ln_gamma & 15) || ((uintptr_t)ln_beta & 15)) return AOT_ERR_UNSUPPORTED;
+  ConvParams p;
+  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
+  p.B = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = M; p.K = K; p.act = act;
+  GnStatsOut gn{};
+  gn.eps = eps; gn.ln_gamma = ln_gamma; gn.ln_beta = ln_beta; gn.ln_out = ln_out; gn.ld_ln = ld_ln;
   if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &gn);
   return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &gn);
 }
@@ -782,12 +806,13 @@ extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cou
 
 // out = act(LayerNorm(x) W + bias (+ res)) in ONE launch on the bf16x6 family (round 6; SURVEY 8b's aot_layernorm_linear, reference
 // transformer.py:321-323 norm1 -> linear_Q|K|V and :355-359 norm3 -> linear1): x [M, lda] un-normalised, w6 = aot_pack_bf16x6_f32 of
-// diag(gamma) W, bias = beta W + b -- both folded by the caller -- so the kernel normalises rows only ((x - mean) before the split, rstd
-// at the tile end); eps as nn.LayerNorm.  gn_part (optional): the GroupNorm partials of `out` as aot_linear_gn_bf16x6_f32 writes them.
-extern "C" int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
-                                               float* out, int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act,
-                                               float eps, float* gn_part, long gn_part_floats, void* stream) {
-  if (!in || !w6 || !out || M <= 0 || K <= 0 || Cout <= 0 || !(eps > 0.f)) return AOT_ERR_BADARG;
+// W' = diag(gamma) W, bias = beta W + b, colsum [Cout] = the column sums of W' -- all folded by the caller -- so the kernel normalises rows
+// only (statistics along the k-loop, correction at the tile end: gemm_x6.hip); eps as nn.LayerNorm.  gn_part (optional): the GroupNorm
+// partials of `out` as aot_linear_gn_bf16x6_f32 writes them.
+extern "C" int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* colsum,
+                                               const float* res, float* out, int M, int K, int Cout, int lda, int ldc, int ldr,
+                                               int res_rows, int act, float eps, float* gn_part, long gn_part_floats, void* stream) {
+  if (!in || !w6 || !colsum || !out || M <= 0 || K <= 0 || Cout <= 0 || !(eps > 0.f)) return AOT_ERR_BADARG;
   if ((lda & 3) || lda < K || ldc < Cout || (K % 32)) return AOT_ERR_BADARG;
   if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
   if (gn_part && ((Cout % 32) || gn_part_floats < 2L * ((M + 63) / 64) * (Cout / 32) * 2)) return AOT_ERR_BADARG;
@@ -797,7 +822,7 @@ extern "C" int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, 
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = M; p.K = K; p.act = act;
-  return launch_gemm_x6rd_ln(p, w6, cout_pad, (hipStream_t)stream, eps, gn_part);
+  return launch_gemm_x6rd_ln(p, w6, cout_pad, (hipStream_t)stream, eps, colsum, gn_part);
 }
 
 // KxK convolution of B four-channel NHWC images (the ResNet stem: the image padded to r, g, b, 0) in the bf16x6 family: one 16-byte chunk

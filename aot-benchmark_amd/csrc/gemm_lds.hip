@@ -716,15 +716,24 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 // wave, then the four waves in order), publishes G partial pairs and draws a ticket; the last workgroup to arrive adds the partials of
 // all workgroups in index order and writes (mean, rstd) exactly as gn_stats_kernel does.  Deterministic; no statistics launch and no
 // second pass over the map.  Needs Cout / 4 and Cout / (4 G) powers of two with Cout / 4 <= 64 (checked by the host).
+// LNO (round 6; Cout == 256: a row of the result is exactly one wave): the launch also writes LayerNorm(result) to a second map -- the
+// wave holds the row, so the statistics are two butterflies; same arithmetic and order as layernorm_kernel<1> (bit-identical to a
+// LayerNorm launch on the stored result).  The LSTT block's linear2 (+ residual) followed by the stack's output norm
+// (transformer.py:124-135, 359-362 in the reference).
 struct GnReduce {
   double* part;        // [workgroups][G][2]
   double* stats;       // [G][2] (mean, rstd)
   unsigned* ticket;    // one word, zero between launches
   int G;
   float eps;
+  const float* ln_gamma;   // LNO
+  const float* ln_beta;
+  float* ln_out;
+  int ld_ln;
 };
-template <bool GN>
+template <bool GN, bool LNO = false>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch, const GnReduce gn) {
+  static_assert(!(GN && LNO), "one fused consumer per launch");
   const int nq = (p.Cout + 3) >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const bool live = idx < (long)p.M * nq;
@@ -759,6 +768,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
     } else {
       for (int c = 0; c < cnt; ++c) dst[c] = o[c];
     }
+    if (LNO) {          // nq == 64: the 64 lanes of this wave hold row m (every lane of the wave is live or none)
+      float sm = (o[0] + o[1]) + (o[2] + o[3]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off);
+      const float mean = sm / (float)p.Cout;
+      const float a = o[0] - mean, b = o[1] - mean, c = o[2] - mean, d = o[3] - mean;
+      float sq = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+      const float rstd = 1.f / sqrtf(sq / (float)p.Cout + gn.eps);
+      const float4 g4 = *reinterpret_cast<const float4*>(gn.ln_gamma + n0), b4 = *reinterpret_cast<const float4*>(gn.ln_beta + n0);
+      float4 y;
+      y.x = (o[0] - mean) * rstd * g4.x + b4.x;
+      y.y = (o[1] - mean) * rstd * g4.y + b4.y;
+      y.z = (o[2] - mean) * rstd * g4.z + b4.z;
+      y.w = (o[3] - mean) * rstd * g4.w + b4.w;
+      *reinterpret_cast<float4*>(gn.ln_out + (long)m * gn.ld_ln + n0) = y;
+    }
   }
   if (!GN) return;
   // ---- GroupNorm statistics of the stored values ----
@@ -791,28 +818,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, 
   }
   __syncthreads();
   if (!last_flag) return;
-  // the last workgroup: thread t adds the partials of workgroups t, t + 256, ... of every group, then the 256 threads meet in a fixed tree
-  const int nwg = (int)gridDim.x;
-  for (int g = 0; g < G; ++g) {
+  // the last workgroup: all G groups at once (a first version walked the groups one after the other -- eight dependent round trips to the
+  // partials: +6 us per launch) -- thread t = (group t % G, strand t / G): its strand's workgroups in index order, all loads in flight
+  // together; then thread g < G adds the 256 / G strands of its group in strand order.  G divides 256 (host check).
+  {
+    const int nwg = (int)gridDim.x, g = t % G, strand = t / G, nstr = 256 / G;
     double ts = 0.0, tq = 0.0;
-    for (int w2 = t; w2 < nwg; w2 += 256) {
+    for (int w2 = strand; w2 < nwg; w2 += nstr) {
       ts += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       tq += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { ts += __shfl_xor(ts, off); tq += __shfl_xor(tq, off); }
-    __syncthreads();          // (the previous round's readers are done with red)
-    if (lane == 0) { red[wave][0][0] = ts; red[wave][0][1] = tq; }
+    __shared__ double fin[256][2];
+    fin[t][0] = ts;
+    fin[t][1] = tq;
     __syncthreads();
-    if (t == 0) {
-      const double as = (red[0][0][0] + red[1][0][0]) + (red[2][0][0] + red[3][0][0]);
-      const double aq = (red[0][0][1] + red[1][0][1]) + (red[2][0][1] + red[3][0][1]);
+    if (t < G) {
+      double as = 0.0, aq = 0.0;
+      for (int i = 0; i < nstr; ++i) { as += fin[i * G + t][0]; aq += fin[i * G + t][1]; }
       const double cnt_g = (double)p.M * (p.Cout / G);
       const double mean = as / cnt_g;
       double var = aq / cnt_g - mean * mean;
       if (var < 0.0) var = 0.0;
-      gn.stats[g * 2] = mean;
-      gn.stats[g * 2 + 1] = 1.0 / sqrt(var + (double)gn.eps);
+      gn.stats[t * 2] = mean;
+      gn.stats[t * 2 + 1] = 1.0 / sqrt(var + (double)gn.eps);
     }
   }
   if (t == 0) __hip_atomic_store(gn.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call / replay
@@ -876,15 +904,23 @@ void launch_splitk_reduce(const ConvParams& p, int ksplit, const float* scratch,
 // ... and the GroupNorm statistics of the result from the same launch (splitk_reduce_kernel<true>); gn_part: workgroups x G x 2 doubles
 int splitk_reduce_gn_workgroups(int M, int Cout) { return (int)cdiv((long)M * (Cout >> 2), 256); }
 bool splitk_reduce_gn_ok(int Cout, int G) {
-  if (G <= 0 || (Cout & 3) || Cout % G) return false;
+  if (G <= 0 || (Cout & 3) || Cout % G || 256 % G) return false;
   const int nq = Cout >> 2, L = nq / G;
   return nq <= 64 && (nq & (nq - 1)) == 0 && nq % G == 0 && L >= 1 && (L & (L - 1)) == 0;
 }
 void launch_splitk_reduce_gn(const ConvParams& p, int ksplit, const float* scratch, int G, double* gn_part, double* stats, unsigned* ticket,
                              float eps, hipStream_t s) {
-  GnReduce gn;
+  GnReduce gn{};
   gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.G = G; gn.eps = eps;
   hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(splitk_reduce_gn_workgroups(p.M, p.Cout)), dim3(256), 0, s, p, ksplit, scratch, gn);
+}
+// ... or LayerNorm(result) as a second output (Cout == 256, 16-byte aligned rows everywhere: checked by the caller)
+void launch_splitk_reduce_ln(const ConvParams& p, int ksplit, const float* scratch, const float* gamma, const float* beta, float* ln_out,
+                             int ld_ln, float eps, hipStream_t s) {
+  GnReduce gn{};
+  gn.eps = eps; gn.ln_gamma = gamma; gn.ln_beta = beta; gn.ln_out = ln_out; gn.ld_ln = ld_ln;
+  const long n = (long)p.M * (p.Cout >> 2);
+  hipLaunchKernelGGL((splitk_reduce_kernel<false, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, gn);
 }
 
 int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s) {

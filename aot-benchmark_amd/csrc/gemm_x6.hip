@@ -627,14 +627,18 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 // zero-padded matrix).  The last big layer that was still on the fp32 matrix cores in bf16x6 engines.
 // LN (a linear layer, unsplit; round 6 -- the `aot_layernorm_linear` of SURVEY 8b, transformer.py:321-359): the A operand is the
 // LayerNorm of `in` over its K channels, never materialised.  gamma is folded into the weight and beta into the bias by the host
-// (W' = diag(gamma) W, b' = beta W + b), so the kernel owes (x - mean) * rstd per row: the row MEAN comes from a pass of the staging
-// threads over their own chunks of the tile's rows when an item starts (four threads per row, quad reduce; the lines are the ones the
-// k-loop then re-reads from L1 / L2), the deviations x - mean are what gets split into planes, their squares are summed on the way
-// (two-pass variance, no cancellation), and RSTD -- a per-row factor of the whole product -- scales the accumulator at the tile end
-// (through 64 floats of LDS, double-buffered by item parity: the staging side runs two steps ahead of the MFMAs).
+// (W' = diag(gamma) W, b' = beta W + b), so the kernel owes (x - mean) * rstd per row -- and both statistics RIDE ALONG the k-loop, no
+// pass over the rows in front of it (a first version read the rows once for the mean before the pipeline started: as slow as the
+// LayerNorm launch it replaced, profiles/r06_fusions_ab.txt).  With c = the row's first element (a shift inside the row's range):
+// d = x - c is the operand that gets split into planes; sum d and sum d^2 are added up by the staging threads on the way (four threads
+// per row, quad reduce after the item's last step); then m' = mean - c = sum d / K, var = sum d^2 / K - m'^2 (|m'| is of the order of
+// the row's spread: no cancellation between large numbers, neither here nor in the product), and since
+//     (x - mean) W' = d W' - m' * colsum(W')
+// the tile end turns the accumulator d W' into rstd * (acc - m' * s_n) with s = the column sums of W' (ln_colsum, from the host).
+// (m', rstd) reach the tile end through 2 x 64 floats of LDS, double-buffered by item parity: the staging side runs two steps ahead.
 template <bool IS1X1, bool SK, bool GN = false, bool C4 = false, bool LN = false>
 __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch,
-                                                           const float ln_eps) {
+                                                           const float ln_eps, const float* __restrict__ ln_colsum) {
   static_assert(!(SK && GN), "GroupNorm partials come from the unsplit form");
   static_assert(!C4 || (!IS1X1 && !SK && !GN), "the four-channel form: a KxK layer, unsplit");
   static_assert(!LN || (IS1X1 && !SK && !C4), "the LayerNorm prologue: a linear layer, unsplit");
@@ -648,6 +652,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   static_assert(NT == 4 * BM, "one A fragment per thread and k-step");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
   __shared__ __attribute__((aligned(16))) float ln_rstd[LN ? 2 * BM : 4];       // LN: 1 / sqrt(var + eps) of the tile's rows, by item parity
+  __shared__ __attribute__((aligned(16))) float ln_mp[LN ? 2 * BM : 4];         // LN: mean - shift of the tile's rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -707,7 +712,7 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   int tap_c = 0, tap_ky = 0, tap_kx = 0;
   u32x4v sa[2];                                                  // the staged step: 8 fp32 activations
   bf16x8 fb[2][3][2];                                            // [register set][plane][sub-step]: this step's and the next step's weights
-  float ln_mu = 0.f, ln_q = 0.f;                                 // LN: the row mean of the item being staged; this thread's share of sum (x - mean)^2
+  float ln_c = 0.f, ln_s = 0.f, ln_q = 0.f;                      // LN: the row's shift; this thread's share of sum (x - c) and sum (x - c)^2
   int sw_kt = 0, sw_i = 0;                                       // LN: the staging side's own step / item counters
   auto setup_item = [&](int i) __attribute__((always_inline)) {
     const bool live = i < mine;
@@ -722,18 +727,6 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
     a_off = (((b * p.H + a_iy0) * p.W + a_ix0) * p.lda + (C4 ? 0 : 4 * c0)) * 4;
     if (IS1X1 && !a_ok) a_off = (int)OOB;
     s_k = SK ? it.kt0 * BK * 4 : 0;
-    if (LN) {            // the row's mean: this thread's 2 x nk chunks, then the four threads of the row (rows past M read zeros)
-      float s = 0.f;
-#pragma unroll 8
-      for (int kt = 0; kt < nk; ++kt) {
-        const f32x4 t0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off, kt * BK * 4, 0));
-        const f32x4 t1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off + 32, kt * BK * 4, 0));
-        s += ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      ln_mu = s / (float)p.K;
-    }
     if (!IS1X1) {
       if (SK) {            // the slice's first k-step names its filter tap
         const int k0 = it.kt0 * BK, tap = k0 / p.Cin;
@@ -794,20 +787,29 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
   auto stage_write = [&](auto BUFI) __attribute__((always_inline)) {   // registers -> split -> LDS buffer BUFI
     unsigned char* st = lds + decltype(BUFI)::value * BUF;
     bf16x8 pl3[3];
-    if (LN) {            // the deviations from the row mean are the operand; their squares add up to the row's variance
+    if (LN) {            // d = x - c is the operand; sum d and sum d^2 give the row's mean and variance at the item's end
       f32x4 d0 = __builtin_bit_cast(f32x4, sa[0]), d1 = __builtin_bit_cast(f32x4, sa[1]);
+      if (sw_kt == 0) ln_c = __shfl(d0[0], lane & ~3);            // the row's first element (the quad's slot-0 thread holds chunk 0)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        d0[e] -= ln_mu;
-        d1[e] -= ln_mu;
+        d0[e] -= ln_c;
+        d1[e] -= ln_c;
+        ln_s += d0[e] + d1[e];
         ln_q = fmaf(d0[e], d0[e], ln_q);
         ln_q = fmaf(d1[e], d1[e], ln_q);
       }
       split3(d0, d1, pl3);
-      if (++sw_kt == nk) {            // the item's last step is staged: rstd of the row -> LDS (read by the tile end >= one barrier later)
-        float q = ln_q + __shfl_xor(ln_q, 1);
+      if (++sw_kt == nk) {            // the item's last step is staged: (m', rstd) of the row -> LDS (read by the tile end >= one barrier later)
+        float sd = ln_s + __shfl_xor(ln_s, 1), q = ln_q + __shfl_xor(ln_q, 1);
+        sd += __shfl_xor(sd, 2);
         q += __shfl_xor(q, 2);
-        if (sh == 0) ln_rstd[(sw_i & 1) * BM + srow] = 1.f / sqrtf(q / (float)p.K + ln_eps);
+        const float mp = sd / (float)p.K;
+        const float var = fmaxf(q / (float)p.K - mp * mp, 0.f);
+        if (sh == 0) {
+          ln_rstd[(sw_i & 1) * BM + srow] = 1.f / sqrtf(var + ln_eps);
+          ln_mp[(sw_i & 1) * BM + srow] = mp;
+        }
+        ln_s = 0.f;
         ln_q = 0.f;
         sw_kt = 0;
         ++sw_i;
@@ -884,10 +886,15 @@ __global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, c
         continue;
       }
       const int vbase = col_ok ? (mlane * p.ldc + n) * 4 : (int)OOB;
-      if (LN) {            // (x - mean) W' is in the accumulator: times the row's rstd
+      if (LN) {            // d W' is in the accumulator: (x - mean) W' * rstd = (acc - m' * colsum) * rstd
         const float* rs = ln_rstd + (c_i & 1) * BM + wm + 4 * half;
+        const float* ms = ln_mp + (c_i & 1) * BM + wm + 4 * half;
+        const float sn = col_ok ? ln_colsum[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][nb][r] *= rs[(r & 3) + 8 * (r >> 2)];
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          acc[0][nb][r] = (acc[0][nb][r] - ms[rr] * sn) * rs[rr];
+        }
       }
       if (has_bias) {
 #pragma unroll
@@ -1356,7 +1363,8 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
     hipLaunchKernelGGL((gemm_x6pp_kernel<true, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
   else
     hipLaunchKernelGGL((gemm_x6pp_kernel<false, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
-  if (gn) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+  if (gn && gn->G > 0) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+  else if (gn) launch_splitk_reduce_ln(p, ksplit, scratch, gn->ln_gamma, gn->ln_beta, gn->ln_out, gn->ld_ln, gn->eps, s);
   else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }
@@ -1371,16 +1379,17 @@ int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, 0.f);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, 0.f, nullptr);
   AOT_LAUNCH_CHECK();
 }
 
 // LayerNorm + linear layer in one launch (gemm_x6rd_kernel<true, false, GN, false, true>): `in` is the un-normalised [M, K] map, w6 the
-// planes of diag(gamma) W, bias = beta W + b (folded by the caller); gn_part != nullptr: the GroupNorm partials of the output as well
-int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, float* gn_part) {
+// planes of W' = diag(gamma) W, bias = beta W + b, colsum = the column sums of W' (all folded by the caller); gn_part != nullptr: the
+// GroupNorm partials of the output as well
+int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, const float* colsum, float* gn_part) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
-  if (!(p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1) || !(eps > 0.f)) return AOT_ERR_BADARG;
+  if (!(p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1) || !(eps > 0.f) || !colsum) return AOT_ERR_BADARG;
   if (gn_part && (p.Cout & 31)) return AOT_ERR_BADARG;
   X6Weight wq;
   wq.w6 = w6;
@@ -1388,9 +1397,9 @@ int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipSt
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
   if (gn_part)
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, eps);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, eps, colsum);
   else
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, eps);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, eps, colsum);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1408,7 +1417,7 @@ int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1423,10 +1432,11 @@ int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, h
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64) * ksplit;
   const int grid = nit < 1024 ? nit : 1024;                  // (the split-K form needs 118 registers: four workgroups per CU)
   if (p.KH == 1 && p.KW == 1 && p.pad == 0)
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr);
   else
-    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f);
-  if (gn) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr);
+  if (gn && gn->G > 0) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
+  else if (gn) launch_splitk_reduce_ln(p, ksplit, scratch, gn->ln_gamma, gn->ln_beta, gn->ln_out, gn->ld_ln, gn->eps, s);
   else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }
@@ -1473,9 +1483,9 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
     const int gr = nit < 768 ? nit : 768;
     if (is1x1)
-      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
     else
-      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
     AOT_LAUNCH_CHECK();
   }
   if (tile == 129) {            // the register-staged 128x128 form: eight waves, one workgroup per CU

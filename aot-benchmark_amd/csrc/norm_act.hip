@@ -211,9 +211,9 @@ extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, cons
 // tile of one (lane, group): the 12x12 input halo is normalised and activated ONCE per element on its way into LDS (the
 // conv zero-pads AFTER the activation), then every thread (pixel, 8 channels) walks the 25 taps out of LDS.
 // PART (round 5): the statistics arrive as the PARTIAL sums the producing GEMM's tile end wrote (aot_linear_gn_bf16x6_f32:
-// part[P][G][2] floats, one (sum, sum of squares) per 32-row block and group; one lane): every workgroup adds its group's P partials
-// in double -- thread t takes partials t, t + 256, ... in index order, then a fixed tree over the 256 threads: the same bits in every
-// workgroup and every run -- and forms (mean, rstd) exactly as gn_stats_kernel does.  The statistics launch and its pass over the map
+// part[P][G][2] floats, one (sum, squared deviations) per 32-row block and group; one lane): every wave adds its group's P partials
+// in double -- lane l takes partials l, l + 64, ... in index order, then a fixed butterfly over the 64 lanes: the same bits in every
+// wave, workgroup and run -- and forms (mean, rstd) as gn_stats_kernel does.  The statistics launch and its pass over the map
 // are gone.
 template <bool PART>
 __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
@@ -232,37 +232,29 @@ __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __rest
     // partial i = (sum, sum of squared deviations from its own mean) of rows [32 i, 32 i + 32) x this group's CB channels, written by
     // the producing GEMM's tile end; combined with Chan's formula in double, in index order (fixed tree): first the grand mean, then
     // M2 = sum_i [M2_i + n_i (mean_i - mean)^2]
-    __shared__ double red[256];
+    // (round 6: every WAVE adds the partials on its own -- lane l takes partials l, l + 64, ... in index order, then one butterfly over
+    //  the 64 lanes: the same bits in every wave, workgroup and run, and no workgroup barrier; the 256-thread tree of round 5 spent
+    //  sixteen barriers on 54 numbers)
     const long rows = (long)H * W;
+    const int ln = t & 63;
     double ps = 0.0;
-    for (int i = t; i < P; i += 256) ps += (double)part[((long)i * G + g) * 2];
-    red[t] = ps;
-    __syncthreads();
+    for (int i = ln; i < P; i += 64) ps += (double)part[((long)i * G + g) * 2];
 #pragma unroll
-    for (int off = 128; off > 0; off >>= 1) {
-      if (t < off) red[t] += red[t + off];
-      __syncthreads();
-    }
+    for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
     const double cnt = (double)rows * CB;
-    const double m = red[0] / cnt;
-    __syncthreads();
+    const double m = ps / cnt;
     double pq = 0.0;
-    for (int i = t; i < P; i += 256) {
+    for (int i = ln; i < P; i += 64) {
       const long nr = min(32L, max(0L, rows - 32L * i));
       if (nr > 0) {
         const double ni = (double)nr * CB, di = (double)part[((long)i * G + g) * 2] / ni - m;
         pq += (double)part[((long)i * G + g) * 2 + 1] + ni * di * di;
       }
     }
-    red[t] = pq;
-    __syncthreads();
 #pragma unroll
-    for (int off = 128; off > 0; off >>= 1) {
-      if (t < off) red[t] += red[t + off];
-      __syncthreads();
-    }
+    for (int off = 32; off > 0; off >>= 1) pq += __shfl_xor(pq, off);
     mean = (float)m;
-    rstd = (float)(1.0 / sqrt(red[0] / cnt + (double)eps));
+    rstd = (float)(1.0 / sqrt(pq / cnt + (double)eps));
   } else {
     mean = (float)stats[((long)bl * G + g) * 2];
     rstd = (float)stats[((long)bl * G + g) * 2 + 1];

@@ -106,8 +106,10 @@ class LongShortTermTransformerBlock(nn.Module):
         return out
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
-    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, pos_qkv=None):
-        """x [B*N, C(ld)] token-major (B lanes).  x6 = the bank's pre-split copy (planes, rows per lane) for the bf16x6 attention
+    def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, pos_qkv=None,
+            out_norm=None):
+        """x [B*N, C(ld)] token-major (B lanes).  out_norm = (gamma, beta, dst, eps): the stack's norm of this layer's output, written to dst
+        by this call (from linear2's reduce launch where that layer runs split-K).  x6 = the bank's pre-split copy (planes, rows per lane) for the bf16x6 attention
         kernel, when the engine keeps one.  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
         (T_dev: device int holding T, for launches replayed from a graph while the bank grows);
         short_mem = (K, V, kv_brows).  dst = (k_out, v_out) [B*N, C] buffers for this frame's K (= linear_Q output) and, on
@@ -195,7 +197,7 @@ class LongShortTermTransformerBlock(nn.Module):
             aot_hip.gn_act_dwconv5_part(f, *p['gn'], p['dw'], g, 32, part, P, h, w, act=aot_hip.ACT_GELU, eps=self.activation.gn.eps,
                                         stream=stream)
             out = ws.get('layer_out_%d' % id(self), (M, C), dev)
-            aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
+            self._linear2(g, out, xb, out_norm, stream)
             return out, qc, x2, fused_v
         if ln_fuse:
             aot_hip.layernorm_linear_x6(xb, *p['ln3_w1'], f, eps=self.norm3.eps, stream=stream)
@@ -211,8 +213,16 @@ class LongShortTermTransformerBlock(nn.Module):
             aot_hip.dwconv2d(g, p['dw'], None, f2, h, w, F1, h, w, 5, 1, 2, 1, B=B, stream=stream)
             g = f2
         out = ws.get('layer_out_%d' % id(self), (M, C), dev)
-        aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
+        self._linear2(g, out, xb, out_norm, stream)
         return out, qc, x2, fused_v
+
+    def _linear2(self, g, out, xb, out_norm, stream):
+        """linear2 + residual (transformer.py:359-362), and the stack's norm of the result when the caller hands it over."""
+        p = self._p
+        if out_norm is None:
+            return aot_hip.linear(g, p['w2'], p['b2'], out, res=xb, stream=stream)
+        gamma, beta, d, eps = out_norm
+        return aot_hip.linear_ln_out(g, p['w2'], p['b2'], out, gamma, beta, d, eps=eps, res=xb, stream=stream)
 
     def fuse_kv_2d(self, v, id_emb, ws, stream, out=None, summed=None):
         """linear_V(V + id_emb) (transformer.py:364-367).  `summed` = V + id_emb already formed (fused id-bank launch)."""
@@ -277,11 +287,6 @@ class LongShortTermTransformer(nn.Module):
         mems = []
         pq = getattr(pos, '_aot_pos_qkv', None) if pos is not None else None      # prepare_pos(): the merged Q|K|V product's residual maps
         for i, layer in enumerate(self.layers):
-            x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
-                                      short_mems[i] if short_mems is not None else None,
-                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
-                                      keep=keep, x6=x6[i] if x6 is not None else None, pos_qkv=pq[i] if pq is not None else None)
-            mems.append((ck, cv, fv))
             is_last = i == L - 1
             norm = None
             if self.decoder_norms is not None:
@@ -290,9 +295,14 @@ class LongShortTermTransformer(nn.Module):
                 elif not is_last and self.return_intermediate and self.intermediate_norm:
                     norm = self.decoder_norms[i]
             d = out_cat[:, (i + 1) * C:(i + 2) * C]
-            if norm is not None:
-                aot_hip.layernorm(x, norm.weight, norm.bias, d, stream=stream)
-            else:
+            # the stack's norm of the layer output rides on the layer's last launch (round 6)
+            x, ck, cv, fv = layer.run(x, long_mems[i] if long_mems is not None else None,
+                                      short_mems[i] if short_mems is not None else None,
+                                      id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
+                                      keep=keep, x6=x6[i] if x6 is not None else None, pos_qkv=pq[i] if pq is not None else None,
+                                      out_norm=(norm.weight, norm.bias, d, norm.eps) if norm is not None else None)
+            mems.append((ck, cv, fv))
+            if norm is None:
                 d.copy_(x)
         return out_cat, mems
 

@@ -176,16 +176,25 @@ int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cout_pad, cons
 int aot_gn_act_dwconv5p_f32(const float* x, const float* part, int P, const float* gamma, const float* beta, const float* w,
                             float* out, int H, int W, int C, int G, int ldx, int ldo, int act, float eps, void* stream);
 
+/* A split-K linear layer with Cout == 256 whose reduce launch also writes LayerNorm(out) to a second map (round 6): out = act(x W + b
+ * (+ res)) as aot_conv2d_bf16x6k_f32 (ksplit < 0: the 64x64 kernel), ln_out [M, ld_ln] = LayerNorm(out) * gamma + beta with the
+ * arithmetic of aot_layernorm_f32 (bit-identical to that launch on the stored result): a row of 256 channels is one wave of the
+ * reduce.  linear2 (+ residual) of an LSTT block followed by the stack's output norm (networks/layers/transformer.py:124-135, 359-362). */
+int aot_linear_bf16x6k_ln_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out, int M, int K,
+                              int Cout, int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
+                              const float* ln_gamma, const float* ln_beta, float* ln_out, int ld_ln, float eps, void* stream);
+
 /* LayerNorm folded into the consuming GEMM (round 6; SURVEY 8b `aot_layernorm_linear`): out = act(LayerNorm(x) W + b (+ res)) in one
  * launch of the bf16x6 family, the normalised map never materialised.  x [M, lda] un-normalised, K % 32 == 0; the CALLER folds the
- * affine part once per model: w6 = aot_pack_bf16x6_f32 of diag(gamma) W and bias = beta W + b, so the kernel owes (x - mean) * rstd
- * per row -- the mean from a pass of the staging threads over the tile's rows, x - mean split into the bf16 planes, the squared
- * deviations summed on the way (two-pass variance), rstd applied to the accumulator at the tile end; eps as nn.LayerNorm (biased
- * variance).  gn_part / gn_part_floats optional (NULL, 0): the GroupNorm partials of `out` exactly as aot_linear_gn_bf16x6_f32.
- * Replaces norm1 -> linear_Q|K|V of the self-attention and norm3 -> linear1 of the LSTT block
- * (networks/layers/transformer.py:321-323, 355-359 in the reference). */
-int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
-                                    int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, float eps,
+ * affine part once per model: w6 = aot_pack_bf16x6_f32 of W' = diag(gamma) W, bias = beta W + b, colsum [Cout] = the column sums of W'.
+ * The kernel owes (x - mean) * rstd per row, and both statistics ride along its k-loop (no pass over the rows in front of it): with
+ * c = the row's first element, d = x - c is what gets split into the bf16 planes, sum d and sum d^2 are added up by the staging
+ * threads, and the tile end applies rstd * (acc - (mean - c) * colsum) -- a shifted one-pass variance, |mean - c| being of the
+ * order of the row's spread.  eps as nn.LayerNorm (biased variance).  gn_part / gn_part_floats optional (NULL, 0): the GroupNorm
+ * partials of `out` exactly as aot_linear_gn_bf16x6_f32.  Replaces norm1 -> linear_Q|K|V of the self-attention and norm3 -> linear1
+ * of the LSTT block (networks/layers/transformer.py:321-323, 355-359 in the reference). */
+int aot_layernorm_linear_bf16x6_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* colsum, const float* res,
+                                    float* out, int M, int K, int Cout, int lda, int ldc, int ldr, int res_rows, int act, float eps,
                                     float* gn_part, long gn_part_floats, void* stream);
 
 /* Multi-head softmax attention over a key/value bank, flash style (no S materialised):

@@ -420,6 +420,33 @@ def test_gn_conv1x1_bit_identical_to_the_pair(hip, B, M, K, cout):
         assert torch.equal(got, want), scope
 
 
+@pytest.mark.parametrize('M,K', [(1674, 1024), (1590, 1024), (1025, 2048)])
+def test_linear_with_layernorm_output_bit_identical(hip, M, K):
+    """aot_linear_bf16x6k_ln_f32 (round 6): linear2 + residual of an LSTT block on the split-K kernel, whose reduce launch also writes the
+    stack's output norm (transformer.py:124-135, 359-362) into a column slice of the decoder's input -- both outputs bit-identical to
+    linear() followed by aot_layernorm_f32; the neighbouring columns of the slice's buffer untouched."""
+    g = torch.Generator().manual_seed(M + K)
+    N = 256
+    x, res = _dev(torch.randn(M, K, generator=g)), _dev(torch.randn(M, N, generator=g) * 3)
+    w = hip.attach_wt(_dev(torch.randn(K, N, generator=g) / K ** 0.5), K)
+    b, gamma, beta = (_dev(torch.randn(N, generator=g)) for _ in range(3))
+    with hip.use_gemm_table('latency', 'bf16x6'):
+        assert hip.x6_ksplit(M, N, K) != 1
+        want = torch.empty(M, N, device='cuda')
+        hip.linear(x, w, b, want, res=res)
+        cat_w = torch.full((M, 4 * N), 7.0, device='cuda')
+        hip.layernorm(want, gamma, beta, cat_w[:, N:2 * N])
+        got = torch.full((M, N), float('nan'), device='cuda')
+        cat_g = torch.full((M, 4 * N), 7.0, device='cuda')
+        hip.linear_ln_out(x, w, b, got, gamma, beta, cat_g[:, N:2 * N], res=res)
+    assert torch.equal(got, want) and torch.equal(cat_g, cat_w)
+    with hip.use_gemm_table('latency', 'f32'):          # outside the bf16x6 scope: the two-launch form
+        hip.linear(x, w, b, want, res=res)
+        hip.layernorm(want, gamma, beta, cat_w[:, N:2 * N])
+        hip.linear_ln_out(x, w, b, got, gamma, beta, cat_g[:, N:2 * N], res=res)
+    assert torch.equal(got, want) and torch.equal(cat_g, cat_w)
+
+
 @pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
