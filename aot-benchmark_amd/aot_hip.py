@@ -24,6 +24,7 @@ _SIGS = {
     'aot_pack_bf16x6_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16x6_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P],
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
+    'aot_linear_group_bf16x6_f32': [_I, _P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P],
     'aot_linear_bf16x6k_ln_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 9 + [_P, _L, _P, _P, _P, _I, _F, _P],
     'aot_conv2d_bf16x6k_gn_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _I, _P, _L, _P, _P, _F, _P],
     'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
@@ -389,6 +390,36 @@ def conv2d_gn_stats(x, w, bias, out, H, W, Cin, OH, OW, Cout, groups, ws, KH=1, 
             return stats
     conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, B=B, stream=stream)
     return None
+
+
+def linear_group(xs, ws, biases, outs, act=ACT_NONE, ress=None, res_rows=0, stream=None):
+    """outs[g] = act(xs[g] @ ws[g] + biases[g] (+ ress[g])) for up to four linear layers of ONE shape (same M, K, N, leading dimensions).
+    In a bf16x6 scope with the kernel choice left open: ONE launch, the problems side by side in the grid (aot_linear_group_bf16x6_f32);
+    otherwise one linear() each.  AOT_NO_GROUP: always the latter (A/B runs)."""
+    n = len(xs)
+    M, K = xs[0].shape
+    N = outs[0].shape[1]
+    stack = _scopes.stack
+    st = stream if stream is not None else stream_ptr()
+    same = all(x.shape == xs[0].shape and x.stride(0) == xs[0].stride(0) for x in xs) and \
+        all(o.shape == outs[0].shape and o.stride(0) == outs[0].stride(0) for o in outs) and \
+        all(w.shape == ws[0].shape for w in ws) and (ress is None or all(r.stride(0) == ress[0].stride(0) for r in ress)) and \
+        (all(b is None for b in biases) or all(b is not None for b in biases))
+    if 1 < n <= 4 and same and stack and stack[-1][1] and X6_TILE == 0 and K % 32 == 0 and N > 32 and x6_ksplit(M, N, K) == 1 and \
+            -(-M // 64) * -(-N // 64) >= X6_MIN_TILES and not os.environ.get('AOT_NO_GROUP'):
+        w6s = [getattr(w, '_aot_w6', None) for w in ws]
+        w6s = [pack_bf16x6(w) if w6 is None else w6 for w, w6 in zip(ws, w6s)]
+        arr = ctypes.c_void_p * n
+        pb = arr(*[_dev(b) for b in biases]) if biases[0] is not None else None
+        pr = arr(*[_dev(r) for r in ress]) if ress is not None else None
+        _chk(load().aot_linear_group_bf16x6_f32(n, arr(*[_dev(x) for x in xs]), arr(*[_dev(w6) for w6 in w6s]), w6s[0].shape[3], pb, pr,
+                                                arr(*[_dev(o) for o in outs]), M, K, N, xs[0].stride(0), outs[0].stride(0),
+                                                ress[0].stride(0) if ress is not None else 0, res_rows, act, st),
+             'aot_linear_group_bf16x6_f32')
+        return outs
+    for g in range(n):
+        linear(xs[g], ws[g], biases[g], outs[g], res=ress[g] if ress is not None else None, act=act, res_rows=res_rows, stream=st)
+    return outs
 
 
 def linear_ln_out(x, w, bias, out, gamma, beta, ln_out, eps=1e-5, res=None, res_rows=0, stream=None):

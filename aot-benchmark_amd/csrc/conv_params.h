@@ -51,5 +51,8 @@ int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipSt
 // LayerNorm over the K channels of `in` + the linear layer in one launch (gamma / beta folded into w6 / bias by the caller); gn_part
 // optional (the GroupNorm partials of the output as launch_gemm_x6rd_gn writes them)
 int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float eps, const float* colsum, float* gn_part);
+// n <= 4 linear layers of ONE shape (p: M, K, Cout, leading dimensions, res_rows, act) in one launch; per-problem operand pointers
+int launch_gemm_x6rd_group(const ConvParams& p, int n, const float* const* in, const void* const* w6, const float* const* bias,
+                           const float* const* res, float* const* out, int cout_pad, hipStream_t s);
 // a KxK convolution on four input channels (Cin = lda = 4: the ResNet stem) on the same kernel; w6: K rounded up to 8 taps per k-step
 int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s);

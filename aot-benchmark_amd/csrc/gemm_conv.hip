@@ -804,6 +804,23 @@ extern "C" int aot_linear_gn_bf16x6_f32(const float* in, const void* w6, int cou
   return launch_gemm_x6rd_gn(p, w6, cout_pad, (hipStream_t)stream, gn_part);
 }
 
+// n <= 4 independent linear layers of one shape in ONE launch of the bf16x6 family (round 6): out[g] = act(in[g] W[g] + bias[g] (+ res[g])).
+// The pointer arrays are HOST arrays read at launch time (bias / res: NULL, or an array whose entries are all set or all NULL).
+extern "C" int aot_linear_group_bf16x6_f32(int n, const float* const* in, const void* const* w6, int cout_pad, const float* const* bias,
+                                           const float* const* res, float* const* out, int M, int K, int Cout, int lda, int ldc, int ldr,
+                                           int res_rows, int act, void* stream) {
+  if (n < 1 || n > 4 || !in || !w6 || !out || M <= 0 || K <= 0 || Cout <= 0) return AOT_ERR_BADARG;
+  if ((lda & 3) || lda < K || ldc < Cout || (K % 32)) return AOT_ERR_BADARG;
+  if (res && res[0] && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
+  ConvParams p;
+  p.in = in[0]; p.w = nullptr; p.wt = nullptr; p.bias = bias ? bias[0] : nullptr; p.res = res ? res[0] : nullptr; p.out = out[0];
+  p.B = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = Cout;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
+  p.M = M; p.K = K; p.act = act;
+  return launch_gemm_x6rd_group(p, n, in, w6, bias, res, out, cout_pad, (hipStream_t)stream);
+}
+
 // out = act(LayerNorm(x) W + bias (+ res)) in ONE launch on the bf16x6 family (round 6; SURVEY 8b's aot_layernorm_linear, reference
 // transformer.py:321-323 norm1 -> linear_Q|K|V and :355-359 norm3 -> linear1): x [M, lda] un-normalised, w6 = aot_pack_bf16x6_f32 of
 // W' = diag(gamma) W, bias = beta W + b, colsum [Cout] = the column sums of W' -- all folded by the caller -- so the kernel normalises rows

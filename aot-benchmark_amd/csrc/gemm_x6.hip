@@ -636,9 +636,26 @@ __global__ void __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) gemm_x6r_kernel(con
 //     (x - mean) W' = d W' - m' * colsum(W')
 // the tile end turns the accumulator d W' into rstd * (acc - m' * s_n) with s = the column sums of W' (ln_colsum, from the host).
 // (m', rstd) reach the tile end through 2 x 64 floats of LDS, double-buffered by item parity: the staging side runs two steps ahead.
-template <bool IS1X1, bool SK, bool GN = false, bool C4 = false, bool LN = false>
-__global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p, const X6Weight wq, const int ksplit, float* __restrict__ scratch,
-                                                           const float ln_eps, const float* __restrict__ ln_colsum) {
+// GROUP (round 6): up to four products of ONE shape in one launch -- blockIdx.y names the problem, whose operand pointers replace those
+// of `p` / `wq` (independent linear layers on a stride-16 map fill 108 of 256 CUs each: the three layers' linear_V of the memory
+// update, the four value / gate projections of a GPM block's self-propagation).
+struct X6Group {
+  const float* in[4];
+  const void* w6[4];
+  const float* bias[4];
+  const float* res[4];
+  float* out[4];
+};
+template <bool IS1X1, bool SK, bool GN = false, bool C4 = false, bool LN = false, bool GROUP = false>
+__global__ void __launch_bounds__(256, 3) gemm_x6rd_kernel(const ConvParams p_in, const X6Weight wq_in, const int ksplit, float* __restrict__ scratch,
+                                                           const float ln_eps, const float* __restrict__ ln_colsum, const X6Group grp) {
+  ConvParams p = p_in;
+  X6Weight wq = wq_in;
+  if (GROUP) {
+    const int g = blockIdx.y;
+    p.in = grp.in[g]; p.bias = grp.bias[g]; p.res = grp.res[g]; p.out = grp.out[g];
+    wq.w6 = grp.w6[g];
+  }
   static_assert(!(SK && GN), "GroupNorm partials come from the unsplit form");
   static_assert(!C4 || (!IS1X1 && !SK && !GN), "the four-channel form: a KxK layer, unsplit");
   static_assert(!LN || (IS1X1 && !SK && !C4), "the LayerNorm prologue: a linear layer, unsplit");
@@ -1379,7 +1396,7 @@ int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, 0.f, nullptr);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, 0.f, nullptr, X6Group{});
   AOT_LAUNCH_CHECK();
 }
 
@@ -1397,9 +1414,34 @@ int launch_gemm_x6rd_ln(const ConvParams& p, const void* w6, int cout_pad, hipSt
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
   if (gn_part)
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, eps, colsum);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, true, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, gn_part, eps, colsum, X6Group{});
   else
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, eps, colsum);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, eps, colsum, X6Group{});
+  AOT_LAUNCH_CHECK();
+}
+
+// n <= 4 linear layers of one shape in one launch (gemm_x6rd_kernel<true, false, false, false, false, true>, blockIdx.y = the problem)
+int launch_gemm_x6rd_group(const ConvParams& p, int n, const float* const* in, const void* const* w6, const float* const* bias,
+                           const float* const* res, float* const* out, int cout_pad, hipStream_t s) {
+  if (n < 1 || n > 4 || !in || !w6 || !out || (cout_pad % 64) || cout_pad < p.Cout) return AOT_ERR_BADARG;
+  if (!(p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1)) return AOT_ERR_BADARG;
+  if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
+  X6Group grp{};
+  ConvParams q = p;
+  for (int g = 0; g < n; ++g) {
+    q.in = in[g]; q.out = out[g]; q.res = res ? res[g] : nullptr;
+    if (!in[g] || !w6[g] || !out[g] || ((uintptr_t)w6[g] & 15) || !gemm_x6_eligible(q)) return AOT_ERR_UNSUPPORTED;
+    if ((res && res[g] != nullptr) != (res && res[0] != nullptr) || (bias && bias[g] != nullptr) != (bias && bias[0] != nullptr))
+      return AOT_ERR_BADARG;      // bias / residual: for all problems or for none (the kernel tests the pointers of problem 0)
+    grp.in[g] = in[g]; grp.w6[g] = w6[g]; grp.bias[g] = bias ? bias[g] : nullptr; grp.res[g] = res ? res[g] : nullptr; grp.out[g] = out[g];
+  }
+  q.in = in[0]; q.out = out[0]; q.res = res ? res[0] : nullptr; q.bias = bias ? bias[0] : nullptr;
+  X6Weight wq;
+  wq.w6 = w6[0];
+  wq.cout_pad = cout_pad;
+  const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
+  const int gx = nit < 768 ? nit : 768;
+  hipLaunchKernelGGL((gemm_x6rd_kernel<true, false, false, false, false, true>), dim3(gx, n), dim3(256), 0, s, q, wq, 1, nullptr, 0.f, nullptr, grp);
   AOT_LAUNCH_CHECK();
 }
 
@@ -1417,7 +1459,7 @@ int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipSt
   wq.cout_pad = cout_pad;
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
   const int grid = nit < 768 ? nit : 768;
-  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
+  hipLaunchKernelGGL((gemm_x6rd_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr, X6Group{});
   AOT_LAUNCH_CHECK();
 }
 
@@ -1432,9 +1474,9 @@ int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, h
   const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64) * ksplit;
   const int grid = nit < 1024 ? nit : 1024;                  // (the split-K form needs 118 registers: four workgroups per CU)
   if (p.KH == 1 && p.KW == 1 && p.pad == 0)
-    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr, X6Group{});
   else
-    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr);
+    hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr, X6Group{});
   if (gn && gn->G > 0) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
   else if (gn) launch_splitk_reduce_ln(p, ksplit, scratch, gn->ln_gamma, gn->ln_beta, gn->ln_out, gn->ld_ln, gn->eps, s);
   else launch_splitk_reduce(p, ksplit, scratch, s);
@@ -1483,9 +1525,9 @@ int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, 
     const int nit = cdiv(p.M, 64) * cdiv(p.Cout, 64);
     const int gr = nit < 768 ? nit : 768;
     if (is1x1)
-      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<true, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr, X6Group{});
     else
-      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr);
+      hipLaunchKernelGGL((gemm_x6rd_kernel<false, false>), dim3(gr), dim3(256), 0, s, p, wq, 1, nullptr, 0.f, nullptr, X6Group{});
     AOT_LAUNCH_CHECK();
   }
   if (tile == 129) {            // the register-staged 128x128 form: eight waves, one workgroup per CU

@@ -315,6 +315,11 @@ class LongShortTermTransformer(nn.Module):
     def update_values(self, mems, id_sums, ws, stream, dst=None):
         """Memory update of every layer once the frame's mask is known (aot_engine.py:307-338): V <- linear_V(V + id_emb)
         with the sums V + id_emb already formed by the fused id-bank launch.  dst[i] = where layer i's fused V goes."""
+        L = len(mems)
+        if dst is not None and 1 < L <= 4 and all(s is not None for s in id_sums):
+            # the layers' linear_V launches are independent and of one shape: one grouped launch (round 6; each alone fills 108 of 256 CUs)
+            ps = [layer.pack() for layer in self.layers]
+            return aot_hip.linear_group(list(id_sums), [p['v_w'] for p in ps], [p['v_b'] for p in ps], list(dst), stream=stream)
         return [self.layers[i].fuse_kv_2d(m[1], None, ws, stream, out=dst[i] if dst is not None else None, summed=id_sums[i])
                 for i, m in enumerate(mems)]
 
@@ -447,10 +452,10 @@ class GatedPropagationModule(nn.Module):
         aot_hip.linear(z, sp['QK_w'], sp['QK_b'], qk, stream=stream)
         sv = ws.get('gpm_sv', (M, 2 * E), dev)
         su = ws.get('gpm_su', (M, 2 * E), dev)
-        aot_hip.linear(z[:, :D], sp['V1_w'], sp['V1_b'], sv[:, :E], act=aot_hip.ACT_SILU, stream=stream)
-        aot_hip.linear(z[:, D:], sp['V2_w'], sp['V2_b'], sv[:, E:], act=aot_hip.ACT_SILU, stream=stream)
-        aot_hip.linear(z[:, :D], sp['U1_w'], sp['U1_b'], su[:, :E], act=aot_hip.ACT_SILU, stream=stream)
-        aot_hip.linear(z[:, D:], sp['U2_w'], sp['U2_b'], su[:, E:], act=aot_hip.ACT_SILU, stream=stream)
+        # the four value / gate projections: one shape, independent -- one grouped launch in the bf16x6 family (round 6)
+        aot_hip.linear_group([z[:, :D], z[:, D:], z[:, :D], z[:, D:]], [sp['V1_w'], sp['V2_w'], sp['U1_w'], sp['U2_w']],
+                             [sp['V1_b'], sp['V2_b'], sp['U1_b'], sp['U2_b']], [sv[:, :E], sv[:, E:], su[:, :E], su[:, E:]],
+                             act=aot_hip.ACT_SILU, stream=stream)
         self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream, B=B, kv_brows=N)
         Xo = ws.get('gpm_Xo_%d' % self.layer_idx, (M, 2 * D), dev)
         self.self_attn.tail(raw, Xo, size_2d, ws, stream, res=Xm, B=B)

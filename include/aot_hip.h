@@ -184,6 +184,15 @@ int aot_linear_bf16x6k_ln_f32(const float* in, const void* w6, int cout_pad, con
                               int Cout, int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
                               const float* ln_gamma, const float* ln_beta, float* ln_out, int ld_ln, float eps, void* stream);
 
+/* n <= 4 independent linear layers of ONE shape in one launch of the bf16x6 family (round 6): out[g] = act(in[g] W[g] + bias[g] (+ res[g])),
+ * g = blockIdx.y.  in / w6 / bias / res / out are HOST arrays of n device pointers, read at launch time (bias, res: NULL, or arrays
+ * whose entries are all set or all NULL); w6[g] from aot_pack_bf16x6_f32 with one common cout_pad.  A linear layer on the stride-16
+ * map has 108 tiles for 256 CUs: the three layers' linear_V of the memory update (networks/layers/transformer.py:364-367 via
+ * aot_engine.py:307-338) and the value / gate projections of a GPM block's self-propagation (transformer.py:643-653) run side by side. */
+int aot_linear_group_bf16x6_f32(int n, const float* const* in, const void* const* w6, int cout_pad, const float* const* bias,
+                                const float* const* res, float* const* out, int M, int K, int Cout, int lda, int ldc, int ldr,
+                                int res_rows, int act, void* stream);
+
 /* LayerNorm folded into the consuming GEMM (round 6; SURVEY 8b `aot_layernorm_linear`): out = act(LayerNorm(x) W + b (+ res)) in one
  * launch of the bf16x6 family, the normalised map never materialised.  x [M, lda] un-normalised, K % 32 == 0; the CALLER folds the
  * affine part once per model: w6 = aot_pack_bf16x6_f32 of W' = diag(gamma) W, bias = beta W + b, colsum [Cout] = the column sums of W'.

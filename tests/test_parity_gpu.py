@@ -447,6 +447,30 @@ def test_linear_with_layernorm_output_bit_identical(hip, M, K):
     assert torch.equal(got, want) and torch.equal(cat_g, cat_w)
 
 
+@pytest.mark.parametrize('n,M,K,N,act', [(3, 1674, 256, 256, 0), (4, 1674, 256, 512, 4), (2, 5022, 256, 512, 4), (4, 1100, 512, 192, 1)])
+def test_linear_group_bit_identical_to_single_launches(hip, n, M, K, N, act):
+    """aot_linear_group_bf16x6_f32 (round 6): up to four linear layers of one shape in one launch (blockIdx.y = the problem) -- the three
+    layers' linear_V of the memory update, the value / gate projections of a GPM block -- bit-identical to one launch each; inputs and
+    outputs as column slices of wider buffers (the GPM block's z / [V | ID_V] layout)."""
+    g = torch.Generator().manual_seed(n * M + K + N)
+    zin = _dev(torch.randn(M, 2 * K, generator=g))
+    xs = [zin[:, (i % 2) * K:(i % 2 + 1) * K] for i in range(n)]
+    ws = [hip.attach_wt(_dev(torch.randn(K, N, generator=g) / K ** 0.5), K) for _ in range(n)]
+    bs = [_dev(torch.randn(N, generator=g)) for _ in range(n)]
+    res = [_dev(torch.randn(M, N, generator=g)) for _ in range(n)] if act == 1 else None
+    big_w, big_g = torch.full((M, n * N), 5.0, device='cuda'), torch.full((M, n * N), 5.0, device='cuda')
+    with hip.use_gemm_table('throughput', 'bf16x6'):
+        for i in range(n):
+            hip.linear(xs[i], ws[i], bs[i], big_w[:, i * N:(i + 1) * N], res=res[i] if res else None, act=act)
+        hip.linear_group(xs, ws, bs, [big_g[:, i * N:(i + 1) * N] for i in range(n)], act=act, ress=res)
+    assert torch.equal(big_g, big_w)
+    with hip.use_gemm_table('latency', 'f32'):          # outside the bf16x6 scope: one launch each
+        for i in range(n):
+            hip.linear(xs[i], ws[i], bs[i], big_w[:, i * N:(i + 1) * N], res=res[i] if res else None, act=act)
+        hip.linear_group(xs, ws, bs, [big_g[:, i * N:(i + 1) * N] for i in range(n)], act=act, ress=res)
+    assert torch.equal(big_g, big_w)
+
+
 @pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
