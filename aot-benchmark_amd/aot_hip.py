@@ -26,7 +26,6 @@ _SIGS = {
     'aot_conv2d_bf16x6k_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _P],
     'aot_linear_group_bf16x6_f32': [_I, _P, _P, _I, _P, _P, _P] + [_I] * 8 + [_P],
     'aot_linear_bf16x6k_ln_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 9 + [_P, _L, _P, _P, _P, _I, _F, _P],
-    'aot_conv2d_bf16x6k_gn_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _L, _I, _P, _L, _P, _P, _F, _P],
     'aot_conv2d_c4_bf16x6_f32': [_P, _P, _I, _P, _P] + [_I] * 13 + [_P],
     'aot_pack_bf16_f32': [_P, _P, _I, _I, _I, _I, _P],
     'aot_conv2d_bf16_f32': [_P, _P, _I, _P, _P, _P] + [_I] * 18 + [_P, _P],
@@ -358,38 +357,6 @@ def conv2d_x6k(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, p
                                        res_rows, act, ksplit, _opt(scratch), scratch.numel() if scratch is not None else 0,
                                        stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6k_f32')
     return out
-
-
-def conv2d_gn_stats(x, w, bias, out, H, W, Cin, OH, OW, Cout, groups, ws, KH=1, KW=1, stride=1, pad=0, dil=1, eps=1e-5, B=1, stream=None):
-    """out = conv(x) AND the GroupNorm statistics of out where the layer runs split-K in a bf16x6 scope (one lane): the reduce launch
-    forms them (aot_conv2d_bf16x6k_gn_f32) -- returns stats [G][2] doubles (mean, rstd) for aot_groupnorm_apply_f32; otherwise runs the
-    plain conv2d and returns None (the caller launches the statistics pass).  AOT_NO_GNR_FUSE: always the latter (A/B runs)."""
-    global _x6k_ws
-    stack = _scopes.stack
-    M = B * OH * OW
-    if B == 1 and stack and stack[-1][1] and X6_TILE == 0 and Cin % 32 == 0 and Cout > 32 and Cout % 4 == 0 and \
-            -(-M // 64) * -(-Cout // 64) >= X6_MIN_TILES and not os.environ.get('AOT_NO_GNR_FUSE'):
-        nq = Cout // 4
-        ks = x6_ksplit(M, Cout, KH * KW * Cin)
-        if ks != 1 and nq <= 64 and nq & (nq - 1) == 0 and nq % groups == 0 and (nq // groups) & (nq // groups - 1) == 0 and 256 % groups == 0:
-            w6 = getattr(w, '_aot_w6', None)
-            if w6 is None:
-                w6 = pack_bf16x6(w)
-            if _x6k_ws is None:
-                from networks.layers.workspace import Workspace
-                _x6k_ws = Workspace()
-            scratch = _x6k_ws.get('x6k', (max(abs(ks) * M * Cout, X6K_SCRATCH_FLOATS),), x.device)
-            nwg = -(-M * nq // 256)
-            part = ws.get('gnr_part_%d_%d' % (nwg, groups), (nwg * groups * 2,), x.device, torch.float64)
-            stats = ws.get('gnr_stats_%d' % groups, (groups * 2,), x.device, torch.float64)
-            ticket = ws.get_zeroed('gnr_ticket', (1,), x.device, torch.int32)
-            _chk(load().aot_conv2d_bf16x6k_gn_f32(_dev(x), _dev(w6), w6.shape[3], _opt(bias), None, _dev(out), 1, H, W, Cin, OH, OW, Cout,
-                                                  KH, KW, stride, pad, dil, x.stride(0), out.stride(0), 0, 0, ACT_NONE, ks, _dev(scratch),
-                                                  scratch.numel(), groups, _dev(part), part.numel(), _dev(stats), _dev(ticket), eps,
-                                                  stream if stream is not None else stream_ptr()), 'aot_conv2d_bf16x6k_gn_f32')
-            return stats
-    conv2d(x, w, bias, out, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, B=B, stream=stream)
-    return None
 
 
 def linear_group(xs, ws, biases, outs, act=ACT_NONE, ress=None, res_rows=0, stream=None):

@@ -27,25 +27,17 @@ bool gemm_x6_eligible(const ConvParams& p);
 // tile: 0 = chosen by shape, 66 / 129 = forced (the 64x64 direct-weight form / the register-staged 128x128 form); terms 1 = plain bf16
 int launch_gemm_x6(const ConvParams& p, const void* w6, int cout_pad, int tile, hipStream_t s, int terms = 6, int ksplit = 1, float* scratch = nullptr);
 // the phase-shifted 128x128 form (gemm_x6pp_kernel) with split-K over the grid (ksplit >= 2, slabs in scratch)
-// gn != nullptr (both split-K forms): the reduce launch also forms the GroupNorm statistics of the result (one lane): gn->part =
-// splitk_reduce_gn_workgroups(M, Cout) x G x 2 doubles of scratch, gn->stats [G][2] (mean, rstd), gn->ticket one zeroed word
-// (G == 0: instead, LayerNorm(result) over the Cout == 256 channels as a second output map -- ln_gamma / ln_beta / ln_out / ld_ln / eps)
-struct GnStatsOut {
-  int G;
-  double* part;
-  double* stats;
-  unsigned* ticket;
+// ln != nullptr (both split-K forms, Cout == 256): the reduce launch also writes LayerNorm(result) * gamma + beta to ln->out [M, ld]
+struct LnOutArgs {
+  const float* gamma;
+  const float* beta;
+  float* out;
+  int ld;
   float eps;
-  const float* ln_gamma;
-  const float* ln_beta;
-  float* ln_out;
-  int ld_ln;
 };
-int splitk_reduce_gn_workgroups(int M, int Cout);
-bool splitk_reduce_gn_ok(int Cout, int G);
-int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn = nullptr);
+int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const LnOutArgs* ln = nullptr);
 // split-K over the grid on the 64x64 register-staged kernel with the weight fragments straight from global memory
-int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn = nullptr);
+int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const LnOutArgs* ln = nullptr);
 // a linear layer on the same kernel whose tile end also writes GroupNorm partial sums: gn_part [2 * ceil(M / 64)][Cout / 32][2] floats
 int launch_gemm_x6rd_gn(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, float* gn_part);
 // LayerNorm over the K channels of `in` + the linear layer in one launch (gamma / beta folded into w6 / bias by the caller); gn_part

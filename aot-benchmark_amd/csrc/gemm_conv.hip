@@ -734,34 +734,6 @@ extern "C" int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_
   return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch);
 }
 
-// aot_conv2d_bf16x6k_f32 whose reduce launch also forms the GroupNorm statistics of the result (round 6: the ConvGN blocks of the FPN head
-// on the stride-16 / stride-8 maps, one lane): stats [G][2] doubles (mean, rstd) as aot_groupnorm_stats_f32 writes them; gn_part =
-// scratch of ceil(B*OH*OW * Cout/4 / 256) * G * 2 doubles (gn_part_doubles = its size), ticket = one zeroed word (left zero)
-extern "C" int aot_conv2d_bf16x6k_gn_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res,
-                                         float* out, int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-                                         int stride, int pad, int dil, int lda, int ldc, int ldr, int res_rows, int act,
-                                         int ksplit, float* scratch, long scratch_floats, int G, double* gn_part, long gn_part_doubles,
-                                         double* stats, unsigned* ticket, float eps, void* stream) {
-  const int ks = ksplit < 0 ? -ksplit : ksplit;
-  if (!in || !w6 || !out || ks < 2 || ks > 64 || !gn_part || !stats || !ticket || !(eps > 0.f)) return AOT_ERR_BADARG;
-  if (B != 1 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return AOT_ERR_BADARG;
-  if ((lda & 3) || lda < Cin || ldc < Cout) return AOT_ERR_BADARG;
-  if (res && (ldr < Cout || res_rows < 0)) return AOT_ERR_BADARG;
-  if (!scratch || (long)ks * OH * OW * Cout > scratch_floats) return AOT_ERR_BADARG;
-  if (!splitk_reduce_gn_ok(Cout, G)) return AOT_ERR_UNSUPPORTED;
-  if (gn_part_doubles < (long)splitk_reduce_gn_workgroups(OH * OW, Cout) * G * 2) return AOT_ERR_BADARG;
-  ConvParams p;
-  p.in = in; p.w = nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
-  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
-  p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
-  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
-  GnStatsOut gn{};
-  gn.G = G; gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.eps = eps;
-  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &gn);
-  return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &gn);
-}
-
 // aot_conv2d_bf16x6k_f32 as a linear layer with Cout == 256 whose reduce launch also writes LayerNorm(out) to ln_out [M, ld_ln] (round 6:
 // linear2 + residual of an LSTT block followed by the stack's output norm) -- bit-identical to aot_layernorm_f32 on the stored result
 extern "C" int aot_linear_bf16x6k_ln_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
@@ -780,10 +752,10 @@ extern "C" int aot_linear_bf16x6k_ln_f32(const float* in, const void* w6, int co
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
   p.lda = lda; p.ldb = 0; p.ldwt = 0; p.ldc = ldc; p.ldr = ldr; p.res_rows = res_rows;
   p.M = M; p.K = K; p.act = act;
-  GnStatsOut gn{};
-  gn.eps = eps; gn.ln_gamma = ln_gamma; gn.ln_beta = ln_beta; gn.ln_out = ln_out; gn.ld_ln = ld_ln;
-  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &gn);
-  return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &gn);
+  LnOutArgs ln;
+  ln.gamma = ln_gamma; ln.beta = ln_beta; ln.out = ln_out; ln.ld = ld_ln; ln.eps = eps;
+  if (ksplit < 0) return launch_gemm_x6rd_splitk(p, w6, cout_pad, (hipStream_t)stream, -ksplit, scratch, &ln);
+  return launch_gemm_x6pp(p, w6, cout_pad, (hipStream_t)stream, ksplit, scratch, &ln);
 }
 
 // out = act(x W + bias (+ res)) on the bf16x6 family AND the GroupNorm partial sums of `out` (32-channel groups) from the same tile

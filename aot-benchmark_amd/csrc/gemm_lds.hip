@@ -710,140 +710,71 @@ gemm_lean_kernel(const ConvParams p, const int ksplit, float* __restrict__ scrat
 
 // sum of the k-slices in slice order + epilogue; one thread per 4 output channels (16-byte loads and stores where the rows allow it:
 // Cout % 4 == 0 makes every slab row 16-byte aligned).
-// GN (round 6): the launch ALSO forms the GroupNorm statistics of its output (one lane; the ConvGN blocks of the FPN head, whose
-// convolutions are split-K on the stride-16 / stride-8 maps: fpn.py:18-21 / basic.py:38-58 in the reference) -- every workgroup reduces
-// the (sum, sum of squares) of its 1024 outputs per group in double (lanes of a group are neighbours: butterflies, then the rows of the
-// wave, then the four waves in order), publishes G partial pairs and draws a ticket; the last workgroup to arrive adds the partials of
-// all workgroups in index order and writes (mean, rstd) exactly as gn_stats_kernel does.  Deterministic; no statistics launch and no
-// second pass over the map.  Needs Cout / 4 and Cout / (4 G) powers of two with Cout / 4 <= 64 (checked by the host).
 // LNO (round 6; Cout == 256: a row of the result is exactly one wave): the launch also writes LayerNorm(result) to a second map -- the
 // wave holds the row, so the statistics are two butterflies; same arithmetic and order as layernorm_kernel<1> (bit-identical to a
 // LayerNorm launch on the stored result).  The LSTT block's linear2 (+ residual) followed by the stack's output norm
 // (transformer.py:124-135, 359-362 in the reference).
-struct GnReduce {
-  double* part;        // [workgroups][G][2]
-  double* stats;       // [G][2] (mean, rstd)
-  unsigned* ticket;    // one word, zero between launches
-  int G;
+// (Tried in round 6 and removed: the GroupNorm statistics of the result out of this launch -- per-workgroup partials in double, a
+//  device-scope ticket, the last workgroup adds them up.  Correct and deterministic, but 0.6 % SLOWER on the whole frame than the
+//  256-workgroup statistics pass it replaced: profiles/r06_fusions_ab2.txt.)
+struct LnOut {
+  const float* gamma;
+  const float* beta;
+  float* out;
+  int ld;
   float eps;
-  const float* ln_gamma;   // LNO
-  const float* ln_beta;
-  float* ln_out;
-  int ld_ln;
 };
-template <bool GN, bool LNO = false>
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch, const GnReduce gn) {
-  static_assert(!(GN && LNO), "one fused consumer per launch");
+template <bool LNO>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p, const int ksplit, const float* __restrict__ scratch, const LnOut ln) {
   const int nq = (p.Cout + 3) >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = idx < (long)p.M * nq;
-  if (!GN && !live) return;
+  if (idx >= (long)p.M * nq) return;
+  const int m = (int)(idx / nq), n0 = (int)(idx - (long)m * nq) * 4;
+  const long slab = (long)p.M * p.Cout;
+  const float* src = scratch + (long)m * p.Cout + n0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cnt = min(4, p.Cout - n0);
+  const bool vec = (p.Cout & 3) == 0 && ((uintptr_t)scratch & 15) == 0;
+  if (vec) {
+    for (int s = 0; s < ksplit; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (long)s * slab);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+  } else {
+    for (int s = 0; s < ksplit; ++s)
+      for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
+  }
+  const long rrow = p.res_rows ? m % p.res_rows : m;
   float o[4] = {0.f, 0.f, 0.f, 0.f};
-  int cnt = 0;
-  if (live) {
-    const int m = (int)(idx / nq), n0 = (int)(idx - (long)m * nq) * 4;
-    const long slab = (long)p.M * p.Cout;
-    const float* src = scratch + (long)m * p.Cout + n0;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    cnt = min(4, p.Cout - n0);
-    const bool vec = (p.Cout & 3) == 0 && ((uintptr_t)scratch & 15) == 0;
-    if (vec) {
-      for (int s = 0; s < ksplit; ++s) {
-        const float4 t = *reinterpret_cast<const float4*>(src + (long)s * slab);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      }
-    } else {
-      for (int s = 0; s < ksplit; ++s)
-        for (int c = 0; c < cnt; ++c) v[c] += src[(long)s * slab + c];
-    }
-    const long rrow = p.res_rows ? m % p.res_rows : m;
-    for (int c = 0; c < cnt; ++c) {
-      float t = v[c] + (p.bias ? p.bias[n0 + c] : 0.f);
-      if (p.res) t += p.res[rrow * p.ldr + n0 + c];
-      o[c] = apply_act(t, p.act);
-    }
-    float* dst = p.out + (long)m * p.ldc + n0;
-    if (vec && (p.ldc & 3) == 0 && ((uintptr_t)p.out & 15) == 0) {
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-      for (int c = 0; c < cnt; ++c) dst[c] = o[c];
-    }
-    if (LNO) {          // nq == 64: the 64 lanes of this wave hold row m (every lane of the wave is live or none)
-      float sm = (o[0] + o[1]) + (o[2] + o[3]);
+  for (int c = 0; c < cnt; ++c) {
+    float t = v[c] + (p.bias ? p.bias[n0 + c] : 0.f);
+    if (p.res) t += p.res[rrow * p.ldr + n0 + c];
+    o[c] = apply_act(t, p.act);
+  }
+  float* dst = p.out + (long)m * p.ldc + n0;
+  if (vec && (p.ldc & 3) == 0 && ((uintptr_t)p.out & 15) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (int c = 0; c < cnt; ++c) dst[c] = o[c];
+  }
+  if (LNO) {          // nq == 64: the 64 lanes of this wave hold row m (every lane of the wave is live or none)
+    float sm = (o[0] + o[1]) + (o[2] + o[3]);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off);
-      const float mean = sm / (float)p.Cout;
-      const float a = o[0] - mean, b = o[1] - mean, c = o[2] - mean, d = o[3] - mean;
-      float sq = (a * a + b * b) + (c * c + d * d);
+    for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off);
+    const float mean = sm / (float)p.Cout;
+    const float a = o[0] - mean, b = o[1] - mean, c = o[2] - mean, d = o[3] - mean;
+    float sq = (a * a + b * b) + (c * c + d * d);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
-      const float rstd = 1.f / sqrtf(sq / (float)p.Cout + gn.eps);
-      const float4 g4 = *reinterpret_cast<const float4*>(gn.ln_gamma + n0), b4 = *reinterpret_cast<const float4*>(gn.ln_beta + n0);
-      float4 y;
-      y.x = (o[0] - mean) * rstd * g4.x + b4.x;
-      y.y = (o[1] - mean) * rstd * g4.y + b4.y;
-      y.z = (o[2] - mean) * rstd * g4.z + b4.z;
-      y.w = (o[3] - mean) * rstd * g4.w + b4.w;
-      *reinterpret_cast<float4*>(gn.ln_out + (long)m * gn.ld_ln + n0) = y;
-    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.f / sqrtf(sq / (float)p.Cout + ln.eps);
+    const float4 g4 = *reinterpret_cast<const float4*>(ln.gamma + n0), b4 = *reinterpret_cast<const float4*>(ln.beta + n0);
+    float4 y;
+    y.x = (o[0] - mean) * rstd * g4.x + b4.x;
+    y.y = (o[1] - mean) * rstd * g4.y + b4.y;
+    y.z = (o[2] - mean) * rstd * g4.z + b4.z;
+    y.w = (o[3] - mean) * rstd * g4.w + b4.w;
+    *reinterpret_cast<float4*>(ln.out + (long)m * ln.ld + n0) = y;
   }
-  if (!GN) return;
-  // ---- GroupNorm statistics of the stored values ----
-  __shared__ double red[4][64][2];
-  __shared__ int last_flag;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int G = gn.G, L = nq / G;                      // lanes per group (a power of two)
-  double s = 0.0, sq = 0.0;
-  if (live) {
-    s = ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
-    sq = ((double)o[0] * o[0] + (double)o[1] * o[1]) + ((double)o[2] * o[2] + (double)o[3] * o[3]);
-  }
-  for (int off = 1; off < L; off <<= 1) { s += __shfl_xor(s, off); sq += __shfl_xor(sq, off); }        // the group's lanes
-  for (int off = nq; off < 64; off <<= 1) { s += __shfl_xor(s, off); sq += __shfl_xor(sq, off); }      // the wave's rows
-  if (lane < nq && (lane & (L - 1)) == 0) { red[wave][lane / L][0] = s; red[wave][lane / L][1] = sq; }
-  __syncthreads();
-  if (t < 64) {          // (one wave: its stores are one instruction, the wait below covers all of them)
-    if (t < G) {
-      const double ps = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
-      const double pq = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
-      double* dst = gn.part + ((long)blockIdx.x * G + t) * 2;
-      __hip_atomic_store(dst, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(gn.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = prev == gridDim.x - 1;
-    }
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  // the last workgroup: all G groups at once (a first version walked the groups one after the other -- eight dependent round trips to the
-  // partials: +6 us per launch) -- thread t = (group t % G, strand t / G): its strand's workgroups in index order, all loads in flight
-  // together; then thread g < G adds the 256 / G strands of its group in strand order.  G divides 256 (host check).
-  {
-    const int nwg = (int)gridDim.x, g = t % G, strand = t / G, nstr = 256 / G;
-    double ts = 0.0, tq = 0.0;
-    for (int w2 = strand; w2 < nwg; w2 += nstr) {
-      ts += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tq += __hip_atomic_load(gn.part + ((long)w2 * G + g) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __shared__ double fin[256][2];
-    fin[t][0] = ts;
-    fin[t][1] = tq;
-    __syncthreads();
-    if (t < G) {
-      double as = 0.0, aq = 0.0;
-      for (int i = 0; i < nstr; ++i) { as += fin[i * G + t][0]; aq += fin[i * G + t][1]; }
-      const double cnt_g = (double)p.M * (p.Cout / G);
-      const double mean = as / cnt_g;
-      double var = aq / cnt_g - mean * mean;
-      if (var < 0.0) var = 0.0;
-      gn.stats[t * 2] = mean;
-      gn.stats[t * 2 + 1] = 1.0 / sqrt(var + (double)gn.eps);
-    }
-  }
-  if (t == 0) __hip_atomic_store(gn.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call / replay
 }
 
 template <int BMB, int PFD>
@@ -859,7 +790,7 @@ int launch_variant(const ConvParams& p, bool is1x1, int ksplit, float* scratch, 
     hipLaunchKernelGGL((gemm_lds_kernel<BMB, false, PFD>), dim3(grid), dim3(256), 0, s, p, ksplit, scratch);
   if (ksplit > 1) {
     const long n = (long)p.M * ((p.Cout + 3) >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, LnOut{});
   }
   AOT_LAUNCH_CHECK();
 }
@@ -877,7 +808,7 @@ int launch_lean(const ConvParams& p, bool is1x1, int ksplit, float* scratch, hip
     hipLaunchKernelGGL((gemm_lean_kernel<BMB, false>), dim3(grid), dim3(256), 0, s, p, ksplit, scratch);
   if (ksplit > 1) {
     const long n = (long)p.M * ((p.Cout + 3) >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, LnOut{});
   }
   AOT_LAUNCH_CHECK();
 }
@@ -898,29 +829,16 @@ bool gemm_lean_eligible(const ConvParams& p) {
 
 void launch_splitk_reduce(const ConvParams& p, int ksplit, const float* scratch, hipStream_t s) {
   const long n = (long)p.M * ((p.Cout + 3) >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, GnReduce{});
+  hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, LnOut{});
 }
 
-// ... and the GroupNorm statistics of the result from the same launch (splitk_reduce_kernel<true>); gn_part: workgroups x G x 2 doubles
-int splitk_reduce_gn_workgroups(int M, int Cout) { return (int)cdiv((long)M * (Cout >> 2), 256); }
-bool splitk_reduce_gn_ok(int Cout, int G) {
-  if (G <= 0 || (Cout & 3) || Cout % G || 256 % G) return false;
-  const int nq = Cout >> 2, L = nq / G;
-  return nq <= 64 && (nq & (nq - 1)) == 0 && nq % G == 0 && L >= 1 && (L & (L - 1)) == 0;
-}
-void launch_splitk_reduce_gn(const ConvParams& p, int ksplit, const float* scratch, int G, double* gn_part, double* stats, unsigned* ticket,
-                             float eps, hipStream_t s) {
-  GnReduce gn{};
-  gn.part = gn_part; gn.stats = stats; gn.ticket = ticket; gn.G = G; gn.eps = eps;
-  hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(splitk_reduce_gn_workgroups(p.M, p.Cout)), dim3(256), 0, s, p, ksplit, scratch, gn);
-}
 // ... or LayerNorm(result) as a second output (Cout == 256, 16-byte aligned rows everywhere: checked by the caller)
 void launch_splitk_reduce_ln(const ConvParams& p, int ksplit, const float* scratch, const float* gamma, const float* beta, float* ln_out,
                              int ld_ln, float eps, hipStream_t s) {
-  GnReduce gn{};
-  gn.eps = eps; gn.ln_gamma = gamma; gn.ln_beta = beta; gn.ln_out = ln_out; gn.ld_ln = ld_ln;
+  LnOut ln;
+  ln.gamma = gamma; ln.beta = beta; ln.out = ln_out; ln.ld = ld_ln; ln.eps = eps;
   const long n = (long)p.M * (p.Cout >> 2);
-  hipLaunchKernelGGL((splitk_reduce_kernel<false, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, gn);
+  hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, p, ksplit, scratch, ln);
 }
 
 int launch_gemm_lds(const ConvParams& p, int variant, int ksplit, float* scratch, hipStream_t s) {

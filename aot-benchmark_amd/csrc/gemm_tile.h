@@ -71,8 +71,6 @@ __device__ __forceinline__ void buf_store_hi16(const i32x4& desc, int voff, int 
 
 // splitk_reduce_kernel (gemm_lds.hip): sums the [ksplit][M][Cout] slabs in slice order and applies bias / residual / activation
 void launch_splitk_reduce(const ConvParams& p, int ksplit, const float* scratch, hipStream_t s);
-// ... the same launch forming the GroupNorm statistics of the result as well (splitk_reduce_kernel<true>; conv_params.h: GnStatsOut)
+// ... the same launch writing LayerNorm(result) * gamma + beta as a second output (splitk_reduce_kernel<true>; Cout == 256)
 void launch_splitk_reduce_ln(const ConvParams& p, int ksplit, const float* scratch, const float* gamma, const float* beta, float* ln_out,
                              int ld_ln, float eps, hipStream_t s);
-void launch_splitk_reduce_gn(const ConvParams& p, int ksplit, const float* scratch, int G, double* gn_part, double* stats, unsigned* ticket,
-                             float eps, hipStream_t s);

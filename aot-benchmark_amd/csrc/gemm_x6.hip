@@ -1365,7 +1365,7 @@ bool gemm_x6_eligible(const ConvParams& p) {
 
 // the phase-shifted 128x128 form with split-K over the grid (gemm_x6pp_kernel<., true>): slabs [ksplit][M][Cout] in `scratch`
 // (its unsplit form was no faster than the plain 128x128 kernel -- profiles/r05_x6pp.txt -- and is not built)
-int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn) {
+int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const LnOutArgs* ln) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   if (ksplit < 2 || (p.K / BK) % ksplit != 0) return AOT_ERR_BADARG;
@@ -1380,8 +1380,7 @@ int launch_gemm_x6pp(const ConvParams& p, const void* w6, int cout_pad, hipStrea
     hipLaunchKernelGGL((gemm_x6pp_kernel<true, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
   else
     hipLaunchKernelGGL((gemm_x6pp_kernel<false, true>), dim3(grid), dim3(512), 0, s, p, wq, ksplit, scratch);
-  if (gn && gn->G > 0) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
-  else if (gn) launch_splitk_reduce_ln(p, ksplit, scratch, gn->ln_gamma, gn->ln_beta, gn->ln_out, gn->ld_ln, gn->eps, s);
+  if (ln) launch_splitk_reduce_ln(p, ksplit, scratch, ln->gamma, ln->beta, ln->out, ln->ld, ln->eps, s);
   else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }
@@ -1464,7 +1463,7 @@ int launch_gemm_x6rd_c4(const ConvParams& p, const void* w6, int cout_pad, hipSt
 }
 
 // split-K over the grid on the 64x64 register-staged kernel with direct weight fragments (gemm_x6rd_kernel<., true>)
-int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const GnStatsOut* gn) {
+int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, hipStream_t s, int ksplit, float* scratch, const LnOutArgs* ln) {
   if (!gemm_x6_eligible(p) || !w6 || (cout_pad % 64) || cout_pad < p.Cout || ((uintptr_t)w6 & 15)) return AOT_ERR_UNSUPPORTED;
   if (3L * (p.K / 8) * cout_pad * 16 >= 0x7fffffffL) return AOT_ERR_UNSUPPORTED;
   if (ksplit < 2 || (p.K / BK) % ksplit != 0 || !scratch || (long)p.M * p.Cout * 4 >= 0x7fffffffL) return AOT_ERR_BADARG;
@@ -1477,8 +1476,7 @@ int launch_gemm_x6rd_splitk(const ConvParams& p, const void* w6, int cout_pad, h
     hipLaunchKernelGGL((gemm_x6rd_kernel<true, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr, X6Group{});
   else
     hipLaunchKernelGGL((gemm_x6rd_kernel<false, true>), dim3(grid), dim3(256), 0, s, p, wq, ksplit, scratch, 0.f, nullptr, X6Group{});
-  if (gn && gn->G > 0) launch_splitk_reduce_gn(p, ksplit, scratch, gn->G, gn->part, gn->stats, gn->ticket, gn->eps, s);
-  else if (gn) launch_splitk_reduce_ln(p, ksplit, scratch, gn->ln_gamma, gn->ln_beta, gn->ln_out, gn->ld_ln, gn->eps, s);
+  if (ln) launch_splitk_reduce_ln(p, ksplit, scratch, ln->gamma, ln->beta, ln->out, ln->ld, ln->eps, s);
   else launch_splitk_reduce(p, ksplit, scratch, s);
   AOT_LAUNCH_CHECK();
 }

@@ -542,7 +542,7 @@ extern "C" int aot_bilinear_nhwc_f32(const float* in, const float* add, float* o
 }
 
 // out = bilinear(act(GroupNorm(in))) (+ add): aot_groupnorm_apply_f32 + aot_bilinear_nhwc_f32 in one launch, bit-identical to the pair;
-// stats [B][G][2] doubles (mean, rstd) from aot_groupnorm_stats_f32 or aot_conv2d_bf16x6k_gn_f32
+// stats [B][G][2] doubles (mean, rstd) from aot_groupnorm_stats_f32
 extern "C" int aot_gn_bilinear_nhwc_f32(const float* in, const double* stats, const float* gamma, const float* beta, const float* add,
                                         float* out, int B, int IH, int IW, int OH, int OW, int C, int G, int ldi, int ldadd, int ldo,
                                         int align_corners, int add_shared, int act, void* stream) {

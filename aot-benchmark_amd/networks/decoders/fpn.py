@@ -41,34 +41,25 @@ class FPNSegmentationHead(nn.Module):
             self._p = p
         return self._p
 
-    def _gn_relu(self, x, out, key, B, ws, stream, add=None, add_rows=0, stats=None):
-        """relu(gn(x)) (+ add); stats: the statistics when the producing convolution's reduce launch has already formed them."""
+    def _gn_relu(self, x, out, key, B, ws, stream, add=None, add_rows=0):
+        """relu(gn(x)) (+ add): the statistics launch, then the apply launch."""
         p = self._p
-        if stats is not None:
-            return aot_hip.groupnorm_apply(x, stats, *p[key + '_gn'], out, 8, act=aot_hip.ACT_RELU, B=B, add=add, add_rows=add_rows,
-                                           stream=stream)
         aot_hip.groupnorm(x, *p[key + '_gn'], out, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), act=aot_hip.ACT_RELU,
                           eps=getattr(self, key).gn.eps, nsplit=32, B=B, add=add, add_rows=add_rows, stream=stream)
         return out
 
-    def _gn_relu_up(self, x, out, key, B, ws, stream, ih, iw, oh, ow, add, stats=None):
-        """bilinear(relu(gn(x))) + add in one launch (aot_gn_bilinear_nhwc_f32): the normalised map of a block whose only consumer is the
-        next upsampling is never written.  AOT_NO_GN_UP: the separate apply + resize launches (A/B runs)."""
+    def _gn_relu_up(self, x, out, key, B, ws, stream, ih, iw, oh, ow, add):
+        """bilinear(relu(gn(x))) + add: the statistics launch, then ONE launch that normalises the four taps of the resize on the fly
+        (aot_gn_bilinear_nhwc_f32, bit-identical to apply + resize): the normalised map of a block whose only consumer is the next
+        upsampling is never written.  AOT_NO_GN_UP: the separate apply + resize launches (A/B runs)."""
         p = self._p
         if os.environ.get('AOT_NO_GN_UP'):
-            self._gn_relu(x, x, key, B, ws, stream, stats=stats)
+            self._gn_relu(x, x, key, B, ws, stream)
             return aot_hip.bilinear(x, out, ih, iw, oh, ow, x.shape[1], self.align_corners, add=add, B=B, add_shared=True, stream=stream)
-        if stats is None:
-            stats = aot_hip.groupnorm_stats(x, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), B=B, eps=getattr(self, key).gn.eps, nsplit=32,
-                                            stream=stream)
+        stats = aot_hip.groupnorm_stats(x, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), B=B, eps=getattr(self, key).gn.eps, nsplit=32,
+                                        stream=stream)
         return aot_hip.gn_bilinear(x, stats, *p[key + '_gn'], out, ih, iw, oh, ow, x.shape[1], 8, self.align_corners,
                                    act=aot_hip.ACT_RELU, add=add, B=B, add_shared=True, stream=stream)
-
-    def _conv_gn(self, x, out, key, h, w, cin, cout, k, B, ws, stream):
-        """The convolution of a ConvGN block; returns the GroupNorm statistics of `out` when its split-K reduce formed them (bf16x6, one
-        lane: aot_conv2d_bf16x6k_gn_f32), else None."""
-        return aot_hip.conv2d_gn_stats(x, *self._p[key], out, h, w, cin, h, w, cout, 8, ws, KH=k, KW=k, pad=k // 2,
-                                       eps=getattr(self, key).gn.eps, B=B, stream=stream)
 
     def adapters(self, f16, f8, f4, ws, stream, B=1):
         """The three adapter convolutions (fpn.py:36-37,45-46,52-53) of B stacked frames: they read the encoder's shortcut maps only,
@@ -104,14 +95,10 @@ class FPNSegmentationHead(nn.Module):
             ad16 = ws.get('dec_ad16', (n16, hd), dev)
             aot_hip.conv2d(s16, *p['adapter_16x'], ad16, h16, w16, s16.shape[1], h16, w16, hd, stream=stream)
         a = ws.get('dec_a16', (B * n16, hd), dev)
-        if B == 1:
-            st = self._conv_gn(x_in, a, 'conv_in', 1, n16, self.in_dim, hd, 1, 1, ws, stream)
-        else:
-            st = None
-            aot_hip.linear(x_in, *p['conv_in'], a, stream=stream)
+        aot_hip.linear(x_in, *p['conv_in'], a, stream=stream)
         b = ws.get('dec_b16', (B * n16, hd), dev)
-        self._gn_relu(a, b, 'conv_in', B, ws, stream, add=ad16, add_rows=n16, stats=st)      # relu(gn(conv_in)) + adapter_16x
-        st = self._conv_gn(b, a, 'conv_16x', h16, w16, hd, hd, 3, B, ws, stream)
+        self._gn_relu(a, b, 'conv_in', B, ws, stream, add=ad16, add_rows=n16)      # relu(gn(conv_in)) + adapter_16x
+        aot_hip.conv2d(b, *p['conv_16x'], a, h16, w16, hd, h16, w16, hd, 3, 3, 1, 1, 1, B=B, stream=stream)
         # 8x: adapter(shortcut) + bilinear(a)
         if ads is not None:
             ad8 = ads[1]
@@ -119,9 +106,9 @@ class FPNSegmentationHead(nn.Module):
             ad8 = ws.get('dec_ad8', (n8, hd), dev)
             aot_hip.conv2d(s8, *p['adapter_8x'], ad8, h8, w8, s8.shape[1], h8, w8, hd, stream=stream)
         c = ws.get('dec_a8', (B * n8, hd), dev)
-        self._gn_relu_up(a, c, 'conv_16x', B, ws, stream, h16, w16, h8, w8, ad8, stats=st)      # up(relu(gn(conv_16x))) + adapter_8x
+        self._gn_relu_up(a, c, 'conv_16x', B, ws, stream, h16, w16, h8, w8, ad8)      # up(relu(gn(conv_16x))) + adapter_8x
         d = ws.get('dec_b8', (B * n8, hd // 2), dev)
-        st = self._conv_gn(c, d, 'conv_8x', h8, w8, hd, hd // 2, 3, B, ws, stream)
+        aot_hip.conv2d(c, *p['conv_8x'], d, h8, w8, hd, h8, w8, hd // 2, 3, 3, 1, 1, 1, B=B, stream=stream)
         # 4x
         if ads is not None:
             ad4 = ads[2]
@@ -129,17 +116,16 @@ class FPNSegmentationHead(nn.Module):
             ad4 = ws.get('dec_ad4', (n4, hd // 2), dev)
             aot_hip.conv2d(s4, *p['adapter_4x'], ad4, h4, w4, s4.shape[1], h4, w4, hd // 2, stream=stream)
         e = ws.get('dec_a4', (B * n4, hd // 2), dev)
-        self._gn_relu_up(d, e, 'conv_8x', B, ws, stream, h8, w8, h4, w4, ad4, stats=st)
+        self._gn_relu_up(d, e, 'conv_8x', B, ws, stream, h8, w8, h4, w4, ad4)
         f = ws.get('dec_b4', (B * n4, hd // 2), dev)
-        st = self._conv_gn(e, f, 'conv_4x', h4, w4, hd // 2, hd // 2, 3, B, ws, stream)
+        aot_hip.conv2d(e, *p['conv_4x'], f, h4, w4, hd // 2, h4, w4, hd // 2, 3, 3, 1, 1, 1, B=B, stream=stream)
         ldo = (self.out_dim + 3) // 4 * 4
         out = ws.get('dec_logits', (B * n4, ldo), dev)
         if self.out_dim <= 32 and not os.environ.get('AOT_NO_GN_UP'):
             # conv_out reads relu(gn(conv_4x)) through its A loads (aot_gn_conv1x1_f32): the normalised 4x map is never written
-            if st is None:
-                st = aot_hip.groupnorm_stats(f, 8, aot_hip.gn_buffers(ws, dev, B, 8, 32), B=B, eps=self.conv_4x.gn.eps, nsplit=32, stream=stream)
+            st = aot_hip.groupnorm_stats(f, 8, aot_hip.gn_buffers(ws, dev, B, 8, 32), B=B, eps=self.conv_4x.gn.eps, nsplit=32, stream=stream)
             aot_hip.gn_conv1x1(f, st, *p['conv_4x_gn'], *p['conv_out'], out, 8, self.out_dim, gn_act=aot_hip.ACT_RELU, B=B, stream=stream)
         else:
-            self._gn_relu(f, f, 'conv_4x', B, ws, stream, stats=st)
+            self._gn_relu(f, f, 'conv_4x', B, ws, stream)
             aot_hip.conv2d(f, *p['conv_out'], out, 1, B * n4, hd // 2, 1, B * n4, self.out_dim, stream=stream)
         return out[:, :self.out_dim], h4, w4

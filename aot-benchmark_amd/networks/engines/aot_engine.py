@@ -470,8 +470,25 @@ class AOTEngine(nn.Module):
         return buf
 
     # ---- look-ahead encoding -------------------------------------------------------------------
+    def _side(self):
+        """Side stream + its own graph cache (own capture stream, own memory pool: its replays run BESIDE the frame graphs) of the
+        overlapped look-ahead."""
+        if getattr(self, '_side_stream', None) is None:
+            dev = next(self.AOT.parameters()).device
+            self._side_stream = torch.cuda.Stream(dev)
+            self._side_graphs = FrameGraphs(dev)
+        return self._side_stream, self._side_graphs
+
+    def _encode_batch(self, src, slot):
+        ws = self.AOT.ws
+        ws.salt = '' if slot == 0 else '#ahead%d' % slot      # the second feature set lives in buffers of its own
+        try:
+            return self.AOT.encode_tokens(src)
+        finally:
+            ws.salt = ''
+
     @_in_table
-    def encode_ahead(self, imgs):
+    def encode_ahead(self, imgs, overlap=False):
         """Optional: encodes the NEXT frames of the clip (a list of [1,3,H,W] tensors, in the order they will be matched) as
         ONE batch, on the current stream -- the encoder does not depend on the memory state (the reference's offline_encoder,
         aot_engine.py:147-166, likewise encodes every frame it has at once), and a batch of three 480p frames fills the 256
@@ -479,18 +496,44 @@ class AOTEngine(nn.Module):
         receive THE SAME tensors pick their features up; any other image is encoded in line as before.  The batch lives in
         per-stream scratch: a new call replaces whatever an earlier call left unused.  Same arithmetic per output element up
         to the split-K summation order of the GEMM dispatch (parity against the reference: the whole-clip golden tests run
-        with look-ahead on and off).  No-op for encoders that take one image per call."""
-        self._ahead = {}
+        with look-ahead on and off).  No-op for encoders that take one image per call.
+        overlap=True (round 6): the batch is encoded on a SIDE stream while the caller goes on propagating the frames of the
+        previous batch -- the stride-16 stages of a propagated frame (LSTT, the head's first blocks) leave more than half of the
+        CUs idle, and the encoder of the coming frames fills them.  Two feature sets alternate (a call replaces the set encoded
+        two calls ago, which the caller has consumed by then); a frame's first use waits for its batch's event.  Same kernels,
+        same arithmetic: bit-identical to overlap=False."""
+        if not overlap:
+            self._ahead = {}
         if not imgs or len(imgs) < 2 or not getattr(self.AOT.encoder, 'batched', False):
+            if not imgs:
+                self._ahead = {}
             return           # (one frame: nothing to batch -- and a B = 1 encode would share the in-line encoder's scratch)
+        slot = 0
+        if overlap:
+            slot = self._ahead_slot = 1 - getattr(self, '_ahead_slot', 1)
+            self._ahead = {k_: v for k_, v in self._ahead.items() if v[2] != slot}
         k = len(imgs)
-        key = ('imgs_ahead', k, tuple(imgs[0].shape))
+        key = ('imgs_ahead', k, tuple(imgs[0].shape), slot)
         src = self._static.get(key)          # the batch is gathered into one [k,3,H,W] buffer (stable address: replayable)
         if src is None:
             src = self._static[key] = torch.empty((k,) + tuple(imgs[0].shape[1:]), dtype=torch.float32, device=imgs[0].device)
         for b, img in enumerate(imgs):
             src[b:b + 1].copy_(img)
-        if self.use_graph:
+        done = None
+        if overlap:
+            cur = torch.cuda.current_stream()
+            side, graphs = self._side()
+            ev = torch.cuda.Event()
+            ev.record(cur)                   # the images are in place, and the frames that read this slot's previous features are issued
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                if self.use_graph:
+                    feats = graphs.run(ptr_key('encode_ahead', src, aot_hip.gemm_table(), slot), lambda: self._encode_batch(src, slot))
+                else:
+                    feats = self._encode_batch(src, slot)
+                done = torch.cuda.Event()
+                done.record(side)
+        elif self.use_graph:
             feats = self._gx().run(ptr_key('encode_ahead', src, aot_hip.gemm_table()), lambda: self.AOT.encode_tokens(src))
         else:
             feats = self.AOT.encode_tokens(src)
@@ -498,14 +541,18 @@ class AOTEngine(nn.Module):
             # the entry holds the image: its storage cannot be freed and re-used for another frame of the same shape while the
             # features wait, so (address, shape, version) identifies the frame for as long as the entry lives
             self._ahead[_img_key(img)] = (img, feats.frame(b) if hasattr(feats, 'frame') else
-                                          [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats])
+                                          [(f[b * h * w:(b + 1) * h * w], h, w) for (f, h, w) in feats], slot, done)
 
     def _take_ahead(self, img):
         """Features of a frame encoded by encode_ahead(), if `img` is the same memory, unmodified since."""
         if img is None or not self._ahead:
             return None
         hit = self._ahead.pop(_img_key(img), None)
-        return hit[1] if hit is not None else None
+        if hit is None:
+            return None
+        if hit[3] is not None:          # encoded on the side stream: this stream continues when the batch is done
+            torch.cuda.current_stream().wait_event(hit[3])
+        return hit[1]
 
     # ---- frame stages --------------------------------------------------------------------------
     def _encode(self, img, img_embs):
@@ -947,10 +994,11 @@ class AOTInferEngine(nn.Module):
         first = self._cohorts[0]
         self.input_size_2d, self.enc_size_2d, self.enc_hw = first.input_size_2d, first.enc_size_2d, first.enc_hw
 
-    def encode_ahead(self, imgs):
-        """Optional look-ahead (see AOTEngine.encode_ahead): the next frames of the clip, encoded as one batch."""
+    def encode_ahead(self, imgs, overlap=False):
+        """Optional look-ahead (see AOTEngine.encode_ahead): the next frames of the clip, encoded as one batch; overlap=True: on a side
+        stream, beside the propagation of the frames encoded by the previous call."""
         if self._cohorts:
-            self._cohorts[0].encode_ahead(imgs)
+            self._cohorts[0].encode_ahead(imgs, overlap=overlap)
 
     @_in_table
     def match_propogate_one_frame(self, img=None):

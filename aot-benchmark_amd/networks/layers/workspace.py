@@ -8,12 +8,13 @@ import torch
 class Workspace:
     def __init__(self):
         self._bufs = {}
+        self.salt = ''     # appended to every name while set: a second, disjoint set of the same buffers (the engine's overlapped look-ahead)
 
     def get(self, name, shape, device, dtype=torch.float32):
         # (raw stream handle through the C binding: torch.cuda.current_stream() builds a Stream object per call, which at
         #  ~110 lookups per frame cost 0.5 ms of host time per frame)
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        key = (name, tuple(shape), dtype, idx, torch._C._cuda_getCurrentRawStream(idx))
+        key = (name + self.salt if self.salt else name, tuple(shape), dtype, idx, torch._C._cuda_getCurrentRawStream(idx))
         buf = self._bufs.get(key)
         if buf is None:
             buf = torch.empty(shape, dtype=dtype, device=device)

@@ -159,6 +159,9 @@ def one_frame(engine, img, feedback=None):
     return label
 
 
+OVERLAP_ENCODE = False      # --overlap-encode: every StreamClip's look-ahead batches go to the engine's side stream
+
+
 class StreamClip:
     """One clip on one HIP stream with its own engine.  `t` is the next frame to propagate (1 .. CLIP_FRAMES-1)."""
 
@@ -167,7 +170,9 @@ class StreamClip:
         self.t = None
         self.feedback = None    # see one_frame()
         self.ahead = 0          # > 1: the encoder runs over the next `ahead` frames of the clip as one batch (engine.encode_ahead)
+        self.overlap = OVERLAP_ENCODE    # the batch AFTER the one being propagated is encoded meanwhile, on the engine's side stream
         self._encoded = 0       # frames from t on whose features are waiting in the engine
+        self._prefetched = 0    # frames behind those whose batch is in flight on the side stream
 
     def restart(self):
         """restart_engine + add_reference_frame: per-clip set-up, never inside the timed region (the reference's
@@ -177,27 +182,39 @@ class StreamClip:
             self.engine.restart_engine()
             self.engine.add_reference_frame(frames[0], mask, objs, frame_step=0)
         self.t = 1
-        self._encoded = 0
+        self._encoded = self._prefetched = 0
 
     def drop_ahead(self):
         """Forgets features encoded ahead of time: a timed window pays for the encoder of every frame it propagates."""
-        if self._encoded:
+        if self._encoded or self._prefetched:
             with torch.cuda.stream(self.stream):
                 self.engine.encode_ahead([])
-            self._encoded = 0
+            self._encoded = self._prefetched = 0
+
+    def _issue(self, first, limit):
+        """Encodes frames [first, first + n) as one batch, n = min(look-ahead, frames left in the clip, limit); returns n (0: no batch)."""
+        frames = self.clip[0]
+        n = min(self.ahead, len(frames) - first, limit)
+        if n > 1:
+            self.engine.encode_ahead(list(frames[first:first + n]), overlap=self.overlap)
+            return n
+        return 0
 
     def step(self, remaining=None):
-        """Propagates frame t.  `remaining` = frames still to come in the caller's window (this one included): the batch
-        encoded ahead never reaches past it."""
+        """Propagates frame t.  `remaining` = frames still to come in the caller's window (this one included): the batches
+        encoded ahead never reach past it."""
         frames = self.clip[0]
+        left = remaining if remaining is not None else len(frames)
         with torch.cuda.stream(self.stream):
-            if self.ahead > 1 and self._encoded == 0:
-                n = min(self.ahead, len(frames) - self.t, remaining if remaining is not None else self.ahead)
-                if n > 1:
-                    self.engine.encode_ahead(list(frames[self.t:self.t + n]))
-                    self._encoded = n
+            if self.ahead > 1:
+                if self._encoded == 0:
+                    self._encoded = self._issue(self.t, left)
+                if self.overlap and self._encoded and self._prefetched == 0:      # the batch after this one, beside its propagation
+                    self._prefetched = self._issue(self.t + self._encoded, left - self._encoded)
             label = one_frame(self.engine, frames[self.t], self.feedback)
         self._encoded = max(0, self._encoded - 1)
+        if self._encoded == 0 and self._prefetched:
+            self._encoded, self._prefetched = self._prefetched, 0
         self.t += 1
         return label
 
@@ -480,7 +497,7 @@ def other_config_legs(args):
     for name in ('swinb_deaotl', 'r50_deaotl'):
         cmd = [sys.executable, os.path.abspath(__file__), '--model', name, '--leg', '--gpus', '1', '--steps', str(args.steps),
                '--warmup', str(args.warmup), '--streams', str(args.streams), '--graph', str(args.graph), '--repeats', str(args.repeats),
-               '--encode-ahead', str(args.encode_ahead), '--mfma', args.mfma]
+               '--encode-ahead', str(args.encode_ahead), '--overlap-encode', str(args.overlap_encode), '--mfma', args.mfma]
         for flag in ('no_cpu_baseline', 'no_roofline', 'no_jf', 'no_whole_clip'):
             if getattr(args, flag):
                 cmd.append('--' + flag.replace('_', '-'))
@@ -549,7 +566,7 @@ class _DryClip:
 
 
 def main(argv=None):
-    global MODEL, IN_SIZE
+    global MODEL, IN_SIZE, OVERLAP_ENCODE
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -567,6 +584,10 @@ def main(argv=None):
                     help='K > 1 (default 3): the encoder runs over the next K frames of a clip as one batch on the clip\'s own '
                          'stream (engine.encode_ahead; the encoder does not depend on the mask feedback), never past the end of '
                          'a timed window and never before its start; 1: every frame is encoded when it is matched')
+    ap.add_argument('--overlap-encode', type=int, default=0, choices=[0, 1],
+                    help='1: the look-ahead batch AFTER the one being propagated is encoded meanwhile on a side stream of the engine '
+                         '(engine.encode_ahead(..., overlap=True)): the encoder of the coming frames fills the CUs the stride-16 stages '
+                         'of the propagated frame leave idle; same kernels, bit-identical results')
     ap.add_argument('--mfma', default='bf16x6', choices=['f32', 'bf16x6'],
                     help="matrix-core arithmetic of the run: 'bf16x6' (default since round 4: the fp32-equivalent six-term bf16 split -- "
                          "every fp32 operand as three truncated bf16 numbers, six of the nine partial products, fp32 accumulation; dtype "
@@ -598,6 +619,7 @@ def main(argv=None):
         raise SystemExit('bench.py: --gpus and --steps must be >= 1')
     default_model = args.model == MODEL
     MODEL = args.model
+    OVERLAP_ENCODE = bool(args.overlap_encode)
     if MODEL.startswith('swinb'):
         IN_SIZE = (480, 848)          # align_corners = False models take multiples of 16 (video_transforms.py:640-655)
     if args.backend == 'gloo' and not args.dry_run:
@@ -901,7 +923,7 @@ def main(argv=None):
                        'elapsed_max_s': round(tmax, 6),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': table,
-                       'encode_ahead_frames': max(1, args.encode_ahead),
+                       'encode_ahead_frames': max(1, args.encode_ahead), 'encode_overlapped': bool(args.overlap_encode),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
                        'timed_region': 'wall clock (barrier + device sync on both sides) over the propagated frames '
                                        'only: windows of consecutive frames spread over the 70-frame clip so that the '

@@ -88,16 +88,6 @@ int aot_conv2d_bf16x6k_f32(const float* in, const void* w6, int cout_pad, const 
                            int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
                            int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
                            void* stream);
-/* The same with the GroupNorm statistics of the result out of the REDUCE launch (round 6; one lane, B == 1): every workgroup of the
- * reduce adds (sum, sum of squares) of its outputs per group in double, the last one to arrive (device-scope ticket) adds the
- * workgroups' partials in index order and writes stats [G][2] doubles = (mean, rstd) exactly as aot_groupnorm_stats_f32 -- no
- * statistics launch, no second pass over the map.  Cout / 4 <= 64 and Cout / (4 G) powers of two (else AOT_ERR_UNSUPPORTED);
- * gn_part = ceil(OH*OW * (Cout/4) / 256) * G * 2 doubles of scratch, ticket = one zeroed word (left zero).  Replaces conv + the
- * statistics half of gn in the ConvGN blocks of the FPN head (networks/layers/basic.py:38-58, networks/decoders/fpn.py:18-21). */
-int aot_conv2d_bf16x6k_gn_f32(const float* in, const void* w6, int cout_pad, const float* bias, const float* res, float* out,
-                              int B, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                              int lda, int ldc, int ldr, int res_rows, int act, int ksplit, float* scratch, long scratch_floats,
-                              int G, double* gn_part, long gn_part_doubles, double* stats, unsigned* ticket, float eps, void* stream);
 /* The ResNet stem in the same family (round 5): a KxK convolution of B NHWC images with FOUR channels (the image padded to r, g, b, 0 by
  * aot_nchw_to_nhwc_f32): one 16-byte chunk of an im2col row is one filter tap, a k-step is eight taps.  w6 = aot_pack_bf16x6_f32 of the
  * weight [Kp, ldb] with rows k = 4 * tap + channel, Kp = ceil(KH * KW / 8) * 32, zero rows past KH * KW * 4.  in [B*H*W, 4], out

@@ -703,3 +703,26 @@ def test_bf16x6_split_k_rule_and_feature_slices():
     assert torch.equal(one[0][0], maps[0][0][30:60]) and torch.equal(one[2][0], maps[2][0][4:8])
     assert torch.equal(one.ads[0], f.ads[0][4:8]) and torch.equal(one.ads[1], f.ads[1][12:24]) and torch.equal(one.ads[2], f.ads[2][30:60])
     assert Feats(maps).frame(0).ads is None
+
+
+def test_every_binding_the_product_calls_exists():
+    """Every `aot_hip.<name>` the package, bench.py and the GPU tests refer to is an attribute of the binding module (a wrapper dropped by
+    an edit would otherwise only show on the GPU box), and every wrapper names a C entry that the ctypes table declares."""
+    import glob
+    import aot_hip
+    names = {}
+    files = glob.glob(os.path.join(ROOT, 'aot-benchmark_amd', '**', '*.py'), recursive=True) + [os.path.join(ROOT, 'bench.py'),
+                                                                                              os.path.join(ROOT, '__graft_entry__.py')]
+    files += glob.glob(os.path.join(ROOT, 'tests', 'test_*gpu*.py'))
+    for f in files:
+        src = open(f).read()
+        for m in re.finditer(r'(?<!ops\.)\baot_hip\.([A-Za-z_][A-Za-z0-9_]*)', src):      # (torch.ops.aot_hip.* is the op namespace)
+            names.setdefault(m.group(1), f)
+        if os.path.basename(f).startswith('test_'):
+            for m in re.finditer(r'\bhip\.([A-Za-z_][A-Za-z0-9_]*)', src):      # the tests' fixture `hip` is the module
+                names.setdefault(m.group(1), f)
+    missing = sorted(n for n in names if not hasattr(aot_hip, n) and n not in ('py', 'h', 'so', 'hip'))
+    assert not missing, {n: os.path.relpath(names[n], ROOT) for n in missing}
+    src = open(os.path.join(ROOT, 'aot-benchmark_amd', 'aot_hip.py')).read()
+    called = set(re.findall(r'load\(\)\.(aot_[a-z0-9_]+)\(', src))
+    assert called <= set(aot_hip._SIGS) | {'aot_hip_version'}, sorted(called - set(aot_hip._SIGS))

@@ -333,46 +333,6 @@ def test_layernorm_linear_x6_vs_fp64(hip, M, K, N, shift, lanes):
         assert float((pp - pq).abs().max()) <= 1e-4 * float(pq.abs().max())
 
 
-@pytest.mark.parametrize('h,w,cin,cout,k', [(31, 54, 1024, 256, 1), (31, 54, 256, 256, 3), (61, 107, 256, 128, 3), (30, 53, 256, 256, 3)])
-def test_gn_statistics_from_splitk_reduce(hip, h, w, cin, cout, k):
-    """aot_conv2d_bf16x6k_gn_f32 (round 6): the ConvGN blocks of the FPN head on the stride-16 / stride-8 maps (fpn.py:18-21,
-    basic.py:38-58) -- the split-K reduce launch also forms the GroupNorm(8) statistics of its output.  Against conv2d + the
-    statistics launch: the convolution output bit-identical, (mean, rstd) equal to fp64 statistics of that output to 1e-11 and to
-    aot_groupnorm_stats_f32's, the ticket word back at zero, repeats bit-identical (the last-arriver adds in index order)."""
-    g = torch.Generator().manual_seed(h * w + cin + cout)
-    M, K = h * w, k * k * cin
-    x = _dev(torch.randn(M, cin, generator=g) + 0.5)
-    wk = hip.attach_wt(_dev(torch.randn(K, cout, generator=g) / K ** 0.5), cin)
-    b = _dev(torch.randn(cout, generator=g))
-    Workspace = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace
-    ws = Workspace()
-    kw = dict(KH=k, KW=k, pad=k // 2)
-    with hip.use_gemm_table('latency', 'bf16x6'):
-        assert hip.x6_ksplit(M, cout, K) != 1
-        ref = torch.empty(M, cout, device='cuda')
-        hip.conv2d(x, wk, b, ref, h, w, cin, h, w, cout, k, k, 1, k // 2, 1)
-        want = hip.groupnorm_stats(ref, 8, hip.gn_buffers(ws, x.device, 1, 8, 32), nsplit=32).clone()
-        out = torch.full((M, cout), float('nan'), device='cuda')
-        st = hip.conv2d_gn_stats(x, wk, b, out, h, w, cin, h, w, cout, 8, ws, **kw)
-        assert st is not None
-        got = st.clone()
-        out2 = torch.empty(M, cout, device='cuda')
-        again = hip.conv2d_gn_stats(x, wk, b, out2, h, w, cin, h, w, cout, 8, ws, **kw).clone()
-    assert torch.equal(out, ref) and torch.equal(out2, ref)
-    assert torch.equal(got, again)
-    assert int(ws.get('gnr_ticket', (1,), x.device, torch.int32).item()) == 0
-    rd = ref.double().view(M, 8, cout // 8)
-    mean = rd.mean((0, 2))
-    rstd = 1.0 / torch.sqrt(((rd - mean.view(1, 8, 1)) ** 2).mean((0, 2)) + 1e-5)
-    gs = got.view(8, 2)
-    assert float((gs[:, 0] - mean).abs().max()) <= 1e-11 * max(1.0, float(mean.abs().max()))
-    assert float((gs[:, 1] / rstd - 1).abs().max()) <= 1e-9
-    assert float((got - want).abs().max()) <= 1e-10 * float(want.abs().max())
-    with hip.use_gemm_table('latency', 'bf16x6'):      # the fallbacks: a layer that is not split, several lanes
-        assert hip.conv2d_gn_stats(x[:, :64].contiguous(), hip.attach_wt(_dev(torch.randn(64, cout, generator=g)), 64), b, out, 1, M, 64, 1, M,
-                                   cout, 8, ws) is None
-
-
 @pytest.mark.parametrize('B,ih,iw,oh,ow,C,align', [(1, 31, 54, 61, 107, 256, True), (3, 31, 54, 61, 107, 256, True), (1, 61, 107, 121, 213, 128, True),
                                                   (2, 9, 11, 18, 22, 64, False)])
 def test_gn_bilinear_bit_identical_to_the_pair(hip, B, ih, iw, oh, ow, C, align):
@@ -2141,6 +2101,60 @@ def test_encode_ahead_matches_inline_encoding(hip):
         assert (a[live] - b[live]).abs().max().item() < 2e-5, 'frame %d: look-ahead encoding differs by %g' % (
             i + 1, (a[live] - b[live]).abs().max().item())
         assert torch.equal(b, c), 'frame %d: graph replay of the look-ahead path differs from eager' % (i + 1)
+
+
+@pytest.mark.parametrize('mfma', ['f32', 'bf16x6'])
+def test_overlapped_encode_ahead_bit_identical(hip, mfma):
+    """engine.encode_ahead(..., overlap=True) (round 6): the batch AFTER the one being propagated is encoded on the engine's side stream
+    (own graph cache, own memory pool, two alternating feature sets) while the caller propagates -- the same kernels on the same
+    inputs: every frame's logits bit-identical to the engine that encodes its batches in line, free-running over 13 frames (five
+    batches: the feature sets are overwritten twice), eager and under hipGraph replay; a batch dropped unconsumed (encode_ahead([]))
+    and a last batch of one frame are handled."""
+    from networks.engines import build_engine
+    from utils.synth import synth_clip
+    cfg, model, sd = synth_model_state('r50_aotl')
+    model = model.cuda().eval()
+    model.prepare()
+    size, osz = (241, 321), (240, 320)
+    fr, m, ob, _ = synth_clip(22, 14, size, osz, 4, device='cuda')
+
+    def run(overlap, graph):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=3, graph=graph, mfma=mfma)
+        outs = []
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            eng.restart_engine()
+            eng.add_reference_frame(fr[0], m, ob, frame_step=0)
+            enc = pre = 0
+            for t in range(1, len(fr)):
+                def issue(first):
+                    n = min(3, len(fr) - first)
+                    if n > 1:
+                        eng.encode_ahead(list(fr[first:first + n]), overlap=overlap)
+                        return n
+                    return 0
+                if enc == 0:
+                    enc = issue(t)
+                if overlap and enc and pre == 0:
+                    pre = issue(t + enc)
+                eng.match_propogate_one_frame(fr[t])
+                lg = eng.decode_current_logits(osz)
+                eng.update_memory(F.interpolate(torch.argmax(lg, 1, keepdim=True).float(), size=eng.input_size_2d, mode='nearest'))
+                outs.append(lg.clone())
+                enc = max(0, enc - 1)
+                if enc == 0 and pre:
+                    enc, pre = pre, 0
+                if t == 9:                      # drop what is waiting: the next frames start afresh
+                    eng.encode_ahead([])
+                    enc = pre = 0
+        torch.cuda.synchronize()
+        return outs
+    with torch.no_grad():
+        base = run(False, False)
+        for overlap, graph in ((True, False), (True, True), (False, True)):
+            got = run(overlap, graph)
+            for i, (a, b) in enumerate(zip(base, got)):
+                assert torch.equal(a, b), 'frame %d differs (overlap=%s graph=%s)' % (i + 1, overlap, graph)
 
 
 def test_reference_api_surface(hip):
