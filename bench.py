@@ -159,7 +159,8 @@ def one_frame(engine, img, feedback=None):
     return label
 
 
-OVERLAP_ENCODE = False      # --overlap-encode: every StreamClip's look-ahead batches go to the engine's side stream
+OVERLAP_ENCODE = -1         # --overlap-encode: 1 / 0 = every StreamClip's look-ahead batches do / do not go to the engine's side stream;
+                            # -1 (default) = in the one-clip-at-a-time legs only (measured: +9 % there, -3 % with three clips per GPU)
 
 
 class StreamClip:
@@ -170,7 +171,7 @@ class StreamClip:
         self.t = None
         self.feedback = None    # see one_frame()
         self.ahead = 0          # > 1: the encoder runs over the next `ahead` frames of the clip as one batch (engine.encode_ahead)
-        self.overlap = OVERLAP_ENCODE    # the batch AFTER the one being propagated is encoded meanwhile, on the engine's side stream
+        self.overlap = OVERLAP_ENCODE == 1    # the batch AFTER the one being propagated is encoded meanwhile, on the engine's side stream
         self._encoded = 0       # frames from t on whose features are waiting in the engine
         self._prefetched = 0    # frames behind those whose batch is in flight on the side stream
 
@@ -584,10 +585,12 @@ def main(argv=None):
                     help='K > 1 (default 3): the encoder runs over the next K frames of a clip as one batch on the clip\'s own '
                          'stream (engine.encode_ahead; the encoder does not depend on the mask feedback), never past the end of '
                          'a timed window and never before its start; 1: every frame is encoded when it is matched')
-    ap.add_argument('--overlap-encode', type=int, default=0, choices=[0, 1],
+    ap.add_argument('--overlap-encode', type=int, default=-1, choices=[-1, 0, 1],
                     help='1: the look-ahead batch AFTER the one being propagated is encoded meanwhile on a side stream of the engine '
                          '(engine.encode_ahead(..., overlap=True)): the encoder of the coming frames fills the CUs the stride-16 stages '
-                         'of the propagated frame leave idle; same kernels, bit-identical results')
+                         'of the propagated frame leave idle; same kernels, bit-identical results.  -1 (default): only where one clip '
+                         'runs at a time (--streams 1 and the single_stream leg; profiles/r06_group_overlap_ab.txt: +9 %% there, -3 %% '
+                         'with three clips per GPU, whose other clips already fill those CUs); 0: never')
     ap.add_argument('--mfma', default='bf16x6', choices=['f32', 'bf16x6'],
                     help="matrix-core arithmetic of the run: 'bf16x6' (default since round 4: the fp32-equivalent six-term bf16 split -- "
                          "every fp32 operand as three truncated bf16 numbers, six of the nine partial products, fp32 accumulation; dtype "
@@ -619,7 +622,7 @@ def main(argv=None):
         raise SystemExit('bench.py: --gpus and --steps must be >= 1')
     default_model = args.model == MODEL
     MODEL = args.model
-    OVERLAP_ENCODE = bool(args.overlap_encode)
+    OVERLAP_ENCODE = args.overlap_encode
     if MODEL.startswith('swinb'):
         IN_SIZE = (480, 848)          # align_corners = False models take multiples of 16 (video_transforms.py:640-655)
     if args.backend == 'gloo' and not args.dry_run:
@@ -699,6 +702,7 @@ def main(argv=None):
         lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
         for lane in lanes:
             lane.ahead = max(1, args.encode_ahead)
+            lane.overlap = args.overlap_encode == 1 or (args.overlap_encode < 0 and S == 1)
 
         def set_clip(lane, j):
             lane.clip = clips[j]
@@ -770,13 +774,15 @@ def main(argv=None):
         if S > 1 and rank == 0 and not dry:      # the same job one clip at a time (the reference's evaluation mode)
             one = StreamClip(new_engine('latency'), streams[0], clips[0])
             one.ahead = lanes[0].ahead
+            one.overlap = args.overlap_encode != 0
             one.restart()                        # untimed: one clip under the latency table (graph mode captures its states)
             for t in range(1, CLIP_FRAMES):
                 one.step()
             sruns = [run_plan([one], plan_windows(args.steps, 1), lambda pi, i: 0, collective=False) for _ in range(R)]
             e1, f1, m1 = median_run(sruns)
             single = {'fps': round(f1 / e1, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in sruns],
-                      'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead}
+                      'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead,
+                      'encode_overlapped': bool(one.overlap and one.ahead > 1)}
             del one
             # ... and STRICTLY ONLINE, timed the reference's way (evaluator.py:325-330, 444-446, 486-498): one clip, no encoder
             # look-ahead (every frame is encoded when it arrives), a device event just before match_propogate_one_frame and one
@@ -923,7 +929,7 @@ def main(argv=None):
                        'elapsed_max_s': round(tmax, 6),
                        'launch': 'hipGraph replay per frame stage' if args.graph else 'host launches',
                        'gemm_table': table,
-                       'encode_ahead_frames': max(1, args.encode_ahead), 'encode_overlapped': bool(args.overlap_encode),
+                       'encode_ahead_frames': max(1, args.encode_ahead), 'encode_overlapped': bool(getattr(lanes[0], 'overlap', False) and lanes[0].ahead > 1),
                        'weights': 'keyed synthetic (utils/synth.py)', 'peak_mem_gib': round(float(stats[:, 2].max()), 2),
                        'timed_region': 'wall clock (barrier + device sync on both sides) over the propagated frames '
                                        'only: windows of consecutive frames spread over the 70-frame clip so that the '
