@@ -71,50 +71,6 @@ __device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3]
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
-// Softmax weights on TWO planes (build switch AOT_P16, round 6 probe): p~ = p with the low 8 of its 24 significand bits cleared IS the
-// sum of two truncated-bf16 numbers exactly (8 + 8 bits), so the value product needs five MFMAs per sub-step instead of six (the
-// term v0 * p2 is gone) and the split one and / sub round less; the row sum l is taken over the SAME p~, so the truncation acts
-// as a relative perturbation of every softmax weight by at most 2^-16 whose common part cancels in o = sum p~ v / sum p~: what is
-// left is |do| <= 2^-17 / sqrt(3) * sqrt(sum w_i^2 (v_i - o)^2) (w = the normalised weights) -- below the fp32 kernel's own
-// rounding of the scores for any but two-point distributions.
-__device__ __forceinline__ void split2_p16(float (&x)[8], bf16x8 (&out)[3]) {      // x is replaced by p~ (what the row sum adds up)
-  u32x4 w[2];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float r0 = __uint_as_float(__float_as_uint(x[2 * e]) & 0xffffff00u), r1 = __uint_as_float(__float_as_uint(x[2 * e + 1]) & 0xffffff00u);
-    x[2 * e] = r0;
-    x[2 * e + 1] = r1;
-    w[0][e] = pack_hi16(r0, r1);
-    r0 -= __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-    r1 -= __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-    w[1][e] = pack_hi16(r0, r1);      // exact: at most 8 significant bits are left
-  }
-  out[0] = __builtin_bit_cast(bf16x8, w[0]);
-  out[1] = __builtin_bit_cast(bf16x8, w[1]);
-}
-__device__ __forceinline__ float mask_p16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffffff00u); }
-__device__ __forceinline__ void split2_masked(const float (&x)[8], bf16x8 (&out)[3]) {      // x = mask_p16(p): exactly two planes
-  u32x4 w[2];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float r0 = x[2 * e], r1 = x[2 * e + 1];
-    w[0][e] = pack_hi16(r0, r1);
-    r0 -= __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-    r1 -= __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-    w[1][e] = pack_hi16(r0, r1);
-  }
-  out[0] = __builtin_bit_cast(bf16x8, w[0]);
-  out[1] = __builtin_bit_cast(bf16x8, w[1]);
-}
-// acc += (a0 + a1 + a2) x (b0 + b1): the five products of order <= 2, smallest first
-__device__ __forceinline__ void mfma5(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
-}
-
 // Round 3 shipped this kernel with a warning that its instruction order was part of its correctness: some orders gave wrong O for
 // 16 of the 32 queries of sporadic tiles, and the MFMA wait states were suspected.  Round 4 found the cause, and it is not in the
 // loop (profiles/r04_hazard.txt): the (O, m, l) LDS merge at the end was compiled by hipcc's SLP vectoriser into an IN-PLACE packed
@@ -228,13 +184,9 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       pf[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], AOT_LOG2E, -m));      // as exp2_w() of attention.hip
-#ifndef AOT_P16
       ps += pf[r];
-#endif
     }
-#ifndef AOT_P16
     l += ps;
-#endif
     load_k(ka, kt + 64);
     // P^T as the B operand of the value product: the lane's registers 8 c .. 8 c + 7 are keys 16 c + 8 (i >> 2) + 4 hi + (i & 3),
     // the order the packed V rows are stored in
@@ -244,19 +196,9 @@ __global__ void __launch_bounds__(256, 2) attn_x6_d32_kernel(const AttnX6Params 
 #pragma unroll
       for (int i = 0; i < 8; ++i) x8[i] = pf[8 * c + i];
       bf16x8 pp[3];
-#ifdef AOT_P16
-      split2_p16(x8, pp);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ps += x8[i];
-      mfma5(va[c], pp, o);
-#else
       split3(x8, pp);
       mfma6(va[c], pp, o);
-#endif
     }
-#ifdef AOT_P16
-    l += ps;
-#endif
     load_v(va, kt + 32);
   };
   int kt = t0;
@@ -615,9 +557,6 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Pa
     for (int i = 0; i < 8; ++i) {
       const float sv = sc_half ? sm_sc[8 + i] : sm_sc[i];
       sm_p[i] = (mnew == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, AOT_LOG2E, -mnew));
-#ifdef AOT_P16
-      sm_p[i] = mask_p16(sm_p[i]);      // the weight the value product will see: the row sum adds up the same number
-#endif
       ps += sm_p[i];
     }
     l = l * alpha + ps;
@@ -625,15 +564,9 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Pa
   };
   auto softmax_c = [&](int buf) {      // the three bf16 planes of the eight weights -> LDS
     bf16x8 pl3[3];
-#ifdef AOT_P16
-    split2_masked(sm_p, pl3);
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) pbuf[buf][st][sc_half][pl][lane] = __builtin_bit_cast(u32x4, pl3[pl]);
-#else
     split3(sm_p, pl3);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) pbuf[buf][st][sc_half][pl][lane] = __builtin_bit_cast(u32x4, pl3[pl]);
-#endif
   };
 
   bf16x8 ka[2][3], vb[NVB][2][3];
@@ -665,11 +598,7 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Pa
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-#ifdef AOT_P16
-        for (int pl = 0; pl < 2; ++pl) pp[t][c][pl] = __builtin_bit_cast(bf16x8, pbuf[buf][t][c][pl][lane]);
-#else
         for (int pl = 0; pl < 3; ++pl) pp[t][c][pl] = __builtin_bit_cast(bf16x8, pbuf[buf][t][c][pl][lane]);
-#endif
     const float al0 = abuf[buf][0][lane], al1 = abuf[buf][1][lane];
     if (__any(al0 != 1.f || al1 != 1.f)) {      // (rare after the first tiles of a range)
 #pragma unroll
@@ -705,13 +634,8 @@ __global__ void __launch_bounds__(256, 1) attn_x6_wide64p_kernel(const GatedX6Pa
       if (d == 6) qk_part(ka, buf, 1);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-#ifdef AOT_P16
-        mfma5(vb[d % NVB][c], pp[0][c], o[0][d]);
-        mfma5(vb[d % NVB][c], pp[1][c], o[1][d]);
-#else
         mfma6(vb[d % NVB][c], pp[0][c], o[0][d]);
         mfma6(vb[d % NVB][c], pp[1][c], o[1][d]);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
