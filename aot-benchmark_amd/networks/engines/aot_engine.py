@@ -59,14 +59,8 @@ class AOTEngine(nn.Module):
     0..max_obj_num as they are."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, long_term_mem_max=None, lanes=1,
-                 group0=None, graph=False, gemm_table='latency', mfma='f32', branches=False):
+                 group0=None, graph=False, gemm_table='latency', mfma='f32'):
         super().__init__()
-        # branches=True (round 6): the short-term (windowed) attention of every layer runs on a second stream BESIDE the long-term
-        # attention over the bank -- both read the layer's query, neither reads the other (transformer.py:343-353 / 622-641 in the
-        # reference) -- as a fork / join inside the match stage (and inside its captured graph).  Same kernels, same inputs:
-        # bit-identical.  For one clip at a time: several clips on their own streams already fill the gaps.
-        self.branches = bool(branches)
-        self._branch_stream = None
         # matrix-core arithmetic of the conv / linear layers: 'f32' (exact fp32 products, default) or 'bf16x6' (the
         # fp32-equivalent six-term bf16 split, aot_conv2d_bf16x6_f32: a second, parity-gated kernel family)
         if mfma not in aot_hip.MFMA_MODES:
@@ -458,14 +452,6 @@ class AOTEngine(nn.Module):
         self._short.append(entry)
         self._short = self._short[-self.short_term_mem_skip:]
 
-    def _side_kw(self):
-        """side=<stream> for LSTT.run when the engine forks its independent attention branches (branches=True)."""
-        if not self.branches:
-            return {}
-        if self._branch_stream is None:
-            self._branch_stream = torch.cuda.Stream(next(self.AOT.parameters()).device)
-        return {'side': self._branch_stream}
-
     # ---- hipGraph replay -----------------------------------------------------------------------
     def _gx(self):
         if self._graphs is None:
@@ -632,7 +618,7 @@ class AOTEngine(nn.Module):
         direct = self._direct()
         dst = self._slot_views(slot) if direct else self._scratch_set()
         self._dec_in, mems = self.AOT.LSTT.run(x16, None, None, id_emb, self.pos_emb, self.enc_size_2d, self.AOT.ws, stream,
-                                               B=self.lanes, dst=dst, keep=self._arena, **self._side_kw())
+                                               B=self.lanes, dst=dst, keep=self._arena)
         self._curr = mems
         if not direct:
             self._store(dst, slot)
@@ -677,7 +663,7 @@ class AOTEngine(nn.Module):
         def launch(img_, embs_):
             feats = ahead if ahead is not None else self._encode(img_, embs_)
             dec_in, mems = self.AOT.LSTT.run(feats[3][0], long_m, short, None, self.pos_emb, self.enc_size_2d, self.AOT.ws,
-                                             aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena, **x6, **self._side_kw())
+                                             aot_hip.stream_ptr(), B=self.lanes, dst=dst, keep=self._arena, **x6)
             return feats, dec_in, mems
 
         if self.use_graph:
@@ -685,7 +671,7 @@ class AOTEngine(nn.Module):
             # state-free: the bank length is not part of the key (only whether the bank is still the reference frame alone:
             # that launch is planned for its exact length)
             bank_state = T <= self.enc_hw if sf else T
-            key = ptr_key('match', self.branches, src, img_embs, [f[0] for f in ahead] if ahead is not None else None,
+            key = ptr_key('match', src, img_embs, [f[0] for f in ahead] if ahead is not None else None,
                           [m[:2] for m in long_m], brows, bank_state, short, dst, self.pos_emb, self.lanes, self.enc_size_2d,
                           aot_hip.gemm_table(), [b[0] for b in self._bank_x6] if self._x6_attn else None)
             self._feats, self._dec_in, self._curr = self._gx().run(key, lambda: launch(src, img_embs))
@@ -918,12 +904,11 @@ class AOTInferEngine(nn.Module):
     cohort_cls = AOTEngine
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None,
-                 long_term_mem_max=None, graph=False, gemm_table='latency', mfma='f32', branches=False):
+                 long_term_mem_max=None, graph=False, gemm_table='latency', mfma='f32'):
         super().__init__()
         if mfma not in aot_hip.MFMA_MODES:
             raise ValueError('mfma must be one of %s' % (aot_hip.MFMA_MODES,))
         self.mfma = mfma                 # matrix-core arithmetic of every cohort (see AOTEngine)
-        self.branches = bool(branches)   # fork / join of the independent attention branches inside the match stage (see AOTEngine)
         if gemm_table not in aot_hip.GEMM_TABLES:
             raise ValueError('gemm_table must be one of %s' % sorted(aot_hip.GEMM_TABLES))
         self.gemm_table = gemm_table     # conv / linear dispatch table of every cohort of this engine (see AOTEngine)
@@ -962,7 +947,7 @@ class AOTInferEngine(nn.Module):
                 return c
         c = self.cohort_cls(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip,
                             long_term_mem_max=self.long_term_mem_max, lanes=lanes, group0=group0, graph=self.use_graph,
-                            gemm_table=self.gemm_table, mfma=self.mfma, branches=self.branches)
+                            gemm_table=self.gemm_table, mfma=self.mfma)
         c.eval()
         return c
 

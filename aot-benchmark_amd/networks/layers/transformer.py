@@ -107,7 +107,7 @@ class LongShortTermTransformerBlock(nn.Module):
 
     # ---- reference transformer.py:312-362 -----------------------------------------------------
     def run(self, x, long_mem, short_mem, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, pos_qkv=None,
-            out_norm=None, side=None):
+            out_norm=None):
         """x [B*N, C(ld)] token-major (B lanes).  out_norm = (gamma, beta, dst, eps): the stack's norm of this layer's output, written to dst
         by this call (from linear2's reduce launch where that layer runs split-K).  x6 = the bank's pre-split copy (planes, rows per lane) for the bf16x6 attention
         kernel, when the engine keeps one.  long_mem = (K, V, T, kv_brows[, T_dev]): lane b's bank = rows b*kv_brows .. + T
@@ -171,19 +171,9 @@ class LongShortTermTransformerBlock(nn.Module):
             gk, gv, t, g_brows, *t_dev = long_mem
             lk, lv, l_brows = short_mem
         cat = ws.get('lst_cat', (M, 2 * C), dev)
-        if side is not None:        # fork: the windowed attention beside the attention over the bank (both read qc, write halves of cat)
-            fork = torch.cuda.Event()
-            fork.record()
-            side.wait_event(fork)
-            self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, side.cuda_stream, B=B, kv_brows=l_brows)
-            join = torch.cuda.Event()
-            join.record(side)
         self.long_term_attn.core(qc, gk, gv, cat[:, :C], t, ws, stream, t_dev=t_dev[0] if t_dev else None, B=B,
                                  kv_brows=g_brows, x6=x6 if id_emb is None else None)
-        if side is not None:
-            torch.cuda.current_stream().wait_event(join)
-        else:
-            self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream, B=B, kv_brows=l_brows)
+        self.short_term_attn.core(qc, lk, lv, cat[:, C:], size_2d, stream, B=B, kv_brows=l_brows)
         xb = ws.get('xb', (M, C), dev)
         aot_hip.linear(cat, p['lst_w'], p['lst_b'], xb, res=xa, stream=stream)
 
@@ -281,9 +271,8 @@ class LongShortTermTransformer(nn.Module):
         num_norms = (num_layers - 1 if intermediate_norm else 0) + (1 if final_norm else 0)
         self.decoder_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_norms)]) if num_norms > 0 else None
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, side=None):
-        """Runs the stack for B lanes on the projected encoder feature x0 [N, C] (shared by the lanes).  side = a second stream: every layer
-        forks its windowed attention onto it beside the attention over the bank (engine option branches=True).  Returns
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
+        """Runs the stack for B lanes on the projected encoder feature x0 [N, C] (shared by the lanes).  Returns
         (dec_in, mems): dec_in is the decoder's concatenated input [B*N, (L+1)*C] (models/aot.py:86-92) -- block 0 = x0,
         blocks 1.. = the layer outputs after their decoder norm (transformer.py:124-135), written in place so the concat is
         never a copy; mems[i] = (curr_K, curr_V, fused_V | None) of layer i."""
@@ -311,7 +300,7 @@ class LongShortTermTransformer(nn.Module):
                                       short_mems[i] if short_mems is not None else None,
                                       id_emb, pos, size_2d, ws, stream, B=B, dst=dst[i] if dst is not None else None,
                                       keep=keep, x6=x6[i] if x6 is not None else None, pos_qkv=pq[i] if pq is not None else None,
-                                      out_norm=(norm.weight, norm.bias, d, norm.eps) if norm is not None else None, side=side)
+                                      out_norm=(norm.weight, norm.bias, d, norm.eps) if norm is not None else None)
             mems.append((ck, cv, fv))
             if norm is None:
                 d.copy_(x)
@@ -505,9 +494,8 @@ class DualBranchGPM(nn.Module):
         if intermediate_norm:
             raise NotImplementedError('DeAOT decodes the last GPM output only (default_deaot.py:12)')
 
-    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None, side=None):
-        """B lanes on the shared feature x0 [N, D].  (side: accepted for the engine's sake; the GPM block's local propagation adds
-        into what the global one produced -- transformer.py:633-641 -- and is not forked.)  Returns (dec_in [B*N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last
+    def run(self, x0, long_mems, short_mems, id_emb, pos, size_2d, ws, stream, B=1, dst=None, keep=None, x6=None):
+        """B lanes on the shared feature x0 [N, D].  Returns (dec_in [B*N, 2D] = GroupNorm(2)(cat[tgt, tgt_id]) of the last
         layer, mems): mems[i] = (curr_K, curr_Vcat, curr_ID_V_input) of layer i."""
         N, D = x0.shape
         dev = x0.device

@@ -694,9 +694,9 @@ def main(argv=None):
             frames, mask, objs, _ = synth_clip(cid, CLIP_FRAMES, IN_SIZE, OUT_SIZE, NUM_OBJ, device=device)
             clips.append((frames, mask, objs))
 
-        def new_engine(tbl, graph=bool(args.graph), mfma=args.mfma, branches=False):
+        def new_engine(tbl, graph=bool(args.graph), mfma=args.mfma):
             return build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=device.index or 0, long_term_mem_gap=gap,
-                                graph=graph, gemm_table=tbl, mfma=mfma, branches=branches)
+                                graph=graph, gemm_table=tbl, mfma=mfma)
         engines = [engine] + [new_engine(table) for _ in range(S - 1)]
         streams = [torch.cuda.Stream(device) for _ in range(S)]
         lanes = [StreamClip(engines[i], streams[i], clips[i]) for i in range(S)]
@@ -772,9 +772,7 @@ def main(argv=None):
         phase('warm-up + %d timed runs' % R)
         single = None
         if S > 1 and rank == 0 and not dry:      # the same job one clip at a time (the reference's evaluation mode)
-            # one clip at a time leaves CUs idle that three clips fill: the look-ahead encoder goes to a side stream and the windowed
-            # attention of every layer runs beside the attention over the bank (same kernels, bit-identical; --overlap-encode 0 = neither)
-            one = StreamClip(new_engine('latency', branches=args.overlap_encode != 0 and not os.environ.get('AOT_NO_BRANCHES')), streams[0], clips[0])
+            one = StreamClip(new_engine('latency'), streams[0], clips[0])
             one.ahead = lanes[0].ahead
             one.overlap = args.overlap_encode != 0
             one.restart()                        # untimed: one clip under the latency table (graph mode captures its states)
@@ -784,8 +782,7 @@ def main(argv=None):
             e1, f1, m1 = median_run(sruns)
             single = {'fps': round(f1 / e1, 2), 'repeat_fps': [round(f / e, 2) for e, f, _ in sruns],
                       'timed_M_mean': round(m1 / f1, 2), 'gemm_table': 'latency', 'encode_ahead_frames': one.ahead,
-                      'encode_overlapped': bool(one.overlap and one.ahead > 1),
-                      'attention_branches_forked': bool(getattr(one.engine, 'branches', False))}
+                      'encode_overlapped': bool(one.overlap and one.ahead > 1)}
             del one
             # ... and STRICTLY ONLINE, timed the reference's way (evaluator.py:325-330, 444-446, 486-498): one clip, no encoder
             # look-ahead (every frame is encoded when it arrives), a device event just before match_propogate_one_frame and one

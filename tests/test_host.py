@@ -348,8 +348,7 @@ def test_infer_engine_cohort_orchestration_vs_reference(monkeypatch):
     class Cohort:                                   # the surface AOTInferEngine and _decode use of an AOTEngine
         use_graph = False
 
-        def __init__(self, model, gpu_id, gap, skip, long_term_mem_max=None, lanes=1, group0=None, graph=False, gemm_table='latency', mfma='f32',
-                     branches=False):
+        def __init__(self, model, gpu_id, gap, skip, long_term_mem_max=None, lanes=1, group0=None, graph=False, gemm_table='latency', mfma='f32'):
             self.lanes, self.group0, self.first_group, self.gap = lanes, group0, group0 or 0, gap
             self.restart_engine()
 
