@@ -58,6 +58,9 @@ class SwinTransformerBlock(nn.Module):
                  'table': self.attn.relative_position_bias_table.detach().float().contiguous()}
             for k, m in (('qkv', self.attn.qkv), ('proj', self.attn.proj), ('fc1', self.mlp.fc1), ('fc2', self.mlp.fc2)):
                 p[k + '_w'], p[k + '_b'] = linear_t(m)
+            # LayerNorm as the prologue of the GEMM behind it (round 6, aot_layernorm_linear_bf16x6_f32): norm1 -> qkv, norm2 -> fc1
+            p['ln_qkv'] = aot_hip.fold_layernorm(p['qkv_w'], p['qkv_b'], *p['n1'])
+            p['ln_fc1'] = aot_hip.fold_layernorm(p['fc1_w'], p['fc1_b'], *p['n2'])
             self._p = p
         return self._p
 
@@ -68,9 +71,12 @@ class SwinTransformerBlock(nn.Module):
         N, C = x.shape
         dev = x.device
         x1 = ws.get('sw_x1', (N, C), dev)
-        aot_hip.layernorm(x, *p['n1'], x1, stream=stream)
         qkv = ws.get('sw_qkv', (N, 3 * C), dev)
-        aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
+        if aot_hip.x6_ln_fusable(N, C, 3 * C):          # the normalised map is never written (bf16x6 engines)
+            aot_hip.layernorm_linear_x6(x, *p['ln_qkv'], qkv, eps=self.norm1.eps, stream=stream)
+        else:
+            aot_hip.layernorm(x, *p['n1'], x1, eps=self.norm1.eps, stream=stream)
+            aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
         a = ws.get('sw_a', (N, C), dev)
         n1 = H * W
         for b in range(B):
@@ -78,9 +84,12 @@ class SwinTransformerBlock(nn.Module):
                                           self.num_heads, self.shift_size, self.attn.scale, stream=stream)
         xa = ws.get('sw_xa', (N, C), dev)
         aot_hip.linear(a, p['proj_w'], p['proj_b'], xa, res=x, stream=stream)
-        aot_hip.layernorm(xa, *p['n2'], x1, stream=stream)
         f = ws.get('sw_f', (N, 4 * C), dev)
-        aot_hip.linear(x1, p['fc1_w'], p['fc1_b'], f, act=aot_hip.ACT_GELU, stream=stream)
+        if aot_hip.x6_ln_fusable(N, C, 4 * C):
+            aot_hip.layernorm_linear_x6(xa, *p['ln_fc1'], f, eps=self.norm2.eps, act=aot_hip.ACT_GELU, stream=stream)
+        else:
+            aot_hip.layernorm(xa, *p['n2'], x1, eps=self.norm2.eps, stream=stream)
+            aot_hip.linear(x1, p['fc1_w'], p['fc1_b'], f, act=aot_hip.ACT_GELU, stream=stream)
         aot_hip.linear(f, p['fc2_w'], p['fc2_b'], out, res=xa, stream=stream)
         return out
 
@@ -95,7 +104,9 @@ class PatchMerging(nn.Module):
 
     def run(self, x, H, W, ws, stream, B=1):
         if self._p is None:
-            self._p = (_ln(self.norm), linear_t(self.reduction)[0])
+            w_ = linear_t(self.reduction)[0]
+            self._p = (_ln(self.norm), w_)
+            self._ln_w = aot_hip.fold_layernorm(w_, None, *self._p[0])
         (g, b), w = self._p
         C = self.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
@@ -103,9 +114,12 @@ class PatchMerging(nn.Module):
         gth = ws.get('sw_merge', (B * H2 * W2, 4 * C), dev)
         for i in range(B):
             aot_hip.patch_merge(x[i * H * W:(i + 1) * H * W], gth[i * H2 * W2:(i + 1) * H2 * W2], H, W, C, stream=stream)
-        aot_hip.layernorm(gth, g, b, gth, stream=stream)
         out = ws.get('sw_merged_%d' % C, (B * H2 * W2, 2 * C), dev)
-        aot_hip.linear(gth, w, None, out, stream=stream)
+        if aot_hip.x6_ln_fusable(B * H2 * W2, 4 * C, 2 * C):
+            aot_hip.layernorm_linear_x6(gth, *self._ln_w, out, eps=self.norm.eps, stream=stream)
+        else:
+            aot_hip.layernorm(gth, g, b, gth, eps=self.norm.eps, stream=stream)
+            aot_hip.linear(gth, w, None, out, stream=stream)
         return out, H2, W2
 
 

@@ -26,6 +26,13 @@ S = [('stem7x7s2', 481, 849, 4, 64, 7, 2, 1),
      ('dec ad8 512>256', 61, 107, 512, 256, 1, 1, 1), ('dec c8 3x3 256>128', 61, 107, 256, 128, 3, 1, 1),
      ('dec ad4 256>128', 121, 213, 256, 128, 1, 1, 1), ('dec c4 3x3 128', 121, 213, 128, 128, 3, 1, 1),
      ('dec out 128>11', 121, 213, 128, 11, 1, 1, 1)]
+if os.environ.get('AOT_MB_SHAPES') == 'swin':      # the linears of the Swin-B trunk at 480 x 848 (tokens 120x212 / 60x106 / 30x53 / 15x27; depths 2, 2, 18, 2)
+    S = []
+    for st, (hh, ww, C, depth) in enumerate(((120, 212, 128, 2), (60, 106, 256, 2), (30, 53, 512, 18), (15, 27, 1024, 2))):
+        S += [('s%d qkv %d>%d' % (st, C, 3 * C), 1, hh * ww, C, 3 * C, 1, 1, depth), ('s%d proj %d>%d' % (st, C, C), 1, hh * ww, C, C, 1, 1, depth),
+              ('s%d fc1 %d>%d' % (st, C, 4 * C), 1, hh * ww, C, 4 * C, 1, 1, depth), ('s%d fc2 %d>%d' % (st, 4 * C, C), 1, hh * ww, 4 * C, C, 1, 1, depth)]
+        if st < 3:
+            S.append(('s%d merge %d>%d' % (st, 4 * C, 2 * C), 1, hh * ww // 4, 4 * C, 2 * C, 1, 1, 1))
 tot = {c: 0.0 for c in cfgs}; totf = 0.0
 print('%-20s %7s %5s %5s %8s | ' % ('shape', 'M', 'K', 'N', 'GF') + ' | '.join('cfg%3s us    TF' % c for c in cfgs))
 for (name, H, W, Cin, Cout, K, s, cnt) in S:
