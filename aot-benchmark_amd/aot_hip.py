@@ -54,7 +54,7 @@ _SIGS = {
     'aot_gated_attn_f32': [_P] * 6 + [_I, _L, _I, _I, _P] + [_I] * 7 + [_F, _I, _P],
     'aot_local_attn_f32': [_P] * 7 + [_I, _L] + [_I] * 9 + [_F, _P],
     'aot_local_gated_f32': [_P] * 8 + [_I, _L] + [_I] * 10 + [_F, _P],
-    'aot_swin_window_attn_f32': [_P] * 4 + [_I] * 8 + [_F, _P],
+    'aot_swin_window_attn_f32': [_P] * 4 + [_I] * 9 + [_F, _P],
     'aot_patch_merge_f32': [_P, _P] + [_I] * 4 + [_P],
     'aot_idbank_f32': [_P] * 5 + [_I] * 13 + [_P, _P] + [_I] * 3 + [_P],
     'aot_bilinear_nhwc_f32': [_P] * 3 + [_I] * 11 + [_P],
@@ -713,8 +713,9 @@ def local_gated(q, k, v, gate, relk_t, relk_b, prob, out, h, w, scale_div, max_d
     return out
 
 
-def swin_window_attention(qkv, qkv_bias, table, out, H, W, C, nH, shift, scale, stream=None):
-    _chk(load().aot_swin_window_attn_f32(_dev(qkv), _dev(qkv_bias), _dev(table), _dev(out), H, W, C, nH, 7, shift,
+def swin_window_attention(qkv, qkv_bias, table, out, H, W, C, nH, shift, scale, B=1, stream=None):
+    """qkv / out hold B images of H x W tokens stacked along the rows: one launch for the batch."""
+    _chk(load().aot_swin_window_attn_f32(_dev(qkv), _dev(qkv_bias), _dev(table), _dev(out), B, H, W, C, nH, 7, shift,
                                          qkv.stride(0), out.stride(0), scale,
                                          stream if stream is not None else stream_ptr()), 'aot_swin_window_attn_f32')
     return out

@@ -16,6 +16,7 @@ struct SwinAttnParams {
   float* out;          // [H*W, ldo]
   int H, W, C, nH, ld, ldo, shift, Hp, Wp;
   float scale;
+  long img_rows;       // rows between the maps of consecutive images of the batch (blockIdx.z): H*W
 };
 
 __global__ void __launch_bounds__(64) swin_window_attn_kernel(const SwinAttnParams p) {
@@ -32,7 +33,7 @@ __global__ void __launch_bounds__(64) swin_window_attn_kernel(const SwinAttnPara
   const int sy = WY * WS + wy, sx = WX * WS + wx;            // coordinates in the shifted map
   const int py = (sy + p.shift) % p.Hp, px = (sx + p.shift) % p.Wp;
   const bool valid = py < p.H && px < p.W;
-  const long tok = (long)py * p.W + px;
+  const long tok = (long)blockIdx.z * p.img_rows + (long)py * p.W + px;      // (blockIdx.z: image of the batch -- round 6: one launch for all)
   const float* row = p.qkv + tok * p.ld + hd * D;
   float q[D];
 #pragma unroll
@@ -106,17 +107,18 @@ __global__ void __launch_bounds__(64) swin_window_attn_kernel(const SwinAttnPara
   }
 }
 
-extern "C" int aot_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* rpb_table, float* out, int H,
+extern "C" int aot_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* rpb_table, float* out, int B, int H,
                                         int W, int C, int nH, int window, int shift, int ld, int ldo, float scale,
                                         void* stream) {
-  if (!qkv || !qkv_bias || !rpb_table || !out || H <= 0 || W <= 0 || nH <= 0) return AOT_ERR_BADARG;
+  if (!qkv || !qkv_bias || !rpb_table || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0 || nH <= 0) return AOT_ERR_BADARG;
   if (window != 7 || C != nH * 32 || shift < 0 || shift >= window) return AOT_ERR_UNSUPPORTED;
   if ((ld & 3) || (ldo & 3) || ld < 3 * C || ldo < C) return AOT_ERR_BADARG;
   SwinAttnParams p;
   p.qkv = qkv; p.bias = qkv_bias; p.table = rpb_table; p.out = out;
   p.H = H; p.W = W; p.C = C; p.nH = nH; p.ld = ld; p.ldo = ldo; p.shift = shift;
   p.Hp = cdiv(H, 7) * 7; p.Wp = cdiv(W, 7) * 7; p.scale = scale;
-  hipLaunchKernelGGL(swin_window_attn_kernel, dim3((p.Hp / 7) * (p.Wp / 7), nH), dim3(64), 0, (hipStream_t)stream, p);
+  p.img_rows = (long)H * W;
+  hipLaunchKernelGGL(swin_window_attn_kernel, dim3((p.Hp / 7) * (p.Wp / 7), nH, B), dim3(64), 0, (hipStream_t)stream, p);
   AOT_LAUNCH_CHECK();
 }
 

@@ -6,6 +6,8 @@
                  -> LN -> fc1 GEMM with exact-GELU epilogue -> fc2 GEMM (+residual)
   patch merge  = 2x2 gather -> LN(4C) -> bias-free GEMM
 """
+import os
+
 import torch
 from torch import nn
 
@@ -58,38 +60,35 @@ class SwinTransformerBlock(nn.Module):
                  'table': self.attn.relative_position_bias_table.detach().float().contiguous()}
             for k, m in (('qkv', self.attn.qkv), ('proj', self.attn.proj), ('fc1', self.mlp.fc1), ('fc2', self.mlp.fc2)):
                 p[k + '_w'], p[k + '_b'] = linear_t(m)
-            # LayerNorm as the prologue of the GEMM behind it (round 6, aot_layernorm_linear_bf16x6_f32): norm1 -> qkv, norm2 -> fc1
-            p['ln_qkv'] = aot_hip.fold_layernorm(p['qkv_w'], p['qkv_b'], *p['n1'])
-            p['ln_fc1'] = aot_hip.fold_layernorm(p['fc1_w'], p['fc1_b'], *p['n2'])
             self._p = p
         return self._p
 
     def run(self, x, out, H, W, ws, stream, B=1):
         """x [B*H*W, C] -> out [B*H*W, C] (reference SwinTransformerBlock.forward, :262-318); B images stacked along the rows:
-        the GEMMs and LayerNorms see one tall matrix, the window attention runs per image."""
+        the GEMMs, LayerNorms and the window attention (image = grid z) see one tall matrix."""
         p = self.pack()
         N, C = x.shape
         dev = x.device
         x1 = ws.get('sw_x1', (N, C), dev)
         qkv = ws.get('sw_qkv', (N, 3 * C), dev)
-        if aot_hip.x6_ln_fusable(N, C, 3 * C):          # the normalised map is never written (bf16x6 engines)
-            aot_hip.layernorm_linear_x6(x, *p['ln_qkv'], qkv, eps=self.norm1.eps, stream=stream)
-        else:
-            aot_hip.layernorm(x, *p['n1'], x1, eps=self.norm1.eps, stream=stream)
-            aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
+        # (LayerNorm as the prologue of these GEMMs -- aot_layernorm_linear_bf16x6_f32, as in the LSTT -- was measured here too: no faster
+        #  (270.2 against 271.4 fps on SwinB-DeAOTL) and one free-running flip off the reference's near-ties: profiles/r06_swin_ln_fuse.txt)
+        aot_hip.layernorm(x, *p['n1'], x1, eps=self.norm1.eps, stream=stream)
+        aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
         a = ws.get('sw_a', (N, C), dev)
-        n1 = H * W
-        for b in range(B):
-            aot_hip.swin_window_attention(qkv[b * n1:(b + 1) * n1], p['qkv_b'], p['table'], a[b * n1:(b + 1) * n1], H, W, C,
-                                          self.num_heads, self.shift_size, self.attn.scale, stream=stream)
+        if os.environ.get('AOT_SWIN_PER_IMAGE'):      # (A/B runs: one launch per image, the form of rounds 1-5)
+            n1 = H * W
+            for b in range(B):
+                aot_hip.swin_window_attention(qkv[b * n1:(b + 1) * n1], p['qkv_b'], p['table'], a[b * n1:(b + 1) * n1], H, W, C,
+                                              self.num_heads, self.shift_size, self.attn.scale, stream=stream)
+        else:
+            aot_hip.swin_window_attention(qkv, p['qkv_b'], p['table'], a, H, W, C, self.num_heads, self.shift_size, self.attn.scale, B=B,
+                                          stream=stream)          # (one launch for the B images: round 6)
         xa = ws.get('sw_xa', (N, C), dev)
         aot_hip.linear(a, p['proj_w'], p['proj_b'], xa, res=x, stream=stream)
         f = ws.get('sw_f', (N, 4 * C), dev)
-        if aot_hip.x6_ln_fusable(N, C, 4 * C):
-            aot_hip.layernorm_linear_x6(xa, *p['ln_fc1'], f, eps=self.norm2.eps, act=aot_hip.ACT_GELU, stream=stream)
-        else:
-            aot_hip.layernorm(xa, *p['n2'], x1, eps=self.norm2.eps, stream=stream)
-            aot_hip.linear(x1, p['fc1_w'], p['fc1_b'], f, act=aot_hip.ACT_GELU, stream=stream)
+        aot_hip.layernorm(xa, *p['n2'], x1, eps=self.norm2.eps, stream=stream)
+        aot_hip.linear(x1, p['fc1_w'], p['fc1_b'], f, act=aot_hip.ACT_GELU, stream=stream)
         aot_hip.linear(f, p['fc2_w'], p['fc2_b'], out, res=xa, stream=stream)
         return out
 
@@ -104,9 +103,7 @@ class PatchMerging(nn.Module):
 
     def run(self, x, H, W, ws, stream, B=1):
         if self._p is None:
-            w_ = linear_t(self.reduction)[0]
-            self._p = (_ln(self.norm), w_)
-            self._ln_w = aot_hip.fold_layernorm(w_, None, *self._p[0])
+            self._p = (_ln(self.norm), linear_t(self.reduction)[0])
         (g, b), w = self._p
         C = self.dim
         H2, W2 = (H + 1) // 2, (W + 1) // 2
@@ -115,11 +112,8 @@ class PatchMerging(nn.Module):
         for i in range(B):
             aot_hip.patch_merge(x[i * H * W:(i + 1) * H * W], gth[i * H2 * W2:(i + 1) * H2 * W2], H, W, C, stream=stream)
         out = ws.get('sw_merged_%d' % C, (B * H2 * W2, 2 * C), dev)
-        if aot_hip.x6_ln_fusable(B * H2 * W2, 4 * C, 2 * C):
-            aot_hip.layernorm_linear_x6(gth, *self._ln_w, out, eps=self.norm.eps, stream=stream)
-        else:
-            aot_hip.layernorm(gth, g, b, gth, eps=self.norm.eps, stream=stream)
-            aot_hip.linear(gth, w, None, out, stream=stream)
+        aot_hip.layernorm(gth, g, b, gth, eps=self.norm.eps, stream=stream)
+        aot_hip.linear(gth, w, None, out, stream=stream)
         return out, H2, W2
 
 

@@ -297,11 +297,11 @@ int aot_local_gated_f32(const float* q, const float* k, const float* v, const fl
                         void* stream);
 
 /* Swin window attention (W-MSA / SW-MSA, 7x7 windows, heads of width 32), fused with the reference's pad / roll /
- * window_partition / window_reverse / crop: qkv [H*W, ld] = [q | k | v] (C each) is the output of the qkv Linear on the
- * LayerNormed tokens, qkv_bias [3C] is its bias (the value padded tokens take), rpb_table [169, nH], out [H*W, ldo]
- * (pre-projection).  shift = 0 or 3.  Replaces WindowAttention.forward + the index plumbing of
+ * window_partition / window_reverse / crop: qkv [B*H*W, ld] = [q | k | v] (C each) is the output of the qkv Linear on the
+ * LayerNormed tokens of B images stacked along the rows (round 6: one launch for the whole batch), qkv_bias [3C] is its bias
+ * (the value padded tokens take), rpb_table [169, nH], out [B*H*W, ldo] (pre-projection).  shift = 0 or 3.  Replaces WindowAttention.forward + the index plumbing of
  * SwinTransformerBlock.forward, networks/encoders/swin/swin_transformer.py:159-199, 262-312. */
-int aot_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* rpb_table, float* out, int H, int W,
+int aot_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* rpb_table, float* out, int B, int H, int W,
                              int C, int nH, int window, int shift, int ld, int ldo, float scale, void* stream);
 /* PatchMerging gather (swin_transformer.py:338-356): x [H*W, ldx] -> out [ceil(H/2)*ceil(W/2), 4C], zero padded. */
 int aot_patch_merge_f32(const float* x, float* out, int H, int W, int C, int ldx, void* stream);

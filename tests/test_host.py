@@ -286,7 +286,7 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 3, 4, 4, 8, 1, 1, 1, 0, 1, 4, 8, 0, 8, 0, 0, 0, -1, None) == -1  # Cin % 4
     assert lib.aot_conv2d_nhwc_f32(P(16), P(16), None, None, None, P(16), None, 0, 1, 4, 4, 32, 4, 4, 64, 1, 1, 1, 0, 1, 32, 64, 0, 64, 0, 0, 0, 117, None) == -2  # LDS-direct kernel without a k-contiguous weight
     assert lib.aot_gated_attn_f32(P(16), P(16), P(16), None, P(16), None, 1, 0, 8, 8, None, 64, 1024, 64, 64, 1024, 0, 1024, 8.0, 1, None) == -2
-    assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2
+    assert lib.aot_swin_window_attn_f32(P(16), P(16), P(16), P(16), 1, 14, 14, 128, 4, 8, 0, 384, 128, 0.17, None) == -2
 
 
 def test_torch_library_ops_are_registered_and_have_no_cpu_kernel():
