@@ -399,7 +399,8 @@ def linear_ln_out(x, w, bias, out, gamma, beta, ln_out, eps=1e-5, res=None, res_
     stack = _scopes.stack
     st = stream if stream is not None else stream_ptr()
     if stack and stack[-1][1] and X6_TILE == 0 and N == 256 and K % 32 == 0 and -(-M // 64) * 4 >= X6_MIN_TILES and \
-            ln_out.stride(0) % 4 == 0 and ln_out.data_ptr() % 16 == 0 and not os.environ.get('AOT_NO_LNO_FUSE'):
+            ln_out.stride(0) % 4 == 0 and ln_out.data_ptr() % 16 == 0 and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0 and \
+            not os.environ.get('AOT_NO_LNO_FUSE'):
         ks = x6_ksplit(M, N, K)
         if ks != 1:
             w6 = getattr(w, '_aot_w6', None)
