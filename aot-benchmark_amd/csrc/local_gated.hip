@@ -195,34 +195,65 @@ __global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ pr
   }
 }
 
-template <int NWV>
+// CB = channels of the value a workgroup aggregates (32 or 16).  The wave-private slab is (64 + 2 R + 2) x (CB + 4) floats: with CB = 32
+// the eight slabs of a workgroup are 92 KB, ONE workgroup per CU and two waves per SIMD -- every exposed load of the stage -> compute
+// chain idles the SIMD; CB = 16 (51 KB) lets three workgroups share a CU: 75.3 -> 71.7 us for the three launches of a 480p frame,
+// R50-DeAOTL +0.9 % (profiles/r06_lgp_cb.txt).  The sums per output are the same in the same order: bit-identical.
+#ifndef AOT_LGP_CB
+#define AOT_LGP_CB 16
+#endif
+template <int NWV, int CB>
 __global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams pin) {
-  __shared__ __attribute__((aligned(16))) float lds[NWV * LGP_SLAB];
+  constexpr int LD = CB + 4, C4 = CB / 4;
+  constexpr int NF4 = LGP_NPOS * C4, PER = (NF4 + 63) / 64, SLAB = (LGP_NPOS + 2) * LD;
+  static_assert(SLAB >= CB * 64, "the slab doubles as the cross-wave reduction buffer");
+  __shared__ __attribute__((aligned(16))) float lds[NWV * SLAB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bl = blockIdx.y / pin.h;
   const LgpParams p = lgp_lane(pin, bl);
-  const int x0 = blockIdx.x * 64, y = blockIdx.y - bl * pin.h, c0 = blockIdx.z * 32;
+  const int x0 = blockIdx.x * 64, y = blockIdx.y - bl * pin.h, c0 = blockIdx.z * CB;
   const bool active = x0 + lane < p.w;
   const int x = active ? x0 + lane : p.w - 1;
   const int n = y * p.w + x;
   const int N = p.h * p.w;
-  float* slab = lds + wave * LGP_SLAB;
-  float o[32];
+  float* slab = lds + wave * SLAB;
+  float o[CB];
 #pragma unroll
-  for (int c = 0; c < 32; ++c) o[c] = 0.f;
+  for (int c = 0; c < CB; ++c) o[c] = 0.f;
   for (int dy = wave; dy < LGP_WS; dy += NWV) {
     const int ky = y + dy - LGP_R;
     if (ky < 0 || ky >= p.h) continue;
     float pw[LGP_WS];
 #pragma unroll
     for (int dx = 0; dx < LGP_WS; ++dx) pw[dx] = p.prob[(long)(dy * LGP_WS + dx) * N + n];
-    lgp_stage(p.v, p.ldv, c0, ky, x0, p.w, lane, slab);
+    {          // stage CB channels [c0, c0 + CB) of image row ky, positions x0 - R .. x0 + 63 + R, into the wave's slab
+      float4 st[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int f = lane + i * 64;
+        const int pos = f / C4, c4 = f - pos * C4;
+        const int kx = x0 - LGP_R + pos;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < NF4 && kx >= 0 && kx < p.w) t = *reinterpret_cast<const float4*>(p.v + ((long)ky * p.w + kx) * p.ldv + c0 + c4 * 4);
+        st[i] = t;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int f = lane + i * 64;
+        if (f < NF4) *reinterpret_cast<float4*>(&slab[(f / C4) * LD + (f % C4) * 4]) = st[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 #pragma unroll
     for (int dx = 0; dx < LGP_WS; ++dx) {
 #pragma unroll
-      for (int c4 = 0; c4 < 8; ++c4) {
-        const float4 vv = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LGP_LD + c4 * 4]);
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float4 vv = *reinterpret_cast<const float4*>(&slab[(lane + dx) * LD + c4 * 4]);
         o[4 * c4] = fmaf(pw[dx], vv.x, o[4 * c4]);
         o[4 * c4 + 1] = fmaf(pw[dx], vv.y, o[4 * c4 + 1]);
         o[4 * c4 + 2] = fmaf(pw[dx], vv.z, o[4 * c4 + 2]);
@@ -235,20 +266,20 @@ __global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams
   // sum the NWV partials in fixed order
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 32; ++c) slab[c * 64 + lane] = o[c];
+  for (int c = 0; c < CB; ++c) slab[c * 64 + lane] = o[c];
   __syncthreads();
   if (wave == 0 && active) {
-    float t[32];
+    float t[CB];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) t[c] = 0.f;
+    for (int c = 0; c < CB; ++c) t[c] = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < NWV; ++w2)
 #pragma unroll
-      for (int c = 0; c < 32; ++c) t[c] += lds[w2 * LGP_SLAB + c * 64 + lane];
+      for (int c = 0; c < CB; ++c) t[c] += lds[w2 * SLAB + c * 64 + lane];
     float4* dst = reinterpret_cast<float4*>(p.out + (long)n * p.ldo + c0);
     const float4* g = p.gate ? reinterpret_cast<const float4*>(p.gate + (long)n * p.ldg + c0) : nullptr;
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4) {
+    for (int c4 = 0; c4 < C4; ++c4) {
       float4 r = make_float4(t[4 * c4], t[4 * c4 + 1], t[4 * c4 + 2], t[4 * c4 + 3]);
       if (g) { const float4 u = g[c4]; r.x *= u.x; r.y *= u.y; r.z *= u.z; r.w *= u.w; }
       dst[c4] = r;
@@ -273,6 +304,6 @@ extern "C" int aot_local_gated_f32(const float* q, const float* k, const float* 
   constexpr int NWV = 8;
   hipLaunchKernelGGL(lgp_scores_kernel, dim3(cdiv(w, 64), h, B * LGP_WS), dim3(256), 0, s, p);
   hipLaunchKernelGGL(lgp_softmax_kernel, dim3(cdiv(h * w, 16), B), dim3(256), 0, s, prob, h * w);
-  hipLaunchKernelGGL((lgp_aggregate_kernel<NWV>), dim3(cdiv(w, 64), B * h, dv / 32), dim3(NWV * 64), 0, s, p);
+  hipLaunchKernelGGL((lgp_aggregate_kernel<NWV, AOT_LGP_CB>), dim3(cdiv(w, 64), B * h, dv / AOT_LGP_CB), dim3(NWV * 64), 0, s, p);
   AOT_LAUNCH_CHECK();
 }
