@@ -197,10 +197,10 @@ __global__ void __launch_bounds__(256) lgp_softmax_kernel(float* __restrict__ pr
 
 // CB = channels of the value a workgroup aggregates (32 or 16).  The wave-private slab is (64 + 2 R + 2) x (CB + 4) floats: with CB = 32
 // the eight slabs of a workgroup are 92 KB, ONE workgroup per CU and two waves per SIMD -- every exposed load of the stage -> compute
-// chain idles the SIMD; CB = 16 (51 KB) lets three workgroups share a CU: 75.3 -> 71.7 us for the three launches of a 480p frame,
-// R50-DeAOTL +0.9 % (profiles/r06_lgp_cb.txt).  The sums per output are the same in the same order: bit-identical.
+// chain idles the SIMD; CB = 16 (51 KB) lets three workgroups share a CU, CB = 8 (31 KB) five: 75.3 -> 71.7 -> 60.1 us for the three
+// launches of a 480p frame (profiles/r06_lgp_cb.txt).  The sums per output are the same in the same order: bit-identical.
 #ifndef AOT_LGP_CB
-#define AOT_LGP_CB 16
+#define AOT_LGP_CB 8
 #endif
 template <int NWV, int CB>
 __global__ void __launch_bounds__(NWV * 64) lgp_aggregate_kernel(const LgpParams pin) {

@@ -215,7 +215,10 @@ extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, cons
 // in double -- lane l takes partials l, l + 64, ... in index order, then a fixed butterfly over the 64 lanes: the same bits in every
 // wave, workgroup and run -- and forms (mean, rstd) as gn_stats_kernel does.  The statistics launch and its pass over the map
 // are gone.
-template <bool PART>
+// PLAIN (round 6): no normalisation, no activation -- the tiled 5x5 depthwise convolution on its own (the dw_conv of the GPM blocks' tails,
+// attention.py:709-710): the 12x12 halo of an 8x8 tile goes through LDS once instead of 25 reads of every element from L2; the taps are
+// added in dwconv_kernel's order (zero-padded taps contribute exact zeros): bit-identical to it.
+template <bool PART, bool PLAIN = false>
 __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ w, float* __restrict__ out, int H,
@@ -227,8 +230,9 @@ __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __rest
   const int g = blockIdx.y, bl = blockIdx.z;
   const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
   const int t = threadIdx.x;
-  float mean, rstd;
-  if (PART) {
+  float mean = 0.f, rstd = 1.f;
+  if (PLAIN) {
+  } else if (PART) {
     // partial i = (sum, sum of squared deviations from its own mean) of rows [32 i, 32 i + 32) x this group's CB channels, written by
     // the producing GEMM's tile end; combined with Chan's formula in double, in index order (fixed tree): first the grand mean, then
     // M2 = sum_i [M2_i + n_i (mean_i - mean)^2]
@@ -261,17 +265,21 @@ __global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __rest
   }
   const float* xb = x + (long)bl * H * W * ldx + g * CB;
   const int c4 = t & 7;                          // channel quad of the group
-  const float4 ga = *reinterpret_cast<const float4*>(gamma + g * CB + c4 * 4);
-  const float4 be = *reinterpret_cast<const float4*>(beta + g * CB + c4 * 4);
+  const float4 ga = PLAIN ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(gamma + g * CB + c4 * 4);
+  const float4 be = PLAIN ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(beta + g * CB + c4 * 4);
   for (int i = t >> 3; i < IH * IW; i += 32) {
     const int iy = ty0 - R + i / IW, ix = tx0 - R + i % IW;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
       const float4 v = *reinterpret_cast<const float4*>(xb + ((long)iy * W + ix) * ldx + c4 * 4);
-      o.x = gn_act((v.x - mean) * rstd * ga.x + be.x, act);
-      o.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
-      o.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
-      o.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+      if (PLAIN) {
+        o = v;
+      } else {
+        o.x = gn_act((v.x - mean) * rstd * ga.x + be.x, act);
+        o.y = gn_act((v.y - mean) * rstd * ga.y + be.y, act);
+        o.z = gn_act((v.z - mean) * rstd * ga.z + be.z, act);
+        o.w = gn_act((v.w - mean) * rstd * ga.w + be.w, act);
+      }
     }
     *reinterpret_cast<float4*>(&tile[i][c4 * 4]) = o;
   }
@@ -372,6 +380,13 @@ extern "C" int aot_dwconv2d_nhwc_f32(const float* in, const float* w, const floa
                                      int C, int OH, int OW, int KH, int KW, int stride, int pad, int dil, int act,
                                      void* stream) {
   if (!in || !w || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || OH <= 0 || OW <= 0) return AOT_ERR_BADARG;
+  if (KH == 5 && KW == 5 && stride == 1 && pad == 2 && dil == 1 && OH == H && OW == W && !bias && act == 0 && (C & 31) == 0 && C / 32 <= 65535) {
+    // the LDS-tiled form (gn_act_dwconv5_kernel<false, true>): bit-identical to dwconv_kernel (profiles/r06_dwconv_tiled.txt: +2 % on R50-DeAOTL)
+    const int tx = cdiv(W, 8), ty = cdiv(H, 8);
+    hipLaunchKernelGGL((gn_act_dwconv5_kernel<false, true>), dim3(tx * ty, C / 32, B), dim3(256), 0, (hipStream_t)stream, in, (const double*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, w, out, H, W, C, C / 32, C, C, 0, tx, (const float*)nullptr, 0, 0.f);
+    AOT_LAUNCH_CHECK();
+  }
   const long total = (long)OH * OW * (C / 4);
   hipLaunchKernelGGL(dwconv_kernel, dim3(cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, C,
                      OH, OW, KH, KW, stride, pad, dil, act);

@@ -456,7 +456,15 @@ class GatedPropagationModule(nn.Module):
         aot_hip.linear_group([z[:, :D], z[:, D:], z[:, :D], z[:, D:]], [sp['V1_w'], sp['V2_w'], sp['U1_w'], sp['U2_w']],
                              [sp['V1_b'], sp['V2_b'], sp['U1_b'], sp['U2_b']], [sv[:, :E], sv[:, E:], su[:, :E], su[:, E:]],
                              act=aot_hip.ACT_SILU, stream=stream)
-        self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream, B=B, kv_brows=N)
+        sx6 = None
+        if x6 is not None and da == 128 and 2 * E == 1024 and not os.environ.get('AOT_NO_SELF_X6'):
+            # bf16x6 engines (round 6): the frame's own K / [V1 | V2] split into a one-frame packed bank (aot_attn_pack_x6_part_f32), then the
+            # 64-query kernel of the long-term propagation instead of the fp32 kernel (98.6 -> ~81 us per layer at 480p)
+            cap = (N + 31) // 32 * 32
+            sx6 = (ws.get_zeroed('gpm_sx6_k', (B * cap * da * 3,), dev, torch.int16),
+                   ws.get_zeroed('gpm_sx6_v', (B * cap * 2 * E * 3,), dev, torch.int16), cap)
+            aot_hip.gated_pack_x6(qk, sv, sx6, N, B=B, src_brows=N, stream=stream)
+        self.self_attn.core(qk, qk, sv, su, raw, N, ws, stream, B=B, kv_brows=N, x6=sx6)
         Xo = ws.get('gpm_Xo_%d' % self.layer_idx, (M, 2 * D), dev)
         self.self_attn.tail(raw, Xo, size_2d, ws, stream, res=Xm, B=B)
         return Xo, qc, vcat, xi

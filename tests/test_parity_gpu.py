@@ -431,6 +431,22 @@ def test_linear_group_bit_identical_to_single_launches(hip, n, M, K, N, act):
     assert torch.equal(big_g, big_w)
 
 
+@pytest.mark.parametrize('B,h,w,C', [(1, 31, 54, 1024), (3, 30, 53, 1024), (2, 9, 11, 64), (1, 5, 70, 32)])
+def test_dwconv5_tiled_bit_identical(hip, B, h, w, C):
+    """The LDS-tiled 5x5 depthwise convolution (gn_act_dwconv5_kernel<false, true>, round 6: the dw_conv of the GPM blocks' tails,
+    attention.py:709-710; what aot_dwconv2d_nhwc_f32 dispatches a 5x5 / stride 1 / pad 2 layer on C % 32 == 0 channels to) against the
+    per-tap kernel (dwconv_kernel, reached here through a bias of zeros): bit-identical, per lane, also on maps narrower than a tile."""
+    g = torch.Generator().manual_seed(B * 100 + h + w + C)
+    x = _dev(torch.randn(B * h * w, C, generator=g))
+    wk = _dev(torch.randn(25, C, generator=g) / 5)
+    a, b = torch.full((B * h * w, C), float('nan'), device='cuda'), torch.full((B * h * w, C), float('nan'), device='cuda')
+    hip.dwconv2d(x, wk, None, a, h, w, C, h, w, 5, 1, 2, 1, B=B)
+    hip.dwconv2d(x, wk, torch.zeros(C, device='cuda'), b, h, w, C, h, w, 5, 1, 2, 1, B=B)      # (a bias keeps the per-tap kernel: acc starts at +0.0 too)
+    assert not torch.isnan(a).any() and torch.equal(a, b)
+    want = F.conv2d(x.view(B, h, w, C).permute(0, 3, 1, 2), wk.t().reshape(C, 1, 5, 5), padding=2, groups=C).permute(0, 2, 3, 1).reshape(B * h * w, C)
+    assert float((a - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize('h,w', [(31, 54), (30, 53), (9, 11)])
 def test_gn_partials_from_gemm_tile_end(hip, h, w):
     """aot_linear_gn_bf16x6_f32 + aot_gn_act_dwconv5p_f32 (round 5): the GroupNorm statistics as partial sums out of the producing
