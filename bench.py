@@ -11,17 +11,28 @@ tools/demo.py:219-235).  Clips are 70 frames (the long-term bank grows from 1 to
 are resident in HBM before the timed region.  Per-video inference is embarrassingly parallel, so each GPU
 runs --streams S clips concurrently, one HIP stream and one engine (memory bank, scratch) each, sharing the
 weights: most kernels of one 480p frame cannot fill 256 CUs on their own.  `value` is the whole-job
-throughput; `config.single_stream_fps` is the same job with S = 1 (one clip at a time, the reference's
-evaluation mode).  Clips shard over ranks with no data-path collective
-("weak" scaling: every rank runs K frames); RCCL is used only for the barrier, the max-over-ranks time and
-one all_gather of a small stats vector (replaces the reference's mp.Queue, evaluator.py:507-531).
+throughput.  Clips shard over ranks with no data-path collective ("weak" scaling: every rank runs K frames);
+RCCL is used only for the barrier, the max-over-ranks time and one all_gather of a small stats vector (replaces
+the reference's mp.Queue, evaluator.py:507-531).
 
 The JSON line also carries
-  roofline     -- the long-term attention kernel (attn_fwd_d32_pipe_kernel) timed live with HIP events on its
-                  stream: achieved = 4*N*T*C FLOP per launch / mean launch time, against the 157.3 TFLOP/s fp32
-                  MFMA peak;
-  cpu_baseline -- the CPU oracle (oracle/aot_oracle.py, a port of the reference's algorithm; the reference
-                  itself cannot travel to the GPU box) timed on the host cores on the first frames of the same clip.
+  roofline       -- the long-term / self attention kernel of the timed arithmetic (attn_x6_d32_kernel; the gated kernel for
+                    DeAOT models) timed live with HIP events on its stream over one clip's launch mix: achieved = algorithmic
+                    FLOP per launch / mean launch time against the roof of the arithmetic (bf16x6: 2500 / 6 TF-equivalent;
+                    fp32: 157.3 TF), fabric bytes per launch from the committed rocprofv3 PMC passes of the kernel as built
+                    (profiles/r06_*traffic.json); roofline.gemm: the same for every conv / linear call of the clip;
+                    roofline.other_arithmetic: the other kernel family;
+  cpu_baseline   -- the CPU oracle (oracle/aot_oracle.py, a port of the reference's algorithm; the reference itself
+                    cannot travel to the GPU box) timed on the host cores on the first frames of the same clip;
+  config.whole_clip      -- whole 70-frame clips on every stream;
+  config.single_stream   -- ONE clip at a time over a whole clip (the reference's evaluation mode; the look-ahead encoder on the
+                            engine's side stream), `windows_fps` = the same in the --steps form, `online` = no look-ahead at
+                            all, timed with device events per frame as evaluator.py:325-330,444-446,486-498 does;
+  config.fp32_exact      -- the same plan on exact fp32 products;
+  config.jf_vs_reference -- free-running masks against the real reference's over the 70-frame golden, every differing
+                            pixel classified on the reference's own near-tie map and on its fp64 run (non-zero exit on a
+                            pixel outside the near-ties);
+  config.other_configs   -- BASELINE config 3 (SwinB-DeAOTL, 480 x 848) and R50-DeAOTL as sub-runs of the same script.
 """
 import argparse
 import importlib
