@@ -6,8 +6,6 @@
                  -> LN -> fc1 GEMM with exact-GELU epilogue -> fc2 GEMM (+residual)
   patch merge  = 2x2 gather -> LN(4C) -> bias-free GEMM
 """
-import os
-
 import torch
 from torch import nn
 
@@ -76,14 +74,8 @@ class SwinTransformerBlock(nn.Module):
         aot_hip.layernorm(x, *p['n1'], x1, eps=self.norm1.eps, stream=stream)
         aot_hip.linear(x1, p['qkv_w'], p['qkv_b'], qkv, stream=stream)
         a = ws.get('sw_a', (N, C), dev)
-        if os.environ.get('AOT_SWIN_PER_IMAGE'):      # (A/B runs: one launch per image, the form of rounds 1-5)
-            n1 = H * W
-            for b in range(B):
-                aot_hip.swin_window_attention(qkv[b * n1:(b + 1) * n1], p['qkv_b'], p['table'], a[b * n1:(b + 1) * n1], H, W, C,
-                                              self.num_heads, self.shift_size, self.attn.scale, stream=stream)
-        else:
-            aot_hip.swin_window_attention(qkv, p['qkv_b'], p['table'], a, H, W, C, self.num_heads, self.shift_size, self.attn.scale, B=B,
-                                          stream=stream)          # (one launch for the B images: round 6)
+        aot_hip.swin_window_attention(qkv, p['qkv_b'], p['table'], a, H, W, C, self.num_heads, self.shift_size, self.attn.scale, B=B,
+                                      stream=stream)          # (one launch for the B images: round 6, profiles/r06_swin_batched_attn.txt)
         xa = ws.get('sw_xa', (N, C), dev)
         aot_hip.linear(a, p['proj_w'], p['proj_b'], xa, res=x, stream=stream)
         f = ws.get('sw_f', (N, 4 * C), dev)
