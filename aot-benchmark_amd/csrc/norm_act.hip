@@ -219,7 +219,7 @@ extern "C" int aot_groupnorm_apply_f32(const float* x, const double* stats, cons
 // attention.py:709-710): the 12x12 halo of an 8x8 tile goes through LDS once instead of 25 reads of every element from L2; the taps are
 // added in dwconv_kernel's order (zero-padded taps contribute exact zeros): bit-identical to it.
 template <bool PART, bool PLAIN = false>
-__global__ void __launch_bounds__(256) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+__global__ void __launch_bounds__(256, 4) gn_act_dwconv5_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ w, float* __restrict__ out, int H,
                                                              int W, int C, int G, int ldx, int ldo, int act, int tiles_x,
