@@ -148,6 +148,79 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
   }
 }
 
+// Round 6: the statistics pass with WHOLE ROWS per workgroup.  gn_stats_kernel gives every (row range, group) its own workgroup, which
+// reads one group's 64- or 128-byte piece of every 512-byte row (12 us for the 13 MB stride-4 map of the FPN head: 1.1 TB/s).  Here a
+// workgroup owns a row range and ALL groups: thread = (float4 column, row of the pass), fully coalesced rows; the per-thread fp64 partials
+// of a group meet in LDS (fixed order), one (sum, sum of squares) pair per (range, group) is published, and the last workgroup of a lane
+// to arrive adds the ranges in index order -- the same two-level fp64 reduction and the same ticket protocol as gn_stats_kernel, hence the
+// same statistics up to the order of fp64 additions.  Needs C / 4 <= 256 dividing 256 and (C / G) % 4 == 0.
+__global__ void __launch_bounds__(256) gn_stats_rows_kernel(const float* __restrict__ x, double* __restrict__ scratch,
+                                                            double* __restrict__ stats, unsigned* __restrict__ ticket, int M,
+                                                            int C, int G, int ldx, int nsplit, float eps) {
+  const int sp = blockIdx.x, bl = blockIdx.y, t = threadIdx.x;
+  const int nv = C >> 2, rpp = 256 / nv, v4g = (C / G) >> 2;      // float4 per row, rows per pass, float4 per group and row
+  const int c4 = t % nv, rin = t / nv;
+  const int rows = (M + nsplit - 1) / nsplit;
+  const int r0 = sp * rows, r1 = min(M, r0 + rows);
+  const float* xb = x + (long)bl * M * ldx;
+  double s = 0.0, sq = 0.0;
+  for (int r = r0 + rin; r < r1; r += rpp) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (long)r * ldx + c4 * 4);
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  __shared__ double red[256][2];
+  __shared__ int last_flag;
+  red[t][0] = s;
+  red[t][1] = sq;
+  __syncthreads();
+  double* part = scratch + (long)bl * G * nsplit * 2;          // [G][nsplit][2]
+  if (t < 64) {          // (one wave: its stores are one instruction each, the wait below covers all of them)
+    if (t < G) {
+      double ps = 0.0, pq = 0.0;
+      for (int ri = 0; ri < rpp; ++ri)
+        for (int c = 0; c < v4g; ++c) {
+          ps += red[ri * nv + t * v4g + c][0];
+          pq += red[ri * nv + t * v4g + c][1];
+        }
+      __hip_atomic_store(&part[((long)t * nsplit + sp) * 2], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&part[((long)t * nsplit + sp) * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) {
+      const unsigned prev = nsplit > 1 ? __hip_atomic_fetch_add(&ticket[(long)bl * G], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      last_flag = prev == (unsigned)(nsplit - 1);
+    }
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // the last workgroup of the lane: thread = (group t % G, strand t / G); strand i adds ranges i, i + 256 / G, ... in index order, then thread
+  // g < G adds its group's strands in strand order
+  {
+    const int g = t % G, strand = t / G, nstr = 256 / G;
+    double ts = 0.0, tq = 0.0;
+    for (int i = strand; i < nsplit; i += nstr) {
+      ts += __hip_atomic_load(&part[((long)g * nsplit + i) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tq += __hip_atomic_load(&part[((long)g * nsplit + i) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    red[t][0] = ts;
+    red[t][1] = tq;
+    __syncthreads();
+    if (t < G) {
+      double as = 0.0, aq = 0.0;
+      for (int i = 0; i < nstr; ++i) { as += red[i * G + t][0]; aq += red[i * G + t][1]; }
+      const double cnt = (double)M * (C / G);
+      const double mean = as / cnt;
+      double var = aq / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[((long)bl * G + t) * 2] = mean;
+      stats[((long)bl * G + t) * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+    }
+    if (t == 0 && nsplit > 1) __hip_atomic_store(&ticket[(long)bl * G], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __device__ __forceinline__ float gn_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact-erf GELU (F.gelu default)
@@ -188,6 +261,13 @@ extern "C" int aot_groupnorm_stats_f32(const float* x, double* scratch, double* 
     return AOT_ERR_BADARG;
   if (nsplit > 1 && !ticket) return AOT_ERR_BADARG;
   if ((C / G) / 4 > 256 || B > 65535) return AOT_ERR_UNSUPPORTED;
+  const int nv = C / 4;
+  if (nv <= 256 && 256 % nv == 0 && ((C / G) & 3) == 0 && 256 % G == 0 && G <= 64 && nsplit >= 64) {
+    // whole rows per workgroup (round 6): the callers that ask for many row ranges (the FPN head's maps) get the coalesced form
+    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(nsplit, B), dim3(256), 0, (hipStream_t)stream, x, scratch, stats, ticket, M, C, G, ldx,
+                       nsplit, eps);
+    AOT_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, G, B), dim3(256), 0, (hipStream_t)stream, x, scratch, stats, ticket, M, C,
                      G, ldx, nsplit, eps);
   AOT_LAUNCH_CHECK();

@@ -12,6 +12,11 @@ from networks.layers.basic import ConvGN
 from networks.layers.normalization import fold_conv_bn
 
 
+# row ranges of a GroupNorm statistics launch: >= 64 selects the whole-row kernel (gn_stats_rows_kernel, round 6: +0.6 % over the per-group kernel
+# at 32 ranges, profiles/r06_gn_stats_rows.txt)
+GN_SPLIT = 128
+
+
 class FPNSegmentationHead(nn.Module):
     def __init__(self, in_dim, out_dim, decode_intermediate_input=True, hidden_dim=256,
                  shortcut_dims=[24, 32, 96, 1280], align_corners=True):
@@ -44,8 +49,8 @@ class FPNSegmentationHead(nn.Module):
     def _gn_relu(self, x, out, key, B, ws, stream, add=None, add_rows=0):
         """relu(gn(x)) (+ add): the statistics launch, then the apply launch."""
         p = self._p
-        aot_hip.groupnorm(x, *p[key + '_gn'], out, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), act=aot_hip.ACT_RELU,
-                          eps=getattr(self, key).gn.eps, nsplit=32, B=B, add=add, add_rows=add_rows, stream=stream)
+        aot_hip.groupnorm(x, *p[key + '_gn'], out, 8, aot_hip.gn_buffers(ws, x.device, B, 8, GN_SPLIT), act=aot_hip.ACT_RELU,
+                          eps=getattr(self, key).gn.eps, nsplit=GN_SPLIT, B=B, add=add, add_rows=add_rows, stream=stream)
         return out
 
     def _gn_relu_up(self, x, out, key, B, ws, stream, ih, iw, oh, ow, add):
@@ -56,7 +61,7 @@ class FPNSegmentationHead(nn.Module):
         if os.environ.get('AOT_NO_GN_UP'):
             self._gn_relu(x, x, key, B, ws, stream)
             return aot_hip.bilinear(x, out, ih, iw, oh, ow, x.shape[1], self.align_corners, add=add, B=B, add_shared=True, stream=stream)
-        stats = aot_hip.groupnorm_stats(x, 8, aot_hip.gn_buffers(ws, x.device, B, 8, 32), B=B, eps=getattr(self, key).gn.eps, nsplit=32,
+        stats = aot_hip.groupnorm_stats(x, 8, aot_hip.gn_buffers(ws, x.device, B, 8, GN_SPLIT), B=B, eps=getattr(self, key).gn.eps, nsplit=GN_SPLIT,
                                         stream=stream)
         return aot_hip.gn_bilinear(x, stats, *p[key + '_gn'], out, ih, iw, oh, ow, x.shape[1], 8, self.align_corners,
                                    act=aot_hip.ACT_RELU, add=add, B=B, add_shared=True, stream=stream)
@@ -123,7 +128,7 @@ class FPNSegmentationHead(nn.Module):
         out = ws.get('dec_logits', (B * n4, ldo), dev)
         if self.out_dim <= 32 and not os.environ.get('AOT_NO_GN_UP'):
             # conv_out reads relu(gn(conv_4x)) through its A loads (aot_gn_conv1x1_f32): the normalised 4x map is never written
-            st = aot_hip.groupnorm_stats(f, 8, aot_hip.gn_buffers(ws, dev, B, 8, 32), B=B, eps=self.conv_4x.gn.eps, nsplit=32, stream=stream)
+            st = aot_hip.groupnorm_stats(f, 8, aot_hip.gn_buffers(ws, dev, B, 8, GN_SPLIT), B=B, eps=self.conv_4x.gn.eps, nsplit=GN_SPLIT, stream=stream)
             aot_hip.gn_conv1x1(f, st, *p['conv_4x_gn'], *p['conv_out'], out, 8, self.out_dim, gn_act=aot_hip.ACT_RELU, B=B, stream=stream)
         else:
             self._gn_relu(f, f, 'conv_4x', B, ws, stream)

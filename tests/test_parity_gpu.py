@@ -615,6 +615,28 @@ def test_layernorm_groupnorm(hip):
         assert torch.equal(out, out2), 'GroupNorm must be deterministic whichever workgroup arrives last'
 
 
+@pytest.mark.parametrize('B,M,C,G', [(1, 121 * 213, 128, 8), (1, 1674, 256, 8), (3, 6527, 256, 8), (2, 1674, 512, 2), (1, 1674, 1024, 32), (1, 100, 64, 8)])
+def test_groupnorm_statistics_whole_row_kernel(hip, B, M, C, G):
+    """gn_stats_rows_kernel (round 6: a workgroup owns a row range and ALL groups, coalesced rows; what aot_groupnorm_stats_f32 runs for
+    >= 64 row ranges) against gn_stats_kernel (one workgroup per range and group): the same two-level fp64 reduction -- (mean, rstd)
+    equal to 1e-12, equal to fp64 statistics of the map, ticket words back at zero, repeats bit-identical."""
+    g = torch.Generator().manual_seed(B + M + C + G)
+    x = _dev(torch.randn(B * M, C, generator=g) * 2 + 0.7)
+    ws = __import__('networks.layers.workspace', fromlist=['Workspace']).Workspace()
+    old = hip.groupnorm_stats(x, G, hip.gn_buffers(ws, x.device, B, G, 32), B=B, nsplit=32).clone()
+    bufs = hip.gn_buffers(ws, x.device, B, G, 128)
+    new = hip.groupnorm_stats(x, G, bufs, B=B, nsplit=128).clone()
+    again = hip.groupnorm_stats(x, G, bufs, B=B, nsplit=128).clone()
+    assert torch.equal(new, again) and int(bufs[2].abs().sum()) == 0
+    assert float(((new - old) / old.abs().clamp(min=1e-30)).abs().max()) <= 1e-12
+    xd = x.double().view(B, M, G, C // G)
+    mean = xd.mean((1, 3))
+    rstd = 1.0 / torch.sqrt(((xd - mean.view(B, 1, G, 1)) ** 2).mean((1, 3)) + 1e-5)
+    got = new.view(B, G, 2)
+    assert float((got[..., 0] - mean).abs().max()) <= 1e-11 * max(1.0, float(mean.abs().max()))
+    assert float((got[..., 1] / rstd - 1).abs().max()) <= 1e-9
+
+
 def test_lane_batched_glue_kernels(hip):
     """B lanes stacked along the rows (object groups of one frame): per-lane GroupNorm statistics, GN + shared add, the fused
     GN-apply + GELU + 5x5 depthwise conv, depthwise conv, bilinear with a shared add map, LayerNorm with a shared positional
