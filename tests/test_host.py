@@ -726,3 +726,84 @@ def test_every_binding_the_product_calls_exists():
     src = open(os.path.join(ROOT, 'aot-benchmark_amd', 'aot_hip.py')).read()
     called = set(re.findall(r'load\(\)\.(aot_[a-z0-9_]+)\(', src))
     assert called <= set(aot_hip._SIGS) | {'aot_hip_version'}, sorted(called - set(aot_hip._SIGS))
+
+
+def test_fold_layernorm_algebra_and_column_sums():
+    """aot_hip.fold_layernorm (round 6): (n * gamma + beta) W + b == n (diag(gamma) W) + (beta W + b) for any row-normalised n, and the
+    column sums it attaches are those of the folded weight -- the kernel's mean correction (x - mean) W' = (x - c) W' - (mean - c) colsum."""
+    import aot_hip
+    g = torch.Generator().manual_seed(3)
+    K, N, M = 64, 48, 9
+    w, b = torch.randn(K, N, generator=g), torch.randn(N, generator=g)
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    wf, bf = aot_hip.fold_layernorm(w, b, gamma, beta)
+    x = torch.randn(M, K, generator=g, dtype=torch.float64) * 3 + 5
+    mu = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    want = ((x - mu) * rstd * gamma.double() + beta.double()) @ w.double() + b.double()
+    got = ((x - mu) * rstd) @ wf.double() + bf.double()
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert torch.allclose(wf._aot_colsum.double(), wf.double().sum(0), rtol=0, atol=1e-6)
+    # the kernel's form: a shift c inside the row's range instead of the mean, corrected at the tile end
+    c = x[:, :1]
+    d = x - c
+    mp = d.mean(1, keepdim=True)
+    var = (d ** 2).mean(1, keepdim=True) - mp ** 2
+    kern = (d @ wf.double() - mp * wf._aot_colsum.double()) / torch.sqrt(var + 1e-5) + bf.double()
+    assert float((kern - want).abs().max()) < 1e-5 * float(want.abs().max())
+    wf2, bf2 = aot_hip.fold_layernorm(w, None, gamma, beta)
+    assert torch.allclose(bf2.double(), beta.double() @ w.double(), atol=1e-5)
+
+
+def test_bench_overlapped_lookahead_schedule():
+    """bench.StreamClip with overlap: the batch AFTER the one being propagated is issued at the first frame of the current one, never
+    reaches past the window or the clip, a one-frame remainder is not batched, and every frame is propagated exactly once in order."""
+    import bench
+
+    class FakeEngine:
+        def __init__(self):
+            self.calls = []
+
+        def restart_engine(self):
+            self.calls.append(('restart',))
+
+        def add_reference_frame(self, *a, **k):
+            self.calls.append(('ref',))
+
+        def encode_ahead(self, imgs, overlap=False):
+            self.calls.append(('ahead', [int(i) for i in imgs], overlap))
+
+    frames = list(range(20))                      # frame "tensors" are their indices
+    eng = FakeEngine()
+    done = []
+    orig = bench.one_frame
+    bench.one_frame = lambda engine, img, feedback=None: done.append(int(img))
+    try:
+        class NullStream:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+        real_stream = torch.cuda.stream
+        torch.cuda.stream = lambda s: NullStream()
+        try:
+            lane = bench.StreamClip(eng, None, (frames, None, None))
+            lane.ahead, lane.overlap = 3, True
+            lane.restart()
+            for left in range(8, 0, -1):           # a window of 8 frames: 1..8
+                lane.step(left)
+            lane.drop_ahead()
+            for left in range(4, 0, -1):           # a window of 4 frames: 9..12 (3 + a remainder of 1)
+                lane.step(left)
+        finally:
+            torch.cuda.stream = real_stream
+    finally:
+        bench.one_frame = orig
+    assert done == list(range(1, 13))
+    ahead = [c for c in eng.calls if c[0] == 'ahead' and c[1]]
+    assert [c[1] for c in ahead] == [[1, 2, 3], [4, 5, 6], [7, 8], [9, 10, 11]], ahead      # (7, 8): clipped at the window end; 12 alone: not batched
+    assert all(c[2] for c in ahead)
+    # the second batch is issued before frame 1 is propagated, the third before frame 4 (= when the second becomes current)
+    order = [c for c in eng.calls if c[0] == 'ahead']
+    assert order[0][1] == [1, 2, 3] and order[1][1] == [4, 5, 6]
