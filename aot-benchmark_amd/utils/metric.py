@@ -6,30 +6,53 @@ import torch.nn.functional as F
 
 
 def _boundary(mask):
-    """1-pixel inner boundary of boolean [..., H, W] masks (pixels whose right / down / diagonal neighbour differs)."""
-    e = torch.zeros_like(mask)
-    e[..., :, :-1] |= mask[..., :, :-1] != mask[..., :, 1:]
-    e[..., :-1, :] |= mask[..., :-1, :] != mask[..., 1:, :]
-    e[..., :-1, :-1] |= mask[..., :-1, :-1] != mask[..., 1:, 1:]
-    return e & mask
+    """Boundary map of boolean [..., H, W] masks as the DAVIS toolkit's seg2bmap forms it (davis2017-evaluation, metrics.py): a pixel is
+    a boundary pixel when its right, lower or lower-right neighbour differs; the last row / column compare with the one neighbour they
+    have, the last pixel is never one."""
+    e, s_, se = torch.zeros_like(mask), torch.zeros_like(mask), torch.zeros_like(mask)
+    e[..., :, :-1] = mask[..., :, 1:]
+    s_[..., :-1, :] = mask[..., 1:, :]
+    se[..., :-1, :-1] = mask[..., 1:, 1:]
+    b = (mask ^ e) | (mask ^ s_) | (mask ^ se)
+    b[..., -1, :] = mask[..., -1, :] ^ e[..., -1, :]
+    b[..., :, -1] = mask[..., :, -1] ^ s_[..., :, -1]
+    b[..., -1, -1] = False
+    return b
 
 
 def _dilate(b, r):
-    """Dilation by a (2r+1) x (2r+1) square as two 1-D max filters; b: boolean [..., H, W]."""
+    """Dilation by a disk of radius r (x^2 + y^2 <= r^2: skimage.morphology.disk, the toolkit's structuring element); b: boolean
+    [..., H, W].  The disk is a stack of horizontal runs, one per row offset dy, of half width floor(sqrt(r^2 - dy^2)): each run is a
+    1-D max filter of the map shifted by dy rows (ATen pooling kernels only -- no convolution library is involved)."""
     if r <= 0:
         return b
-    x = b.to(torch.float32).reshape(-1, 1, *b.shape[-2:])
-    x = F.max_pool2d(x, (2 * r + 1, 1), 1, (r, 0))
-    x = F.max_pool2d(x, (1, 2 * r + 1), 1, (0, r))
-    return x.reshape(b.shape) > 0
+    H, W = b.shape[-2:]
+    x = b.to(torch.float32).reshape(-1, 1, H, W)
+    out = torch.zeros_like(x)
+    for dy in range(-r, r + 1):
+        hw = int((r * r - dy * dy) ** 0.5)
+        while (hw + 1) ** 2 + dy * dy <= r * r:      # (exact integer half width whatever the float square root did)
+            hw += 1
+        while hw * hw + dy * dy > r * r:
+            hw -= 1
+        run = F.max_pool2d(x, (1, 2 * hw + 1), 1, (0, hw)) if hw > 0 else x
+        # out[y] |= run[y - dy]: a source pixel at row y - dy reaches row y
+        if dy >= 0:
+            if dy < H:
+                out[..., dy:, :] = torch.maximum(out[..., dy:, :], run[..., :H - dy, :])
+        elif -dy < H:
+            out[..., :H + dy, :] = torch.maximum(out[..., :H + dy, :], run[..., -dy:, :])
+    return (out > 0.5).reshape(b.shape)
 
 
 def jf_per_object(pred, ref, num_obj, bound_th=0.008):
     """pred, ref: integer label maps [H,W]; returns (J, F) averaged over objects 1..num_obj present in either map.
-    F follows the DAVIS definition: boundary precision/recall with a tolerance of bound_th * image diagonal.
-    All objects are scored in one pass over [num_obj, H, W] stacks."""
+    F follows the DAVIS toolkit's f_measure (restated from its published code; the toolkit is not installed here: tests/test_host.py
+    checks this implementation against an independent numpy / scipy restatement): seg2bmap boundaries, a tolerance of
+    ceil(bound_th * ||(H, W)||) pixels as a disk dilation, precision / recall of the boundary pixels, their special cases for empty
+    boundaries.  All objects are scored in one pass over [num_obj, H, W] stacks."""
     H, W = ref.shape[-2:]
-    r = max(1, int(round(bound_th * (H * H + W * W) ** 0.5)))
+    r = int(bound_th) if bound_th >= 1 else int(-(-(bound_th * (H * H + W * W) ** 0.5) // 1))
     if num_obj < 1:
         return 1.0, 1.0
     ids = torch.arange(1, num_obj + 1, device=ref.device).view(-1, 1, 1)
@@ -46,10 +69,14 @@ def jf_per_object(pred, ref, num_obj, bound_th=0.008):
         if not there:
             continue
         js.append(i / u if u else 1.0)
-        if np_ == 0 and ng == 0:
-            fs.append(1.0)
-            continue
-        prec, rec = hp / max(1, np_), hg / max(1, ng)
+        if np_ == 0 and ng > 0:
+            prec, rec = 1.0, 0.0
+        elif np_ > 0 and ng == 0:
+            prec, rec = 0.0, 1.0
+        elif np_ == 0 and ng == 0:
+            prec, rec = 1.0, 1.0
+        else:
+            prec, rec = hp / np_, hg / ng
         fs.append(0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec))
     if not js:
         return 1.0, 1.0

@@ -251,6 +251,66 @@ def test_jf_metric():
     assert jf_per_object(torch.zeros_like(a), a, 2)[0] == 0.0
 
 
+def test_f_measure_against_an_independent_restatement():
+    """The boundary measure F of utils/metric.py against a second, independent restatement of the DAVIS toolkit's f_measure (numpy +
+    scipy.ndimage: seg2bmap, ceil(0.008 * diagonal) as the radius of a disk dilation, the precision / recall special cases) on random
+    blob masks of several sizes, incl. objects missing from one side (F was checked against nothing external;
+    the toolkit itself is not installable here, so the pin is two implementations written apart from its published code)."""
+    import numpy as np
+    from scipy import ndimage
+    from utils.metric import jf_per_object
+
+    def seg2bmap(seg):
+        seg = seg.astype(bool)
+        e, s_, se = np.zeros_like(seg), np.zeros_like(seg), np.zeros_like(seg)
+        e[:, :-1] = seg[:, 1:]
+        s_[:-1, :] = seg[1:, :]
+        se[:-1, :-1] = seg[1:, 1:]
+        b = (seg ^ e) | (seg ^ s_) | (seg ^ se)
+        b[-1, :] = seg[-1, :] ^ e[-1, :]
+        b[:, -1] = seg[:, -1] ^ s_[:, -1]
+        b[-1, -1] = 0
+        return b
+
+    def f_measure(fg, gt, bound_th=0.008):
+        r = int(bound_th if bound_th >= 1 else np.ceil(bound_th * np.linalg.norm(fg.shape)))
+        yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+        disk = (xx ** 2 + yy ** 2) <= r * r
+        fb, gb = seg2bmap(fg), seg2bmap(gt)
+        fd, gd = ndimage.binary_dilation(fb, structure=disk), ndimage.binary_dilation(gb, structure=disk)
+        nf, ng = fb.sum(), gb.sum()
+        if nf == 0 and ng > 0:
+            p, rc = 1.0, 0.0
+        elif nf > 0 and ng == 0:
+            p, rc = 0.0, 1.0
+        elif nf == 0 and ng == 0:
+            p, rc = 1.0, 1.0
+        else:
+            p, rc = (fb & gd).sum() / float(nf), (gb & fd).sum() / float(ng)
+        return 0.0 if p + rc == 0 else 2 * p * rc / (p + rc)
+
+    rng = np.random.RandomState(7)
+    for (H, W, K) in ((60, 80, 3), (121, 97, 4), (240, 427, 5)):
+        def blobs(shift):
+            m = np.zeros((H, W), np.int64)
+            for k in range(1, K + 1):
+                cy, cx = rng.randint(H // 6, 5 * H // 6), rng.randint(W // 6, 5 * W // 6)
+                ry, rx = rng.randint(4, H // 4), rng.randint(4, W // 4)
+                yy, xx = np.ogrid[:H, :W]
+                m[((yy - cy - shift) / ry) ** 2 + ((xx - cx + shift) / rx) ** 2 <= 1] = k
+            return m
+        state = rng.get_state()
+        ref = blobs(0)
+        rng.set_state(state)
+        pred = blobs(rng.randint(1, 6))
+        pred[pred == K] = 0                     # the last object is missing from the prediction
+        present = [k for k in range(1, K + 1) if (ref == k).any() or (pred == k).any()]
+        want_f = np.mean([f_measure(pred == k, ref == k) for k in present])
+        want_j = np.mean([((pred == k) & (ref == k)).sum() / float(((pred == k) | (ref == k)).sum()) for k in present])
+        j, f = jf_per_object(torch.from_numpy(pred), torch.from_numpy(ref), K)
+        assert abs(j - want_j) < 1e-9 and abs(f - want_f) < 1e-9, (H, W, j, want_j, f, want_f)
+
+
 def test_cabi_rejects_bad_arguments_without_a_gpu():
     """Every entry point validates its arguments before any HIP call: AOT_ERR_BADARG (-1) / AOT_ERR_UNSUPPORTED (-2),
     never an exception or a launch (include/aot_hip.h conventions)."""
